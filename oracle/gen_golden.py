@@ -1,0 +1,240 @@
+'''Golden-vector generator (container-only; test infrastructure).
+
+Imports the REAL Python reference from /root/reference/src through the import
+shim in oracle/refshim (stand-ins for its absent third-party packages; the
+polynomial stand-in is oracle/poly.py) and records, for a ladder of small cases,
+the INPUT tables of the element-integration + sparse-assembly hot path and the
+reference's OUTPUT (CSR triplets, residual vectors, sampled values).  The
+results are committed as small ``.npz`` files under tests/golden/.  Nothing here
+travels to the GPU box except those data files.
+
+Usage:  python oracle/gen_golden.py            (regenerates tests/golden/*.npz)
+'''
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = '/root/reference'
+if not os.path.isdir(REF + '/src/nutils'):
+    raise SystemExit('the reference is not present; golden vectors can only be regenerated in the build container')
+sys.path[:0] = [os.path.join(HERE, 'refshim'), REF + '/src', REF]
+
+import numpy  # noqa: E402
+from nutils import mesh, function  # noqa: E402
+from nutils.expression_v2 import Namespace  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def basis_tables(basis, nelems):
+    '''Per-element dofs and coefficient tables via the public accessors
+    (function.py:2794-2837).  Ragged: concatenated with offsets.'''
+    dofs = [numpy.asarray(basis.get_dofs(e), dtype=numpy.int64) for e in range(nelems)]
+    coeffs = [numpy.asarray(basis.get_coefficients(e), dtype=float) for e in range(nelems)]
+    offsets = numpy.cumsum([0] + [len(d) for d in dofs]).astype(numpy.int64)
+    ncs = sorted({c.shape[1] for c in coeffs})
+    out = dict(dof_offsets=offsets, dofs=numpy.concatenate(dofs))
+    if len(ncs) == 1:
+        out['coeffs'] = numpy.concatenate(coeffs, axis=0)
+    else:  # mixed polynomial degree: pad to the largest (never happens in the cases below)
+        raise NotImplementedError
+    return out
+
+
+def gauss_tables(domain, degree):
+    smp = domain.sample('gauss', degree)
+    pts = smp.points[0]
+    return dict(gauss_coords=numpy.asarray(pts.coords, dtype=float), gauss_weights=numpy.asarray(pts.weights, dtype=float)), smp
+
+
+def csr(prefix, integral, arguments=None):
+    values, rowptr, colidx = function.eval(function.as_csr(integral), arguments or {})
+    assert rowptr.dtype == numpy.int64 and colidx.dtype == numpy.int64
+    return {prefix + '_values': values, prefix + '_rowptr': rowptr, prefix + '_colidx': colidx}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    numpy.savez_compressed(path, **arrays)
+    print(f'{name}: {os.path.getsize(path)} bytes; ' + ', '.join(f'{k}{tuple(numpy.shape(v))}' for k, v in arrays.items()))
+
+
+def perturbed(shape, rng):
+    nd = len(shape)
+    verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, nd)
+    return verts + rng.uniform(-.2, .2, verts.shape)
+
+
+def scalar_case(name, shape, btype, degree, iso, seed=0):
+    '''Laplace stiffness, mass matrix, Laplace residual and load vector for a
+    scalar basis on mesh.rectilinear(shape); geometry either the exact uniform
+    one or an isoparametric P1 map with seeded vertex perturbation.'''
+    rng = numpy.random.default_rng(seed)
+    domain, geom0 = mesh.rectilinear(list(shape))
+    nelems = len(domain)
+    data = dict(shape=numpy.array(shape), degree=degree, iso=int(iso))
+    gbasis = domain.basis('std', degree=1)
+    if iso:
+        verts = perturbed(shape, rng)
+        geom = gbasis @ verts
+        data['verts'] = verts
+        g = basis_tables(gbasis, nelems)
+        data['gdofs'] = g['dofs']
+        data['gdof_offsets'] = g['dof_offsets']
+        data['gcoeffs'] = g['coeffs']
+    else:
+        geom = geom0
+    basis = domain.basis(btype, degree=degree)
+    data.update(basis_tables(basis, nelems))
+    gt, smp = gauss_tables(domain, 2 * degree)
+    data.update(gt)
+    ns = Namespace()
+    ns.x = geom
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    ns.basis = basis
+    u = rng.normal(size=len(basis))
+    ns.u = function.dotarg('u', basis)
+    data['u'] = u
+    data.update(csr('K', smp.integral('∇_i(basis_m) ∇_i(basis_n) dV' @ ns)))
+    data.update(csr('M', smp.integral('basis_m basis_n dV' @ ns)))
+    data['res_laplace'] = smp.integrate('∇_i(basis_m) ∇_i(u) dV' @ ns, arguments=dict(u=u))
+    data['res_mass'] = smp.integrate('basis_m u dV' @ ns, arguments=dict(u=u))
+    data['load_one'] = smp.integrate('basis_m dV' @ ns)
+    data['volume'] = smp.integrate('dV' @ ns)
+    data['energy'] = smp.integrate('.5 ∇_i(u) ∇_i(u) dV' @ ns, arguments=dict(u=u))
+    # Sample.eval: field value, gradient and geometry at the gauss points
+    data['eval_u'] = smp.eval('u' @ ns, arguments=dict(u=u))
+    data['eval_gradu'] = smp.eval('∇_i(u)' @ ns, arguments=dict(u=u))
+    data['eval_x'] = smp.eval('x_i' @ ns)
+    data['eval_detJ'] = smp.eval('dV' @ ns)
+    save(name, **data)
+
+
+def elasticity_case(name, shape, degree, iso, poisson=.3, seed=1):
+    '''Linear elasticity as in examples/elasticity.py:46-54 (lambda = 1,
+    mu = .5/poisson - 1), vector field with ndims components interleaved
+    (flat dof = iscalar * ncomp + comp, function.py:2598-2627).'''
+    rng = numpy.random.default_rng(seed)
+    nd = len(shape)
+    domain, geom0 = mesh.rectilinear(list(shape))
+    nelems = len(domain)
+    data = dict(shape=numpy.array(shape), degree=degree, iso=int(iso), lam=1., mu=.5 / poisson - 1)
+    gbasis = domain.basis('std', degree=1)
+    if iso:
+        verts = perturbed(shape, rng)
+        geom = gbasis @ verts
+        data['verts'] = verts
+        g = basis_tables(gbasis, nelems)
+        data['gdofs'] = g['dofs']
+        data['gdof_offsets'] = g['dof_offsets']
+        data['gcoeffs'] = g['coeffs']
+    else:
+        geom = geom0
+    sbasis = domain.basis('std', degree=degree)
+    data.update(basis_tables(sbasis, nelems))
+    gt, smp = gauss_tables(domain, 2 * degree)
+    data.update(gt)
+    ns = Namespace()
+    ns.δ = function.eye(nd)
+    ns.x = geom
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    ns.u = domain.field('u', btype='std', degree=degree, shape=[nd])
+    ns.v = domain.field('v', btype='std', degree=degree, shape=[nd])
+    ns.λ = 1
+    ns.μ = .5 / poisson - 1
+    ns.ε_ij = '.5 (∇_i(u_j) + ∇_j(u_i))'
+    ns.σ_ij = 'λ ε_kk δ_ij + 2 μ ε_ij'
+    ns.η_ij = '.5 (∇_i(v_j) + ∇_j(v_i))'
+    res = smp.integral('η_ij σ_ij dV' @ ns)
+    u = rng.normal(size=(len(sbasis), nd))
+    data['u'] = u
+    jac = function.derivative(function.derivative(res, 'v'), 'u')  # shape (ns, nd, ns, nd)
+    jac = function.Array.cast(jac)
+    jac2 = function.Array.cast(numpy.reshape(jac, (len(sbasis) * nd, len(sbasis) * nd)))
+    data.update(csr('K', jac2, dict(u=u * 0, v=u * 0)))
+    r = function.eval(function.derivative(res, 'v'), dict(u=u, v=u * 0))
+    data['res'] = numpy.asarray(r)
+    data['energy'] = smp.integrate('.5 ε_ij σ_ij dV' @ ns, arguments=dict(u=u))
+    save(name, **data)
+
+
+def hierarchical_case(name, ndim):
+    '''Ragged case: tests/test_basis.py:94-116 (th-spline / h-spline degree 2 on a
+    locally refined 6^ndim mesh; known nnz 60/66/70 (1-D), 3012/3216/3424 (2-D)).'''
+    import itertools
+    topo, geom = mesh.rectilinear([6] * ndim)
+    topo = topo.refined_by(set(map(topo.transforms.index, itertools.chain(topo[1:3].transforms, topo[-2:].transforms))))
+    nelems = len(topo)
+    data = dict(ndim=ndim)
+    smp = topo.sample('gauss', 5)
+    # per-element gauss tables are identical for all elements (same reference element)
+    pts = smp.points[0]
+    data['gauss_coords'] = numpy.asarray(pts.coords, dtype=float)
+    data['gauss_weights'] = numpy.asarray(pts.weights, dtype=float)
+    ns = Namespace()
+    ns.x = geom
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    # element geometry: x = offset + scale * xi for each (axis-aligned) element
+    x_at_0 = topo.sample('bezier', 2).eval(geom)
+    npe = 2 ** ndim
+    x_el = x_at_0.reshape(nelems, npe, ndim)
+    data['elem_origin'] = x_el.min(axis=1)
+    data['elem_size'] = x_el.max(axis=1) - x_el.min(axis=1)
+    for key, btype, kw in (('t', 'th-spline', dict(truncation_tolerance=1e-14)), ('h', 'h-spline', {})):
+        basis = topo.basis(btype, degree=2, **kw)
+        tb = basis_tables(basis, nelems)
+        data[key + '_dofs'] = tb['dofs']
+        data[key + '_dof_offsets'] = tb['dof_offsets']
+        data[key + '_coeffs'] = tb['coeffs']
+        data[key + '_ndofs'] = len(basis)
+        ns.b = basis
+        data.update(csr(key + 'K', smp.integral('∇_k(b_i) ∇_k(b_j) dV' @ ns)))
+    save(name, **data)
+
+
+def example_vectors():
+    '''Decoded assertAlmostEqual64 payloads of the reference examples
+    (examples/laplace.py:111-152, examples/elasticity.py:89-146): the embedded
+    base64 strings are data; store the decoded arrays with their tolerance.'''
+    from nutils import numeric
+    import examples.laplace as lap
+    out = {}
+    for nelems, etype, btype, degree, tag in ((4, 'square', 'std', 1, 'default'), (4, 'square', 'spline', 2, 'spline')):
+        cons, lhs, err = lap.main(nelems=nelems, etype=etype, btype=btype, degree=degree)
+        out[f'laplace_{tag}_cons'] = cons
+        out[f'laplace_{tag}_lhs'] = lhs
+        out[f'laplace_{tag}_err'] = err
+    cons, lhs, err = lap.main(nelems=32, etype='square', btype='std', degree=1)
+    out['laplace_c1_cons'] = cons
+    out['laplace_c1_lhs'] = lhs
+    out['laplace_c1_err'] = err
+    save('examples_laplace', **out)
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    scalar_case('lap1d_p1_5', (5,), 'std', 1, iso=False)
+    scalar_case('lap2d_p1_4x4', (4, 4), 'std', 1, iso=False)
+    scalar_case('lap2d_p1_4x3_iso', (4, 3), 'std', 1, iso=True)
+    scalar_case('lap2d_p2_3x4_iso', (3, 4), 'std', 2, iso=True)
+    scalar_case('lap2d_spline2_4x4', (4, 4), 'spline', 2, iso=False)
+    scalar_case('lap2d_spline2_5x4_iso', (5, 4), 'spline', 2, iso=True)
+    scalar_case('lap3d_p1_2', (2, 2, 2), 'std', 1, iso=False)
+    scalar_case('lap3d_p1_3', (3, 3, 3), 'std', 1, iso=False)
+    scalar_case('lap3d_p1_4', (4, 4, 4), 'std', 1, iso=False)
+    scalar_case('lap3d_p1_234', (2, 3, 4), 'std', 1, iso=False)
+    scalar_case('lap3d_p1_3_iso', (3, 3, 3), 'std', 1, iso=True)
+    scalar_case('lap3d_p1_543_iso', (5, 4, 3), 'std', 1, iso=True)
+    scalar_case('lap3d_p2_2_iso', (2, 2, 2), 'std', 2, iso=True)
+    scalar_case('lap3d_spline2_3_iso', (3, 3, 3), 'spline', 2, iso=True)
+    scalar_case('lap3d_spline3_3', (3, 4, 3), 'spline', 3, iso=False)
+    elasticity_case('elast2d_p1_3x3', (3, 3), 1, iso=False)
+    elasticity_case('elast2d_p2_3x2_iso', (3, 2), 2, iso=True)
+    elasticity_case('elast3d_p1_2_iso', (2, 2, 2), 1, iso=True)
+    elasticity_case('elast3d_p2_2', (2, 2, 2), 2, iso=False)
+    elasticity_case('elast3d_p2_2_iso', (2, 2, 2), 2, iso=True)
+    hierarchical_case('hier_spline2_1d', 1)
+    hierarchical_case('hier_spline2_2d', 2)
+    example_vectors()
