@@ -1,0 +1,206 @@
+/* nutils_hip.h -- C ABI of libnutils_hip.so, the MI355X (gfx950) element-integration
+ * and sparse-assembly backend for Nutils.
+ *
+ * The reference (/root/reference, pure Python) has no FFI for this path: the work is
+ * done by a generated numpy-per-element Python loop.  Each entry point below names the
+ * reference code it replaces (paths relative to /root/reference/src/nutils).  The
+ * boundary is plain C: opaque handles, device/host pointers, sizes, an int status
+ * (0 = ok, negative = error, message via nh_last_error) -- the convention the reference
+ * itself uses for its only native binding (matrix/_mkl.py:29-42,76-82), loaded with
+ * ctypes like _util.py:195-237 (loadlib).
+ *
+ * Conventions
+ *   - all "dev" pointers are HIP device pointers (hipMalloc / torch.cuda allocations);
+ *     "host" pointers are ordinary memory.  `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  Calls are asynchronous on `stream` unless stated.
+ *   - floating point data is IEEE f64 throughout (the reference computes in float64);
+ *     index OUTPUTS are int64 (the reference's CSR index arrays are int64 and are
+ *     compared bit-exactly); connectivity INPUTS are int32 on the device.
+ *   - tabulated basis layout  T[fn][q][S], S = 1 + ndims: value, then d/dxi_j.
+ *   - element-local ordering, dof numbering and CSR ordering follow the reference:
+ *     CSR rows/cols sorted lexicographically, structural zeros retained, flat vector
+ *     dof = scalar_dof * ncomp + comp (function.py:2598-2627).
+ *   - thread model: one host thread per device context (the reference never threads;
+ *     under NUTILS_NPROCS>1 it forks -- do not initialise before a fork).
+ */
+#ifndef NUTILS_HIP_H
+#define NUTILS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NH_OK 0
+#define NH_EINVAL (-1)  /* invalid argument */
+#define NH_EHIP (-2)    /* HIP runtime error (message has the HIP error string) */
+#define NH_ELIMIT (-3)  /* problem exceeds a compiled-in limit of the kernel */
+#define NH_ENOMEM (-4)
+
+#define NH_ABI_VERSION 1
+
+/* ---- runtime ------------------------------------------------------------------- */
+int nh_abi_version(void);
+const char *nh_last_error(void);
+int nh_device_count(int *count);
+int nh_set_device(int device);
+/* name: caller buffer of namelen bytes; cus, lds_bytes, hbm_bytes may be NULL */
+int nh_device_info(int device, char *name, size_t namelen, int *cus, int64_t *lds_bytes, int64_t *hbm_bytes);
+int nh_malloc(void **dev, size_t bytes);
+int nh_free(void *dev);
+int nh_memcpy_h2d(void *dev, const void *host, size_t bytes, void *stream);
+int nh_memcpy_d2h(void *host, const void *dev, size_t bytes, void *stream);
+int nh_memset(void *dev, int byte, size_t bytes, void *stream);
+int nh_stream_sync(void *stream);
+
+/* ---- K2: basis tabulation -------------------------------------------------------
+ * replaces nutils_poly eval_outer / GradPlan as called from generated code
+ * (evaluable.py:4366-4374 Polyval, :4584-4653 PolyGrad).
+ * coeffs[nfn][ncoeffs] in the reference coefficient order (evaluable.py:4331-4340),
+ * points[nq][ndims]  ->  T[nfn][nq][1+ndims]. */
+int nh_poly_tabulate(const double *coeffs_dev, int64_t nfn, int ncoeffs, const double *points_dev, int nq, int ndims,
+                     double *T_dev, void *stream);
+
+/* ---- K1: structured dof maps ----------------------------------------------------
+ * replaces StructuredBasis.f_dofs_coeffs' integer part (function.py:3080-3093:
+ * divmod unravel, Range + offsets, RavelIndex/Ravel).  shape[ndims] elements per axis
+ * (element index: last axis fastest), start_dev[axis][shape[axis]] first dof per element
+ * (concatenated over axes), per-axis dofs-per-element nloc[axis], per-axis dof counts
+ * ndofs_axis[axis] (dofs wrap modulo ndofs_axis).  Output dofs[nelems][prod nloc] int32. */
+int nh_structured_dofs(int ndims, const int *shape, const int *nloc, const int *ndofs_axis, const int *start_dev,
+                       int64_t elem_begin, int64_t nelems, int32_t *dofs_dev, void *stream);
+
+/* ---- K6: sparsity pattern --------------------------------------------------------
+ * replaces Array.assparse's unique(flatindex) = ArgSort(stable)+UniqueMask+UniqueInverse
+ * and as_csr's CompressIndices (evaluable.py:588-616, 5560-5682; numeric.py:687-711).
+ * Builds the SCALAR pattern (rows = test dofs, cols = trial dofs) row-wise on the
+ * device, plus the element map emap[e][m][n] = position of trial dof n of element e in
+ * the sorted scalar row of test dof m.  Ragged bases pass offsets (prefix sums of dofs
+ * per element, int64[nelems+1], host... see fields). */
+typedef struct nh_pattern nh_pattern; /* opaque, owns device memory */
+
+typedef struct {
+  int64_t nelems;
+  int64_t nrows, ncols;        /* scalar dof counts of test / trial basis */
+  int nbt, nbr;                /* dofs per element if uniform; 0 if ragged (use offsets) */
+  const int32_t *tdofs_dev;    /* test dofs, concatenated per element */
+  const int32_t *rdofs_dev;    /* trial dofs (may alias tdofs_dev) */
+  const int64_t *toff_dev;     /* ragged: int64[nelems+1] prefix sums, else NULL */
+  const int64_t *roff_dev;
+} nh_pattern_args;
+
+int nh_pattern_build(const nh_pattern_args *args, nh_pattern **out, void *stream);
+int nh_pattern_free(nh_pattern *p);
+/* scalar nnz, and device pointers owned by the pattern (valid until nh_pattern_free);
+ * eoff (ragged bases only, else NULL): int64[nelems+1] prefix sums of nbt_e*nbr_e indexing emap */
+int nh_pattern_info(const nh_pattern *p, int64_t *nnz_scalar, const int64_t **srowptr_dev, const int32_t **scolidx_dev,
+                    const int32_t **emap_dev, int64_t *emap_len, const int64_t **eoff_dev);
+/* Expanded CSR index arrays for nct x ncr components with block mask[nct][ncr] (host,
+ * nonzero = block present; NULL = all): rowptr_dev int64[nrows*nct+1], colidx_dev
+ * int64[nnz]; nnz returned by nh_pattern_expanded_nnz.  Hand-back format of
+ * matrix/__init__.py:30-70 (assemble_csr) -- indices int64, rows sorted, cols strictly
+ * increasing within a row. */
+int nh_pattern_expanded_nnz(const nh_pattern *p, int nct, int ncr, const unsigned char *mask, int64_t *nnz);
+int nh_pattern_expand(const nh_pattern *p, int nct, int ncr, const unsigned char *mask, int64_t *rowptr_dev,
+                      int64_t *colidx_dev, void *stream);
+
+/* ---- geometry descriptor ---------------------------------------------------------
+ * replaces _TransformsCoords/_Jacobian lowering + numeric.inv + linalg.det
+ * (function.py:1162-1181,1284-1295; evaluable.py:1403-1490; numeric.py:221-241). */
+#define NH_GEOM_ISO 1    /* x = sum_a N_a(xi) X[gdofs[e][a]]; gT = tabulated geometry basis [ngb][nq][S] */
+#define NH_GEOM_BOX 2    /* x = origin[e] + size[e] * xi  (axis aligned; rectilinear + hierarchical refinements) */
+
+typedef struct {
+  int kind;
+  int ngb;                   /* ISO: geometry basis functions per element (uniform) */
+  const double *gT_dev;      /* ISO: [ngb][nq][S] */
+  const int32_t *gdofs_dev;  /* ISO: [nelems][ngb] */
+  const double *verts_dev;   /* ISO: [nverts][ndims] */
+  const double *origin_dev;  /* BOX: [nelems][ndims] */
+  const double *size_dev;    /* BOX: [nelems][ndims] */
+} nh_geometry;
+
+/* ---- basis-on-elements descriptor ------------------------------------------------ */
+typedef struct {
+  int nb;                    /* functions per element if uniform, 0 if ragged */
+  const double *T_dev;       /* tabulated functions [nfn][nq][S] */
+  const int32_t *dofs_dev;   /* concatenated element dofs */
+  const int64_t *off_dev;    /* ragged: int64[nelems+1] (dofs AND first-function offsets), else NULL */
+  const int32_t *tab_dev;    /* uniform nb, several tables: table index per element (first fn = tab*nb); NULL = table 0.
+                                Ragged: ignored (first function of element e = off[e]). */
+} nh_basis;
+
+/* ---- K3+K4+K5: matrix assembly ---------------------------------------------------
+ * replaces the generated element loop (evaluable.py:6773-6786) for a bilinear integrand
+ *   A[(m,c),(n,d)] = sum_q w_q |det J_q| sum_{a,b} Dt[q,m,a] C[c,a,d,b] Dr[q,n,b]
+ * (D[.,.,0] = value, D[.,.,1+i] = d/dx_i: Basis.lower function.py:2758-2762, _Gradient
+ * :1221-1231; einsum contraction evaluable.py:1885-1886, 6414-6505; sample.py:951-956)
+ * and the scatter/accumulate of its sparse dedup (evaluable.py:603-605; numeric.accumulate
+ * numeric.py:434-460) into `values_dev` laid out by the pattern. values are ACCUMULATED:
+ * zero them first (nh_memset) for a fresh assembly. */
+typedef struct {
+  int64_t nelems;
+  const int32_t *elist_dev;  /* optional element subset (bucket), NULL = 0..nelems-1; nelems counts the list */
+  int ndims, nq;
+  const double *weights_dev; /* [nq] */
+  nh_geometry geom;
+  nh_basis test, trial;
+  int nct, ncr;              /* components of test / trial field */
+  const double *C_host;      /* [nct][S][ncr][S] constant coefficient tensor (host memory) */
+  const unsigned char *mask_host; /* [nct][ncr] block mask used for the pattern, NULL = all */
+  const int64_t *srowptr_dev;/* scalar pattern */
+  const int32_t *emap_dev;   /* element map from nh_pattern_info */
+  const int64_t *eoff_dev;   /* ragged: int64[nelems+1] prefix sums of nbt_e*nbr_e, else NULL */
+  double *values_dev;        /* [nnz of the expanded pattern] */
+} nh_matrix_args;
+
+int nh_assemble_matrix(const nh_matrix_args *args, void *stream);
+
+/* ---- vector / functional assembly, point evaluation --------------------------------
+ * r[(m,c)] += sum_q w_q |det J_q| sum_a Dt[q,m,a] F[q,c,a],
+ * F[q,c,a] = f[c][a] + sum_{d,b} C[c,a,d,b] U[q,d,b],  U[q,d,b] = sum_n Dr[q,n,b] u[rdofs[n]][d]
+ * replaces Inflate/Assemble scatter (evaluable.py:3341-3495, 3552-3645; numpy.add.at /
+ * numeric.accumulate) of a linear-form element loop.  With out_scalar_dev != NULL also
+ * accumulates the functional  sum_q w|J| (f0 + 1/2 sum U[q,c,a] (C U)[q,c,a])  there
+ * (Sample.integrate of a scalar, sample.py:160-175).  u_dev / C_host may be NULL. */
+typedef struct {
+  int64_t nelems;
+  const int32_t *elist_dev;
+  int ndims, nq;
+  const double *weights_dev;
+  nh_geometry geom;
+  nh_basis test, trial;
+  int nct, ncr;
+  const double *C_host;      /* [nct][S][ncr][S] or NULL */
+  const double *f_host;      /* [nct][S] constant source or NULL */
+  const double *u_dev;       /* [ncols][ncr] trial coefficients or NULL */
+  double *out_dev;           /* [nrows][nct] accumulated, or NULL */
+  double f0;                 /* constant integrand of the functional */
+  double *out_scalar_dev;    /* [1] accumulated, or NULL */
+} nh_vector_args;
+
+int nh_assemble_vector(const nh_vector_args *args, void *stream);
+
+/* Sample.eval / bind (sample.py:192-232, _ConcatenatePoints.lower :966-975;
+ * LoopConcatenate evaluable.py:5383-5508): values at all quadrature points, element
+ * major.  Any output may be NULL.  x[e][q][ndims], detj[e][q],
+ * U[e][q][ncr][S] (value and physical gradient of the field u). */
+typedef struct {
+  int64_t nelems;
+  int ndims, nq;
+  nh_geometry geom;
+  nh_basis trial;
+  int ncr;
+  const double *points_dev;  /* [nq][ndims] reference coordinates (needed for BOX geometry x) */
+  const double *u_dev;
+  double *x_dev, *detj_dev, *U_dev;
+} nh_eval_args;
+
+int nh_sample_eval(const nh_eval_args *args, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

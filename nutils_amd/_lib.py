@@ -1,0 +1,121 @@
+'''ctypes binding of libnutils_hip.so (include/nutils_hip.h).
+
+The library is loaded the way the reference loads its only native dependency
+(``_util.loadlib``, /root/reference/src/nutils/_util.py:195-237; used by
+matrix/_mkl.py:10): ``ctypes.CDLL`` on an explicit path.  There is NO fallback:
+if the shared object is missing or a call fails, an exception is raised -- the
+product path never computes on the CPU.
+'''
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, 'libnutils_hip.so')
+
+c_i64 = ctypes.c_int64
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+
+
+class NutilsHipError(RuntimeError):
+    '''Raised for any non-zero status of the C ABI (cf. matrix.MatrixError,
+    /root/reference/src/nutils/matrix/_base.py:9-12).'''
+
+
+class Geometry(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int), ('ngb', ctypes.c_int), ('gT_dev', vp), ('gdofs_dev', vp), ('verts_dev', vp),
+                ('origin_dev', vp), ('size_dev', vp)]
+
+
+class Basis(ctypes.Structure):
+    _fields_ = [('nb', ctypes.c_int), ('T_dev', vp), ('dofs_dev', vp), ('off_dev', vp), ('tab_dev', vp)]
+
+
+class PatternArgs(ctypes.Structure):
+    _fields_ = [('nelems', c_i64), ('nrows', c_i64), ('ncols', c_i64), ('nbt', ctypes.c_int), ('nbr', ctypes.c_int),
+                ('tdofs_dev', vp), ('rdofs_dev', vp), ('toff_dev', vp), ('roff_dev', vp)]
+
+
+class MatrixArgs(ctypes.Structure):
+    _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp),
+                ('geom', Geometry), ('test', Basis), ('trial', Basis), ('nct', ctypes.c_int), ('ncr', ctypes.c_int),
+                ('C_host', vp), ('mask_host', vp), ('srowptr_dev', vp), ('emap_dev', vp), ('eoff_dev', vp), ('values_dev', vp)]
+
+
+class VectorArgs(ctypes.Structure):
+    _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp),
+                ('geom', Geometry), ('test', Basis), ('trial', Basis), ('nct', ctypes.c_int), ('ncr', ctypes.c_int),
+                ('C_host', vp), ('f_host', vp), ('u_dev', vp), ('out_dev', vp), ('f0', ctypes.c_double), ('out_scalar_dev', vp)]
+
+
+class EvalArgs(ctypes.Structure):
+    _fields_ = [('nelems', c_i64), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('geom', Geometry), ('trial', Basis),
+                ('ncr', ctypes.c_int), ('points_dev', vp), ('u_dev', vp), ('x_dev', vp), ('detj_dev', vp), ('U_dev', vp)]
+
+
+GEOM_ISO = 1
+GEOM_BOX = 2
+
+# name -> (restype, argtypes); kept in step with include/nutils_hip.h (tests/test_abi.py parses the header)
+SIGNATURES = {
+    'nh_abi_version': (ctypes.c_int, []),
+    'nh_last_error': (ctypes.c_char_p, []),
+    'nh_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'nh_set_device': (ctypes.c_int, [ctypes.c_int]),
+    'nh_device_info': (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), c_i64p, c_i64p]),
+    'nh_malloc': (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_size_t]),
+    'nh_free': (ctypes.c_int, [vp]),
+    'nh_memcpy_h2d': (ctypes.c_int, [vp, vp, ctypes.c_size_t, vp]),
+    'nh_memcpy_d2h': (ctypes.c_int, [vp, vp, ctypes.c_size_t, vp]),
+    'nh_memset': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_size_t, vp]),
+    'nh_stream_sync': (ctypes.c_int, [vp]),
+    'nh_poly_tabulate': (ctypes.c_int, [vp, c_i64, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    'nh_structured_dofs': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                          ctypes.POINTER(ctypes.c_int), vp, c_i64, c_i64, vp, vp]),
+    'nh_pattern_build': (ctypes.c_int, [ctypes.POINTER(PatternArgs), ctypes.POINTER(vp), vp]),
+    'nh_pattern_free': (ctypes.c_int, [vp]),
+    'nh_pattern_info': (ctypes.c_int, [vp, c_i64p, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), c_i64p, ctypes.POINTER(vp)]),
+    'nh_pattern_expanded_nnz': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, c_i64p]),
+    'nh_pattern_expand': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
+    'nh_assemble_matrix': (ctypes.c_int, [ctypes.POINTER(MatrixArgs), vp]),
+    'nh_assemble_vector': (ctypes.c_int, [ctypes.POINTER(VectorArgs), vp]),
+    'nh_sample_eval': (ctypes.c_int, [ctypes.POINTER(EvalArgs), vp]),
+}
+
+_lib = None
+
+
+def load():
+    '''Return the loaded library; raise if it has not been built.'''
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise NutilsHipError(f'{LIBPATH} not found: build it with `make -C nutils_amd/csrc` (or __graft_entry__.build()); '
+                                 'nutils_amd has no CPU fallback')
+        # Share ONE HIP runtime with PyTorch-ROCm (our allocator / stream owner): torch bundles its own
+        # libamdhip64, and device pointers or streams cannot cross runtimes.  Importing torch first makes the
+        # dynamic linker resolve our libamdhip64.so.7 dependency to the copy torch already mapped.
+        if os.environ.get('NUTILS_HIP_STANDALONE', '0') != '1':
+            import torch  # noqa: F401
+        lib = ctypes.CDLL(LIBPATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.nh_abi_version() != 1:
+            raise NutilsHipError('libnutils_hip.so ABI version mismatch')
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().nh_last_error().decode(errors='replace')
+        raise NutilsHipError(f'libnutils_hip status {status}: {msg}')
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

@@ -1,0 +1,543 @@
+// Generic element kernels: one wavefront (64 lanes) per element, any basis size,
+// 1-3 dimensions, constant coefficient tensor.  Correct for every configuration the
+// host layer can describe (ragged bases, several tables, mixed test/trial bases,
+// isoparametric or box geometry); the specialised kernels (nh_assemble_p1.hip,
+// nh_assemble_mfma.hip) overtake it on the headline configurations.
+//
+// Stages per element (LDS-staged, separated by wave-level barriers):
+//   1. lanes over q:      J_q, J_q^{-1}, w_q |det J_q|            (K3)
+//   2. lanes over (q,m):  D[q][m][0] = N_m, D[q][m][1+i] = sum_j dN_m/dxi_j Jinv[j][i]   (K2 tables -> physical)
+//   3. lanes over entries (m,c,n,d): A = sum_q wdet sum_ab Dt C Dr                         (K4)
+//      atomicAdd into values[slot(e,m,c,n,d)] via the element map                       (K5)
+#include "nh_common.h"
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int MAXC = 4;            // components
+constexpr int MAXS = 4;            // 1 + ndims
+constexpr int LDS_BUDGET = 60000;  // bytes of D tables per workgroup (q-chunked beyond that)
+
+struct FormK {
+  int nct, ncr;
+  double C[MAXC * MAXS * MAXC * MAXS];  // [c][a][d][b]
+  double f[MAXC * MAXS];                // [c][a]
+  int cnt[MAXC], cum[MAXC], tot;
+  unsigned char mask[MAXC][MAXC];
+  signed char dpos[MAXC][MAXC];
+  int hasC, hasf;
+  int pad[2];
+};
+constexpr int FORMD = (int)((sizeof(FormK) + 15) / 16 * 2);  // doubles reserved at the start of dynamic LDS
+
+__device__ __forceinline__ const FormK &stage_form(double *lds, const FormK &arg, int lane) {
+  const double *src = reinterpret_cast<const double *>(&arg);
+  for (int i = lane; i < (int)(sizeof(FormK) / 8); i += 64) lds[i] = src[i];
+  __syncthreads();
+  return *reinterpret_cast<const FormK *>(lds);
+}
+
+template <int ND>
+__device__ __forceinline__ void invert(const double (&J)[ND][ND], double (&Ji)[ND][ND], double &det) {
+  if constexpr (ND == 1) {
+    det = J[0][0];
+    Ji[0][0] = 1. / det;
+  } else if constexpr (ND == 2) {
+    det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double r = 1. / det;
+    Ji[0][0] = J[1][1] * r;
+    Ji[0][1] = -J[0][1] * r;
+    Ji[1][0] = -J[1][0] * r;
+    Ji[1][1] = J[0][0] * r;
+  } else {
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double r = 1. / det;
+    Ji[0][0] = c00 * r;
+    Ji[1][0] = c01 * r;
+    Ji[2][0] = c02 * r;
+    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+  }
+}
+
+// geometry at point q of element e: Jinv (row-major [j][i]), det, optionally x
+template <int ND>
+__device__ __forceinline__ void geometry_at(const GeomK &g, i64 e, int q, int nq, const double *points, double (&Ji)[ND][ND], double &det,
+                                            double *x) {
+  constexpr int S = 1 + ND;
+  double J[ND][ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+#pragma unroll
+    for (int j = 0; j < ND; ++j) J[i][j] = 0;
+  if (g.kind == NH_GEOM_ISO) {
+    if (x)
+      for (int i = 0; i < ND; ++i) x[i] = 0;
+    for (int a = 0; a < g.ngb; ++a) {
+      const double *X = g.verts + (i64)g.gdofs[e * g.ngb + a] * ND;
+      const double *t = g.gT + ((i64)a * nq + q) * S;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const double xi = X[i];
+        if (x) x[i] += xi * t[0];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) J[i][j] += xi * t[1 + j];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      J[i][i] = g.size[e * ND + i];
+      if (x) x[i] = g.origin[e * ND + i] + J[i][i] * points[q * ND + i];
+    }
+  }
+  invert<ND>(J, Ji, det);
+}
+
+__device__ __forceinline__ i64 boff(const BasisK &b, i64 e) { return b.off ? b.off[e] : e * (i64)b.nb; }
+__device__ __forceinline__ int bnb(const BasisK &b, i64 e) { return b.off ? (int)(b.off[e + 1] - b.off[e]) : b.nb; }
+__device__ __forceinline__ i64 bfn(const BasisK &b, i64 e) { return b.off ? b.off[e] : (b.tab ? (i64)b.tab[e] * b.nb : 0); }
+
+// stage 2 helper: fill D[(q - q0)][m][S] for q in [q0, q1)
+template <int ND>
+__device__ __forceinline__ void fill_D(double *D, const BasisK &b, i64 e, int nb, int nq, int q0, int q1, const double *Jw, int lane) {
+  constexpr int S = 1 + ND, JW = ND * ND + 1;
+  const i64 fn0 = bfn(b, e);
+  const int n = (q1 - q0) * nb;
+  for (int t = lane; t < n; t += 64) {
+    const int ql = t / nb, m = t % nb, q = q0 + ql;
+    const double *T = b.T + ((fn0 + m) * nq + q) * S;
+    const double *Ji = Jw + q * JW;
+    double *o = D + (ql * nb + m) * S;
+    o[0] = T[0];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      double s = 0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) s += T[1 + j] * Ji[j * ND + i];
+      o[1 + i] = s;
+    }
+  }
+}
+
+struct MatK {
+  i64 nelems;
+  const int32_t *elist;
+  int nq;
+  const double *weights;
+  GeomK geom;
+  BasisK test, trial;
+  int same;  // trial tables alias test tables
+  const i64 *srowptr;
+  const int32_t *emap;
+  const i64 *eoff;
+  double *values;
+  int qchunk;
+  int maxnbt, maxnbr;
+};
+
+template <int ND>
+__global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
+  constexpr int S = 1 + ND, JW = ND * ND + 1;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const FormK &form = stage_form(lds, formarg, threadIdx.x);
+  double *Jw = lds + FORMD;                           // [nq][JW]
+  double *Dt = Jw + p.nq * JW;                        // [qchunk][maxnbt][S]
+  double *Dr = p.same ? Dt : Dt + p.qchunk * p.maxnbt * S;
+  const int lane = threadIdx.x;
+  for (i64 ie = blockIdx.x; ie < p.nelems; ie += gridDim.x) {
+    const i64 e = p.elist ? p.elist[ie] : ie;
+    const int nbt = bnb(p.test, e), nbr = bnb(p.trial, e);
+    for (int q = lane; q < p.nq; q += 64) {
+      double Ji[ND][ND], det;
+      geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) Jw[q * JW + j * ND + i] = Ji[j][i];
+      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det);
+    }
+    __syncthreads();
+    const i64 tdof0 = boff(p.test, e);
+    const i64 emap0 = p.eoff ? p.eoff[e] : e * (i64)nbt * nbr;
+    const int nentries = nbt * form.nct * nbr * form.ncr;
+    for (int q0 = 0; q0 < p.nq; q0 += p.qchunk) {
+      const int q1 = min(p.nq, q0 + p.qchunk);
+      fill_D<ND>(Dt, p.test, e, nbt, p.nq, q0, q1, Jw, lane);
+      if (!p.same) fill_D<ND>(Dr, p.trial, e, nbr, p.nq, q0, q1, Jw, lane);
+      __syncthreads();
+      for (int k = lane; k < nentries; k += 64) {
+        int r = k;
+        const int d = r % form.ncr; r /= form.ncr;
+        const int n = r % nbr; r /= nbr;
+        const int c = r % form.nct;
+        const int m = r / form.nct;
+        if (!form.mask[c][d]) continue;
+        const double *Cc = form.C + ((c * S) * form.ncr + d) * S;  // C[c][a][d][b] = Cc[a*ncr*S + b]
+        double acc = 0;
+        for (int q = q0; q < q1; ++q) {
+          const double *dt = Dt + ((q - q0) * nbt + m) * S;
+          const double *dr = Dr + ((q - q0) * nbr + n) * S;
+          double s = 0;
+#pragma unroll
+          for (int a = 0; a < S; ++a) {
+            double t = 0;
+#pragma unroll
+            for (int b = 0; b < S; ++b) t += Cc[a * form.ncr * S + b] * dr[b];
+            s += dt[a] * t;
+          }
+          acc += Jw[q * JW + ND * ND] * s;
+        }
+        const i64 row = p.test.dofs[tdof0 + m];
+        const i64 a0 = p.srowptr[row], len = p.srowptr[row + 1] - a0;
+        const i64 slot = a0 * form.tot + len * form.cum[c] + (i64)p.emap[emap0 + m * nbr + n] * form.cnt[c] + form.dpos[c][d];
+        atomicAdd(p.values + slot, acc);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct VecK {
+  i64 nelems;
+  const int32_t *elist;
+  int nq;
+  const double *weights;
+  GeomK geom;
+  BasisK test, trial;
+  int same;
+  const double *u;
+  double *out;
+  double f0;
+  double *out_scalar;
+  int qchunk, maxnbt, maxnbr;
+};
+
+template <int ND>
+__global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
+  constexpr int S = 1 + ND, JW = ND * ND + 1;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const FormK &form = stage_form(lds, formarg, threadIdx.x);
+  double *Jw = lds + FORMD;
+  double *Dt = Jw + p.nq * JW;
+  double *Dr = p.same ? Dt : Dt + p.qchunk * p.maxnbt * S;
+  double *U = Dr + (p.same ? p.qchunk * p.maxnbt * S : p.qchunk * p.maxnbr * S);  // [qchunk][ncr][S]
+  double *F = U + p.qchunk * MAXC * S;                                              // [qchunk][nct][S]
+  const int lane = threadIdx.x;
+  double fsum = 0;
+  for (i64 ie = blockIdx.x; ie < p.nelems; ie += gridDim.x) {
+    const i64 e = p.elist ? p.elist[ie] : ie;
+    const int nbt = bnb(p.test, e), nbr = bnb(p.trial, e);
+    for (int q = lane; q < p.nq; q += 64) {
+      double Ji[ND][ND], det;
+      geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) Jw[q * JW + j * ND + i] = Ji[j][i];
+      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det);
+    }
+    __syncthreads();
+    const i64 tdof0 = boff(p.test, e), rdof0 = boff(p.trial, e);
+    for (int q0 = 0; q0 < p.nq; q0 += p.qchunk) {
+      const int q1 = min(p.nq, q0 + p.qchunk), nql = q1 - q0;
+      fill_D<ND>(Dt, p.test, e, nbt, p.nq, q0, q1, Jw, lane);
+      if (!p.same) fill_D<ND>(Dr, p.trial, e, nbr, p.nq, q0, q1, Jw, lane);
+      __syncthreads();
+      // U[q][d][b]
+      for (int t = lane; t < nql * form.ncr * S; t += 64) {
+        const int b = t % S, d = (t / S) % form.ncr, ql = t / (S * form.ncr);
+        double s = 0;
+        if (p.u)
+          for (int n = 0; n < nbr; ++n) s += Dr[(ql * nbr + n) * S + b] * p.u[(i64)p.trial.dofs[rdof0 + n] * form.ncr + d];
+        U[(ql * MAXC + d) * S + b] = s;
+      }
+      __syncthreads();
+      // F[q][c][a] = f[c][a] + sum_db C[c][a][d][b] U[q][d][b]
+      for (int t = lane; t < nql * form.nct * S; t += 64) {
+        const int a = t % S, c = (t / S) % form.nct, ql = t / (S * form.nct);
+        double s = form.hasf ? form.f[c * S + a] : 0.;
+        if (form.hasC)
+          for (int d = 0; d < form.ncr; ++d)
+            for (int b = 0; b < S; ++b) s += form.C[((c * S + a) * form.ncr + d) * S + b] * U[(ql * MAXC + d) * S + b];
+        F[(ql * MAXC + c) * S + a] = s;
+      }
+      __syncthreads();
+      if (p.out) {
+        for (int k = lane; k < nbt * form.nct; k += 64) {
+          const int c = k % form.nct, m = k / form.nct;
+          double acc = 0;
+          for (int ql = 0; ql < nql; ++ql) {
+            double s = 0;
+#pragma unroll
+            for (int a = 0; a < S; ++a) s += Dt[(ql * nbt + m) * S + a] * F[(ql * MAXC + c) * S + a];
+            acc += Jw[(q0 + ql) * JW + ND * ND] * s;
+          }
+          atomicAdd(p.out + (i64)p.test.dofs[tdof0 + m] * form.nct + c, acc);
+        }
+      }
+      if (p.out_scalar) {
+        for (int ql = lane; ql < nql; ql += 64) {
+          double s = p.f0;
+          if (form.hasC) {
+            // 1/2 U . (F - f)
+            double h = 0;
+            for (int c = 0; c < form.nct; ++c)
+              for (int a = 0; a < S; ++a)
+                h += U[(ql * MAXC + c) * S + a] * (F[(ql * MAXC + c) * S + a] - (form.hasf ? form.f[c * S + a] : 0.));
+            s += .5 * h;
+          }
+          if (form.hasf) {
+            for (int c = 0; c < form.nct; ++c)
+              for (int a = 0; a < S; ++a) s += form.f[c * S + a] * U[(ql * MAXC + c) * S + a];
+          }
+          fsum += Jw[(q0 + ql) * JW + ND * ND] * s;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (p.out_scalar) {
+    for (int o = 32; o; o >>= 1) fsum += __shfl_xor(fsum, o);
+    if (lane == 0) atomicAdd(p.out_scalar, fsum);
+  }
+}
+
+struct EvalK {
+  i64 nelems;
+  int nq;
+  GeomK geom;
+  BasisK trial;
+  int ncr;
+  const double *points;
+  const double *u;
+  double *x, *detj, *U;
+};
+
+template <int ND>
+__global__ void k_sample_eval(EvalK p) {
+  constexpr int S = 1 + ND;
+  const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.nelems * p.nq) return;
+  const i64 e = t / p.nq;
+  const int q = (int)(t % p.nq);
+  double Ji[ND][ND], det, x[ND];
+  geometry_at<ND>(p.geom, e, q, p.nq, p.points, Ji, det, x);
+  if (p.x)
+    for (int i = 0; i < ND; ++i) p.x[t * ND + i] = x[i];
+  if (p.detj) p.detj[t] = fabs(det);
+  if (p.U && p.u) {
+    const int nb = bnb(p.trial, e);
+    const i64 d0 = boff(p.trial, e), fn0 = bfn(p.trial, e);
+    for (int d = 0; d < p.ncr; ++d) {
+      double v = 0, g[ND];
+      for (int i = 0; i < ND; ++i) g[i] = 0;
+      for (int n = 0; n < nb; ++n) {
+        const double *T = p.trial.T + ((fn0 + n) * p.nq + q) * S;
+        const double un = p.u[(i64)p.trial.dofs[d0 + n] * p.ncr + d];
+        v += T[0] * un;
+        for (int j = 0; j < ND; ++j) g[j] += T[1 + j] * un;
+      }
+      double *o = p.U + (t * p.ncr + d) * S;
+      o[0] = v;
+      for (int i = 0; i < ND; ++i) {
+        double s = 0;
+        for (int j = 0; j < ND; ++j) s += g[j] * Ji[j][i];
+        o[1 + i] = s;
+      }
+    }
+  }
+}
+
+int make_form(int nd, int nct, int ncr, const double *C, const double *f, const unsigned char *mask, FormK *fk) {
+  const int S = 1 + nd;
+  NH_REQUIRE(nct >= 1 && nct <= MAXC && ncr >= 1 && ncr <= MAXC, "component counts must be 1..%d (got %d, %d)", MAXC, nct, ncr);
+  memset(fk, 0, sizeof *fk);
+  fk->nct = nct;
+  fk->ncr = ncr;
+  fk->hasC = C != nullptr;
+  fk->hasf = f != nullptr;
+  if (C) memcpy(fk->C, C, sizeof(double) * nct * S * ncr * S);
+  if (f) memcpy(fk->f, f, sizeof(double) * nct * S);
+  for (int c = 0; c < nct; ++c) {
+    fk->cum[c] = fk->tot;
+    for (int d = 0; d < ncr; ++d) {
+      fk->mask[c][d] = mask ? (mask[c * ncr + d] != 0) : 1;
+      fk->dpos[c][d] = (signed char)fk->cnt[c];
+      fk->cnt[c] += fk->mask[c][d];
+    }
+    fk->tot += fk->cnt[c];
+  }
+  return NH_OK;
+}
+
+int check_geom(const nh_geometry &g) {
+  if (g.kind == NH_GEOM_ISO) {
+    NH_REQUIRE(g.ngb > 0 && g.gT_dev && g.gdofs_dev && g.verts_dev, "isoparametric geometry needs ngb, gT, gdofs, verts");
+  } else if (g.kind == NH_GEOM_BOX) {
+    NH_REQUIRE(g.origin_dev && g.size_dev, "box geometry needs origin and size");
+  } else {
+    nh_set_error("unknown geometry kind %d", g.kind);
+    return NH_EINVAL;
+  }
+  return NH_OK;
+}
+
+int max_nb(const nh_basis &b, i64 nelems, int *out) {
+  if (b.nb > 0) {
+    *out = b.nb;
+    return NH_OK;
+  }
+  NH_REQUIRE(b.off_dev, "ragged basis needs off_dev");
+  // ragged: scan the offsets on the host (called once per bucket; small)
+  std::vector<i64> h(nelems + 1);
+  NH_CHECK_HIP(hipMemcpy(h.data(), b.off_dev, sizeof(i64) * (nelems + 1), hipMemcpyDeviceToHost));
+  i64 m = 0;
+  for (i64 e = 0; e < nelems; ++e) m = std::max(m, h[e + 1] - h[e]);
+  *out = (int)m;
+  return NH_OK;
+}
+
+}  // namespace
+
+static int grid_for(i64 nelems) { return (int)std::min<i64>(nelems, 256 * 32); }
+
+extern "C" {
+
+int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
+  NH_REQUIRE(a, "nh_assemble_matrix: NULL args");
+  NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
+  NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
+  NH_REQUIRE(a->C_host && a->srowptr_dev && a->emap_dev && a->values_dev, "nh_assemble_matrix: NULL coefficient / pattern / values");
+  NH_REQUIRE(a->test.T_dev && a->test.dofs_dev && a->trial.T_dev && a->trial.dofs_dev, "basis tables missing");
+  int rc = check_geom(a->geom);
+  if (rc) return rc;
+  if (a->nelems == 0) return NH_OK;
+  FormK form;
+  rc = make_form(a->ndims, a->nct, a->ncr, a->C_host, nullptr, a->mask_host, &form);
+  if (rc) return rc;
+  const int S = 1 + a->ndims, JW = a->ndims * a->ndims + 1;
+  MatK p;
+  p.nelems = a->nelems;
+  p.elist = a->elist_dev;
+  p.nq = a->nq;
+  p.weights = a->weights_dev;
+  p.geom = to_k(a->geom);
+  p.test = to_k(a->test);
+  p.trial = to_k(a->trial);
+  p.same = (a->test.T_dev == a->trial.T_dev && a->test.off_dev == a->trial.off_dev && a->test.tab_dev == a->trial.tab_dev &&
+            a->test.nb == a->trial.nb);
+  p.srowptr = (const i64 *)a->srowptr_dev;
+  p.emap = a->emap_dev;
+  p.eoff = (const i64 *)a->eoff_dev;
+  p.values = a->values_dev;
+  NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "nh_assemble_matrix: elist with ragged bases is not supported");
+  if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
+  if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
+  const int per_q = (p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S * (int)sizeof(double);
+  p.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / std::max(per_q, 1)));
+  const size_t lds = sizeof(double) * ((size_t)FORMD + (size_t)a->nq * JW) + (size_t)p.qchunk * per_q;
+  NH_REQUIRE(lds <= 160 * 1024, "element too large for LDS (%zu bytes)", lds);
+  hipStream_t s = nh_stream(stream);
+  dim3 grid(grid_for(a->nelems)), block(64);
+#define LAUNCH(ND)                                                                                                          \
+  do {                                                                                                                      \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_matrix_generic<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k_matrix_generic<ND>, grid, block, lds, s, p, form);                                                 \
+  } while (0)
+  if (a->ndims == 1) LAUNCH(1);
+  if (a->ndims == 2) LAUNCH(2);
+  if (a->ndims == 3) LAUNCH(3);
+#undef LAUNCH
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+int nh_assemble_vector(const nh_vector_args *a, void *stream) {
+  NH_REQUIRE(a, "nh_assemble_vector: NULL args");
+  NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
+  NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
+  NH_REQUIRE(a->out_dev || a->out_scalar_dev, "nh_assemble_vector: no output");
+  NH_REQUIRE(a->test.T_dev && a->test.dofs_dev && a->trial.T_dev && a->trial.dofs_dev, "basis tables missing");
+  NH_REQUIRE(!(a->C_host && !a->u_dev), "nh_assemble_vector: coefficient tensor given without field u");
+  NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "elist with ragged bases is not supported");
+  int rc = check_geom(a->geom);
+  if (rc) return rc;
+  if (a->nelems == 0) return NH_OK;
+  FormK form;
+  rc = make_form(a->ndims, a->nct, a->ncr, a->C_host, a->f_host, nullptr, &form);
+  if (rc) return rc;
+  const int S = 1 + a->ndims, JW = a->ndims * a->ndims + 1;
+  VecK p;
+  p.nelems = a->nelems;
+  p.elist = a->elist_dev;
+  p.nq = a->nq;
+  p.weights = a->weights_dev;
+  p.geom = to_k(a->geom);
+  p.test = to_k(a->test);
+  p.trial = to_k(a->trial);
+  p.same = (a->test.T_dev == a->trial.T_dev && a->test.off_dev == a->trial.off_dev && a->test.tab_dev == a->trial.tab_dev &&
+            a->test.nb == a->trial.nb);
+  p.u = a->u_dev;
+  p.out = a->out_dev;
+  p.f0 = a->f0;
+  p.out_scalar = a->out_scalar_dev;
+  if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
+  if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
+  const int per_q = ((p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S + 2 * MAXC * S) * (int)sizeof(double);
+  p.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / per_q));
+  const size_t lds = sizeof(double) * ((size_t)FORMD + (size_t)a->nq * JW) + (size_t)p.qchunk * per_q;
+  NH_REQUIRE(lds <= 160 * 1024, "element too large for LDS (%zu bytes)", lds);
+  hipStream_t s = nh_stream(stream);
+  dim3 grid(grid_for(a->nelems)), block(64);
+#define LAUNCH(ND)                                                                                                          \
+  do {                                                                                                                      \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_vector_generic<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k_vector_generic<ND>, grid, block, lds, s, p, form);                                                 \
+  } while (0)
+  if (a->ndims == 1) LAUNCH(1);
+  if (a->ndims == 2) LAUNCH(2);
+  if (a->ndims == 3) LAUNCH(3);
+#undef LAUNCH
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+int nh_sample_eval(const nh_eval_args *a, void *stream) {
+  NH_REQUIRE(a, "nh_sample_eval: NULL args");
+  NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
+  int rc = check_geom(a->geom);
+  if (rc) return rc;
+  NH_REQUIRE(a->geom.kind != NH_GEOM_BOX || !a->x_dev || a->points_dev, "box geometry coordinates need points_dev");
+  NH_REQUIRE(!a->U_dev || (a->u_dev && a->trial.T_dev && a->trial.dofs_dev && a->ncr >= 1), "field evaluation needs u, tables and dofs");
+  const i64 n = a->nelems * a->nq;
+  if (!n) return NH_OK;
+  EvalK p;
+  p.nelems = a->nelems;
+  p.nq = a->nq;
+  p.geom = to_k(a->geom);
+  p.trial = to_k(a->trial);
+  p.ncr = a->ncr;
+  p.points = a->points_dev;
+  p.u = a->u_dev;
+  p.x = a->x_dev;
+  p.detj = a->detj_dev;
+  p.U = a->U_dev;
+  dim3 grid((unsigned)((n + 127) / 128)), block(128);
+  hipStream_t s = nh_stream(stream);
+  if (a->ndims == 1) hipLaunchKernelGGL(k_sample_eval<1>, grid, block, 0, s, p);
+  if (a->ndims == 2) hipLaunchKernelGGL(k_sample_eval<2>, grid, block, 0, s, p);
+  if (a->ndims == 3) hipLaunchKernelGGL(k_sample_eval<3>, grid, block, 0, s, p);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// Shared helpers for libnutils_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/nutils_hip.h"
+
+typedef int64_t i64;
+
+void nh_set_error(const char *fmt, ...);
+
+#define NH_CHECK_HIP(expr)                                                                      \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      nh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+      return NH_EHIP;                                                                           \
+    }                                                                                           \
+  } while (0)
+
+#define NH_REQUIRE(cond, ...)   \
+  do {                          \
+    if (!(cond)) {              \
+      nh_set_error(__VA_ARGS__);\
+      return NH_EINVAL;         \
+    }                           \
+  } while (0)
+
+#define NH_LAUNCH_CHECK() NH_CHECK_HIP(hipGetLastError())
+
+static inline hipStream_t nh_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// exclusive scan of n int32 counts into int64 offsets (out has n+1 entries; out[n] = total)
+int nh_scan_exclusive(const int32_t *in_dev, i64 *out_dev, i64 n, hipStream_t stream);
+int nh_scan_exclusive64(const i64 *in_dev, i64 *out_dev, i64 n, hipStream_t stream);
+
+// geometry / basis structs are passed by value to kernels
+struct GeomK {
+  int kind, ngb;
+  const double *gT;
+  const int32_t *gdofs;
+  const double *verts;
+  const double *origin;
+  const double *size;
+};
+
+struct BasisK {
+  int nb;
+  const double *T;
+  const int32_t *dofs;
+  const i64 *off;
+  const int32_t *tab;
+};
+
+static inline GeomK to_k(const nh_geometry &g) { return GeomK{g.kind, g.ngb, g.gT_dev, g.gdofs_dev, g.verts_dev, g.origin_dev, g.size_dev}; }
+static inline BasisK to_k(const nh_basis &b) { return BasisK{b.nb, b.T_dev, b.dofs_dev, b.off_dev, b.tab_dev}; }

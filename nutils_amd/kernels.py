@@ -1,0 +1,112 @@
+'''Python faces of the C-ABI entry points (one function per kernel family).
+Arguments are device tensors (see device.py); nothing here computes.'''
+
+import ctypes
+import numpy
+
+from . import _lib, device
+
+
+def tabulate(coeffs_dev, nfn, ncoeffs, points_dev, nq, ndims):
+    '''K2 (nh_poly_tabulate): T[nfn][nq][1+ndims].'''
+    T = device.empty(nfn * nq * (1 + ndims), 'float64')
+    _lib.call('nh_poly_tabulate', device.ptr(coeffs_dev), nfn, ncoeffs, device.ptr(points_dev), nq, ndims, device.ptr(T), device.stream())
+    return T
+
+
+def structured_dofs(shape, nloc, ndofs_axis, start_concat_dev, elem_begin, nelems):
+    '''K1 (nh_structured_dofs).'''
+    nd = len(shape)
+    arr = ctypes.c_int * nd
+    nb = int(numpy.prod(nloc))
+    out = device.empty(nelems * nb, 'int32')
+    _lib.call('nh_structured_dofs', nd, arr(*shape), arr(*nloc), arr(*ndofs_axis), device.ptr(start_concat_dev), elem_begin, nelems,
+              device.ptr(out), device.stream())
+    return out
+
+
+class Pattern:
+    '''K6 (nh_pattern_*): scalar sparsity pattern + element map, device resident.'''
+
+    def __init__(self, nelems, nrows, ncols, tdofs, rdofs, nbt=0, nbr=0, toff=None, roff=None):
+        args = _lib.PatternArgs(nelems, nrows, ncols, nbt, nbr, device.ptr(tdofs), device.ptr(rdofs), device.ptr(toff), device.ptr(roff))
+        handle = ctypes.c_void_p()
+        _lib.call('nh_pattern_build', ctypes.byref(args), ctypes.byref(handle), device.stream())
+        self._handle = handle
+        self._keep = (tdofs, rdofs, toff, roff)
+        nnz = ctypes.c_int64()
+        emap_len = ctypes.c_int64()
+        srowptr, scol, emap, eoff = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.call('nh_pattern_info', handle, ctypes.byref(nnz), ctypes.byref(srowptr), ctypes.byref(scol), ctypes.byref(emap),
+                  ctypes.byref(emap_len), ctypes.byref(eoff))
+        self.nrows, self.ncols, self.nelems = nrows, ncols, nelems
+        self.nnz_scalar = nnz.value
+        self.srowptr_ptr, self.scol_ptr, self.emap_ptr, self.eoff_ptr = srowptr, scol, emap, eoff
+        self.emap_len = emap_len.value
+
+    def expanded_nnz(self, nct, ncr, mask=None):
+        nnz = ctypes.c_int64()
+        m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
+        _lib.call('nh_pattern_expanded_nnz', self._handle, nct, ncr, device.host_ptr(m), ctypes.byref(nnz))
+        return nnz.value
+
+    def expand(self, nct=1, ncr=1, mask=None):
+        '''(rowptr, colidx) int64 device tensors of the component-expanded CSR.'''
+        m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
+        nnz = self.expanded_nnz(nct, ncr, m)
+        rowptr = device.empty(self.nrows * nct + 1, 'int64')
+        colidx = device.empty(nnz, 'int64')
+        _lib.call('nh_pattern_expand', self._handle, nct, ncr, device.host_ptr(m), device.ptr(rowptr), device.ptr(colidx), device.stream())
+        return rowptr, colidx
+
+    def __del__(self):
+        h = getattr(self, '_handle', None)
+        if h:
+            try:
+                _lib.load().nh_pattern_free(h)
+            except Exception:
+                pass
+            self._handle = None
+
+
+def geometry_iso(ngb, gT, gdofs, verts):
+    g = _lib.Geometry(_lib.GEOM_ISO, ngb, device.ptr(gT), device.ptr(gdofs), device.ptr(verts), None, None)
+    g._keep = (gT, gdofs, verts)
+    return g
+
+
+def geometry_box(origin, size):
+    g = _lib.Geometry(_lib.GEOM_BOX, 0, None, None, None, device.ptr(origin), device.ptr(size))
+    g._keep = (origin, size)
+    return g
+
+
+def basis(T, dofs, nb=0, off=None, tab=None):
+    b = _lib.Basis(nb, device.ptr(T), device.ptr(dofs), device.ptr(off), device.ptr(tab))
+    b._keep = (T, dofs, off, tab)
+    return b
+
+
+def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None):
+    '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.'''
+    C = numpy.ascontiguousarray(C, dtype=float)
+    m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
+    args = _lib.MatrixArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
+                           device.host_ptr(m), pattern.srowptr_ptr, pattern.emap_ptr, pattern.eoff_ptr, device.ptr(values))
+    _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
+
+
+def assemble_vector(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C=None, f=None, u=None, out=None, f0=0., out_scalar=None,
+                    elist=None):
+    C = None if C is None else numpy.ascontiguousarray(C, dtype=float)
+    f = None if f is None else numpy.ascontiguousarray(f, dtype=float)
+    args = _lib.VectorArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
+                           device.host_ptr(f), device.ptr(u), device.ptr(out), float(f0), device.ptr(out_scalar))
+    _lib.call('nh_assemble_vector', ctypes.byref(args), device.stream())
+
+
+def sample_eval(*, nelems, ndims, nq, geom, trial=None, ncr=1, points=None, u=None, x=None, detj=None, U=None):
+    if trial is None:
+        trial = _lib.Basis(0, None, None, None, None)
+    args = _lib.EvalArgs(nelems, ndims, nq, geom, trial, ncr, device.ptr(points), device.ptr(u), device.ptr(x), device.ptr(detj), device.ptr(U))
+    _lib.call('nh_sample_eval', ctypes.byref(args), device.stream())

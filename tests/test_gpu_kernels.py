@@ -1,0 +1,189 @@
+'''GPU parity tests at the C-ABI level: the INPUT tables come straight from the
+golden files (real reference output), the result must match the reference's CSR:
+rowptr/colidx bit-exact (int64), values within 1e-13 relative (the device sums
+element contributions with atomics in a different order than the reference's
+stable-sort bincount).'''
+import os
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-13
+SCALAR = ['lap1d_p1_5', 'lap2d_p1_4x4', 'lap2d_p1_4x3_iso', 'lap2d_p2_3x4_iso', 'lap2d_spline2_4x4', 'lap2d_spline2_5x4_iso',
+          'lap3d_p1_2', 'lap3d_p1_3', 'lap3d_p1_4', 'lap3d_p1_234', 'lap3d_p1_3_iso', 'lap3d_p1_543_iso', 'lap3d_p2_2_iso',
+          'lap3d_spline2_3_iso', 'lap3d_spline3_3']
+ELAST = ['elast2d_p1_3x3', 'elast2d_p2_3x2_iso', 'elast3d_p1_2_iso', 'elast3d_p2_2', 'elast3d_p2_2_iso']
+
+
+def close(a, b, scale=None):
+    a = numpy.asarray(a)
+    b = numpy.asarray(b)
+    assert a.shape == b.shape
+    s = numpy.abs(b).max() if scale is None else scale
+    err = numpy.abs(a - b).max()
+    assert err <= RTOL * max(s, 1e-300), err / s
+
+
+class Case:
+    '''Device-side setup of one golden case through the raw kernel wrappers.'''
+
+    def __init__(self, g):
+        from nutils_amd import device, kernels
+        self.g = g
+        shape = tuple(g['shape'])
+        self.nd = nd = len(shape)
+        self.nelems = ne = int(numpy.prod(shape))
+        self.nb = nb = len(g['dofs']) // ne
+        self.ndofs = int(g['dofs'].max() + 1)
+        pts = g['gauss_coords']
+        self.nq = nq = len(pts)
+        self.points = device.to_dev(pts, 'float64')
+        self.weights = device.to_dev(g['gauss_weights'], 'float64')
+        coeffs = device.to_dev(g['coeffs'], 'float64')
+        T = kernels.tabulate(coeffs, ne * nb, g['coeffs'].shape[1], self.points, nq, nd)
+        self.T_host = device.to_host(T).reshape(ne, nb, nq, 1 + nd)
+        self.dofs = device.to_dev(g['dofs'], 'int32')
+        tab = device.to_dev(numpy.arange(ne), 'int32')
+        self.basis = kernels.basis(T, self.dofs, nb=nb, tab=tab)
+        if int(g['iso']):
+            ngb = 2 ** nd
+            gco = device.to_dev(g['gcoeffs'][:ngb], 'float64')
+            gT = kernels.tabulate(gco, ngb, g['gcoeffs'].shape[1], self.points, nq, nd)
+            self.geom = kernels.geometry_iso(ngb, gT, device.to_dev(g['gdofs'], 'int32'), device.to_dev(g['verts'], 'float64'))
+        else:
+            origin = numpy.array(list(numpy.ndindex(*shape)), dtype=float)
+            self.geom = kernels.geometry_box(device.to_dev(origin, 'float64'), device.to_dev(numpy.ones_like(origin), 'float64'))
+        self.pattern = kernels.Pattern(ne, self.ndofs, self.ndofs, self.dofs, self.dofs, nbt=nb, nbr=nb)
+
+    def matrix(self, C, nc=1, mask=None):
+        from nutils_amd import device, kernels
+        rowptr, colidx = self.pattern.expand(nc, nc, mask)
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=self.nelems, ndims=self.nd, nq=self.nq, weights=self.weights, geom=self.geom, test=self.basis,
+                                trial=self.basis, nct=nc, ncr=nc, C=C, mask=mask, pattern=self.pattern, values=values)
+        return device.to_host(values), device.to_host(rowptr), device.to_host(colidx)
+
+    def vector(self, nc=1, C=None, f=None, u=None, functional=False, f0=0.):
+        from nutils_amd import device, kernels
+        out = device.zeros(self.ndofs * nc, 'float64')
+        sc = device.zeros(1, 'float64') if functional else None
+        ud = None if u is None else device.to_dev(u, 'float64')
+        kernels.assemble_vector(nelems=self.nelems, ndims=self.nd, nq=self.nq, weights=self.weights, geom=self.geom, test=self.basis,
+                                trial=self.basis, nct=nc, ncr=nc, C=C, f=f, u=ud, out=out, f0=f0, out_scalar=sc)
+        return device.to_host(out).reshape(self.ndofs, nc), (float(device.to_host(sc)[0]) if functional else None)
+
+
+@pytest.mark.parametrize('name', SCALAR)
+def test_tabulate(golden, name):
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    N, dN = oa.tabulate(g['coeffs'].reshape(c.nelems, c.nb, -1), g['gauss_coords'])
+    close(c.T_host[..., 0], N.transpose(0, 2, 1), 1.)
+    close(c.T_host[..., 1:], dN.transpose(0, 2, 1, 3), numpy.abs(dN).max())
+
+
+@pytest.mark.parametrize('name', SCALAR)
+def test_scalar_forms(golden, name):
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    for key, C in (('K', oa.laplace_coefficient(c.nd)), ('M', oa.mass_coefficient(c.nd))):
+        v, rp, ci = c.matrix(C)
+        assert rp.dtype == ci.dtype == numpy.int64
+        assert numpy.array_equal(rp, g[key + '_rowptr']) and numpy.array_equal(ci, g[key + '_colidx'])
+        close(v, g[key + '_values'])
+    r, _ = c.vector(C=oa.laplace_coefficient(c.nd), u=g['u'])
+    close(r[:, 0], g['res_laplace'])
+    r, _ = c.vector(C=oa.mass_coefficient(c.nd), u=g['u'])
+    close(r[:, 0], g['res_mass'])
+    f = numpy.zeros((1, 1 + c.nd))
+    f[0, 0] = 1
+    r, _ = c.vector(f=f)
+    close(r[:, 0], g['load_one'])
+    _, vol = c.vector(functional=True, f0=1.)
+    close(vol, g['volume'])
+    _, en = c.vector(C=oa.laplace_coefficient(c.nd), u=g['u'], functional=True)
+    close(en, g['energy'])
+
+
+@pytest.mark.parametrize('name', SCALAR)
+def test_sample_eval(golden, name):
+    from nutils_amd import device, kernels
+    g = golden(name)
+    c = Case(g)
+    n = c.nelems * c.nq
+    x = device.empty(n * c.nd, 'float64')
+    dj = device.empty(n, 'float64')
+    U = device.empty(n * (1 + c.nd), 'float64')
+    kernels.sample_eval(nelems=c.nelems, ndims=c.nd, nq=c.nq, geom=c.geom, trial=c.basis, ncr=1, points=c.points,
+                        u=device.to_dev(g['u'], 'float64'), x=x, detj=dj, U=U)
+    U = device.to_host(U).reshape(n, 1 + c.nd)
+    close(device.to_host(x).reshape(n, c.nd), g['eval_x'])
+    close(device.to_host(dj), g['eval_detJ'])
+    close(U[:, 0], g['eval_u'])
+    close(U[:, 1:], g['eval_gradu'])
+
+
+@pytest.mark.parametrize('name', ELAST)
+def test_elasticity(golden, name):
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    C = oa.elasticity_coefficient(c.nd, float(g['lam']), float(g['mu']))
+    v, rp, ci = c.matrix(C, nc=c.nd, mask=oa.block_mask(C))
+    assert numpy.array_equal(rp, g['K_rowptr']) and numpy.array_equal(ci, g['K_colidx'])
+    close(v, g['K_values'])
+    r, en = c.vector(nc=c.nd, C=C, u=g['u'], functional=True)
+    close(r, g['res'])
+    close(en, g['energy'])
+
+
+def test_vector_laplace_block_pruning(golden):
+    '''Component-decoupled blocks are absent from the pattern (the simplifier prunes them symbolically).'''
+    from oracle import assemble as oa
+    g = golden('lap3d_p1_3_iso')
+    c = Case(g)
+    C = oa.laplace_coefficient(3, 3)
+    mask = oa.block_mask(C)
+    v, rp, ci = c.matrix(C, nc=3, mask=mask)
+    assert len(v) == 3 * len(g['K_values'])
+    pts, w = g['gauss_coords'], g['gauss_weights']
+    dofs = g['dofs'].reshape(c.nelems, c.nb)
+    N, dN = oa.tabulate(g['coeffs'].reshape(c.nelems, c.nb, -1), pts)
+    gN, gdN = oa.tabulate(g['gcoeffs'].reshape(c.nelems, 8, -1), pts)
+    x, J = oa.geometry_iso(g['verts'], g['gdofs'].reshape(c.nelems, 8), gN, gdN)
+    D, det = oa.physical_tables(N, dN, J)
+    vo, rpo, cio = oa.assemble_csr(oa.local_matrices(D, D, det * w, C), dofs, dofs, c.ndofs, c.ndofs, mask)
+    assert numpy.array_equal(rp, rpo) and numpy.array_equal(ci, cio)
+    close(v, vo)
+
+
+@pytest.mark.parametrize('ndim,nnz_t,nnz_h', [(1, 60, 70), (2, 3012, 3424)])
+def test_hierarchical_ragged(golden, ndim, nnz_t, nnz_h):
+    '''Ragged nbasis-per-element (th-/h-spline on a locally refined mesh); known nnz from
+    /root/reference/tests/test_basis.py:87-116.'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden(f'hier_spline2_{ndim}d')
+    pts = device.to_dev(g['gauss_coords'], 'float64')
+    w = device.to_dev(g['gauss_weights'], 'float64')
+    nq = len(g['gauss_weights'])
+    geom = kernels.geometry_box(device.to_dev(g['elem_origin'], 'float64'), device.to_dev(g['elem_size'], 'float64'))
+    for key, nnz in (('t', nnz_t), ('h', nnz_h)):
+        off_h = g[key + '_dof_offsets']
+        ne = len(off_h) - 1
+        ndofs = int(g[key + '_ndofs'])
+        off = device.to_dev(off_h, 'int64')
+        dofs = device.to_dev(g[key + '_dofs'], 'int32')
+        T = kernels.tabulate(device.to_dev(g[key + '_coeffs'], 'float64'), len(g[key + '_dofs']), g[key + '_coeffs'].shape[1], pts, nq, ndim)
+        b = kernels.basis(T, dofs, nb=0, off=off)
+        pat = kernels.Pattern(ne, ndofs, ndofs, dofs, dofs, toff=off, roff=off)
+        rowptr, colidx = pat.expand()
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=ne, ndims=ndim, nq=nq, weights=w, geom=geom, test=b, trial=b, nct=1, ncr=1,
+                                C=oa.laplace_coefficient(ndim), mask=None, pattern=pat, values=values)
+        assert colidx.numel() == nnz
+        assert numpy.array_equal(device.to_host(rowptr), g[key + 'K_rowptr']) and numpy.array_equal(device.to_host(colidx), g[key + 'K_colidx'])
+        close(device.to_host(values), g[key + 'K_values'])
