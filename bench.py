@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+'''bench.py -- elements assembled/sec for the global stiffness matrix K.
+
+Workload (BASELINE.json configs[1]): 3-D Poisson on a 128^3 structured hex mesh,
+p=1, 2x2x2 Gauss, stiffness-matrix assembly on one MI355X.  Geometry variant:
+isoparametric (vertices perturbed by default_rng(0).uniform(-.2,.2))
+so that Jacobians, inverses and the local contraction are really computed per
+element; `--variant uniform` times the exact-uniform mesh instead.
+
+A "step" is one full (re)assembly of the CSR values with all inputs resident in HBM
+(connectivity, vertex coordinates, tabulated bases, sparsity pattern): zero-fill (if
+the kernel accumulates) + element kernel.  The one-time pattern build is reported
+separately (`pattern_ms`).  With --gpus N every rank assembles its own 128^3-element
+slab of a (128 N) x 128 x 128 mesh (weak scaling) and the shared dof plane between
+neighbouring slabs is reduced over RCCL.
+
+Prints ONE JSON line on rank 0.
+'''
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--n', type=int, default=128, help='elements per axis per GPU')
+    ap.add_argument('--variant', choices=['iso', 'uniform'], default='iso')
+    ap.add_argument('--kernel', choices=['auto', 'generic', 'fast'], default='auto')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--check', action='store_true', help='verify the result against the oracle port on a small mesh first')
+    return ap.parse_args()
+
+
+def cpu_baseline(variant):
+    '''Oracle port (oracle/c, kind "port") on the host cores: bounded sample of the same workload.'''
+    import numpy
+    from oracle import assemble as oa, port
+    if not port.available():
+        return None
+    cores = len(os.sched_getaffinity(0))
+    pts, w = oa.gauss(2, 3)
+    _, coeffs, _ = oa.structured_basis((1, 1, 1), 'std', 1)
+    N, dN = oa.tabulate(coeffs[0], pts)
+    T = numpy.concatenate([N.T[:, :, None], dN.transpose(1, 0, 2)], axis=2)
+
+    def run(n):
+        verts = None
+        if variant == 'iso':
+            rng = numpy.random.default_rng(0)
+            verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.)] * 3, indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, ((n + 1) ** 3, 3))
+        t0 = time.perf_counter()
+        v, rp, ci, (tl, td) = port.laplace3d((n, n, n), 1, T, T, w, verts, threads=cores)
+        return time.perf_counter() - t0, tl, td
+
+    t32, _, _ = run(32)
+    n = 32
+    for cand in (64, 96, 128):
+        if t32 * (cand / 32) ** 3 <= 25.:
+            n = cand
+    t, tl, td = (t32, 0, 0) if n == 32 else run(n)
+    return {'value': n ** 3 / t, 'unit': 'elements/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n}^3-element {variant} P1 hex Laplace, full COO->sort->CSR assembly, {t:.2f} s '
+                      f'(element loop {tl:.2f} s on {cores} OpenMP threads, serial radix-sort dedup {td:.2f} s)'}
+
+
+def main():
+    a = parse()
+    import numpy
+    import torch
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    from nutils_amd import workloads
+    wl = workloads.PoissonSlab(n=a.n, rank=rank, world=world, variant=a.variant, kernel=a.kernel)
+    t0 = time.perf_counter()
+    wl.setup()
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    wl.build_pattern()
+    torch.cuda.synchronize()
+    pattern_ms = (time.perf_counter() - t0) * 1e3
+
+    if a.check and rank == 0:
+        wl.self_check()
+
+    for _ in range(a.warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        wl.step(kernel_events=kev[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(s.elapsed_time(e) for s, e in kev) / a.steps
+
+    if rank == 0:
+        nelems_total = wl.nelems * world
+        value = nelems_total * a.steps / elapsed
+        bytes_per_elem = wl.algorithmic_bytes_per_element()
+        achieved = bytes_per_elem * wl.nelems / (kernel_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'elements assembled/sec (global stiffness K)', 'value': value, 'unit': 'elements/s', 'n_gpus': world,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'3D Poisson stiffness, {a.n}^3 structured hex per GPU, p=1, 2x2x2 Gauss, {a.variant} geometry '
+                                   f'(BASELINE.json configs[1])', 'nelems_per_gpu': wl.nelems, 'nnz_per_gpu': wl.nnz, 'kernel': wl.kernel_name,
+                       'parallelism': f'element slabs x{world}, halo-plane reduce' if world > 1 else 'single GPU'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bytes_per_elem},
+            'pattern_ms': pattern_ms, 'setup_s': setup_s,
+        }
+        if not a.no_cpu and world == 1:
+            cb = cpu_baseline(a.variant)
+            if cb:
+                out['cpu_baseline'] = cb
+                out['speedup_vs_cpu_port'] = value / cb['value']
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

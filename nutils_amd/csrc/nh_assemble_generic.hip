@@ -392,11 +392,10 @@ int check_geom(const nh_geometry &g) {
 }
 
 int max_nb(const nh_basis &b, i64 nelems, int *out) {
-  if (b.nb > 0) {
+  if (b.nb > 0 || !b.off_dev) {
     *out = b.nb;
     return NH_OK;
   }
-  NH_REQUIRE(b.off_dev, "ragged basis needs off_dev");
   // ragged: scan the offsets on the host (called once per bucket; small)
   std::vector<i64> h(nelems + 1);
   NH_CHECK_HIP(hipMemcpy(h.data(), b.off_dev, sizeof(i64) * (nelems + 1), hipMemcpyDeviceToHost));
@@ -466,7 +465,8 @@ int nh_assemble_vector(const nh_vector_args *a, void *stream) {
   NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
   NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
   NH_REQUIRE(a->out_dev || a->out_scalar_dev, "nh_assemble_vector: no output");
-  NH_REQUIRE(a->test.T_dev && a->test.dofs_dev && a->trial.T_dev && a->trial.dofs_dev, "basis tables missing");
+  NH_REQUIRE((a->test.nb == 0 && !a->test.off_dev) || (a->test.T_dev && a->test.dofs_dev), "test basis tables missing");
+  NH_REQUIRE((a->trial.nb == 0 && !a->trial.off_dev) || (a->trial.T_dev && a->trial.dofs_dev), "trial basis tables missing");
   NH_REQUIRE(!(a->C_host && !a->u_dev), "nh_assemble_vector: coefficient tensor given without field u");
   NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "elist with ragged bases is not supported");
   int rc = check_geom(a->geom);

@@ -1,0 +1,492 @@
+'''Symbolic side of the hot path, reduced to what the assembly kernels consume.
+
+The reference lowers arbitrary ``function.Array`` expressions to an evaluable
+graph and generates a Python loop (function.py:356-361, evaluable.py:6532-6838).
+This backend accelerates the loop shapes named in SURVEY 8a -- integrals of
+products of (derivatives of) basis functions / fields with constant coefficients
+-- and represents exactly those: every operand is LINEAR in one argument (a basis
+used as an array, or a named field, cf. ``function.field`` function.py:2598-2627)
+and is stored as the constant tensor ``P[free..., comp, slot]`` that maps the
+argument's value (slot 0) and physical gradient (slots 1..ndims) to the operand's
+free axes.  Products of two operands give the coefficient tensor
+``C[c, a, d, b]`` of nh_assemble_matrix.  Expressions outside this class raise
+NotImplementedError (the reference path is the fallback for those, see
+INTEGRATION.md) -- nothing is ever evaluated on the CPU here.
+'''
+
+import numpy
+
+
+# ---- geometry ---------------------------------------------------------------------
+
+class Geometry:
+    '''A coordinate map usable as integration geometry / gradient reference.'''
+    ndims: int
+
+
+class RectilinearGeometry(Geometry):
+    '''x = offset + scale * (element multi-index + xi): the geometry returned by
+    mesh.rectilinear (mesh.py:45-52).'''
+
+    def __init__(self, topo, offset, scale):
+        self.topo = topo
+        self.ndims = topo.ndims
+        self.offset = numpy.asarray(offset, dtype=float)
+        self.scale = numpy.asarray(scale, dtype=float)
+
+    def element_boxes(self):
+        idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n, dtype=float) for n in self.topo.shape], indexing='ij'), -1).reshape(-1, self.ndims)
+        origin = self.offset + self.scale * idx
+        size = numpy.broadcast_to(self.scale, origin.shape)
+        return origin, size
+
+
+class BoxGeometry(Geometry):
+    '''Axis-aligned box per element (hierarchically refined rectilinear meshes).'''
+
+    def __init__(self, origin, size):
+        self.origin = numpy.ascontiguousarray(origin, dtype=float)
+        self.size = numpy.ascontiguousarray(size, dtype=float)
+        self.ndims = self.origin.shape[1]
+
+    def element_boxes(self):
+        return self.origin, self.size
+
+
+class IsoGeometry(Geometry):
+    '''x = sum_a N_a(xi) X_a  (``geom = gbasis @ verts`` in a Nutils script).'''
+
+    def __init__(self, basis, verts):
+        verts = numpy.asarray(verts, dtype=float)
+        if verts.ndim != 2 or verts.shape[0] != basis.ndofs or verts.shape[1] != basis.ndims:
+            raise ValueError(f'vertex array of shape {verts.shape} does not match basis ({basis.ndofs} dofs, {basis.ndims} dims)')
+        if getattr(basis, 'nclasses', 1) != 1:
+            raise NotImplementedError('isoparametric geometry needs a basis with one coefficient table for all elements (btype std)')
+        self.basis = basis
+        self.verts = numpy.ascontiguousarray(verts)
+        self.ndims = basis.ndims
+
+
+def dot_basis(basis, values):
+    '''``basis @ values``: geometry if values is (ndofs, ndims), else a scalar/vector field value.'''
+    values = numpy.asarray(values, dtype=float)
+    if values.ndim == 2 and values.shape == (basis.ndofs, basis.ndims):
+        return IsoGeometry(basis, values)
+    raise NotImplementedError('basis @ array is supported for geometry construction only; use fields with arguments otherwise')
+
+
+class Measure:
+    '''J(geom): the volume measure |det dx/dxi| (function.py:1266-1295).'''
+
+    __array_ufunc__ = None
+
+    def __init__(self, geom):
+        if not isinstance(geom, Geometry):
+            raise TypeError('J expects a geometry')
+        self.geom = geom
+
+    def __mul__(self, other):
+        return _as_integrand(other).with_measure(self.geom)
+
+    __rmul__ = __mul__
+
+
+def J(geom):
+    return Measure(geom)
+
+
+# ---- arguments and operands ----------------------------------------------------------
+
+class Arg:
+    '''The thing an operand is linear in: a basis with `ncomp` components.  `name` is
+    None for a basis used directly as an array (its dof axis is an array axis).'''
+
+    def __init__(self, basis, ncomp, name):
+        self.basis, self.ncomp, self.name = basis, int(ncomp), name
+
+    def same(self, other):
+        return self is other or (self.name is not None and self.name == other.name and self.basis is other.basis and self.ncomp == other.ncomp)
+
+
+def _bcast(a, b, keep):
+    '''Broadcast the leading (free) axes of a and b numpy-style, keeping `keep` trailing axes of each aside.'''
+    fa, fb = a.shape[:a.ndim - keep[0]], b.shape[:b.ndim - keep[1]]
+    free = numpy.broadcast_shapes(fa, fb)
+    a = numpy.broadcast_to(a.reshape((1,) * (len(free) - len(fa)) + a.shape), free + a.shape[len(fa):])
+    b = numpy.broadcast_to(b.reshape((1,) * (len(free) - len(fb)) + b.shape), free + b.shape[len(fb):])
+    return a, b, free
+
+
+class Operand:
+    '''Tensor-valued expression, linear in one argument: value[free...] =
+    sum_{c,s} P[free..., c, s] D[c, s],  D[c,0] = arg_c, D[c,1+i] = d arg_c / d x_i.'''
+
+    __array_ufunc__ = None
+
+    def __init__(self, arg, P, geom=None):
+        self.arg, self.P, self.geom = arg, numpy.asarray(P, dtype=float), geom
+
+    @property
+    def shape(self):
+        free = self.P.shape[:-2]
+        return ((self.arg.basis.ndofs,) if self.arg.name is None else ()) + free
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def _free_axis(self, axis):
+        nfree = self.P.ndim - 2
+        lead = 1 if self.arg.name is None else 0
+        if axis < 0:
+            axis += nfree + lead
+        axis -= lead
+        if not 0 <= axis < nfree:
+            raise ValueError('axis out of range (the dof axis of a basis cannot be reduced)')
+        return axis
+
+    def grad(self, geom):
+        if not isinstance(geom, Geometry):
+            raise TypeError('grad expects a geometry')
+        if numpy.abs(self.P[..., 1:]).sum() != 0:
+            raise NotImplementedError('second derivatives are outside the accelerated path')
+        nd = geom.ndims
+        P = numpy.zeros(self.P.shape[:-2] + (nd,) + self.P.shape[-2:-1] + (1 + nd,))
+        for j in range(nd):
+            P[..., j, :, 1 + j] = self.P[..., :, 0]
+        return Operand(self.arg, P, geom)
+
+    def _const(self, other):
+        other = numpy.asarray(other, dtype=float)
+        a, b, free = _bcast(self.P, other, (2, 0))
+        return Operand(self.arg, a * b[..., None, None], self.geom)
+
+    def __mul__(self, other):
+        if isinstance(other, Measure):
+            return other.__mul__(self)
+        from .basis import Basis
+        if isinstance(other, Basis):
+            other = _as_operand(other)
+        if isinstance(other, Operand):
+            return _product(self, other)
+        if isinstance(other, Integrand):
+            return NotImplemented
+        return self._const(other)
+
+    def __rmul__(self, other):
+        return self._const(other)
+
+    def __truediv__(self, other):
+        return self._const(1. / numpy.asarray(other, dtype=float))
+
+    def __neg__(self):
+        return Operand(self.arg, -self.P, self.geom)
+
+    def __add__(self, other):
+        if not isinstance(other, Operand) or not other.arg.same(self.arg):
+            raise NotImplementedError('operands can only be added to operands of the same argument')
+        a, b, _ = _bcast(self.P, other.P, (2, 2))
+        return Operand(self.arg, a + b, self.geom or other.geom)
+
+    def __sub__(self, other):
+        return self + (-other)
+
+    def sum(self, axis=-1):
+        return Operand(self.arg, self.P.sum(self._free_axis(axis)), self.geom)
+
+    def transpose(self, a=-2, b=-1):
+        return Operand(self.arg, numpy.swapaxes(self.P, self._free_axis(a), self._free_axis(b)), self.geom)
+
+    @property
+    def T(self):
+        return self.transpose()
+
+    def trace(self, a=-2, b=-1):
+        return Operand(self.arg, numpy.trace(self.P, axis1=self._free_axis(a), axis2=self._free_axis(b)), self.geom)
+
+    def __getitem__(self, item):
+        if not isinstance(item, tuple):
+            item = item,
+        if self.arg.name is None:
+            if item[0] != slice(None):
+                raise NotImplementedError('the dof axis of a basis array cannot be indexed')
+            item = item[1:]
+        return Operand(self.arg, self.P[tuple(item) + (Ellipsis, slice(None), slice(None))], self.geom)
+
+
+def trace(op, a=-2, b=-1):
+    return op.trace(a, b)
+
+
+def grad(op, geom):
+    return _as_operand(op).grad(geom)
+
+
+def symgrad(op, geom):
+    g = _as_operand(op).grad(geom)
+    return (g + g.T) * .5
+
+
+def div(op, geom):
+    return _as_operand(op).grad(geom).trace()
+
+
+def eye(n):
+    return numpy.eye(n)
+
+
+def field(name, basis, shape=()):
+    '''Named argument field (function.field, function.py:2598-2627): argument array of
+    shape (ndofs, *shape); flat dof = scalar dof * ncomp + comp.'''
+    shape = tuple(shape)
+    if len(shape) > 1:
+        raise NotImplementedError('fields of rank > 1')
+    ncomp = shape[0] if shape else 1
+    arg = Arg(basis, ncomp, name)
+    if shape:
+        P = numpy.zeros((ncomp, ncomp, 1))
+        P[numpy.arange(ncomp), numpy.arange(ncomp), 0] = 1
+    else:
+        P = numpy.ones((1, 1))
+    return Operand(arg, P)
+
+
+def dotarg(name, basis, shape=()):
+    return field(name, basis, shape)
+
+
+def _as_operand(obj):
+    from .basis import Basis
+    if isinstance(obj, Operand):
+        return obj
+    if isinstance(obj, Basis):
+        if not hasattr(obj, '_as_operand'):
+            obj._as_operand = Operand(Arg(obj, 1, None), numpy.ones((1, 1)))
+        return obj._as_operand
+    raise TypeError(f'cannot interpret {type(obj).__name__} as an operand')
+
+
+# ---- integrands ------------------------------------------------------------------------
+
+class Integrand:
+    '''sum of: bilinear  B[c,a,d,b] Dtest[c,a] Dtrial[d,b]  (+ free axes until summed),
+    linear  L[c,a] Dtest[c,a],  constant f0;  times the measure of `geom`.'''
+
+    __array_ufunc__ = None
+
+    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False):
+        self.test, self.trial, self.B, self.L, self.f0 = test, trial, B, L, f0
+        self.geom = geom        # geometry the gradients refer to
+        self.measure = measure  # geometry of the measure
+        self.rows, self.cols = rows, cols  # dof axis of test / trial is an array axis (else: bound to an argument value)
+
+    def _copy(self, **kw):
+        d = dict(test=self.test, trial=self.trial, B=self.B, L=self.L, f0=self.f0, geom=self.geom, measure=self.measure, rows=self.rows, cols=self.cols)
+        d.update(kw)
+        return Integrand(**d)
+
+    @property
+    def _tensor(self):
+        return self.B if self.B is not None else self.L if self.L is not None else numpy.asarray(self.f0)
+
+    @property
+    def _keep(self):
+        return 4 if self.B is not None else 2 if self.L is not None else 0
+
+    @property
+    def shape(self):
+        t = self._tensor
+        free = t.shape[:t.ndim - self._keep]
+        lead = ((self.test.basis.ndofs,) if self.rows and self.test.name is None else ()) + ((self.trial.basis.ndofs,) if self.cols and self.trial.name is None else ())
+        return lead + free
+
+    def _set(self, t):
+        return self._copy(**{'B' if self.B is not None else 'L' if self.L is not None else 'f0': t})
+
+    def with_measure(self, geom):
+        if self.measure is not None:
+            raise NotImplementedError('integrand already carries a measure')
+        if self.geom is not None and self.geom is not geom:
+            raise NotImplementedError('gradient geometry and measure geometry differ')
+        return self._copy(measure=geom)
+
+    def __mul__(self, other):
+        if isinstance(other, Measure):
+            return self.with_measure(other.geom)
+        if isinstance(other, (Operand, Integrand)):
+            raise NotImplementedError('products of more than two argument-dependent factors are outside the accelerated path')
+        other = numpy.asarray(other, dtype=float)
+        t = self._tensor
+        a, b, _ = _bcast(t, other, (self._keep, 0))
+        return self._set(a * b.reshape(b.shape + (1,) * self._keep))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self._set(-self._tensor)
+
+    def sum(self, axis=-1):
+        t = self._tensor
+        nfree = t.ndim - self._keep
+        lead = len(self.shape) - nfree
+        if axis < 0:
+            axis += nfree + lead
+        axis -= lead
+        if not 0 <= axis < nfree:
+            raise ValueError('axis out of range')
+        return self._set(t.sum(axis))
+
+    def _compatible(self, other):
+        def same(a, b):
+            return (a is None and b is None) or (a is not None and b is not None and a.same(b))
+        return same(self.test, other.test) and same(self.trial, other.trial) and self.rows == other.rows and self.cols == other.cols \
+            and self.measure is other.measure and (self.B is None) == (other.B is None) and (self.L is None) == (other.L is None)
+
+    def __add__(self, other):
+        other = _as_integrand(other)
+        if not self._compatible(other):
+            raise NotImplementedError('only integrands of the same kind can be added before integration; add the integrals instead')
+        a, b, _ = _bcast(self._tensor, other._tensor, (self._keep, other._keep))
+        return self._set(a + b)._copy(geom=self.geom or other.geom)
+
+    def __sub__(self, other):
+        return self + (-_as_integrand(other))
+
+
+def _as_integrand(obj):
+    if isinstance(obj, Integrand):
+        return obj
+    if isinstance(obj, Measure):
+        return Integrand(f0=numpy.ones(()), measure=obj.geom)
+    if isinstance(obj, (int, float, numpy.ndarray)):
+        return Integrand(f0=numpy.asarray(obj, dtype=float))
+    op = _as_operand(obj)
+    return Integrand(test=op.arg, L=op.P, geom=op.geom, rows=op.arg.name is None)
+
+
+def _product(a, b, outer=False):
+    '''a * b for two operands: test side = a, trial side = b.'''
+    if a.geom is not None and b.geom is not None and a.geom is not b.geom:
+        raise NotImplementedError('factors differentiate with respect to different geometries')
+    Pa, Pb, free = _bcast(a.P, b.P, (2, 2))
+    B = Pa[..., :, :, None, None] * Pb[..., None, None, :, :]
+    return Integrand(test=a.arg, trial=b.arg, B=B, geom=a.geom or b.geom, rows=a.arg.name is None, cols=b.arg.name is None)
+
+
+def outer(a, b=None):
+    '''Outer product over the dof axes of two basis arrays, elementwise over the
+    remaining axes (function.outer in the reference): shape (ndofs_a, ndofs_b, ...).'''
+    a = _as_operand(a)
+    b = a if b is None else _as_operand(b)
+    if a.arg.name is not None or b.arg.name is not None:
+        raise TypeError('outer expects basis arrays; multiply fields directly')
+    return _product(a, b)
+
+
+def inner(a, b):
+    '''Full contraction over all free axes of two operands.'''
+    p = _product(_as_operand(a), _as_operand(b))
+    while p.B.ndim > 4:
+        p = p._set(p.B.sum(0))
+    return p
+
+
+# ---- integrals --------------------------------------------------------------------------
+
+class Integral:
+    '''Postponed integral: sum of (sample, integrand, factor) terms
+    (sample.py:944-956 ``_Integral``); evaluated on the GPU by function.eval.'''
+
+    def __init__(self, terms):
+        self.terms = tuple(terms)
+
+    def __add__(self, other):
+        if not isinstance(other, Integral):
+            return NotImplemented
+        return Integral(self.terms + other.terms)
+
+    def __neg__(self):
+        return Integral((s, i, -f) for s, i, f in self.terms)
+
+    def __sub__(self, other):
+        return self + (-other)
+
+    def __mul__(self, scalar):
+        return Integral((s, i, f * float(scalar)) for s, i, f in self.terms)
+
+    __rmul__ = __mul__
+
+    @property
+    def shape(self):
+        return self.terms[0][1].shape
+
+    def derivative(self, name):
+        return derivative(self, name)
+
+    def eval(self, **arguments):
+        return eval(self, **arguments)
+
+
+def derivative(integral, name):
+    '''Derivative with respect to the named field argument (function.derivative):
+    exposes that argument's dof axis.  Terms that do not depend on it vanish.'''
+    out = []
+    for smp, itg, fac in integral.terms:
+        t_hit = itg.test is not None and itg.test.name == name and not itg.rows
+        r_hit = itg.trial is not None and itg.trial.name == name and not itg.cols
+        if itg.B is not None and t_hit and r_hit:
+            if itg.cols or itg.rows:
+                raise NotImplementedError
+            # quadratic in the field: d/du B(u,u) = B(du,u) + B(u,du)
+            Bt = numpy.moveaxis(itg.B, (-4, -3, -2, -1), (-2, -1, -4, -3))
+            out.append((smp, itg._copy(B=itg.B + Bt, rows=True), fac))
+        elif t_hit:
+            if itg.rows or (itg.cols and itg.B is None):
+                raise NotImplementedError
+            if itg.cols:  # keep the convention rows = first differentiated axis: transpose
+                out.append((smp, itg._copy(B=numpy.moveaxis(itg.B, (-4, -3, -2, -1), (-2, -1, -4, -3)), test=itg.trial, trial=itg.test, rows=True, cols=True), fac))
+            else:
+                out.append((smp, itg._copy(rows=True), fac))
+        elif r_hit:
+            if itg.rows:
+                out.append((smp, itg._copy(cols=True), fac))
+            else:  # derivative w.r.t. the trial-side field first: swap roles
+                out.append((smp, itg._copy(B=numpy.moveaxis(itg.B, (-4, -3, -2, -1), (-2, -1, -4, -3)), test=itg.trial, trial=itg.test, rows=True, cols=False), fac))
+    return Integral(out)
+
+
+class _AsCSR:
+    def __init__(self, integral):
+        self.integral = integral
+
+
+def as_csr(integral):
+    '''function.as_csr (function.py:2432-2437): evaluates to (values, rowptr, colidx);
+    index arrays int64, rows/cols sorted, structural zeros retained.'''
+    if not isinstance(integral, Integral):
+        raise TypeError('as_csr expects an Integral')
+    return _AsCSR(integral)
+
+
+class _AsCOO:
+    def __init__(self, integral):
+        self.integral = integral
+
+
+def as_coo(integral):
+    '''function.as_coo (function.py:2440-2452): (values, rowidx, colidx).'''
+    return _AsCOO(integral)
+
+
+def eval(funcs, /, arguments=None, **kwargs):
+    '''function.eval (function.py:2408-2429): evaluate one or several integrals
+    (optionally wrapped in as_csr / as_coo) with the given arguments.'''
+    from . import sample as _sample
+    arguments = dict(arguments or {}, **kwargs)
+    single = not isinstance(funcs, (tuple, list))
+    items = (funcs,) if single else tuple(funcs)
+    results = tuple(_sample.evaluate(f, arguments) for f in items)
+    return results[0] if single else results
+
+
+evaluate = eval

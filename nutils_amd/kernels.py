@@ -87,12 +87,13 @@ def basis(T, dofs, nb=0, off=None, tab=None):
     return b
 
 
-def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None):
+def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0):
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.'''
     C = numpy.ascontiguousarray(C, dtype=float)
     m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
     args = _lib.MatrixArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
-                           device.host_ptr(m), pattern.srowptr_ptr, pattern.emap_ptr, pattern.eoff_ptr, device.ptr(values))
+                           device.host_ptr(m), pattern.srowptr_ptr, ctypes.c_void_p(pattern.emap_ptr.value + 4 * emap_offset), pattern.eoff_ptr,
+                           device.ptr(values))
     _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
 
 

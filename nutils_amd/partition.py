@@ -1,0 +1,102 @@
+'''Multi-GPU element partition for structured slabs.
+
+The reference's only parallelism is fork + shared mmap arrays over the element
+loop (/root/reference/src/nutils/parallel.py:27-154; locks around in-place adds,
+evaluable.py:7116-7133).  Here: one process per GPU; the global mesh is cut into
+contiguous slabs of element layers along the slowest axis, so that -- with the
+reference's element order (last axis fastest) and dof order (first axis slowest)
+-- the rows a rank owns are one contiguous block of the global CSR and the global
+matrix is the concatenation of the per-rank blocks in rank order.
+
+rank r assembles its own element layers only.  Its local mesh additionally holds
+ONE ghost element layer below (r > 0) that contributes to the local sparsity
+PATTERN but not to the values: this makes the pattern of the interface dof plane
+complete on its owner (rank r owns the plane it shares with rank r-1) without any
+communication.  The only exchange is the reduce of the partial VALUES of the
+interface plane: rank r sends the rows of its top plane (a contiguous tail of its
+values array: cols in planes I-1 and I) to rank r+1, where they are the leading 2/3
+of each owned interface row (cols sorted plane-first).  Point-to-point over
+RCCL/xGMI (torch.distributed backend nccl; gloo on CPU tensors in the tests).
+'''
+
+import numpy
+
+
+class Slab:
+    '''Index bookkeeping of one rank's slab (P1 dofs: one dof plane per element-layer boundary).'''
+
+    def __init__(self, n, rank, world, shape_jk):
+        self.n, self.rank, self.world = int(n), int(rank), int(world)
+        self.nj, self.nk = (int(x) for x in shape_jk)
+        if not 0 <= rank < world:
+            raise ValueError('rank out of range')
+        self.ghost_layers = 1 if rank > 0 else 0
+        self.own_layers = self.n
+        self.local_layers = self.n + self.ghost_layers
+        self.first_global_plane = rank * self.n - self.ghost_layers  # global index of local dof plane 0 (= element layer 0)
+        self.plane = (self.nj + 1) * (self.nk + 1)                   # dofs per plane
+        self.own_plane_begin = self.ghost_layers
+        self.own_plane_end = self.ghost_layers + self.n + (1 if rank == world - 1 else 0)
+        self.sends = rank < world - 1   # top plane (local index ghost+n) -> rank+1
+        self.recvs = rank > 0           # into local plane `ghost_layers` (= 1) <- rank-1
+        self.send_plane = self.ghost_layers + self.n
+        self.recv_plane = self.ghost_layers
+
+
+class HaloPlan:
+    '''Pre-computed send range and receive scatter indices for the interface-plane reduce.
+    Works on CUDA tensors (RCCL) and CPU tensors (gloo).'''
+
+    def __init__(self, slab, rowptr):
+        import torch
+        self.slab = slab
+        p = slab.plane
+        if slab.sends:
+            r0 = slab.send_plane * p
+            self.send_a, self.send_b = int(rowptr[r0]), int(rowptr[r0 + p])
+        if slab.recvs:
+            r0 = slab.recv_plane * p
+            rp = rowptr[r0:r0 + p + 1]
+            lens = rp[1:] - rp[:-1]
+            if int((lens % 3).abs().sum()) != 0:
+                raise ValueError('interface rows are expected to couple three dof planes')
+            slen = lens * 2 // 3
+            starts = torch.cumsum(slen, 0) - slen
+            total = int(slen.sum())
+            within = torch.arange(total, device=rowptr.device, dtype=rowptr.dtype) - torch.repeat_interleave(starts, slen)
+            self.recv_idx = torch.repeat_interleave(rp[:-1], slen) + within
+            self.recv_buf = torch.empty(total, dtype=torch.float64, device=rowptr.device)
+
+    def exchange(self, values):
+        import torch.distributed as dist
+        s = self.slab
+        ops = []
+        if s.sends:
+            ops.append(dist.P2POp(dist.isend, values[self.send_a:self.send_b], s.rank + 1))
+        if s.recvs:
+            ops.append(dist.P2POp(dist.irecv, self.recv_buf, s.rank - 1))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if s.recvs:
+            values.index_add_(0, self.recv_idx, self.recv_buf)
+
+
+def owned_rows(slab, values, rowptr, colidx):
+    '''Host arrays of the CSR rows owned by this rank in GLOBAL numbering
+    (rows re-based to the first owned row; cols shifted by the slab's first plane).'''
+    a, b = slab.own_plane_begin * slab.plane, slab.own_plane_end * slab.plane
+    lo, hi = rowptr[a], rowptr[b]
+    return values[lo:hi], rowptr[a:b + 1] - lo, colidx[lo:hi] + slab.first_global_plane * slab.plane
+
+
+def concatenate(blocks):
+    '''Global CSR from the per-rank owned blocks in rank order.'''
+    values = numpy.concatenate([b[0] for b in blocks])
+    colidx = numpy.concatenate([b[2] for b in blocks])
+    rowptr = [numpy.zeros(1, dtype=numpy.int64)]
+    off = 0
+    for b in blocks:
+        rowptr.append(b[1][1:] + off)
+        off += b[1][-1]
+    return values, numpy.concatenate(rowptr), colidx

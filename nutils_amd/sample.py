@@ -1,0 +1,287 @@
+'''Sample: quadrature points on a topology, and the evaluator that turns
+integrals into kernel launches.
+
+Mirrors the reference's ``Sample.integrate / integral / eval / bind``
+(/root/reference/src/nutils/sample.py:160-232).  Where the reference lowers
+``_Integral`` to ``loop_sum(einsum(weights, integrand))`` (sample.py:951-956) and
+runs a generated Python loop, this class keeps the per-sample device tables
+(quadrature, tabulated bases, geometry, sparsity patterns) in HBM and calls
+libnutils_hip.so.  No CPU fallback.
+'''
+
+import numpy
+
+from . import device, function, kernels, matrix as _matrix
+from .basis import StructuredBasis, PlainBasis
+
+
+class _BasisTables:
+    '''Device tables of one basis at the sample's points.'''
+
+    def __init__(self, smp, basis):
+        pts = smp._points_dev
+        nq, nd = smp.points.npoints, smp.ndims
+        self.basis = basis
+        if isinstance(basis, StructuredBasis):
+            coeffs = basis.all_class_coefficients()
+            self.T = kernels.tabulate(device.to_dev(coeffs, 'float64'), len(coeffs), coeffs.shape[1], pts, nq, nd)
+            start = device.to_dev(numpy.concatenate(basis.start_dofs), 'int32')
+            self.dofs = kernels.structured_dofs(basis.shape, basis.nloc, basis.dofs_shape, start, 0, basis.nelems)
+            self.tab = device.to_dev(basis.element_classes(), 'int32') if basis.nclasses > 1 else None
+            self.off = None
+            self.nb = basis.nb
+        elif isinstance(basis, PlainBasis):
+            dofs, coeffs = basis.concatenated()
+            self.T = kernels.tabulate(device.to_dev(coeffs, 'float64'), len(coeffs), coeffs.shape[1], pts, nq, nd)
+            self.dofs = device.to_dev(dofs, 'int32')
+            self.off = device.to_dev(basis.offsets, 'int64')
+            self.tab = None
+            self.nb = 0
+        else:
+            raise TypeError(f'unsupported basis type {type(basis).__name__}')
+        self.struct = kernels.basis(self.T, self.dofs, nb=self.nb, off=self.off, tab=self.tab)
+
+
+class Sample:
+
+    def __init__(self, topo, points):
+        self.topo = topo
+        self.points = points
+        self.ndims = topo.ndims
+        self.nelems = topo.nelems
+        self.npoints = self.nelems * points.npoints
+        self._tables = {}
+        self._geoms = {}
+        self._patterns = {}
+        self.__dev = None
+
+    # -- device caches --
+
+    @property
+    def _points_dev(self):
+        if self.__dev is None:
+            self.__dev = device.to_dev(self.points.coords, 'float64'), device.to_dev(self.points.weights, 'float64')
+        return self.__dev[0]
+
+    @property
+    def _weights_dev(self):
+        self._points_dev
+        return self.__dev[1]
+
+    def tables(self, basis):
+        if basis.nelems != self.nelems or basis.ndims != self.ndims:
+            raise ValueError('basis does not live on the topology of this sample')
+        t = self._tables.get(id(basis))
+        if t is None:
+            t = self._tables[id(basis)] = _BasisTables(self, basis)
+        return t
+
+    def geometry(self, geom):
+        g = self._geoms.get(id(geom))
+        if g is None:
+            if isinstance(geom, function.IsoGeometry):
+                t = self.tables(geom.basis)
+                g = kernels.geometry_iso(geom.basis.nb, t.T, t.dofs, device.to_dev(geom.verts, 'float64'))
+            elif isinstance(geom, (function.RectilinearGeometry, function.BoxGeometry)):
+                origin, size = geom.element_boxes()
+                if len(origin) != self.nelems:
+                    raise ValueError('geometry does not match the sample')
+                g = kernels.geometry_box(device.to_dev(origin, 'float64'), device.to_dev(size, 'float64'))
+            else:
+                raise TypeError(f'unsupported geometry {type(geom).__name__}')
+            self._geoms[id(geom)] = g
+        return g
+
+    def pattern(self, test_basis, trial_basis):
+        key = id(test_basis), id(trial_basis)
+        p = self._patterns.get(key)
+        if p is None:
+            tt, tr = self.tables(test_basis), self.tables(trial_basis)
+            p = self._patterns[key] = kernels.Pattern(self.nelems, test_basis.ndofs, trial_basis.ndofs, tt.dofs, tr.dofs, nbt=tt.nb, nbr=tr.nb,
+                                                      toff=tt.off, roff=tr.off)
+        return p
+
+    # -- reference interface --
+
+    def integral(self, func):
+        '''Postponed integration (sample.py:177-190).'''
+        itg = function._as_integrand(func)
+        if itg._tensor.ndim - itg._keep:
+            raise NotImplementedError(f'integrand has unreduced axes {itg.shape}; sum or contract them first')
+        return function.Integral([(self, itg, 1.)])
+
+    def integrate(self, funcs, /, arguments=None, **kwargs):
+        '''Integrate functions (sample.py:160-175).'''
+        single = not isinstance(funcs, (tuple, list))
+        items = (funcs,) if single else tuple(funcs)
+        out = function.eval([self.integral(f) for f in items], dict(arguments or {}, **kwargs))
+        return out[0] if single else out
+
+    def eval(self, funcs, /, arguments=None, **kwargs):
+        '''Evaluate at all sample points, element-major (sample.py:192-204 / bind
+        :217-232, _ConcatenatePoints :966-975).  Supported: a geometry (coordinates),
+        J(geom), a field, grad(field, geom).'''
+        arguments = dict(arguments or {}, **kwargs)
+        single = not isinstance(funcs, (tuple, list))
+        items = (funcs,) if single else tuple(funcs)
+        out = tuple(self._eval_one(f, arguments) for f in items)
+        return out[0] if single else out
+
+    def _eval_one(self, f, arguments):
+        nq, nd, ne = self.points.npoints, self.ndims, self.nelems
+        n = ne * nq
+        if isinstance(f, function.Geometry):
+            x = device.empty(n * nd, 'float64')
+            kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(f), points=self._points_dev, x=x)
+            return device.to_host(x).reshape(n, nd)
+        if isinstance(f, function.Measure):
+            dj = device.empty(n, 'float64')
+            kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(f.geom), points=self._points_dev, detj=dj)
+            return device.to_host(dj)
+        if isinstance(f, function.Operand):
+            if f.arg.name is None:
+                raise NotImplementedError('evaluating a basis array at all points is a dense (npoints x ndofs) result; evaluate a field instead')
+            u = _argument(arguments, f.arg)
+            geom = f.geom
+            if geom is None:
+                geom = _default_geometry(self.topo)
+            nc = f.arg.ncomp
+            U = device.empty(n * nc * (1 + nd), 'float64')
+            kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(geom), trial=self.tables(f.arg.basis).struct, ncr=nc,
+                                points=self._points_dev, u=device.to_dev(u, 'float64'), U=U)
+            Uh = device.to_host(U).reshape(n, nc, 1 + nd)
+            # tiny host contraction with the operand's constant tensor: value[free] = P[free,c,s] U[c,s]
+            return numpy.einsum('...cs,ncs->n...', f.P, Uh)
+        raise NotImplementedError(f'Sample.eval of {type(f).__name__}')
+
+
+def _default_geometry(topo):
+    return function.RectilinearGeometry(topo, numpy.zeros(topo.ndims), numpy.ones(topo.ndims))
+
+
+def _argument(arguments, arg):
+    if arg.name not in arguments:
+        raise KeyError(f'argument {arg.name!r} missing')
+    u = numpy.asarray(arguments[arg.name], dtype=float)
+    expect = (arg.basis.ndofs, arg.ncomp) if arg.ncomp > 1 or u.ndim == 2 else (arg.basis.ndofs,)
+    if u.shape != expect:
+        raise ValueError(f'argument {arg.name!r} has shape {u.shape}, expected {expect}')
+    return u.reshape(arg.basis.ndofs, arg.ncomp)
+
+
+def _block_mask(B):
+    return (numpy.abs(B).sum(axis=(1, 3)) != 0)
+
+
+class _MatrixPlan:
+    '''All matrix-type terms of one integral share test/trial basis; accumulate into one values buffer.'''
+
+    def __init__(self, terms):
+        smp0, itg0, _ = terms[0]
+        for smp, itg, fac in terms:
+            if itg.B is None or not (itg.rows and itg.cols):
+                raise ValueError('as_csr needs a matrix-valued integral (both dof axes exposed)')
+            if smp is not smp0 and (smp.topo is not smp0.topo):
+                raise NotImplementedError('matrix terms on different topologies')
+            if not (itg.test.basis is itg0.test.basis and itg.trial.basis is itg0.trial.basis and itg.test.ncomp == itg0.test.ncomp
+                    and itg.trial.ncomp == itg0.trial.ncomp):
+                raise NotImplementedError('matrix terms with different bases')
+        self.terms = terms
+        self.test, self.trial = itg0.test, itg0.trial
+        self.mask = numpy.zeros((self.test.ncomp, self.trial.ncomp), dtype=bool)
+        for smp, itg, fac in terms:
+            self.mask |= _block_mask(itg.B)
+        self.smp0 = smp0
+
+    def run(self):
+        pat = self.smp0.pattern(self.test.basis, self.trial.basis)
+        nct, ncr = self.test.ncomp, self.trial.ncomp
+        mask = None if self.mask.all() else self.mask
+        rowptr, colidx = pat.expand(nct, ncr, mask)
+        values = device.zeros(colidx.numel(), 'float64')
+        for smp, itg, fac in self.terms:
+            if itg.measure is None:
+                raise NotImplementedError('integrand without J(geom): reference-space integrals are outside the accelerated path')
+            tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
+            kernels.assemble_matrix(nelems=smp.nelems, ndims=smp.ndims, nq=smp.points.npoints, weights=smp._weights_dev,
+                                    geom=smp.geometry(itg.measure), test=tt.struct, trial=tr.struct, nct=nct, ncr=ncr, C=itg.B * fac,
+                                    mask=mask, pattern=smp.pattern(itg.test.basis, itg.trial.basis), values=values)
+        return values, rowptr, colidx, self.trial.basis.ndofs * ncr
+
+
+def _vector_term(smp, itg, fac, arguments, out, scalar):
+    nd, nq = smp.ndims, smp.points.npoints
+    if itg.measure is None:
+        raise NotImplementedError('integrand without J(geom)')
+    geom = smp.geometry(itg.measure)
+    if itg.B is not None:
+        tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
+        if itg.rows and not itg.cols:
+            u = device.to_dev(_argument(arguments, itg.trial), 'float64')
+            kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+                                    nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=out)
+            return
+        if not itg.rows and not itg.cols:
+            if itg.test.same(itg.trial):
+                u = device.to_dev(_argument(arguments, itg.trial), 'float64')
+                kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+                                        nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * (2 * fac), u=u, out_scalar=scalar[0])
+            else:
+                tmp = device.zeros(itg.test.basis.ndofs * itg.test.ncomp, 'float64')
+                u = device.to_dev(_argument(arguments, itg.trial), 'float64')
+                kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+                                        nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=tmp)
+                # v . r for two different bound fields: O(ndofs) post-processing on the host
+                scalar[1] += float(numpy.dot(device.to_host(tmp), _argument(arguments, itg.test).ravel()))
+            return
+        raise NotImplementedError('unsupported combination of exposed axes')
+    if itg.L is not None:
+        tt = smp.tables(itg.test.basis)
+        if itg.rows:
+            kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
+                                    nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, out=out)
+        else:
+            u = device.to_dev(_argument(arguments, itg.test), 'float64')
+            kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
+                                    nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, u=u, out_scalar=scalar[0])
+        return
+    # constant integrand (volume-type functional): basis-free launch
+    none = kernels.basis(None, None)
+    kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=none, trial=none, nct=1, ncr=1,
+                            f0=float(itg.f0) * fac, out_scalar=scalar[0])
+
+
+def evaluate(f, arguments):
+    '''Evaluate one Integral / as_csr / as_coo wrapper.'''
+    if isinstance(f, (function._AsCSR, function._AsCOO)):
+        terms = f.integral.terms
+        if not terms:
+            raise ValueError('empty integral')
+        values, rowptr, colidx, ncols = _MatrixPlan(terms).run()
+        values, rowptr, colidx = device.to_host(values), device.to_host(rowptr), device.to_host(colidx)
+        if isinstance(f, function._AsCOO):
+            rowidx = numpy.repeat(numpy.arange(len(rowptr) - 1, dtype=numpy.int64), numpy.diff(rowptr))
+            return values, rowidx, colidx
+        return values, rowptr, colidx
+    if not isinstance(f, function.Integral):
+        raise TypeError(f'cannot evaluate {type(f).__name__}')
+    kinds = {(itg.rows, itg.cols) for _, itg, _ in f.terms}
+    if kinds == {(True, True)}:
+        values, rowptr, colidx, ncols = _MatrixPlan(f.terms).run()
+        return _matrix.assemble_csr(device.to_host(values), device.to_host(rowptr), device.to_host(colidx), ncols).export('dense')
+    if (True, True) in kinds:
+        raise NotImplementedError('mixing matrix and vector terms in one integral')
+    exposed = [itg for _, itg, _ in f.terms if itg.rows]
+    out = None
+    if exposed:
+        a0 = exposed[0].test
+        if len(exposed) != len(f.terms) or not all(itg.test.basis is a0.basis and itg.test.ncomp == a0.ncomp for itg in exposed):
+            raise NotImplementedError('vector terms with different test spaces')
+        out = device.zeros(a0.basis.ndofs * a0.ncomp, 'float64')
+    scalar = [device.zeros(1, 'float64'), 0.]  # device accumulator, host-side addend
+    for smp, itg, fac in f.terms:
+        _vector_term(smp, itg, fac, arguments, out, scalar)
+    if out is not None:
+        res = device.to_host(out)
+        return res.reshape(a0.basis.ndofs, a0.ncomp) if a0.ncomp > 1 else res
+    return float(device.to_host(scalar[0])[0]) + scalar[1]

@@ -1,0 +1,109 @@
+'''Synthetic workloads of BASELINE.json, set up through the product path and kept
+resident in HBM, for bench.py and the large-size GPU tests.
+
+PoissonSlab = configs[1]: 3-D Poisson stiffness on a structured hex mesh, p=1.
+With world > 1 the global mesh is (n*world) x n x n; rank r owns element layers
+[r*n, (r+1)*n) and the dof planes [r*n, (r+1)*n) (the last rank also the final
+plane); see nutils_amd/partition.py for the exchange.
+'''
+
+import numpy
+
+from . import device, function, kernels, mesh, partition
+
+
+class PoissonSlab:
+
+    def __init__(self, n=128, rank=0, world=1, variant='iso', kernel='auto', seed=0):
+        self.n, self.rank, self.world, self.variant = int(n), int(rank), int(world), variant
+        self.kernel = kernel
+        self.seed = seed
+        self.slab = partition.Slab(self.n, self.rank, self.world, shape_jk=(self.n, self.n))
+
+    def setup(self):
+        s = self.slab
+        n = self.n
+        self.domain, geom0 = mesh.rectilinear([s.local_layers, n, n])
+        self.basis = self.domain.basis('std', degree=1)
+        if self.variant == 'iso':
+            # global vertex field: (I, J, K) + U(-.2, .2)^3 with default_rng(seed) over the GLOBAL mesh;
+            # every rank draws the same stream and keeps its planes
+            rng = numpy.random.default_rng(self.seed)
+            nI = n * self.world + 1
+            pert = rng.uniform(-.2, .2, (nI, n + 1, n + 1, 3))
+            I0 = s.first_global_plane
+            idx = numpy.stack(numpy.meshgrid(numpy.arange(I0, I0 + s.local_layers + 1, dtype=float), numpy.arange(n + 1.), numpy.arange(n + 1.), indexing='ij'), -1)
+            verts = (idx + pert[I0:I0 + s.local_layers + 1]).reshape(-1, 3)
+            self.verts = verts
+            self.geom = self.basis @ verts
+        else:
+            self.verts = None
+            self.geom = function.RectilinearGeometry(self.domain, [float(s.first_global_plane), 0., 0.], [1., 1., 1.])
+        self.smp = self.domain.sample('gauss', 2)
+        self.tables = self.smp.tables(self.basis)
+        self.kgeom = self.smp.geometry(self.geom)
+        self.nelems = s.own_layers * n * n
+        self.C = numpy.zeros((1, 4, 1, 4))
+        for i in range(3):
+            self.C[0, 1 + i, 0, 1 + i] = 1.
+
+    def build_pattern(self):
+        self.pattern = self.smp.pattern(self.basis, self.basis)
+        self.rowptr, self.colidx = self.pattern.expand()
+        self.values = device.zeros(self.colidx.numel(), 'float64')
+        self.nnz = int(self.colidx.numel())
+        self.kernel_name = 'k_matrix_generic<3>'
+        self.halo = partition.HaloPlan(self.slab, self.rowptr) if self.world > 1 else None
+
+    def _own_views(self):
+        '''Structures restricted to the rank's own element layers (skip the ghost layer).'''
+        e0 = self.slab.ghost_layers * self.n * self.n
+        if not hasattr(self, '_views'):
+            t = self.tables
+            test = kernels.basis(t.T, t.dofs[e0 * 8:], nb=8)
+            if self.variant == 'iso':
+                g = kernels.geometry_iso(8, t.T, t.dofs[e0 * 8:], self.kgeom._keep[2])
+            else:
+                g = kernels.geometry_box(self.kgeom._keep[0][e0 * 3:], self.kgeom._keep[1][e0 * 3:])
+            self._views = test, g, e0
+        return self._views
+
+    def step(self, kernel_events=None):
+        test, g, e0 = self._own_views()
+        self.values.zero_()
+        if kernel_events:
+            kernel_events[0].record()
+        kernels.assemble_matrix(nelems=self.nelems, ndims=3, nq=8, weights=self.smp._weights_dev, geom=g, test=test, trial=test, nct=1, ncr=1,
+                                C=self.C, mask=None, pattern=self.pattern, values=self.values, emap_offset=e0 * 64)
+        if kernel_events:
+            kernel_events[1].record()
+        if self.halo is not None:
+            self.halo.exchange(self.values)
+
+    def algorithmic_bytes_per_element(self):
+        '''connectivity + unique vertex coordinates + CSR values written once.'''
+        n = self.n
+        nverts_per_elem = (n + 1) ** 3 / n ** 3
+        nnz_per_elem = (3 * n + 1) ** 3 / n ** 3
+        conn = 8 * 4  # int32 connectivity as read by the kernel
+        coords = nverts_per_elem * 24 if self.variant == 'iso' else 0.
+        return conn + coords + nnz_per_elem * 8
+
+    def owned_csr(self):
+        '''(values, rowptr, colidx) of the rows this rank owns, global numbering, on the host.'''
+        return partition.owned_rows(self.slab, device.to_host(self.values), device.to_host(self.rowptr), device.to_host(self.colidx))
+
+    def self_check(self):
+        from oracle import assemble as oa, port
+        pts, w = oa.gauss(2, 3)
+        _, coeffs, _ = oa.structured_basis((1, 1, 1), 'std', 1)
+        N, dN = oa.tabulate(coeffs[0], pts)
+        T = numpy.concatenate([N.T[:, :, None], dN.transpose(1, 0, 2)], axis=2)
+        s = self.slab
+        self.step()
+        v, rp, ci, _ = port.laplace3d((s.local_layers, self.n, self.n), 1, T, T, w, self.verts)
+        assert numpy.array_equal(device.to_host(self.rowptr), rp) and numpy.array_equal(device.to_host(self.colidx), ci)
+        got = device.to_host(self.values)
+        err = numpy.abs(got - v).max() / numpy.abs(v).max()
+        assert err < 1e-13, err
+        return err
