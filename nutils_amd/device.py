@@ -36,7 +36,7 @@ _NP2T = {'float64': 'float64', 'int32': 'int32', 'int64': 'int64', 'uint8': 'uin
 def to_dev(array, dtype):
     '''Copy a host array to HBM as a contiguous tensor of `dtype` (numpy dtype name).'''
     t = require_gpu()
-    a = numpy.ascontiguousarray(array, dtype=dtype)
+    a = numpy.array(array, dtype=dtype, order='C', copy=True)
     return t.from_numpy(a).to(device='cuda', non_blocking=False)
 
 

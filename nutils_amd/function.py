@@ -151,6 +151,8 @@ class Operand:
         if numpy.abs(self.P[..., 1:]).sum() != 0:
             raise NotImplementedError('second derivatives are outside the accelerated path')
         nd = geom.ndims
+        if self.P.shape[-1] != 1 + nd:
+            raise ValueError('geometry dimension does not match the argument')
         P = numpy.zeros(self.P.shape[:-2] + (nd,) + self.P.shape[-2:-1] + (1 + nd,))
         for j in range(nd):
             P[..., j, :, 1 + j] = self.P[..., :, 0]
@@ -243,11 +245,13 @@ def field(name, basis, shape=()):
         raise NotImplementedError('fields of rank > 1')
     ncomp = shape[0] if shape else 1
     arg = Arg(basis, ncomp, name)
+    S = 1 + basis.ndims
     if shape:
-        P = numpy.zeros((ncomp, ncomp, 1))
+        P = numpy.zeros((ncomp, ncomp, S))
         P[numpy.arange(ncomp), numpy.arange(ncomp), 0] = 1
     else:
-        P = numpy.ones((1, 1))
+        P = numpy.zeros((1, S))
+        P[0, 0] = 1
     return Operand(arg, P)
 
 
@@ -261,7 +265,9 @@ def _as_operand(obj):
         return obj
     if isinstance(obj, Basis):
         if not hasattr(obj, '_as_operand'):
-            obj._as_operand = Operand(Arg(obj, 1, None), numpy.ones((1, 1)))
+            P = numpy.zeros((1, 1 + obj.ndims))
+            P[0, 0] = 1
+            obj._as_operand = Operand(Arg(obj, 1, None), P)
         return obj._as_operand
     raise TypeError(f'cannot interpret {type(obj).__name__} as an operand')
 

@@ -90,6 +90,8 @@ def basis(T, dofs, nb=0, off=None, tab=None):
 def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0):
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.'''
     C = numpy.ascontiguousarray(C, dtype=float)
+    if C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
+        raise ValueError(f'coefficient tensor has shape {C.shape}, expected {(nct, 1 + ndims, ncr, 1 + ndims)}')
     m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
     args = _lib.MatrixArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
                            device.host_ptr(m), pattern.srowptr_ptr, ctypes.c_void_p(pattern.emap_ptr.value + 4 * emap_offset), pattern.eoff_ptr,
@@ -101,6 +103,10 @@ def assemble_vector(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
                     elist=None):
     C = None if C is None else numpy.ascontiguousarray(C, dtype=float)
     f = None if f is None else numpy.ascontiguousarray(f, dtype=float)
+    if C is not None and C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
+        raise ValueError(f'coefficient tensor has shape {C.shape}')
+    if f is not None and f.shape != (nct, 1 + ndims):
+        raise ValueError(f'source tensor has shape {f.shape}')
     args = _lib.VectorArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
                            device.host_ptr(f), device.ptr(u), device.ptr(out), float(f0), device.ptr(out_scalar))
     _lib.call('nh_assemble_vector', ctypes.byref(args), device.stream())
