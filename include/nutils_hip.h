@@ -200,6 +200,32 @@ typedef struct {
 
 int nh_sample_eval(const nh_eval_args *args, void *stream);
 
+/* ---- fast path: structured P1 hexahedra, scalar Laplace ----------------------------
+ * Same result as nh_pattern_* + nh_assemble_matrix for the 3-D trilinear 'std' basis on
+ * mesh.rectilinear (mesh.py:34-60; StructuredBasis function.py:3080-3100) with 2-point
+ * Gauss per axis and isoparametric P1 (or uniform) geometry, but WRITE-ONCE: each
+ * workgroup owns a box of dof rows, recomputes the element matrices that touch it,
+ * reduces them in LDS and streams the finished CSR rows to HBM -- no global atomics, no
+ * zero-fill, no element map.  The pattern is the reference's (sorted unique, structural
+ * zeros kept; (3n+1)^3 law) in closed form: nh_p1hex_pattern writes rowptr (re-based to
+ * row_begin, row_end-row_begin+1 entries) and colidx for rows [row_begin, row_end).
+ * layer_*: element layers along axis 0 that contribute values; plane_*: dof planes along
+ * axis 0 whose rows are written (multi-GPU slabs, nutils_amd/partition.py); values_dev
+ * is indexed with the offsets of the FULL local mesh pattern. */
+typedef struct {
+  int shape[3];
+  int layer_begin, layer_end;
+  int plane_begin, plane_end;
+  const double *verts_dev;   /* [(n0+1)(n1+1)(n2+1)][3]; NULL: x = origin + scale * vertex index */
+  double origin[3], scale[3];
+  double gauss_x[2], gauss_w[2]; /* 1-D Gauss points / weights on [0,1] */
+  double kappa;                  /* constant diffusivity */
+  double *values_dev;
+} nh_p1hex_args;
+
+int nh_p1hex_pattern(const int *shape, int64_t row_begin, int64_t row_end, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream);
+int nh_p1hex_laplace(const nh_p1hex_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,12 @@ class EvalArgs(ctypes.Structure):
                 ('ncr', ctypes.c_int), ('points_dev', vp), ('u_dev', vp), ('x_dev', vp), ('detj_dev', vp), ('U_dev', vp)]
 
 
+class P1HexArgs(ctypes.Structure):
+    _fields_ = [('shape', ctypes.c_int * 3), ('layer_begin', ctypes.c_int), ('layer_end', ctypes.c_int), ('plane_begin', ctypes.c_int),
+                ('plane_end', ctypes.c_int), ('verts_dev', vp), ('origin', ctypes.c_double * 3), ('scale', ctypes.c_double * 3),
+                ('gauss_x', ctypes.c_double * 2), ('gauss_w', ctypes.c_double * 2), ('kappa', ctypes.c_double), ('values_dev', vp)]
+
+
 GEOM_ISO = 1
 GEOM_BOX = 2
 
@@ -83,6 +89,8 @@ SIGNATURES = {
     'nh_assemble_matrix': (ctypes.c_int, [ctypes.POINTER(MatrixArgs), vp]),
     'nh_assemble_vector': (ctypes.c_int, [ctypes.POINTER(VectorArgs), vp]),
     'nh_sample_eval': (ctypes.c_int, [ctypes.POINTER(EvalArgs), vp]),
+    'nh_p1hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64, vp, vp, vp]),
+    'nh_p1hex_laplace': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp]),
 }
 
 _lib = None

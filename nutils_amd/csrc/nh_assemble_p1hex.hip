@@ -1,0 +1,366 @@
+// Fast path for the headline configuration: scalar Laplace stiffness, trilinear ('std'
+// degree 1) basis on a structured hex mesh (mesh.rectilinear, mesh.py:34-60), 2-point
+// Gauss per axis, isoparametric P1 geometry (or the uniform box geometry).
+//
+// WRITE-ONCE design (no global atomics, no zero-fill, CSR values stored exactly once):
+//   * a workgroup OWNS a box of BI x BJ x BK dof rows;
+//   * its threads (one per element) recompute the local matrices of all elements that touch
+//     the box -- (BI+1)(BJ+1)(BK+1), i.e. a one-element halo is recomputed instead of
+//     communicated;
+//   * contributions are reduced in LDS (ds_add_f64) into a [rows][27] slot array
+//     (slot = 9(dI+1) + 3(dJ+1) + (dK+1): column offset relative to the row dof);
+//   * the finished rows are streamed to HBM, coalesced, at closed-form CSR offsets: for the
+//     reference's structured dof numbering the sorted-unique pattern (evaluable.py:588-616)
+//     is the tensor product of per-axis ranges [max(X-1,0), min(X+1,N-1)], so
+//     rowptr(I,J,K) and the position of a column inside its row are pure arithmetic.
+// HBM traffic = vertex coordinates (L2-shared between neighbouring threads) + values.
+#include "nh_common.h"
+
+namespace {
+
+struct P1Args {
+  int n0, n1, n2;          // elements per axis
+  int lay0, lay1;          // element layers [lay0, lay1) along axis 0 that contribute values
+  int pl0, pl1;            // dof planes [pl0, pl1) along axis 0 whose rows are written
+  const double *verts;     // [(n0+1)(n1+1)(n2+1)][3] or NULL (uniform: x = origin + scale*index)
+  double origin[3], scale[3];
+  double n[2][2];          // n[a][q] = N_a(g_q): 1-D shape functions at the 1-D Gauss points
+  double c[3][2];          // c[x+y][q] = n[x][q] n[y][q]
+  double wk[2][2][2];      // kappa w_qa w_qb w_qc
+  double *values;
+  int nbj, nbk;            // boxes per axis (j, k)
+};
+
+__device__ __forceinline__ int len_of(int X, int N) { return (X > 0) + 1 + (X < N - 1); }       // columns coupled along one axis
+__device__ __forceinline__ i64 cum_of(int X, int N) { return X == 0 ? 0 : 3 * (i64)X - 1; }     // sum_{X'<X} len_of (N >= 2)
+
+template <int BI, int BJ, int BK, int NT>
+__global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
+  constexpr int ROWS = BI * BJ * BK;
+  constexpr int EI = BI + 1, EJ = BJ + 1, EK = BK + 1;
+  static_assert(EI * EJ * EK <= NT, "one thread per element");
+  extern __shared__ __attribute__((aligned(16))) double acc[];  // [ROWS][27]
+  const int tid = threadIdx.x;
+  const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
+  int b = blockIdx.x;
+  const int bk = b % p.nbk; b /= p.nbk;
+  const int bj = b % p.nbj;
+  const int bi = b / p.nbj;
+  const int I0 = p.pl0 + bi * BI, J0 = bj * BJ, K0 = bk * BK;
+
+  for (int t = tid; t < ROWS * 27; t += NT) acc[t] = 0.;
+  __syncthreads();
+
+  if (tid < EI * EJ * EK) {
+    const int ek = tid % EK, ej = (tid / EK) % EJ, ei = tid / (EK * EJ);
+    const int gi = I0 - 1 + ei, gj = J0 - 1 + ej, gk = K0 - 1 + ek;
+    if (gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2) {
+      // ---- vertex coordinates -------------------------------------------------------
+      double X[2][2][2][3];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            if (p.verts) {
+              const double *v = p.verts + (((i64)(gi + a) * N1 + (gj + bb)) * N2 + (gk + c)) * 3;
+              X[a][bb][c][0] = v[0];
+              X[a][bb][c][1] = v[1];
+              X[a][bb][c][2] = v[2];
+            } else {
+              X[a][bb][c][0] = p.origin[0] + p.scale[0] * (gi + a);
+              X[a][bb][c][1] = p.origin[1] + p.scale[1] * (gj + bb);
+              X[a][bb][c][2] = p.origin[2] + p.scale[2] * (gk + c);
+            }
+          }
+      // uniform tables (SGPR resident): n[a][q] = N_a(g_q), c[p][q] = n[x][q] n[y][q] with p = x + y, wk = kappa w w w
+      const double (&n)[2][2] = p.n;
+      const double (&c)[3][2] = p.c;
+      // ---- Jacobian columns (sum-factorised: column j is independent of xi_j) --------------
+      double J0[2][2][3], J1[2][2][3], J2[2][2][3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        double e0[2][2], e1[2][2], e2[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            e0[x][y] = X[1][x][y][d] - X[0][x][y][d];
+            e1[x][y] = X[x][1][y][d] - X[x][0][y][d];
+            e2[x][y] = X[x][y][1][d] - X[x][y][0][d];
+          }
+#pragma unroll
+        for (int q1 = 0; q1 < 2; ++q1) {
+          double t0[2], t1[2], t2[2];
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            t0[y] = n[0][q1] * e0[0][y] + n[1][q1] * e0[1][y];
+            t1[y] = n[0][q1] * e1[0][y] + n[1][q1] * e1[1][y];
+            t2[y] = n[0][q1] * e2[0][y] + n[1][q1] * e2[1][y];
+          }
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) {
+            J0[q1][q2][d] = n[0][q2] * t0[0] + n[1][q2] * t0[1];  // (beta, gamma)
+            J1[q1][q2][d] = n[0][q2] * t1[0] + n[1][q2] * t1[1];  // (alpha, gamma)
+            J2[q1][q2][d] = n[0][q2] * t2[0] + n[1][q2] * t2[1];  // (alpha, beta)
+          }
+        }
+      }
+      // ---- metric tensors M_q = kappa w_q / |det J_q| adj(J_q) adj(J_q)^T at the 8 Gauss points --------
+      // K[a][b] = sum_q sum_jk T_q[a][j] T_q[b][k] M_q[j][k]; the reference gradients T factor per axis
+      // (T_q[a][j] = prod_d (d == j ? sigma(a_d) : n[a_d][q_d])), so the q-sum is contracted axis by axis
+      // (sum factorisation) instead of forming the 8 x 3 physical gradients per point.
+      double D0[2][2], D1[2][2], D2[2][2], M01[2][2][2], M02[2][2][2], M12[2][2][2];
+#pragma unroll
+      for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int qc = 0; qc < 2; ++qc) {
+            const double *c0 = J0[qb][qc], *c1 = J1[qa][qc], *c2 = J2[qa][qb];
+            double A[3][3];  // rows of adj(J): A[j] = c_{j+1} x c_{j+2}
+            A[0][0] = c1[1] * c2[2] - c1[2] * c2[1];
+            A[0][1] = c1[2] * c2[0] - c1[0] * c2[2];
+            A[0][2] = c1[0] * c2[1] - c1[1] * c2[0];
+            A[1][0] = c2[1] * c0[2] - c2[2] * c0[1];
+            A[1][1] = c2[2] * c0[0] - c2[0] * c0[2];
+            A[1][2] = c2[0] * c0[1] - c2[1] * c0[0];
+            A[2][0] = c0[1] * c1[2] - c0[2] * c1[1];
+            A[2][1] = c0[2] * c1[0] - c0[0] * c1[2];
+            A[2][2] = c0[0] * c1[1] - c0[1] * c1[0];
+            const double det = c0[0] * A[0][0] + c0[1] * A[0][1] + c0[2] * A[0][2];
+            const double sc = p.wk[qa][qb][qc] / fabs(det);
+            const double m00 = sc * (A[0][0] * A[0][0] + A[0][1] * A[0][1] + A[0][2] * A[0][2]);
+            const double m11 = sc * (A[1][0] * A[1][0] + A[1][1] * A[1][1] + A[1][2] * A[1][2]);
+            const double m22 = sc * (A[2][0] * A[2][0] + A[2][1] * A[2][1] + A[2][2] * A[2][2]);
+            M01[qa][qb][qc] = sc * (A[0][0] * A[1][0] + A[0][1] * A[1][1] + A[0][2] * A[1][2]);
+            M02[qa][qb][qc] = sc * (A[0][0] * A[2][0] + A[0][1] * A[2][1] + A[0][2] * A[2][2]);
+            M12[qa][qb][qc] = sc * (A[1][0] * A[2][0] + A[1][1] * A[2][1] + A[1][2] * A[2][2]);
+            D0[qb][qc] = qa ? D0[qb][qc] + m00 : m00;
+            D1[qa][qc] = qb ? D1[qa][qc] + m11 : m11;
+            D2[qa][qb] = qc ? D2[qa][qb] + m22 : m22;
+          }
+      // ---- axis-by-axis contractions -------------------------------------------------------------------
+      double R0[3][3], R1[3][3], R2[3][3];          // diagonal (j == k) terms, indexed by the pair classes p = a_d + b_d
+      double W01[2][2][3], W02[2][2][3], W12[2][2][3];
+      {
+        double U[2][3];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) U[x][pp] = c[pp][0] * D0[x][0] + c[pp][1] * D0[x][1];
+#pragma unroll
+        for (int p1 = 0; p1 < 3; ++p1)
+#pragma unroll
+          for (int p2 = 0; p2 < 3; ++p2) R0[p1][p2] = c[p1][0] * U[0][p2] + c[p1][1] * U[1][p2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) U[x][pp] = c[pp][0] * D1[x][0] + c[pp][1] * D1[x][1];
+#pragma unroll
+        for (int p0 = 0; p0 < 3; ++p0)
+#pragma unroll
+          for (int p2 = 0; p2 < 3; ++p2) R1[p0][p2] = c[p0][0] * U[0][p2] + c[p0][1] * U[1][p2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) U[x][pp] = c[pp][0] * D2[x][0] + c[pp][1] * D2[x][1];
+#pragma unroll
+        for (int p0 = 0; p0 < 3; ++p0)
+#pragma unroll
+          for (int p1 = 0; p1 < 3; ++p1) R2[p0][p1] = c[p0][0] * U[0][p1] + c[p0][1] * U[1][p1];
+      }
+      {
+        // W01[b0][a1][p2] = sum_al n[b0][al] sum_be n[a1][be] sum_ga c[p2][ga] M01[al][be][ga]
+        double V[2][2][3], V2[2][2][3];
+#pragma unroll
+        for (int al = 0; al < 2; ++al)
+#pragma unroll
+          for (int be = 0; be < 2; ++be)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) V[al][be][pp] = c[pp][0] * M01[al][be][0] + c[pp][1] * M01[al][be][1];
+#pragma unroll
+        for (int al = 0; al < 2; ++al)
+#pragma unroll
+          for (int a1 = 0; a1 < 2; ++a1)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) V2[al][a1][pp] = n[a1][0] * V[al][0][pp] + n[a1][1] * V[al][1][pp];
+#pragma unroll
+        for (int b0 = 0; b0 < 2; ++b0)
+#pragma unroll
+          for (int a1 = 0; a1 < 2; ++a1)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) W01[b0][a1][pp] = n[b0][0] * V2[0][a1][pp] + n[b0][1] * V2[1][a1][pp];
+        // W02[b0][a2][p1] = sum_al n[b0][al] sum_ga n[a2][ga] sum_be c[p1][be] M02[al][be][ga]
+#pragma unroll
+        for (int al = 0; al < 2; ++al)
+#pragma unroll
+          for (int ga = 0; ga < 2; ++ga)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) V[al][ga][pp] = c[pp][0] * M02[al][0][ga] + c[pp][1] * M02[al][1][ga];
+#pragma unroll
+        for (int al = 0; al < 2; ++al)
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) V2[al][a2][pp] = n[a2][0] * V[al][0][pp] + n[a2][1] * V[al][1][pp];
+#pragma unroll
+        for (int b0 = 0; b0 < 2; ++b0)
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) W02[b0][a2][pp] = n[b0][0] * V2[0][a2][pp] + n[b0][1] * V2[1][a2][pp];
+        // W12[b1][a2][p0] = sum_be n[b1][be] sum_ga n[a2][ga] sum_al c[p0][al] M12[al][be][ga]
+#pragma unroll
+        for (int be = 0; be < 2; ++be)
+#pragma unroll
+          for (int ga = 0; ga < 2; ++ga)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) V[be][ga][pp] = c[pp][0] * M12[0][be][ga] + c[pp][1] * M12[1][be][ga];
+#pragma unroll
+        for (int be = 0; be < 2; ++be)
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) V2[be][a2][pp] = n[a2][0] * V[be][0][pp] + n[a2][1] * V[be][1][pp];
+#pragma unroll
+        for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) W12[b1][a2][pp] = n[b1][0] * V2[0][a2][pp] + n[b1][1] * V2[1][a2][pp];
+      }
+      // ---- form K[a][b] (a <= b) entry by entry and reduce it into the LDS row accumulators ---------------
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
+        const int ra0 = ei - 1 + a0, ra1 = ej - 1 + a1, ra2 = ek - 1 + a2;  // row of vertex a relative to the box
+        const bool ina = ra0 >= 0 && ra0 < BI && ra1 >= 0 && ra1 < BJ && ra2 >= 0 && ra2 < BK;
+        const int rowa = ((ra0 * BJ + ra1) * BK + ra2) * 27;
+#pragma unroll
+        for (int bb = a; bb < 8; ++bb) {
+          const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
+          const int p0 = a0 + b0, p1 = a1 + b1, p2 = a2 + b2;
+          const double s00 = (a0 == b0) ? 1. : -1., s11 = (a1 == b1) ? 1. : -1., s22 = (a2 == b2) ? 1. : -1.;
+          const double s01 = (a0 == b1) ? 1. : -1., s10 = (b0 == a1) ? 1. : -1.;
+          const double s02 = (a0 == b2) ? 1. : -1., s20 = (b0 == a2) ? 1. : -1.;
+          const double s12 = (a1 == b2) ? 1. : -1., s21 = (b1 == a2) ? 1. : -1.;
+          const double Kab = s00 * R0[p1][p2] + s11 * R1[p0][p2] + s22 * R2[p0][p1]
+                           + s01 * W01[b0][a1][p2] + s10 * W01[a0][b1][p2]
+                           + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1]
+                           + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
+          const int d0 = b0 - a0, d1 = b1 - a1, d2 = b2 - a2;
+          if (ina) atomicAdd(&acc[rowa + (d0 + 1) * 9 + (d1 + 1) * 3 + (d2 + 1)], Kab);
+          if (bb != a) {
+            const int rb0 = ei - 1 + b0, rb1 = ej - 1 + b1, rb2 = ek - 1 + b2;
+            const bool inb = rb0 >= 0 && rb0 < BI && rb1 >= 0 && rb1 < BJ && rb2 >= 0 && rb2 < BK;
+            if (inb) atomicAdd(&acc[((rb0 * BJ + rb1) * BK + rb2) * 27 + (1 - d0) * 9 + (1 - d1) * 3 + (1 - d2)], Kab);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- stream the finished rows to HBM --------------------------------------------------------
+  const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;  // sum of len over an axis
+  for (int t = tid; t < ROWS * 27; t += NT) {
+    const int r = t / 27, slot = t - r * 27;
+    const int lk = r % BK, lj = (r / BK) % BJ, li = r / (BK * BJ);
+    const int I = I0 + li, J = J0 + lj, Kk = K0 + lk;
+    if (I >= p.pl1 || J >= N1 || Kk >= N2) continue;
+    const int dI = slot / 9 - 1, dJ = (slot / 3) % 3 - 1, dK = slot % 3 - 1;
+    const int cI = I + dI, cJ = J + dJ, cK = Kk + dK;
+    if (cI < 0 || cI >= N0 || cJ < 0 || cJ >= N1 || cK < 0 || cK >= N2) continue;
+    const int lenJ = len_of(J, N1), lenK = len_of(Kk, N2), lenI = len_of(I, N0);
+    const i64 rowptr = cum_of(I, N0) * T1 * T2 + lenI * (cum_of(J, N1) * T2 + (i64)lenJ * cum_of(Kk, N2));
+    const int pos = ((dI + (I > 0)) * lenJ + (dJ + (J > 0))) * lenK + (dK + (Kk > 0));
+    p.values[rowptr + pos] = acc[t];
+  }
+}
+
+__global__ void k_p1hex_pattern(int n0, int n1, int n2, i64 row0, i64 row1, i64 *rowptr, i64 *colidx) {
+  // one thread per (row, slot); rows in [row0, row1); output re-based to row0
+  const int N0 = n0 + 1, N1 = n1 + 1, N2 = n2 + 1;
+  const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 row = row0 + t / 27;
+  const int slot = (int)(t % 27);
+  if (row > row1 || (row == row1 && slot != 0)) return;
+  const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;
+  auto rp = [&](i64 r) -> i64 {
+    if (r >= (i64)N0 * N1 * N2) return (3 * (i64)N0 - 2) * T1 * T2;
+    const int Kk = (int)(r % N2), J = (int)((r / N2) % N1), I = (int)(r / ((i64)N2 * N1));
+    return cum_of(I, N0) * T1 * T2 + len_of(I, N0) * (cum_of(J, N1) * T2 + (i64)len_of(J, N1) * cum_of(Kk, N2));
+  };
+  const i64 base = rp(row0);
+  if (slot == 0) rowptr[row - row0] = rp(row) - base;
+  if (row >= row1) return;
+  const int Kk = (int)(row % N2), J = (int)((row / N2) % N1), I = (int)(row / ((i64)N2 * N1));
+  const int dI = slot / 9 - 1, dJ = (slot / 3) % 3 - 1, dK = slot % 3 - 1;
+  const int cI = I + dI, cJ = J + dJ, cK = Kk + dK;
+  if (cI < 0 || cI >= N0 || cJ < 0 || cJ >= N1 || cK < 0 || cK >= N2) return;
+  const int lenJ = len_of(J, N1), lenK = len_of(Kk, N2);
+  const int pos = ((dI + (I > 0)) * lenJ + (dJ + (J > 0))) * lenK + (dK + (Kk > 0));
+  colidx[rp(row) - base + pos] = ((i64)cI * N1 + cJ) * N2 + cK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nh_p1hex_pattern(const int *shape, int64_t row_begin, int64_t row_end, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream) {
+  NH_REQUIRE(shape && rowptr_dev && colidx_dev, "nh_p1hex_pattern: NULL argument");
+  NH_REQUIRE(shape[0] >= 1 && shape[1] >= 1 && shape[2] >= 1, "nh_p1hex_pattern: empty mesh");
+  const i64 nrows_total = (i64)(shape[0] + 1) * (shape[1] + 1) * (shape[2] + 1);
+  NH_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= nrows_total, "nh_p1hex_pattern: row range out of bounds");
+  const i64 n = (row_end - row_begin + 1) * 27;
+  hipLaunchKernelGGL(k_p1hex_pattern, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nh_stream(stream), shape[0], shape[1], shape[2],
+                     (i64)row_begin, (i64)row_end, (i64 *)rowptr_dev, (i64 *)colidx_dev);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
+  NH_REQUIRE(a && a->values_dev, "nh_p1hex_laplace: NULL argument");
+  NH_REQUIRE(a->shape[0] >= 1 && a->shape[1] >= 1 && a->shape[2] >= 1, "nh_p1hex_laplace: empty mesh");
+  NH_REQUIRE(0 <= a->layer_begin && a->layer_begin <= a->layer_end && a->layer_end <= a->shape[0], "nh_p1hex_laplace: layer range");
+  NH_REQUIRE(0 <= a->plane_begin && a->plane_begin <= a->plane_end && a->plane_end <= a->shape[0] + 1, "nh_p1hex_laplace: plane range");
+  if (a->plane_begin == a->plane_end) return NH_OK;
+  constexpr int BI = 7, BJ = 7, BK = 7, NT = 512;
+  P1Args p;
+  p.n0 = a->shape[0];
+  p.n1 = a->shape[1];
+  p.n2 = a->shape[2];
+  p.lay0 = a->layer_begin;
+  p.lay1 = a->layer_end;
+  p.pl0 = a->plane_begin;
+  p.pl1 = a->plane_end;
+  p.verts = a->verts_dev;
+  for (int d = 0; d < 3; ++d) {
+    p.origin[d] = a->origin[d];
+    p.scale[d] = a->scale[d];
+  }
+  for (int q = 0; q < 2; ++q) {
+    p.n[0][q] = 1. - a->gauss_x[q];
+    p.n[1][q] = a->gauss_x[q];
+    p.c[0][q] = p.n[0][q] * p.n[0][q];
+    p.c[1][q] = p.n[0][q] * p.n[1][q];
+    p.c[2][q] = p.n[1][q] * p.n[1][q];
+  }
+  for (int qa = 0; qa < 2; ++qa)
+    for (int qb = 0; qb < 2; ++qb)
+      for (int qc = 0; qc < 2; ++qc) p.wk[qa][qb][qc] = a->kappa * a->gauss_w[qa] * a->gauss_w[qb] * a->gauss_w[qc];
+  p.values = a->values_dev;
+  const int nbi = (p.pl1 - p.pl0 + BI - 1) / BI;
+  p.nbj = (p.n1 + 1 + BJ - 1) / BJ;
+  p.nbk = (p.n2 + 1 + BK - 1) / BK;
+  const size_t lds = sizeof(double) * BI * BJ * BK * 27;
+  auto kern = k_p1hex_laplace<BI, BJ, BK, NT>;
+  NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nbi * p.nbj * p.nbk)), dim3(NT), lds, nh_stream(stream), p);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+}  // extern "C"

@@ -117,3 +117,47 @@ def sample_eval(*, nelems, ndims, nq, geom, trial=None, ncr=1, points=None, u=No
         trial = _lib.Basis(0, None, None, None, None)
     args = _lib.EvalArgs(nelems, ndims, nq, geom, trial, ncr, device.ptr(points), device.ptr(u), device.ptr(x), device.ptr(detj), device.ptr(U))
     _lib.call('nh_sample_eval', ctypes.byref(args), device.stream())
+
+
+def p1hex_pattern(shape, row_begin=0, row_end=None):
+    '''Closed-form CSR index arrays of the trilinear basis on a structured hex mesh (nh_p1hex_pattern).'''
+    n0, n1, n2 = (int(n) for n in shape)
+    nrows = (n0 + 1) * (n1 + 1) * (n2 + 1)
+    if row_end is None:
+        row_end = nrows
+
+    def cum(X, N):
+        return 0 if X == 0 else (3 * N - 2 if X >= N else 3 * X - 1)
+
+    def rp(r):
+        if r >= nrows:
+            return (3 * n0 + 1) * (3 * n1 + 1) * (3 * n2 + 1)
+        K, J, I = r % (n2 + 1), (r // (n2 + 1)) % (n1 + 1), r // ((n2 + 1) * (n1 + 1))
+        ln = lambda X, N: (X > 0) + 1 + (X < N - 1)
+        return cum(I, n0 + 1) * (3 * n1 + 1) * (3 * n2 + 1) + ln(I, n0 + 1) * (cum(J, n1 + 1) * (3 * n2 + 1) + ln(J, n1 + 1) * cum(K, n2 + 1))
+
+    nnz = rp(row_end) - rp(row_begin)
+    rowptr = device.empty(row_end - row_begin + 1, 'int64')
+    colidx = device.empty(nnz, 'int64')
+    arr = (ctypes.c_int * 3)(n0, n1, n2)
+    _lib.call('nh_p1hex_pattern', arr, row_begin, row_end, device.ptr(rowptr), device.ptr(colidx), device.stream())
+    return rowptr, colidx
+
+
+def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0., 0.), scale=(1., 1., 1.), kappa=1., layers=None, planes=None):
+    '''Write-once structured P1-hex Laplace assembly (nh_p1hex_laplace).'''
+    n0 = int(shape[0])
+    layers = (0, n0) if layers is None else layers
+    planes = (0, n0 + 1) if planes is None else planes
+    a = _lib.P1HexArgs()
+    a.shape[:] = [int(n) for n in shape]
+    a.layer_begin, a.layer_end = layers
+    a.plane_begin, a.plane_end = planes
+    a.verts_dev = device.ptr(verts)
+    a.origin[:] = [float(x) for x in origin]
+    a.scale[:] = [float(x) for x in scale]
+    a.gauss_x[:] = [float(x) for x in gauss_x]
+    a.gauss_w[:] = [float(x) for x in gauss_w]
+    a.kappa = float(kappa)
+    a.values_dev = device.ptr(values)
+    _lib.call('nh_p1hex_laplace', ctypes.byref(a), device.stream())

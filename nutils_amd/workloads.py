@@ -47,13 +47,25 @@ class PoissonSlab:
         for i in range(3):
             self.C[0, 1 + i, 0, 1 + i] = 1.
 
+    @property
+    def fast(self):
+        return self.kernel in ('auto', 'fast')
+
     def build_pattern(self):
-        self.pattern = self.smp.pattern(self.basis, self.basis)
-        self.rowptr, self.colidx = self.pattern.expand()
+        s = self.slab
+        if self.fast:
+            # closed-form structured pattern (K6 without sorting), write-once kernel
+            self.pattern = None
+            self.rowptr, self.colidx = kernels.p1hex_pattern((s.local_layers, self.n, self.n))
+            self.kernel_name = 'k_p1hex_laplace<7,7,7,512>'
+        else:
+            self.pattern = self.smp.pattern(self.basis, self.basis)
+            self.rowptr, self.colidx = self.pattern.expand()
+            self.kernel_name = 'k_matrix_generic<3>'
         self.values = device.zeros(self.colidx.numel(), 'float64')
         self.nnz = int(self.colidx.numel())
-        self.kernel_name = 'k_matrix_generic<3>'
         self.halo = partition.HaloPlan(self.slab, self.rowptr) if self.world > 1 else None
+        self._verts_dev = device.to_dev(self.verts, 'float64') if self.verts is not None else None
 
     def _own_views(self):
         '''Structures restricted to the rank's own element layers (skip the ghost layer).'''
@@ -69,6 +81,21 @@ class PoissonSlab:
         return self._views
 
     def step(self, kernel_events=None):
+        if self.fast:
+            s = self.slab
+            pts = self.smp.points
+            gx = [pts.coords[0, 2], pts.coords[1, 2]]     # 1-D Gauss coordinates (last axis fastest)
+            gw = [pts.weights[0] ** (1 / 3)] * 2 if False else self._gauss_w1()
+            if kernel_events:
+                kernel_events[0].record()
+            kernels.p1hex_laplace(shape=(s.local_layers, self.n, self.n), values=self.values, gauss_x=gx, gauss_w=gw, verts=self._verts_dev,
+                                  origin=(float(s.first_global_plane), 0., 0.), layers=(s.ghost_layers, s.local_layers),
+                                  planes=(s.ghost_layers, s.local_layers + 1))
+            if kernel_events:
+                kernel_events[1].record()
+            if self.halo is not None:
+                self.halo.exchange(self.values)
+            return
         test, g, e0 = self._own_views()
         self.values.zero_()
         if kernel_events:
@@ -80,12 +107,16 @@ class PoissonSlab:
         if self.halo is not None:
             self.halo.exchange(self.values)
 
+    def _gauss_w1(self):
+        from . import points
+        return list(points.gauss1(2)[1])
+
     def algorithmic_bytes_per_element(self):
         '''connectivity + unique vertex coordinates + CSR values written once.'''
         n = self.n
         nverts_per_elem = (n + 1) ** 3 / n ** 3
         nnz_per_elem = (3 * n + 1) ** 3 / n ** 3
-        conn = 8 * 4  # int32 connectivity as read by the kernel
+        conn = 0 if self.fast else 8 * 4  # structured connectivity is generated in-kernel on the fast path; int32 otherwise
         coords = nverts_per_elem * 24 if self.variant == 'iso' else 0.
         return conn + coords + nnz_per_elem * 8
 

@@ -187,3 +187,51 @@ def test_hierarchical_ragged(golden, ndim, nnz_t, nnz_h):
         assert colidx.numel() == nnz
         assert numpy.array_equal(device.to_host(rowptr), g[key + 'K_rowptr']) and numpy.array_equal(device.to_host(colidx), g[key + 'K_colidx'])
         close(device.to_host(values), g[key + 'K_values'])
+
+
+# ---- write-once structured fast path (nh_p1hex_*) -------------------------------------------------
+
+P1HEX = ['lap3d_p1_2', 'lap3d_p1_3', 'lap3d_p1_4', 'lap3d_p1_234', 'lap3d_p1_3_iso', 'lap3d_p1_543_iso']
+
+
+@pytest.mark.parametrize('name', P1HEX)
+def test_p1hex_fast_path_golden(golden, name):
+    from nutils_amd import device, kernels, points
+    g = golden(name)
+    shape = tuple(int(n) for n in g['shape'])
+    rowptr, colidx = kernels.p1hex_pattern(shape)
+    assert numpy.array_equal(device.to_host(rowptr), g['K_rowptr']) and numpy.array_equal(device.to_host(colidx), g['K_colidx'])
+    values = device.empty(colidx.numel(), 'float64')
+    values.fill_(float('nan'))  # write-once: every entry must be stored exactly once, no zero-fill needed
+    x1, w1 = points.gauss1(2)
+    verts = device.to_dev(g['verts'], 'float64') if int(g['iso']) else None
+    kernels.p1hex_laplace(shape=shape, values=values, gauss_x=x1, gauss_w=w1, verts=verts)
+    close(device.to_host(values), g['K_values'])
+
+
+@pytest.mark.parametrize('shape,iso', [((17, 9, 23), True), ((7, 7, 7), False), ((1, 1, 1), True), ((1, 20, 3), True), ((30, 2, 1), False)])
+def test_p1hex_fast_vs_generic(shape, iso):
+    '''Box-boundary / ragged-edge coverage: sizes that are not multiples of the 7^3 dof box, compared with the generic kernel
+    (itself pinned to the golden vectors above).'''
+    from nutils_amd import mesh, function, device, kernels, points
+    rng = numpy.random.default_rng(3)
+    domain, geom = mesh.rectilinear(list(shape))
+    basis = domain.basis('std', degree=1)
+    verts = None
+    if iso:
+        verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, (len(basis), 3))
+        geom = basis @ verts
+    K = domain.integral(function.outer(function.grad(basis, geom)).sum(-1) * function.J(geom), degree=2)
+    vref, rp, ci = function.eval(function.as_csr(K))
+    rowptr, colidx = kernels.p1hex_pattern(shape)
+    assert numpy.array_equal(device.to_host(rowptr), rp) and numpy.array_equal(device.to_host(colidx), ci)
+    values = device.empty(colidx.numel(), 'float64')
+    values.fill_(float('nan'))
+    x1, w1 = points.gauss1(2)
+    kernels.p1hex_laplace(shape=shape, values=values, gauss_x=x1, gauss_w=w1, verts=None if verts is None else device.to_dev(verts, 'float64'))
+    close(device.to_host(values), vref)
+    # row sub-range of the pattern (multi-GPU row blocks)
+    nplane = (shape[1] + 1) * (shape[2] + 1)
+    r0, r1 = nplane, min(3, shape[0] + 1) * nplane
+    rps, cis = kernels.p1hex_pattern(shape, r0, r1)
+    assert numpy.array_equal(device.to_host(rps), rp[r0:r1 + 1] - rp[r0]) and numpy.array_equal(device.to_host(cis), ci[rp[r0]:rp[r1]])
