@@ -15,8 +15,17 @@
 //     rowptr(I,J,K) and the position of a column inside its row are pure arithmetic.
 // HBM traffic = vertex coordinates (L2-shared between neighbouring threads) + values.
 #include "nh_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
+
+// ablation switches for profiling (build with -DNH_ABLATION, select with NH_P1HEX_DEBUG=bits): compiled out otherwise
+#ifdef NH_ABLATION
+#define DEBUG(p) ((p).debug)
+#else
+#define DEBUG(p) 0
+#endif
 
 struct P1Args {
   int n0, n1, n2;          // elements per axis
@@ -29,51 +38,98 @@ struct P1Args {
   double wk[2][2][2];      // kappa w_qa w_qb w_qc
   double *values;
   int nbj, nbk;            // boxes per axis (j, k)
+  int nboxes;
+  int debug;               // ablation switches (NH_P1HEX_DEBUG env): 1 = no LDS reduction, 2 = no HBM stores, 4 = no element math
 };
 
 __device__ __forceinline__ int len_of(int X, int N) { return (X > 0) + 1 + (X < N - 1); }       // columns coupled along one axis
 __device__ __forceinline__ i64 cum_of(int X, int N) { return X == 0 ? 0 : 3 * (i64)X - 1; }     // sum_{X'<X} len_of (N >= 2)
 
-template <int BI, int BJ, int BK, int NT>
+// 1/d for d > 0 of ordinary magnitude (|det J|): hardware reciprocal estimate + two Newton steps (full f64 accuracy without the
+// scaling / fix-up sequence of an IEEE division; det J is never denormal, zero or huge for a valid mesh)
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.), r, r);
+  r = fma(fma(-d, r, 1.), r, r);
+  return r;
+}
+
+// Vertex coordinates of the element handled by thread `tid` in box `box` (or false if the thread has no element there).
+template <int BI, int BJ, int BK>
+__device__ __forceinline__ bool load_element(const P1Args &p, int box, int tid, double (&X)[2][2][2][3]) {
+  constexpr int EI = BI + 1, EJ = BJ + 1, EK = BK + 1;
+  if (box >= p.nboxes || tid >= EI * EJ * EK) return false;
+  const int N1 = p.n1 + 1, N2 = p.n2 + 1;
+  int b = box;
+  const int bk = b % p.nbk; b /= p.nbk;
+  const int bj = b % p.nbj;
+  const int bi = b / p.nbj;
+  const int ek = tid % EK, ej = (tid / EK) % EJ, ei = tid / (EK * EJ);
+  const int gi = p.pl0 + bi * BI - 1 + ei, gj = bj * BJ - 1 + ej, gk = bk * BK - 1 + ek;
+  if (!(gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2) || (DEBUG(p) & 4)) return false;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (p.verts) {
+          const double *v = p.verts + (((i64)(gi + a) * N1 + (gj + bb)) * N2 + (gk + c)) * 3;
+          X[a][bb][c][0] = v[0];
+          X[a][bb][c][1] = v[1];
+          X[a][bb][c][2] = v[2];
+        } else {
+          X[a][bb][c][0] = p.origin[0] + p.scale[0] * (gi + a);
+          X[a][bb][c][1] = p.origin[1] + p.scale[1] * (gj + bb);
+          X[a][bb][c][2] = p.origin[2] + p.scale[2] * (gk + c);
+        }
+      }
+  return true;
+}
+
+template <int BI, int BJ, int BK, int NT, int NBUF>
 __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
   constexpr int ROWS = BI * BJ * BK;
   constexpr int EI = BI + 1, EJ = BJ + 1, EK = BK + 1;
   static_assert(EI * EJ * EK <= NT, "one thread per element");
-  extern __shared__ __attribute__((aligned(16))) double acc[];  // [ROWS][27]
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  // two accumulator sets (double buffering across consecutive boxes of this persistent workgroup):
+  //   acc [ROWS][27] f64, rowbase [ROWS] i64 (CSR offset of the row, -1 = not written), rowflag [ROWS] i32
+  constexpr int SETD = ROWS * 27 + ROWS + (ROWS + 1) / 2 + 1;  // doubles per set (kept even for 16-byte alignment)
+  constexpr int SET = SETD + (SETD & 1);
   const int tid = threadIdx.x;
   const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
-  int b = blockIdx.x;
+  for (int t = tid; t < NBUF * SET; t += NT) lds[t] = 0.;
+  __syncthreads();
+
+  for (int box = blockIdx.x, it = 0; box < p.nboxes; box += gridDim.x, ++it) {
+  double *acc = lds + (NBUF == 2 ? (it & 1) : 0) * SET;
+  i64 *rowbase = reinterpret_cast<i64 *>(acc + ROWS * 27);
+  int *rowflag = reinterpret_cast<int *>(rowbase + ROWS);
+  int b = box;
   const int bk = b % p.nbk; b /= p.nbk;
   const int bj = b % p.nbj;
   const int bi = b / p.nbj;
   const int I0 = p.pl0 + bi * BI, J0 = bj * BJ, K0 = bk * BK;
 
-  for (int t = tid; t < ROWS * 27; t += NT) acc[t] = 0.;
-  __syncthreads();
+  if (tid < ROWS) {  // closed-form CSR row offsets, once per row (not once per entry)
+    const int lk = tid % BK, lj = (tid / BK) % BJ, li = tid / (BK * BJ);
+    const int I = I0 + li, J = J0 + lj, Kk = K0 + lk;
+    i64 base = -1;
+    int flag = 0;
+    if (I < p.pl1 && J < N1 && Kk < N2) {
+      const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;  // sum of len over an axis
+      base = cum_of(I, N0) * T1 * T2 + len_of(I, N0) * (cum_of(J, N1) * T2 + (i64)len_of(J, N1) * cum_of(Kk, N2));
+      flag = (I > 0) | (J > 0) << 1 | (Kk > 0) << 2 | (I < N0 - 1) << 3 | (J < N1 - 1) << 4 | (Kk < N2 - 1) << 5;
+    }
+    rowbase[tid] = base;
+    rowflag[tid] = flag;
+  }
 
-  if (tid < EI * EJ * EK) {
+  {
     const int ek = tid % EK, ej = (tid / EK) % EJ, ei = tid / (EK * EJ);
-    const int gi = I0 - 1 + ei, gj = J0 - 1 + ej, gk = K0 - 1 + ek;
-    if (gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2) {
-      // ---- vertex coordinates -------------------------------------------------------
-      double X[2][2][2][3];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            if (p.verts) {
-              const double *v = p.verts + (((i64)(gi + a) * N1 + (gj + bb)) * N2 + (gk + c)) * 3;
-              X[a][bb][c][0] = v[0];
-              X[a][bb][c][1] = v[1];
-              X[a][bb][c][2] = v[2];
-            } else {
-              X[a][bb][c][0] = p.origin[0] + p.scale[0] * (gi + a);
-              X[a][bb][c][1] = p.origin[1] + p.scale[1] * (gj + bb);
-              X[a][bb][c][2] = p.origin[2] + p.scale[2] * (gk + c);
-            }
-          }
+    double X[2][2][2][3];
+    if (load_element<BI, BJ, BK>(p, box, tid, X)) {
       // uniform tables (SGPR resident): n[a][q] = N_a(g_q), c[p][q] = n[x][q] n[y][q] with p = x + y, wk = kappa w w w
       const double (&n)[2][2] = p.n;
       const double (&c)[3][2] = p.c;
@@ -130,7 +186,7 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
             A[2][1] = c0[2] * c1[0] - c0[0] * c1[2];
             A[2][2] = c0[0] * c1[1] - c0[1] * c1[0];
             const double det = c0[0] * A[0][0] + c0[1] * A[0][1] + c0[2] * A[0][2];
-            const double sc = p.wk[qa][qb][qc] / fabs(det);
+            const double sc = p.wk[qa][qb][qc] * fast_rcp(fabs(det));
             const double m00 = sc * (A[0][0] * A[0][0] + A[0][1] * A[0][1] + A[0][2] * A[0][2]);
             const double m11 = sc * (A[1][0] * A[1][0] + A[1][1] * A[1][1] + A[1][2] * A[1][2]);
             const double m22 = sc * (A[2][0] * A[2][0] + A[2][1] * A[2][1] + A[2][2] * A[2][2]);
@@ -172,64 +228,64 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
           for (int p1 = 0; p1 < 3; ++p1) R2[p0][p1] = c[p0][0] * U[0][p1] + c[p0][1] * U[1][p1];
       }
       {
-        // W01[b0][a1][p2] = sum_al n[b0][al] sum_be n[a1][be] sum_ga c[p2][ga] M01[al][be][ga]
-        double V[2][2][3], V2[2][2][3];
+        // W01[b0][a1][p2] = sum_ga c[p2][ga] sum_be n[a1][be] sum_al n[b0][al] M01[al][be][ga]   (two-term axes first: 16+16+24 ops)
+        double V[2][2][2], V2[2][2][2];
 #pragma unroll
-        for (int al = 0; al < 2; ++al)
+        for (int b0 = 0; b0 < 2; ++b0)
 #pragma unroll
           for (int be = 0; be < 2; ++be)
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) V[al][be][pp] = c[pp][0] * M01[al][be][0] + c[pp][1] * M01[al][be][1];
-#pragma unroll
-        for (int al = 0; al < 2; ++al)
-#pragma unroll
-          for (int a1 = 0; a1 < 2; ++a1)
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) V2[al][a1][pp] = n[a1][0] * V[al][0][pp] + n[a1][1] * V[al][1][pp];
+            for (int ga = 0; ga < 2; ++ga) V[b0][be][ga] = n[b0][0] * M01[0][be][ga] + n[b0][1] * M01[1][be][ga];
 #pragma unroll
         for (int b0 = 0; b0 < 2; ++b0)
 #pragma unroll
           for (int a1 = 0; a1 < 2; ++a1)
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) W01[b0][a1][pp] = n[b0][0] * V2[0][a1][pp] + n[b0][1] * V2[1][a1][pp];
-        // W02[b0][a2][p1] = sum_al n[b0][al] sum_ga n[a2][ga] sum_be c[p1][be] M02[al][be][ga]
+            for (int ga = 0; ga < 2; ++ga) V2[b0][a1][ga] = n[a1][0] * V[b0][0][ga] + n[a1][1] * V[b0][1][ga];
 #pragma unroll
-        for (int al = 0; al < 2; ++al)
+        for (int b0 = 0; b0 < 2; ++b0)
 #pragma unroll
-          for (int ga = 0; ga < 2; ++ga)
+          for (int a1 = 0; a1 < 2; ++a1)
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) V[al][ga][pp] = c[pp][0] * M02[al][0][ga] + c[pp][1] * M02[al][1][ga];
+            for (int pp = 0; pp < 3; ++pp) W01[b0][a1][pp] = c[pp][0] * V2[b0][a1][0] + c[pp][1] * V2[b0][a1][1];
+        // W02[b0][a2][p1] = sum_be c[p1][be] sum_ga n[a2][ga] sum_al n[b0][al] M02[al][be][ga]
 #pragma unroll
-        for (int al = 0; al < 2; ++al)
+        for (int b0 = 0; b0 < 2; ++b0)
 #pragma unroll
-          for (int a2 = 0; a2 < 2; ++a2)
+          for (int be = 0; be < 2; ++be)
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) V2[al][a2][pp] = n[a2][0] * V[al][0][pp] + n[a2][1] * V[al][1][pp];
+            for (int ga = 0; ga < 2; ++ga) V[b0][be][ga] = n[b0][0] * M02[0][be][ga] + n[b0][1] * M02[1][be][ga];
 #pragma unroll
         for (int b0 = 0; b0 < 2; ++b0)
 #pragma unroll
           for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) W02[b0][a2][pp] = n[b0][0] * V2[0][a2][pp] + n[b0][1] * V2[1][a2][pp];
-        // W12[b1][a2][p0] = sum_be n[b1][be] sum_ga n[a2][ga] sum_al c[p0][al] M12[al][be][ga]
+            for (int be = 0; be < 2; ++be) V2[b0][a2][be] = n[a2][0] * V[b0][be][0] + n[a2][1] * V[b0][be][1];
 #pragma unroll
-        for (int be = 0; be < 2; ++be)
-#pragma unroll
-          for (int ga = 0; ga < 2; ++ga)
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) V[be][ga][pp] = c[pp][0] * M12[0][be][ga] + c[pp][1] * M12[1][be][ga];
-#pragma unroll
-        for (int be = 0; be < 2; ++be)
+        for (int b0 = 0; b0 < 2; ++b0)
 #pragma unroll
           for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) V2[be][a2][pp] = n[a2][0] * V[be][0][pp] + n[a2][1] * V[be][1][pp];
+            for (int pp = 0; pp < 3; ++pp) W02[b0][a2][pp] = c[pp][0] * V2[b0][a2][0] + c[pp][1] * V2[b0][a2][1];
+        // W12[b1][a2][p0] = sum_al c[p0][al] sum_ga n[a2][ga] sum_be n[b1][be] M12[al][be][ga]
+#pragma unroll
+        for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+          for (int al = 0; al < 2; ++al)
+#pragma unroll
+            for (int ga = 0; ga < 2; ++ga) V[b1][al][ga] = n[b1][0] * M12[al][0][ga] + n[b1][1] * M12[al][1][ga];
 #pragma unroll
         for (int b1 = 0; b1 < 2; ++b1)
 #pragma unroll
           for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) W12[b1][a2][pp] = n[b1][0] * V2[0][a2][pp] + n[b1][1] * V2[1][a2][pp];
+            for (int al = 0; al < 2; ++al) V2[b1][a2][al] = n[a2][0] * V[b1][al][0] + n[a2][1] * V[b1][al][1];
+#pragma unroll
+        for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) W12[b1][a2][pp] = c[pp][0] * V2[b1][a2][0] + c[pp][1] * V2[b1][a2][1];
       }
       // ---- form K[a][b] (a <= b) entry by entry and reduce it into the LDS row accumulators ---------------
 #pragma unroll
@@ -251,11 +307,12 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
                            + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1]
                            + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
           const int d0 = b0 - a0, d1 = b1 - a1, d2 = b2 - a2;
-          if (ina) atomicAdd(&acc[rowa + (d0 + 1) * 9 + (d1 + 1) * 3 + (d2 + 1)], Kab);
+          if (ina && !(DEBUG(p) & 1)) atomicAdd(&acc[rowa + (d0 + 1) * 9 + (d1 + 1) * 3 + (d2 + 1)], Kab);
+          if ((DEBUG(p) & 1) && Kab == 1.2345e300) acc[0] = Kab;
           if (bb != a) {
             const int rb0 = ei - 1 + b0, rb1 = ej - 1 + b1, rb2 = ek - 1 + b2;
             const bool inb = rb0 >= 0 && rb0 < BI && rb1 >= 0 && rb1 < BJ && rb2 >= 0 && rb2 < BK;
-            if (inb) atomicAdd(&acc[((rb0 * BJ + rb1) * BK + rb2) * 27 + (1 - d0) * 9 + (1 - d1) * 3 + (1 - d2)], Kab);
+            if (inb && !(DEBUG(p) & 1)) atomicAdd(&acc[((rb0 * BJ + rb1) * BK + rb2) * 27 + (1 - d0) * 9 + (1 - d1) * 3 + (1 - d2)], Kab);
           }
         }
       }
@@ -263,21 +320,28 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
   }
   __syncthreads();
 
-  // ---- stream the finished rows to HBM --------------------------------------------------------
-  const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;  // sum of len over an axis
-  for (int t = tid; t < ROWS * 27; t += NT) {
-    const int r = t / 27, slot = t - r * 27;
-    const int lk = r % BK, lj = (r / BK) % BJ, li = r / (BK * BJ);
-    const int I = I0 + li, J = J0 + lj, Kk = K0 + lk;
-    if (I >= p.pl1 || J >= N1 || Kk >= N2) continue;
-    const int dI = slot / 9 - 1, dJ = (slot / 3) % 3 - 1, dK = slot % 3 - 1;
-    const int cI = I + dI, cJ = J + dJ, cK = Kk + dK;
-    if (cI < 0 || cI >= N0 || cJ < 0 || cJ >= N1 || cK < 0 || cK >= N2) continue;
-    const int lenJ = len_of(J, N1), lenK = len_of(Kk, N2), lenI = len_of(I, N0);
-    const i64 rowptr = cum_of(I, N0) * T1 * T2 + lenI * (cum_of(J, N1) * T2 + (i64)lenJ * cum_of(Kk, N2));
-    const int pos = ((dI + (I > 0)) * lenJ + (dJ + (J > 0))) * lenK + (dK + (Kk > 0));
-    p.values[rowptr + pos] = acc[t];
+  // ---- stream the finished rows to HBM: 32 lanes per row (27 slots), NT/32 rows per pass ------------------
+  {
+    const int sl = tid & 31, rsub = tid >> 5;
+    const int dI = sl / 9 - 1, dJ = (sl / 3) % 3 - 1, dK = sl % 3 - 1;
+    // slot is stored iff the column exists: a -1 offset needs the lo flag, a +1 offset the hi flag
+    const int need = (dI < 0 ? 1 : dI > 0 ? 8 : 0) | (dJ < 0 ? 2 : dJ > 0 ? 16 : 0) | (dK < 0 ? 4 : dK > 0 ? 32 : 0);
+    if (sl < 27) {
+      for (int r = rsub; r < ROWS; r += NT / 32) {
+        const i64 base = rowbase[r];
+        const int flag = rowflag[r];
+        if (base >= 0 && (flag & need) == need && !(DEBUG(p) & 2)) {
+          const int loI = flag & 1, loJ = (flag >> 1) & 1, loK = (flag >> 2) & 1;
+          const int lenJ = loJ + 1 + ((flag >> 4) & 1), lenK = loK + 1 + ((flag >> 5) & 1);
+          const int pos = ((dI + loI) * lenJ + (dJ + loJ)) * lenK + (dK + loK);
+          p.values[base + pos] = acc[r * 27 + sl];
+        }
+        acc[r * 27 + sl] = 0.;  // ready for the box after next; ordered by the barrier of the next box
+      }
+    }
   }
+  if (NBUF == 1) __syncthreads();
+  }  // persistent loop over boxes: with NBUF == 2, ONE barrier per box; the stores of this box drain while the next box computes
 }
 
 __global__ void k_p1hex_pattern(int n0, int n1, int n2, i64 row0, i64 row1, i64 *rowptr, i64 *colidx) {
@@ -327,7 +391,7 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
   NH_REQUIRE(0 <= a->layer_begin && a->layer_begin <= a->layer_end && a->layer_end <= a->shape[0], "nh_p1hex_laplace: layer range");
   NH_REQUIRE(0 <= a->plane_begin && a->plane_begin <= a->plane_end && a->plane_end <= a->shape[0] + 1, "nh_p1hex_laplace: plane range");
   if (a->plane_begin == a->plane_end) return NH_OK;
-  constexpr int BI = 7, BJ = 7, BK = 7, NT = 512;
+  constexpr int BI = 7, BJ = 7, BK = 7, NT = 512, NBUF = 2;
   P1Args p;
   p.n0 = a->shape[0];
   p.n1 = a->shape[1];
@@ -355,10 +419,16 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
   const int nbi = (p.pl1 - p.pl0 + BI - 1) / BI;
   p.nbj = (p.n1 + 1 + BJ - 1) / BJ;
   p.nbk = (p.n2 + 1 + BK - 1) / BK;
-  const size_t lds = sizeof(double) * BI * BJ * BK * 27;
-  auto kern = k_p1hex_laplace<BI, BJ, BK, NT>;
+  constexpr int ROWS = BI * BJ * BK, SETD = ROWS * 27 + ROWS + (ROWS + 1) / 2 + 1, SET = SETD + (SETD & 1);
+  const size_t lds = sizeof(double) * NBUF * SET;
+  p.nboxes = nbi * p.nbj * p.nbk;
+  p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
+  int dev = 0, cus = 256;
+  NH_CHECK_HIP(hipGetDevice(&dev));
+  NH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  auto kern = k_p1hex_laplace<BI, BJ, BK, NT, NBUF>;
   NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nbi * p.nbj * p.nbk)), dim3(NT), lds, nh_stream(stream), p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min(p.nboxes, cus)), dim3(NT), lds, nh_stream(stream), p);
   NH_LAUNCH_CHECK();
   return NH_OK;
 }
