@@ -54,6 +54,26 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return r;
 }
 
+struct ElemTables {
+  double R0[3][3], R1[3][3], R2[3][3];             // diagonal (j == k) terms, indexed by the pair classes p = a_d + b_d
+  double W01[2][2][3], W02[2][2][3], W12[2][2][3];  // off-diagonal terms
+};
+
+// Everything per element except the final signed sums: Jacobian columns, metric tensors at the 8 Gauss points, axis-by-axis
+// contractions (see the derivation in DESIGN.md, "P1-hex local matrix by sum factorisation").
+// K[a][b] for local vertices a = (a0,a1,a2), b = (b0,b1,b2): nine signed table entries.
+__device__ __forceinline__ double element_entry(const ElemTables &T, int a, int bb) {
+  const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
+  const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
+  const int p0 = a0 + b0, p1 = a1 + b1, p2 = a2 + b2;
+  const double s00 = (a0 == b0) ? 1. : -1., s11 = (a1 == b1) ? 1. : -1., s22 = (a2 == b2) ? 1. : -1.;
+  const double s01 = (a0 == b1) ? 1. : -1., s10 = (b0 == a1) ? 1. : -1.;
+  const double s02 = (a0 == b2) ? 1. : -1., s20 = (b0 == a2) ? 1. : -1.;
+  const double s12 = (a1 == b2) ? 1. : -1., s21 = (b1 == a2) ? 1. : -1.;
+  return s00 * T.R0[p1][p2] + s11 * T.R1[p0][p2] + s22 * T.R2[p0][p1] + s01 * T.W01[b0][a1][p2] + s10 * T.W01[a0][b1][p2] +
+         s02 * T.W02[b0][a2][p1] + s20 * T.W02[a0][b2][p1] + s12 * T.W12[b1][a2][p0] + s21 * T.W12[a1][b2][p0];
+}
+
 // Vertex coordinates of the element handled by thread `tid` in box `box` (or false if the thread has no element there).
 template <int BI, int BJ, int BK>
 __device__ __forceinline__ bool load_element(const P1Args &p, int box, int tid, double (&X)[2][2][2][3]) {
@@ -130,163 +150,8 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
     const int ek = tid % EK, ej = (tid / EK) % EJ, ei = tid / (EK * EJ);
     double X[2][2][2][3];
     if (load_element<BI, BJ, BK>(p, box, tid, X)) {
-      // uniform tables (SGPR resident): n[a][q] = N_a(g_q), c[p][q] = n[x][q] n[y][q] with p = x + y, wk = kappa w w w
-      const double (&n)[2][2] = p.n;
-      const double (&c)[3][2] = p.c;
-      // ---- Jacobian columns (sum-factorised: column j is independent of xi_j) --------------
-      double J0[2][2][3], J1[2][2][3], J2[2][2][3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        double e0[2][2], e1[2][2], e2[2][2];
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y) {
-            e0[x][y] = X[1][x][y][d] - X[0][x][y][d];
-            e1[x][y] = X[x][1][y][d] - X[x][0][y][d];
-            e2[x][y] = X[x][y][1][d] - X[x][y][0][d];
-          }
-#pragma unroll
-        for (int q1 = 0; q1 < 2; ++q1) {
-          double t0[2], t1[2], t2[2];
-#pragma unroll
-          for (int y = 0; y < 2; ++y) {
-            t0[y] = n[0][q1] * e0[0][y] + n[1][q1] * e0[1][y];
-            t1[y] = n[0][q1] * e1[0][y] + n[1][q1] * e1[1][y];
-            t2[y] = n[0][q1] * e2[0][y] + n[1][q1] * e2[1][y];
-          }
-#pragma unroll
-          for (int q2 = 0; q2 < 2; ++q2) {
-            J0[q1][q2][d] = n[0][q2] * t0[0] + n[1][q2] * t0[1];  // (beta, gamma)
-            J1[q1][q2][d] = n[0][q2] * t1[0] + n[1][q2] * t1[1];  // (alpha, gamma)
-            J2[q1][q2][d] = n[0][q2] * t2[0] + n[1][q2] * t2[1];  // (alpha, beta)
-          }
-        }
-      }
-      // ---- metric tensors M_q = kappa w_q / |det J_q| adj(J_q) adj(J_q)^T at the 8 Gauss points --------
-      // K[a][b] = sum_q sum_jk T_q[a][j] T_q[b][k] M_q[j][k]; the reference gradients T factor per axis
-      // (T_q[a][j] = prod_d (d == j ? sigma(a_d) : n[a_d][q_d])), so the q-sum is contracted axis by axis
-      // (sum factorisation) instead of forming the 8 x 3 physical gradients per point.
-      double D0[2][2], D1[2][2], D2[2][2], M01[2][2][2], M02[2][2][2], M12[2][2][2];
-#pragma unroll
-      for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-          for (int qc = 0; qc < 2; ++qc) {
-            const double *c0 = J0[qb][qc], *c1 = J1[qa][qc], *c2 = J2[qa][qb];
-            double A[3][3];  // rows of adj(J): A[j] = c_{j+1} x c_{j+2}
-            A[0][0] = c1[1] * c2[2] - c1[2] * c2[1];
-            A[0][1] = c1[2] * c2[0] - c1[0] * c2[2];
-            A[0][2] = c1[0] * c2[1] - c1[1] * c2[0];
-            A[1][0] = c2[1] * c0[2] - c2[2] * c0[1];
-            A[1][1] = c2[2] * c0[0] - c2[0] * c0[2];
-            A[1][2] = c2[0] * c0[1] - c2[1] * c0[0];
-            A[2][0] = c0[1] * c1[2] - c0[2] * c1[1];
-            A[2][1] = c0[2] * c1[0] - c0[0] * c1[2];
-            A[2][2] = c0[0] * c1[1] - c0[1] * c1[0];
-            const double det = c0[0] * A[0][0] + c0[1] * A[0][1] + c0[2] * A[0][2];
-            const double sc = p.wk[qa][qb][qc] * fast_rcp(fabs(det));
-            const double m00 = sc * (A[0][0] * A[0][0] + A[0][1] * A[0][1] + A[0][2] * A[0][2]);
-            const double m11 = sc * (A[1][0] * A[1][0] + A[1][1] * A[1][1] + A[1][2] * A[1][2]);
-            const double m22 = sc * (A[2][0] * A[2][0] + A[2][1] * A[2][1] + A[2][2] * A[2][2]);
-            M01[qa][qb][qc] = sc * (A[0][0] * A[1][0] + A[0][1] * A[1][1] + A[0][2] * A[1][2]);
-            M02[qa][qb][qc] = sc * (A[0][0] * A[2][0] + A[0][1] * A[2][1] + A[0][2] * A[2][2]);
-            M12[qa][qb][qc] = sc * (A[1][0] * A[2][0] + A[1][1] * A[2][1] + A[1][2] * A[2][2]);
-            D0[qb][qc] = qa ? D0[qb][qc] + m00 : m00;
-            D1[qa][qc] = qb ? D1[qa][qc] + m11 : m11;
-            D2[qa][qb] = qc ? D2[qa][qb] + m22 : m22;
-          }
-      // ---- axis-by-axis contractions -------------------------------------------------------------------
-      double R0[3][3], R1[3][3], R2[3][3];          // diagonal (j == k) terms, indexed by the pair classes p = a_d + b_d
-      double W01[2][2][3], W02[2][2][3], W12[2][2][3];
-      {
-        double U[2][3];
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp) U[x][pp] = c[pp][0] * D0[x][0] + c[pp][1] * D0[x][1];
-#pragma unroll
-        for (int p1 = 0; p1 < 3; ++p1)
-#pragma unroll
-          for (int p2 = 0; p2 < 3; ++p2) R0[p1][p2] = c[p1][0] * U[0][p2] + c[p1][1] * U[1][p2];
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp) U[x][pp] = c[pp][0] * D1[x][0] + c[pp][1] * D1[x][1];
-#pragma unroll
-        for (int p0 = 0; p0 < 3; ++p0)
-#pragma unroll
-          for (int p2 = 0; p2 < 3; ++p2) R1[p0][p2] = c[p0][0] * U[0][p2] + c[p0][1] * U[1][p2];
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int pp = 0; pp < 3; ++pp) U[x][pp] = c[pp][0] * D2[x][0] + c[pp][1] * D2[x][1];
-#pragma unroll
-        for (int p0 = 0; p0 < 3; ++p0)
-#pragma unroll
-          for (int p1 = 0; p1 < 3; ++p1) R2[p0][p1] = c[p0][0] * U[0][p1] + c[p0][1] * U[1][p1];
-      }
-      {
-        // W01[b0][a1][p2] = sum_ga c[p2][ga] sum_be n[a1][be] sum_al n[b0][al] M01[al][be][ga]   (two-term axes first: 16+16+24 ops)
-        double V[2][2][2], V2[2][2][2];
-#pragma unroll
-        for (int b0 = 0; b0 < 2; ++b0)
-#pragma unroll
-          for (int be = 0; be < 2; ++be)
-#pragma unroll
-            for (int ga = 0; ga < 2; ++ga) V[b0][be][ga] = n[b0][0] * M01[0][be][ga] + n[b0][1] * M01[1][be][ga];
-#pragma unroll
-        for (int b0 = 0; b0 < 2; ++b0)
-#pragma unroll
-          for (int a1 = 0; a1 < 2; ++a1)
-#pragma unroll
-            for (int ga = 0; ga < 2; ++ga) V2[b0][a1][ga] = n[a1][0] * V[b0][0][ga] + n[a1][1] * V[b0][1][ga];
-#pragma unroll
-        for (int b0 = 0; b0 < 2; ++b0)
-#pragma unroll
-          for (int a1 = 0; a1 < 2; ++a1)
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) W01[b0][a1][pp] = c[pp][0] * V2[b0][a1][0] + c[pp][1] * V2[b0][a1][1];
-        // W02[b0][a2][p1] = sum_be c[p1][be] sum_ga n[a2][ga] sum_al n[b0][al] M02[al][be][ga]
-#pragma unroll
-        for (int b0 = 0; b0 < 2; ++b0)
-#pragma unroll
-          for (int be = 0; be < 2; ++be)
-#pragma unroll
-            for (int ga = 0; ga < 2; ++ga) V[b0][be][ga] = n[b0][0] * M02[0][be][ga] + n[b0][1] * M02[1][be][ga];
-#pragma unroll
-        for (int b0 = 0; b0 < 2; ++b0)
-#pragma unroll
-          for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-            for (int be = 0; be < 2; ++be) V2[b0][a2][be] = n[a2][0] * V[b0][be][0] + n[a2][1] * V[b0][be][1];
-#pragma unroll
-        for (int b0 = 0; b0 < 2; ++b0)
-#pragma unroll
-          for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) W02[b0][a2][pp] = c[pp][0] * V2[b0][a2][0] + c[pp][1] * V2[b0][a2][1];
-        // W12[b1][a2][p0] = sum_al c[p0][al] sum_ga n[a2][ga] sum_be n[b1][be] M12[al][be][ga]
-#pragma unroll
-        for (int b1 = 0; b1 < 2; ++b1)
-#pragma unroll
-          for (int al = 0; al < 2; ++al)
-#pragma unroll
-            for (int ga = 0; ga < 2; ++ga) V[b1][al][ga] = n[b1][0] * M12[al][0][ga] + n[b1][1] * M12[al][1][ga];
-#pragma unroll
-        for (int b1 = 0; b1 < 2; ++b1)
-#pragma unroll
-          for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-            for (int al = 0; al < 2; ++al) V2[b1][a2][al] = n[a2][0] * V[b1][al][0] + n[a2][1] * V[b1][al][1];
-#pragma unroll
-        for (int b1 = 0; b1 < 2; ++b1)
-#pragma unroll
-          for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) W12[b1][a2][pp] = c[pp][0] * V2[b1][a2][0] + c[pp][1] * V2[b1][a2][1];
-      }
+      double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3];
+#include "nh_p1hex_math.inc"
       // ---- form K[a][b] (a <= b) entry by entry and reduce it into the LDS row accumulators ---------------
 #pragma unroll
       for (int a = 0; a < 8; ++a) {
@@ -342,6 +207,78 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
   }
   if (NBUF == 1) __syncthreads();
   }  // persistent loop over boxes: with NBUF == 2, ONE barrier per box; the stores of this box drain while the next box computes
+}
+
+// ---- uniform geometry: all element matrices are equal (the reference hoists them out of the loop too) -------------
+// One thread evaluates the element matrix of the unit cell; the assembly is then a pure streaming kernel: every CSR entry is the
+// sum of the <= 8 element-matrix entries of the elements that contain both its row and its column dof.
+__global__ void k_p1hex_unit_matrix(P1Args p, double *Ke) {
+  double X[2][2][2][3];
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int c = 0; c < 2; ++c) {
+        X[a][b][c][0] = p.origin[0] + p.scale[0] * a;
+        X[a][b][c][1] = p.origin[1] + p.scale[1] * b;
+        X[a][b][c][2] = p.origin[2] + p.scale[2] * c;
+      }
+  ElemTables T;
+  {
+    double (&R0)[3][3] = T.R0, (&R1)[3][3] = T.R1, (&R2)[3][3] = T.R2;
+    double (&W01)[2][2][3] = T.W01, (&W02)[2][2][3] = T.W02, (&W12)[2][2][3] = T.W12;
+#include "nh_p1hex_math.inc"
+  }
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) Ke[a * 8 + b] = element_entry(T, a < b ? a : b, a < b ? b : a);
+}
+
+__global__ __launch_bounds__(256) void k_p1hex_uniform(P1Args p, const double *KeG) {
+  // one workgroup per (I, J) dof line; 32 lanes per row (27 slots), 8 rows per pass along K
+  __shared__ double Ke[64];
+  if (threadIdx.x < 64) Ke[threadIdx.x] = KeG[threadIdx.x];
+  __syncthreads();
+  const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
+  const int I = p.pl0 + blockIdx.x / N1, J = blockIdx.x % N1;
+  const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;
+  const int lenI = len_of(I, N0), lenJ = len_of(J, N1);
+  const i64 line = cum_of(I, N0) * T1 * T2 + lenI * (cum_of(J, N1) * T2);  // CSR offset of row (I, J, 0)
+  const int sl = threadIdx.x & 31, rsub = threadIdx.x >> 5;
+  if (sl >= 27) return;
+  const int dI = sl / 9 - 1, dJ = (sl / 3) % 3 - 1, dK = sl % 3 - 1;
+  const int cI = I + dI, cJ = J + dJ;
+  if (cI < 0 || cI >= N0 || cJ < 0 || cJ >= N1) return;
+  // per-thread constants: which of the (<= 4) element columns (i, j) around the dof line contribute, with their local vertices
+  double w[2][2][2];  // [ok][a2][b2] summed over the valid (oi, oj): entry of sum_{oi,oj} Ke[(a0,a1,a2)][(b0,b1,b2)]
+#pragma unroll
+  for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      double v = 0.;
+#pragma unroll
+      for (int oi = -1; oi <= 0; ++oi) {
+        const int i = I + oi, a0 = -oi, b0 = a0 + dI;
+        if (b0 < 0 || b0 > 1 || i < p.lay0 || i >= p.lay1) continue;
+#pragma unroll
+        for (int oj = -1; oj <= 0; ++oj) {
+          const int j = J + oj, a1 = -oj, b1 = a1 + dJ;
+          if (b1 < 0 || b1 > 1 || j < 0 || j >= p.n1) continue;
+          v += Ke[((a0 * 2 + a1) * 2 + a2) * 8 + (b0 * 2 + b1) * 2 + b2];
+        }
+      }
+      w[0][a2][b2] = v;
+    }
+  const int prefix = ((dI + (I > 0)) * lenJ + (dJ + (J > 0)));
+  for (int Kk = rsub; Kk < N2; Kk += 8) {
+    const int cK = Kk + dK;
+    if (cK < 0 || cK >= N2) continue;
+    double v = 0.;
+    // elements k = Kk - 1 (a2 = 1) and k = Kk (a2 = 0); b2 = a2 + dK
+    if (Kk >= 1 && dK <= 0) v += w[0][1][1 + dK];
+    if (Kk < p.n2 && dK >= 0) v += w[0][0][dK];
+    const int lenK = len_of(Kk, N2);
+    p.values[line + (i64)lenI * lenJ * cum_of(Kk, N2) + (prefix * lenK + (dK + (Kk > 0)))] = v;
+  }
 }
 
 __global__ void k_p1hex_pattern(int n0, int n1, int n2, i64 row0, i64 row1, i64 *rowptr, i64 *colidx) {
@@ -419,6 +356,15 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
   const int nbi = (p.pl1 - p.pl0 + BI - 1) / BI;
   p.nbj = (p.n1 + 1 + BJ - 1) / BJ;
   p.nbk = (p.n2 + 1 + BK - 1) / BK;
+  if (!a->verts_dev) {  // uniform geometry: unit element matrix + streaming kernel
+    double *Ke = nullptr;
+    NH_CHECK_HIP(hipMallocAsync((void **)&Ke, 64 * sizeof(double), nh_stream(stream)));
+    hipLaunchKernelGGL(k_p1hex_unit_matrix, dim3(1), dim3(1), 0, nh_stream(stream), p, Ke);
+    hipLaunchKernelGGL(k_p1hex_uniform, dim3((unsigned)((p.pl1 - p.pl0) * (p.n1 + 1))), dim3(256), 0, nh_stream(stream), p, (const double *)Ke);
+    NH_LAUNCH_CHECK();
+    NH_CHECK_HIP(hipFreeAsync(Ke, nh_stream(stream)));
+    return NH_OK;
+  }
   constexpr int ROWS = BI * BJ * BK, SETD = ROWS * 27 + ROWS + (ROWS + 1) / 2 + 1, SET = SETD + (SETD & 1);
   const size_t lds = sizeof(double) * NBUF * SET;
   p.nboxes = nbi * p.nbj * p.nbk;
