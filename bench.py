@@ -41,6 +41,15 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(kernel_name, n):
+    '''HBM bytes per launch measured with rocprofv3 PMC counters for this kernel (profiles/r01_traffic.json), or None.'''
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'))).get(kernel_name)
+        return d['fetch_bytes'] + d['write_bytes'] if d and d['n'] == n else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(variant):
     '''Oracle port (oracle/c, kind "port") on the host cores: bounded sample of the same workload.'''
     import numpy
@@ -136,7 +145,7 @@ def main():
                                    f'(BASELINE.json configs[1])', 'nelems_per_gpu': wl.nelems, 'nnz_per_gpu': wl.nnz, 'kernel': wl.kernel_name,
                        'parallelism': f'element slabs x{world}, halo-plane reduce' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bytes_per_elem},
+                         'traffic': measured_traffic(wl.kernel_name, a.n) if world == 1 else None, 'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bytes_per_elem},
             'pattern_ms': pattern_ms, 'setup_s': setup_s,
         }
         if world == 1 and a.variant == 'iso':
@@ -159,6 +168,7 @@ def main():
             ach = b2 * w2.nelems / (kms * 1e-3) / 1e9
             out['variants'] = {'uniform': {'value': w2.nelems * a.steps / el2, 'unit': 'elements/s', 'ms_per_step': el2 / a.steps * 1e3, 'kernel': w2.kernel_name,
                                            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                                                        'traffic': measured_traffic(w2.kernel_name, a.n),
                                                         'kernel_ms': kms, 'algorithmic_bytes_per_element': b2}}}
             del w2
         if not a.no_cpu and world == 1:

@@ -62,7 +62,7 @@ class PoissonSlab:
             self.pattern = self.smp.pattern(self.basis, self.basis)
             self.rowptr, self.colidx = self.pattern.expand()
             self.kernel_name = 'k_matrix_generic<3>'
-        self.values = device.zeros(self.colidx.numel(), 'float64')
+        self.values = device.zeros(self.colidx.numel(), 'float64')  # rows of a ghost plane are never written: keep them zero
         self.nnz = int(self.colidx.numel())
         self.halo = partition.HaloPlan(self.slab, self.rowptr) if self.world > 1 else None
         self._verts_dev = device.to_dev(self.verts, 'float64') if self.verts is not None else None
@@ -76,11 +76,11 @@ class PoissonSlab:
             if self.variant == 'iso':
                 g = kernels.geometry_iso(8, t.T, t.dofs[e0 * 8:], self.kgeom._keep[2])
             else:
-                g = kernels.geometry_box(self.kgeom._keep[0][e0 * 3:], self.kgeom._keep[1][e0 * 3:])
+                g = kernels.geometry_box(self.kgeom._keep[0].reshape(-1)[e0 * 3:], self.kgeom._keep[1].reshape(-1)[e0 * 3:])
             self._views = test, g, e0
         return self._views
 
-    def step(self, kernel_events=None):
+    def step(self, kernel_events=None, exchange=True):
         if self.fast:
             s = self.slab
             pts = self.smp.points
@@ -93,7 +93,7 @@ class PoissonSlab:
                                   planes=(s.ghost_layers, s.local_layers + 1))
             if kernel_events:
                 kernel_events[1].record()
-            if self.halo is not None:
+            if self.halo is not None and exchange:
                 self.halo.exchange(self.values)
             return
         test, g, e0 = self._own_views()
@@ -104,7 +104,7 @@ class PoissonSlab:
                                 C=self.C, mask=None, pattern=self.pattern, values=self.values, emap_offset=e0 * 64)
         if kernel_events:
             kernel_events[1].record()
-        if self.halo is not None:
+        if self.halo is not None and exchange:
             self.halo.exchange(self.values)
 
     def _gauss_w1(self):

@@ -1,0 +1,93 @@
+'''Multi-rank path on CPU: world_size-2 gloo run of the slab partition + interface-plane
+reduce (nutils_amd/partition.py).  The per-rank local assemblies are produced by the oracle
+(the product has no CPU compute path); what is under test is the product's partition
+bookkeeping, the point-to-point exchange and the owner-side reduce, and that the
+concatenation of the per-rank owned row blocks is the single-process global CSR --
+index arrays bit-exact.'''
+import os
+import socket
+import numpy
+import pytest
+
+from oracle import assemble as oa
+
+
+def local_assembly(n, nj, nk, rank, world, verts_global):
+    '''Oracle stand-in for one rank's device assembly: local mesh = own layers + ghost layer below,
+    values from the own layers only (ghost elements contribute structural zeros = pattern only).'''
+    from nutils_amd import partition
+    slab = partition.Slab(n, rank, world, (nj, nk))
+    shape = (slab.local_layers, nj, nk)
+    dofs, coeffs, ndofs = oa.structured_basis(shape, 'std', 1)
+    pts, w = oa.gauss(2, 3)
+    N, dN = oa.tabulate(coeffs, pts)
+    p0 = slab.first_global_plane
+    verts = verts_global[p0:p0 + slab.local_layers + 1].reshape(-1, 3)
+    x, J = oa.geometry_iso(verts, dofs, N, dN)
+    D, det = oa.physical_tables(N, dN, J)
+    A = oa.local_matrices(D, D, det * w, oa.laplace_coefficient(3))
+    A[:slab.ghost_layers * nj * nk] = 0.
+    return slab, oa.assemble_csr(A, dofs, dofs, ndofs, ndofs)
+
+
+def worker(rank, world, port, n, nj, nk, tmp):
+    import torch
+    import torch.distributed as dist
+    from nutils_amd import partition
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rng = numpy.random.default_rng(0)
+    NI = n * world + 1
+    verts_global = numpy.stack(numpy.meshgrid(numpy.arange(NI, dtype=float), numpy.arange(nj + 1.), numpy.arange(nk + 1.), indexing='ij'), -1) \
+        + rng.uniform(-.2, .2, (NI, nj + 1, nk + 1, 3))
+    slab, (values, rowptr, colidx) = local_assembly(n, nj, nk, rank, world, verts_global)
+    tv, trp = torch.from_numpy(values.copy()), torch.from_numpy(rowptr.copy())
+    plan = partition.HaloPlan(slab, trp)
+    plan.exchange(tv)
+    block = partition.owned_rows(slab, tv.numpy(), rowptr, colidx)
+    numpy.savez(os.path.join(tmp, f'block{rank}.npz'), values=block[0], rowptr=block[1], colidx=block[2])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_slab_partition_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+    from nutils_amd import partition
+    n, nj, nk = 3, 4, 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(worker, args=(world, port, n, nj, nk, str(tmp_path)), nprocs=world, join=True)
+    blocks = []
+    for r in range(world):
+        d = numpy.load(tmp_path / f'block{r}.npz')
+        blocks.append((d['values'], d['rowptr'], d['colidx']))
+    v, rp, ci = partition.concatenate(blocks)
+    # single-process reference: the global mesh in one piece
+    rng = numpy.random.default_rng(0)
+    NI = n * world + 1
+    verts = (numpy.stack(numpy.meshgrid(numpy.arange(NI, dtype=float), numpy.arange(nj + 1.), numpy.arange(nk + 1.), indexing='ij'), -1)
+             + rng.uniform(-.2, .2, (NI, nj + 1, nk + 1, 3))).reshape(-1, 3)
+    shape = (n * world, nj, nk)
+    dofs, coeffs, ndofs = oa.structured_basis(shape, 'std', 1)
+    pts, w = oa.gauss(2, 3)
+    N, dN = oa.tabulate(coeffs, pts)
+    x, J = oa.geometry_iso(verts, dofs, N, dN)
+    D, det = oa.physical_tables(N, dN, J)
+    vo, rpo, cio = oa.assemble_csr(oa.local_matrices(D, D, det * w, oa.laplace_coefficient(3)), dofs, dofs, ndofs, ndofs)
+    assert numpy.array_equal(rp, rpo) and numpy.array_equal(ci, cio)
+    assert numpy.abs(v - vo).max() <= 1e-13 * numpy.abs(vo).max()
+
+
+def test_slab_bookkeeping():
+    from nutils_amd import partition
+    s0, s1, s2 = (partition.Slab(4, r, 3, (5, 6)) for r in range(3))
+    assert (s0.ghost_layers, s1.ghost_layers, s2.ghost_layers) == (0, 1, 1)
+    assert (s0.first_global_plane, s1.first_global_plane, s2.first_global_plane) == (0, 3, 7)
+    # owned planes tile the global plane range [0, 13) without overlap
+    owned = [range(s.first_global_plane + s.own_plane_begin, s.first_global_plane + s.own_plane_end) for s in (s0, s1, s2)]
+    assert [list(o) for o in owned] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11, 12]]
+    assert s0.sends and not s0.recvs and s1.sends and s1.recvs and s2.recvs and not s2.sends
+    with pytest.raises(ValueError):
+        partition.Slab(4, 3, 3, (1, 1))
