@@ -120,6 +120,8 @@ typedef struct {
   const double *verts_dev;   /* ISO: [nverts][ndims] */
   const double *origin_dev;  /* BOX: [nelems][ndims] */
   const double *size_dev;    /* BOX: [nelems][ndims] */
+  int bnd_axis;              /* -1: volume measure |det J|.  a >= 0: the points lie on the reference face xi_a = const and the
+                                measure is the surface measure |det J| |J^-T e_a| (boundary integrals, topology.boundary) */
 } nh_geometry;
 
 /* ---- basis-on-elements descriptor ------------------------------------------------ */
@@ -154,6 +156,8 @@ typedef struct {
   const int32_t *emap_dev;   /* element map from nh_pattern_info */
   const int64_t *eoff_dev;   /* ragged: int64[nelems+1] prefix sums of nbt_e*nbr_e, else NULL */
   double *values_dev;        /* [nnz of the expanded pattern] */
+  const double *scale_dev;   /* optional pointwise factor of the integrand [nelems][nq] (a coefficient function evaluated at
+                                the quadrature points), NULL = 1.  With elist_dev, scale and emap are indexed by LIST position. */
 } nh_matrix_args;
 
 int nh_assemble_matrix(const nh_matrix_args *args, void *stream);
@@ -179,6 +183,7 @@ typedef struct {
   double *out_dev;           /* [nrows][nct] accumulated, or NULL */
   double f0;                 /* constant integrand of the functional */
   double *out_scalar_dev;    /* [1] accumulated, or NULL */
+  const double *scale_dev;   /* optional pointwise factor [nelems][nq] (list position with elist_dev), NULL = 1 */
 } nh_vector_args;
 
 int nh_assemble_vector(const nh_vector_args *args, void *stream);
@@ -189,6 +194,7 @@ int nh_assemble_vector(const nh_vector_args *args, void *stream);
  * U[e][q][ncr][S] (value and physical gradient of the field u). */
 typedef struct {
   int64_t nelems;
+  const int32_t *elist_dev;  /* optional element subset, NULL = 0..nelems-1; outputs are indexed by list position */
   int ndims, nq;
   nh_geometry geom;
   nh_basis trial;

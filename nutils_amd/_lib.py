@@ -27,7 +27,7 @@ class NutilsHipError(RuntimeError):
 
 class Geometry(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int), ('ngb', ctypes.c_int), ('gT_dev', vp), ('gdofs_dev', vp), ('verts_dev', vp),
-                ('origin_dev', vp), ('size_dev', vp)]
+                ('origin_dev', vp), ('size_dev', vp), ('bnd_axis', ctypes.c_int)]
 
 
 class Basis(ctypes.Structure):
@@ -42,17 +42,17 @@ class PatternArgs(ctypes.Structure):
 class MatrixArgs(ctypes.Structure):
     _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp),
                 ('geom', Geometry), ('test', Basis), ('trial', Basis), ('nct', ctypes.c_int), ('ncr', ctypes.c_int),
-                ('C_host', vp), ('mask_host', vp), ('srowptr_dev', vp), ('emap_dev', vp), ('eoff_dev', vp), ('values_dev', vp)]
+                ('C_host', vp), ('mask_host', vp), ('srowptr_dev', vp), ('emap_dev', vp), ('eoff_dev', vp), ('values_dev', vp), ('scale_dev', vp)]
 
 
 class VectorArgs(ctypes.Structure):
     _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp),
                 ('geom', Geometry), ('test', Basis), ('trial', Basis), ('nct', ctypes.c_int), ('ncr', ctypes.c_int),
-                ('C_host', vp), ('f_host', vp), ('u_dev', vp), ('out_dev', vp), ('f0', ctypes.c_double), ('out_scalar_dev', vp)]
+                ('C_host', vp), ('f_host', vp), ('u_dev', vp), ('out_dev', vp), ('f0', ctypes.c_double), ('out_scalar_dev', vp), ('scale_dev', vp)]
 
 
 class EvalArgs(ctypes.Structure):
-    _fields_ = [('nelems', c_i64), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('geom', Geometry), ('trial', Basis),
+    _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('geom', Geometry), ('trial', Basis),
                 ('ncr', ctypes.c_int), ('points_dev', vp), ('u_dev', vp), ('x_dev', vp), ('detj_dev', vp), ('U_dev', vp)]
 
 

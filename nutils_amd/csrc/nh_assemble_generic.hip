@@ -100,6 +100,15 @@ __device__ __forceinline__ void geometry_at(const GeomK &g, i64 e, int q, int nq
     }
   }
   invert<ND>(J, Ji, det);
+  if (g.bnd_axis >= 0) {  // surface measure of the face xi_axis = const: |det J| |J^-T e_axis|
+    double s2 = 0;
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+        if (j == g.bnd_axis) s2 += Ji[j][i] * Ji[j][i];
+    det *= sqrt(s2);
+  }
 }
 
 __device__ __forceinline__ i64 boff(const BasisK &b, i64 e) { return b.off ? b.off[e] : e * (i64)b.nb; }
@@ -140,6 +149,7 @@ struct MatK {
   const int32_t *emap;
   const i64 *eoff;
   double *values;
+  const double *scale;
   int qchunk;
   int maxnbt, maxnbr;
 };
@@ -163,11 +173,11 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
       for (int j = 0; j < ND; ++j)
 #pragma unroll
         for (int i = 0; i < ND; ++i) Jw[q * JW + j * ND + i] = Ji[j][i];
-      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det);
+      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det) * (p.scale ? p.scale[ie * p.nq + q] : 1.);
     }
     __syncthreads();
     const i64 tdof0 = boff(p.test, e);
-    const i64 emap0 = p.eoff ? p.eoff[e] : e * (i64)nbt * nbr;
+    const i64 emap0 = p.eoff ? p.eoff[e] : ie * (i64)nbt * nbr;  // list position (== e without elist)
     const int nentries = nbt * form.nct * nbr * form.ncr;
     for (int q0 = 0; q0 < p.nq; q0 += p.qchunk) {
       const int q1 = min(p.nq, q0 + p.qchunk);
@@ -218,6 +228,7 @@ struct VecK {
   double *out;
   double f0;
   double *out_scalar;
+  const double *scale;
   int qchunk, maxnbt, maxnbr;
 };
 
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
       for (int j = 0; j < ND; ++j)
 #pragma unroll
         for (int i = 0; i < ND; ++i) Jw[q * JW + j * ND + i] = Ji[j][i];
-      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det);
+      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det) * (p.scale ? p.scale[ie * p.nq + q] : 1.);
     }
     __syncthreads();
     const i64 tdof0 = boff(p.test, e), rdof0 = boff(p.trial, e);
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
 
 struct EvalK {
   i64 nelems;
+  const int32_t *elist;
   int nq;
   GeomK geom;
   BasisK trial;
@@ -327,7 +339,7 @@ __global__ void k_sample_eval(EvalK p) {
   constexpr int S = 1 + ND;
   const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= p.nelems * p.nq) return;
-  const i64 e = t / p.nq;
+  const i64 e = p.elist ? p.elist[t / p.nq] : t / p.nq;
   const int q = (int)(t % p.nq);
   double Ji[ND][ND], det, x[ND];
   geometry_at<ND>(p.geom, e, q, p.nq, p.points, Ji, det, x);
@@ -438,6 +450,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   p.emap = a->emap_dev;
   p.eoff = (const i64 *)a->eoff_dev;
   p.values = a->values_dev;
+  p.scale = a->scale_dev;
   NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "nh_assemble_matrix: elist with ragged bases is not supported");
   if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
   if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
@@ -490,6 +503,7 @@ int nh_assemble_vector(const nh_vector_args *a, void *stream) {
   p.out = a->out_dev;
   p.f0 = a->f0;
   p.out_scalar = a->out_scalar_dev;
+  p.scale = a->scale_dev;
   if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
   if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
   const int per_q = ((p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S + 2 * MAXC * S) * (int)sizeof(double);
@@ -522,6 +536,7 @@ int nh_sample_eval(const nh_eval_args *a, void *stream) {
   if (!n) return NH_OK;
   EvalK p;
   p.nelems = a->nelems;
+  p.elist = a->elist_dev;
   p.nq = a->nq;
   p.geom = to_k(a->geom);
   p.trial = to_k(a->trial);

@@ -95,6 +95,43 @@ def J(geom):
     return Measure(geom)
 
 
+class PointFunc:
+    '''Scalar coefficient function of the physical coordinates (e.g. a Neumann flux
+    ``cos(1) cosh(x_1)``, examples/laplace.py:68).  It is evaluated once per sample at the
+    quadrature points -- coordinates come from the device (nh_sample_eval), the callable
+    `func(x: (npoints, ndims)) -> (npoints,)` runs in numpy -- and enters the element
+    kernels as a pointwise factor of the integrand (scale_dev).'''
+
+    __array_ufunc__ = None
+
+    def __init__(self, func, geom):
+        if not isinstance(geom, Geometry):
+            raise TypeError('PointFunc expects a geometry')
+        self.func, self.geom = func, geom
+
+    def __call__(self, x):
+        v = numpy.asarray(self.func(x), dtype=float)
+        if v.shape != (len(x),):
+            v = numpy.broadcast_to(v, (len(x),)).copy()
+        return v
+
+    def __mul__(self, other):
+        if isinstance(other, PointFunc):
+            if other.geom is not self.geom:
+                raise NotImplementedError('coefficient functions of different geometries')
+            f, g = self.func, other.func
+            return PointFunc(lambda x: numpy.asarray(f(x)) * numpy.asarray(g(x)), self.geom)
+        if isinstance(other, (int, float)):
+            f = self.func
+            return PointFunc(lambda x: numpy.asarray(f(x)) * other, self.geom)
+        return _as_integrand(other).with_scale(self)
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self * -1.
+
+
 # ---- arguments and operands ----------------------------------------------------------
 
 class Arg:
@@ -164,7 +201,7 @@ class Operand:
         return Operand(self.arg, a * b[..., None, None], self.geom)
 
     def __mul__(self, other):
-        if isinstance(other, Measure):
+        if isinstance(other, (Measure, PointFunc)):
             return other.__mul__(self)
         from .basis import Basis
         if isinstance(other, Basis):
@@ -280,14 +317,16 @@ class Integrand:
 
     __array_ufunc__ = None
 
-    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False):
+    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False, scale=None):
         self.test, self.trial, self.B, self.L, self.f0 = test, trial, B, L, f0
+        self.scale = scale      # PointFunc multiplying the whole integrand, or None
         self.geom = geom        # geometry the gradients refer to
         self.measure = measure  # geometry of the measure
         self.rows, self.cols = rows, cols  # dof axis of test / trial is an array axis (else: bound to an argument value)
 
     def _copy(self, **kw):
-        d = dict(test=self.test, trial=self.trial, B=self.B, L=self.L, f0=self.f0, geom=self.geom, measure=self.measure, rows=self.rows, cols=self.cols)
+        d = dict(test=self.test, trial=self.trial, B=self.B, L=self.L, f0=self.f0, geom=self.geom, measure=self.measure, rows=self.rows, cols=self.cols,
+                 scale=self.scale)
         d.update(kw)
         return Integrand(**d)
 
@@ -316,9 +355,14 @@ class Integrand:
             raise NotImplementedError('gradient geometry and measure geometry differ')
         return self._copy(measure=geom)
 
+    def with_scale(self, pf):
+        return self._copy(scale=pf if self.scale is None else self.scale * pf)
+
     def __mul__(self, other):
         if isinstance(other, Measure):
             return self.with_measure(other.geom)
+        if isinstance(other, PointFunc):
+            return self.with_scale(other)
         if isinstance(other, (Operand, Integrand)):
             raise NotImplementedError('products of more than two argument-dependent factors are outside the accelerated path')
         other = numpy.asarray(other, dtype=float)
@@ -346,7 +390,8 @@ class Integrand:
         def same(a, b):
             return (a is None and b is None) or (a is not None and b is not None and a.same(b))
         return same(self.test, other.test) and same(self.trial, other.trial) and self.rows == other.rows and self.cols == other.cols \
-            and self.measure is other.measure and (self.B is None) == (other.B is None) and (self.L is None) == (other.L is None)
+            and self.measure is other.measure and (self.B is None) == (other.B is None) and (self.L is None) == (other.L is None) \
+            and self.scale is other.scale
 
     def __add__(self, other):
         other = _as_integrand(other)
@@ -364,6 +409,8 @@ def _as_integrand(obj):
         return obj
     if isinstance(obj, Measure):
         return Integrand(f0=numpy.ones(()), measure=obj.geom)
+    if isinstance(obj, PointFunc):
+        return Integrand(f0=numpy.ones(()), scale=obj)
     if isinstance(obj, (int, float, numpy.ndarray)):
         return Integrand(f0=numpy.asarray(obj, dtype=float))
     op = _as_operand(obj)

@@ -69,14 +69,14 @@ class Pattern:
             self._handle = None
 
 
-def geometry_iso(ngb, gT, gdofs, verts):
-    g = _lib.Geometry(_lib.GEOM_ISO, ngb, device.ptr(gT), device.ptr(gdofs), device.ptr(verts), None, None)
+def geometry_iso(ngb, gT, gdofs, verts, bnd_axis=-1):
+    g = _lib.Geometry(_lib.GEOM_ISO, ngb, device.ptr(gT), device.ptr(gdofs), device.ptr(verts), None, None, bnd_axis)
     g._keep = (gT, gdofs, verts)
     return g
 
 
-def geometry_box(origin, size):
-    g = _lib.Geometry(_lib.GEOM_BOX, 0, None, None, None, device.ptr(origin), device.ptr(size))
+def geometry_box(origin, size, bnd_axis=-1):
+    g = _lib.Geometry(_lib.GEOM_BOX, 0, None, None, None, device.ptr(origin), device.ptr(size), bnd_axis)
     g._keep = (origin, size)
     return g
 
@@ -87,7 +87,7 @@ def basis(T, dofs, nb=0, off=None, tab=None):
     return b
 
 
-def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0):
+def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None):
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.'''
     C = numpy.ascontiguousarray(C, dtype=float)
     if C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
@@ -95,12 +95,12 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
     args = _lib.MatrixArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
                            device.host_ptr(m), pattern.srowptr_ptr, ctypes.c_void_p(pattern.emap_ptr.value + 4 * emap_offset), pattern.eoff_ptr,
-                           device.ptr(values))
+                           device.ptr(values), device.ptr(scale))
     _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
 
 
 def assemble_vector(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C=None, f=None, u=None, out=None, f0=0., out_scalar=None,
-                    elist=None):
+                    elist=None, scale=None):
     C = None if C is None else numpy.ascontiguousarray(C, dtype=float)
     f = None if f is None else numpy.ascontiguousarray(f, dtype=float)
     if C is not None and C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
@@ -108,14 +108,14 @@ def assemble_vector(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     if f is not None and f.shape != (nct, 1 + ndims):
         raise ValueError(f'source tensor has shape {f.shape}')
     args = _lib.VectorArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
-                           device.host_ptr(f), device.ptr(u), device.ptr(out), float(f0), device.ptr(out_scalar))
+                           device.host_ptr(f), device.ptr(u), device.ptr(out), float(f0), device.ptr(out_scalar), device.ptr(scale))
     _lib.call('nh_assemble_vector', ctypes.byref(args), device.stream())
 
 
-def sample_eval(*, nelems, ndims, nq, geom, trial=None, ncr=1, points=None, u=None, x=None, detj=None, U=None):
+def sample_eval(*, nelems, ndims, nq, geom, trial=None, ncr=1, points=None, u=None, x=None, detj=None, U=None, elist=None):
     if trial is None:
         trial = _lib.Basis(0, None, None, None, None)
-    args = _lib.EvalArgs(nelems, ndims, nq, geom, trial, ncr, device.ptr(points), device.ptr(u), device.ptr(x), device.ptr(detj), device.ptr(U))
+    args = _lib.EvalArgs(nelems, device.ptr(elist), ndims, nq, geom, trial, ncr, device.ptr(points), device.ptr(u), device.ptr(x), device.ptr(detj), device.ptr(U))
     _lib.call('nh_sample_eval', ctypes.byref(args), device.stream())
 
 

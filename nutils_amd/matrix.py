@@ -57,7 +57,7 @@ class ScipyMatrix:
         else:
             constrain = numpy.asarray(constrain)
             if constrain.dtype == bool:
-                free = ~constrain
+                free = ~constrain.ravel()
             else:
                 free = numpy.isnan(constrain)
                 x[~free] = constrain[~free]

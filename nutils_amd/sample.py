@@ -44,12 +44,17 @@ class _BasisTables:
 
 class Sample:
 
-    def __init__(self, topo, points):
+    def __init__(self, topo, points, elist=None, bnd_axis=-1):
         self.topo = topo
         self.points = points
         self.ndims = topo.ndims
         self.nelems = topo.nelems
-        self.npoints = self.nelems * points.npoints
+        # a sample on part of the topology (boundary faces): element subset + the reference axis that is constant on the face
+        self.elist = None if elist is None else numpy.ascontiguousarray(elist, dtype=numpy.int32)
+        self.bnd_axis = int(bnd_axis)
+        self.nlist = self.nelems if self.elist is None else len(self.elist)
+        self.npoints = self.nlist * points.npoints
+        self._scales = {}
         self._tables = {}
         self._geoms = {}
         self._patterns = {}
@@ -68,6 +73,24 @@ class Sample:
         self._points_dev
         return self.__dev[1]
 
+    @property
+    def _elist_dev(self):
+        if self.elist is None:
+            return None
+        if not hasattr(self, '_elist_t'):
+            self._elist_t = device.to_dev(self.elist, 'int32')
+        return self._elist_t
+
+    def scale(self, pf):
+        '''Device array [nlist][nq] of a coefficient function at the sample points (None -> None).'''
+        if pf is None:
+            return None
+        s = self._scales.get(id(pf))
+        if s is None:
+            x = self._eval_one(pf.geom, {})
+            s = self._scales[id(pf)] = (device.to_dev(pf(x), 'float64'), pf)
+        return s[0]
+
     def tables(self, basis):
         if basis.nelems != self.nelems or basis.ndims != self.ndims:
             raise ValueError('basis does not live on the topology of this sample')
@@ -81,12 +104,12 @@ class Sample:
         if g is None:
             if isinstance(geom, function.IsoGeometry):
                 t = self.tables(geom.basis)
-                g = kernels.geometry_iso(geom.basis.nb, t.T, t.dofs, device.to_dev(geom.verts, 'float64'))
+                g = kernels.geometry_iso(geom.basis.nb, t.T, t.dofs, device.to_dev(geom.verts, 'float64'), self.bnd_axis)
             elif isinstance(geom, (function.RectilinearGeometry, function.BoxGeometry)):
                 origin, size = geom.element_boxes()
                 if len(origin) != self.nelems:
                     raise ValueError('geometry does not match the sample')
-                g = kernels.geometry_box(device.to_dev(origin, 'float64'), device.to_dev(size, 'float64'))
+                g = kernels.geometry_box(device.to_dev(origin, 'float64'), device.to_dev(size, 'float64'), self.bnd_axis)
             else:
                 raise TypeError(f'unsupported geometry {type(geom).__name__}')
             self._geoms[id(geom)] = g
@@ -97,8 +120,16 @@ class Sample:
         p = self._patterns.get(key)
         if p is None:
             tt, tr = self.tables(test_basis), self.tables(trial_basis)
-            p = self._patterns[key] = kernels.Pattern(self.nelems, test_basis.ndofs, trial_basis.ndofs, tt.dofs, tr.dofs, nbt=tt.nb, nbr=tr.nb,
-                                                      toff=tt.off, roff=tr.off)
+            if self.elist is None:
+                p = kernels.Pattern(self.nelems, test_basis.ndofs, trial_basis.ndofs, tt.dofs, tr.dofs, nbt=tt.nb, nbr=tr.nb, toff=tt.off, roff=tr.off)
+            else:  # pattern of the listed elements only (emap is then indexed by list position)
+                if not (tt.nb and tr.nb):
+                    raise NotImplementedError('element subsets with ragged bases')
+                idx = self._elist_dev.long()
+                td = tt.dofs.view(self.nelems, tt.nb)[idx].reshape(-1).contiguous()
+                rd = tr.dofs.view(self.nelems, tr.nb)[idx].reshape(-1).contiguous()
+                p = kernels.Pattern(self.nlist, test_basis.ndofs, trial_basis.ndofs, td, rd, nbt=tt.nb, nbr=tr.nb)
+            self._patterns[key] = p
         return p
 
     # -- reference interface --
@@ -128,15 +159,16 @@ class Sample:
         return out[0] if single else out
 
     def _eval_one(self, f, arguments):
-        nq, nd, ne = self.points.npoints, self.ndims, self.nelems
+        nq, nd, ne = self.points.npoints, self.ndims, self.nlist
         n = ne * nq
+        el = self._elist_dev
         if isinstance(f, function.Geometry):
             x = device.empty(n * nd, 'float64')
-            kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(f), points=self._points_dev, x=x)
+            kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(f), points=self._points_dev, x=x, elist=el)
             return device.to_host(x).reshape(n, nd)
         if isinstance(f, function.Measure):
             dj = device.empty(n, 'float64')
-            kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(f.geom), points=self._points_dev, detj=dj)
+            kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(f.geom), points=self._points_dev, detj=dj, elist=el)
             return device.to_host(dj)
         if isinstance(f, function.Operand):
             if f.arg.name is None:
@@ -148,7 +180,7 @@ class Sample:
             nc = f.arg.ncomp
             U = device.empty(n * nc * (1 + nd), 'float64')
             kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(geom), trial=self.tables(f.arg.basis).struct, ncr=nc,
-                                points=self._points_dev, u=device.to_dev(u, 'float64'), U=U)
+                                points=self._points_dev, u=device.to_dev(u, 'float64'), U=U, elist=el)
             Uh = device.to_host(U).reshape(n, nc, 1 + nd)
             # tiny host contraction with the operand's constant tensor: value[free] = P[free,c,s] U[c,s]
             return numpy.einsum('...cs,ncs->n...', f.P, Uh)
@@ -181,8 +213,8 @@ class _MatrixPlan:
         for smp, itg, fac in terms:
             if itg.B is None or not (itg.rows and itg.cols):
                 raise ValueError('as_csr needs a matrix-valued integral (both dof axes exposed)')
-            if smp is not smp0 and (smp.topo is not smp0.topo):
-                raise NotImplementedError('matrix terms on different topologies')
+            if smp is not smp0:
+                raise NotImplementedError('matrix terms on different samples in one as_csr: evaluate them separately and add the matrices')
             if not (itg.test.basis is itg0.test.basis and itg.trial.basis is itg0.trial.basis and itg.test.ncomp == itg0.test.ncomp
                     and itg.trial.ncomp == itg0.trial.ncomp):
                 raise NotImplementedError('matrix terms with different bases')
@@ -203,9 +235,10 @@ class _MatrixPlan:
             if itg.measure is None:
                 raise NotImplementedError('integrand without J(geom): reference-space integrals are outside the accelerated path')
             tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
-            kernels.assemble_matrix(nelems=smp.nelems, ndims=smp.ndims, nq=smp.points.npoints, weights=smp._weights_dev,
+            kernels.assemble_matrix(nelems=smp.nlist, ndims=smp.ndims, nq=smp.points.npoints, weights=smp._weights_dev,
                                     geom=smp.geometry(itg.measure), test=tt.struct, trial=tr.struct, nct=nct, ncr=ncr, C=itg.B * fac,
-                                    mask=mask, pattern=smp.pattern(itg.test.basis, itg.trial.basis), values=values)
+                                    mask=mask, pattern=smp.pattern(itg.test.basis, itg.trial.basis), values=values, elist=smp._elist_dev,
+                                    scale=smp.scale(itg.scale))
         return values, rowptr, colidx, self.trial.basis.ndofs * ncr
 
 
@@ -218,18 +251,18 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
         tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
         if itg.rows and not itg.cols:
             u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-            kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                     nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=out)
             return
         if not itg.rows and not itg.cols:
             if itg.test.same(itg.trial):
                 u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-                kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+                kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                         nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * (2 * fac), u=u, out_scalar=scalar[0])
             else:
                 tmp = device.zeros(itg.test.basis.ndofs * itg.test.ncomp, 'float64')
                 u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-                kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+                kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                         nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=tmp)
                 # v . r for two different bound fields: O(ndofs) post-processing on the host
                 scalar[1] += float(numpy.dot(device.to_host(tmp), _argument(arguments, itg.test).ravel()))
@@ -238,16 +271,16 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
     if itg.L is not None:
         tt = smp.tables(itg.test.basis)
         if itg.rows:
-            kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
+            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
                                     nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, out=out)
         else:
             u = device.to_dev(_argument(arguments, itg.test), 'float64')
-            kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
+            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
                                     nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, u=u, out_scalar=scalar[0])
         return
     # constant integrand (volume-type functional): basis-free launch
     none = kernels.basis(None, None)
-    kernels.assemble_vector(nelems=smp.nelems, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=none, trial=none, nct=1, ncr=1,
+    kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=none, trial=none, nct=1, ncr=1,
                             f0=float(itg.f0) * fac, out_scalar=scalar[0])
 
 

@@ -60,6 +60,60 @@ class StructuredTopology(Topology):
             self._bases[key] = _basis.StructuredBasis(self.shape, btype, degree)
         return self._bases[key]
 
+    @property
+    def boundary(self):
+        if not hasattr(self, '_boundary'):
+            self._boundary = _Boundary(self)
+        return self._boundary
+
+
+class BoundaryTopology(Topology):
+    '''One side of a structured topology (``domain.boundary['left']`` etc.; names as in the
+    reference: left/right = first axis, bottom/top = second, front/back = third).  Bases and
+    fields are those of the parent (their traces); samples are Gauss points on the face,
+    embedded in the parent element's reference coordinates.'''
+
+    def __init__(self, parent, axis, side):
+        self.parent, self.axis, self.side = parent, axis, side
+        self.ndims = parent.ndims
+        idx = numpy.arange(parent.nelems).reshape(parent.shape)
+        self.elements = numpy.ascontiguousarray(numpy.take(idx, 0 if side == 0 else parent.shape[axis] - 1, axis=axis).ravel(), dtype=numpy.int32)
+        self.nelems = len(self.elements)
+
+    def basis(self, btype, degree=1):
+        return self.parent.basis(btype, degree)
+
+    def sample(self, ischeme, degree):
+        key = ischeme, degree
+        cache = self.__dict__.setdefault('_samples', {})
+        if key not in cache:
+            if ischeme != 'gauss':
+                raise NotImplementedError(f'point scheme {ischeme!r} on a boundary')
+            nd = self.ndims
+            face = _points.gauss(degree, nd - 1) if nd > 1 else _points.Points(numpy.zeros((1, 0)), numpy.ones(1))
+            coords = numpy.insert(face.coords, self.axis, float(self.side), axis=1)
+            cache[key] = _sample.Sample(self.parent, _points.Points(coords, face.weights), elist=self.elements, bnd_axis=self.axis)
+        return cache[key]
+
+
+_BNAMES = ('left', 'right'), ('bottom', 'top'), ('front', 'back')
+
+
+class _Boundary:
+    def __init__(self, parent):
+        self.parent = parent
+        self._cache = {}
+
+    def __getitem__(self, name):
+        if name not in self._cache:
+            for axis, names in enumerate(_BNAMES[:self.parent.ndims]):
+                if name in names:
+                    self._cache[name] = BoundaryTopology(self.parent, axis, names.index(name))
+                    break
+            else:
+                raise KeyError(name)
+        return self._cache[name]
+
 
 class ElementList(Topology):
     '''Unstructured list of axis-aligned box elements with externally supplied
