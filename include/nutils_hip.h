@@ -232,6 +232,20 @@ typedef struct {
 int nh_p1hex_pattern(const int *shape, int64_t row_begin, int64_t row_end, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream);
 int nh_p1hex_laplace(const nh_p1hex_args *args, void *stream);
 
+/* ---- Monomial: evaluation of factored (pre-integrated) polynomial functionals -------------
+ * replaces evaluable.Monomial (evaluable.py:5693-5751; `out = values.copy(); out *= arg[index]`
+ * + Inflate/add.at), the per-Newton-step work after evaluable.factor (evaluable.py:5785-5874)
+ * has evaluated the sparse Taylor coefficient tensors once with the element loop above.
+ * nh_monomial_csr: y[r] += alpha * sum_k values[k] x[colidx[k]] over CSR row r (rank-2 tensor,
+ *   deterministic, no atomics).
+ * nh_monomial: out[out_index[i]] += alpha values[i] prod_k args[k][indices[k][i]], nargs <= 4;
+ *   out_index NULL: scalar result accumulated in out[0].  args_dev / indices_dev are HOST arrays
+ *   of device pointers. */
+int nh_monomial_csr(int64_t nrows, const int64_t *rowptr_dev, const int64_t *colidx_dev, const double *values_dev, const double *x_dev,
+                    double alpha, double *y_dev, void *stream);
+int nh_monomial(int64_t n, const double *values_dev, int nargs, const double *const *args_dev, const int64_t *const *indices_dev,
+                const int64_t *out_index_dev, double alpha, double *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,85 @@
+// Monomial (evaluable.py:5693-5751, helper of evaluable.factor :5785-5874): gather-multiply-scatter over the entries of a
+// precomputed sparse coefficient tensor:   out[oidx[i]] += alpha * values[i] * prod_k arg_k[idx_k[i]]
+// (the reference: `out = values.copy(); out *= arg[index] ...` followed by Inflate / add.at).  Two forms:
+//   * CSR rows as output index (rank-2 tensors from as_csr): one half-wave per row, no atomics, deterministic;
+//   * general COO with up to 4 gathered arguments and an optional output index (scalar result if NULL).
+#include "nh_common.h"
+#include <algorithm>
+
+namespace {
+
+__global__ void k_monomial_csr(i64 nrows, const i64 *rowptr, const i64 *colidx, const double *values, const double *x, double alpha,
+                               double *y) {
+  const i64 row = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int lane = threadIdx.x & 31;
+  if (row >= nrows) return;
+  double s = 0;
+  for (i64 k = rowptr[row] + lane; k < rowptr[row + 1]; k += 32) s += values[k] * x[colidx[k]];
+#pragma unroll
+  for (int o = 16; o; o >>= 1) s += __shfl_xor(s, o, 32);
+  if (lane == 0) y[row] += alpha * s;
+}
+
+struct MonoK {
+  i64 n;
+  const double *values;
+  int nargs;
+  const double *arg[4];
+  const i64 *idx[4];
+  const i64 *oidx;
+  double alpha;
+  double *out;
+};
+
+__global__ void k_monomial(MonoK p) {
+  double acc = 0;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (i64)gridDim.x * blockDim.x) {
+    double v = p.alpha * p.values[i];
+    for (int k = 0; k < p.nargs; ++k) v *= p.arg[k][p.idx[k][i]];
+    if (p.oidx) atomicAdd(p.out + p.oidx[i], v);
+    else acc += v;
+  }
+  if (!p.oidx) {
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(p.out, acc);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nh_monomial_csr(int64_t nrows, const int64_t *rowptr_dev, const int64_t *colidx_dev, const double *values_dev, const double *x_dev,
+                    double alpha, double *y_dev, void *stream) {
+  NH_REQUIRE(nrows >= 0 && rowptr_dev && colidx_dev && values_dev && x_dev && y_dev, "nh_monomial_csr: invalid argument");
+  if (!nrows) return NH_OK;
+  hipLaunchKernelGGL(k_monomial_csr, dim3((unsigned)((nrows * 32 + 255) / 256)), dim3(256), 0, nh_stream(stream), (i64)nrows, (const i64 *)rowptr_dev,
+                     (const i64 *)colidx_dev, values_dev, x_dev, alpha, y_dev);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+int nh_monomial(int64_t n, const double *values_dev, int nargs, const double *const *args_dev, const int64_t *const *indices_dev,
+                const int64_t *out_index_dev, double alpha, double *out_dev, void *stream) {
+  NH_REQUIRE(n >= 0 && values_dev && out_dev, "nh_monomial: invalid argument");
+  NH_REQUIRE(nargs >= 0 && nargs <= 4, "nh_monomial: at most 4 gathered arguments (got %d)", nargs);
+  if (!n) return NH_OK;
+  MonoK p;
+  p.n = n;
+  p.values = values_dev;
+  p.nargs = nargs;
+  for (int k = 0; k < 4; ++k) {
+    p.arg[k] = k < nargs ? args_dev[k] : nullptr;
+    p.idx[k] = k < nargs ? (const i64 *)indices_dev[k] : nullptr;
+    NH_REQUIRE(k >= nargs || (p.arg[k] && p.idx[k]), "nh_monomial: NULL argument %d", k);
+  }
+  p.oidx = (const i64 *)out_index_dev;
+  p.alpha = alpha;
+  p.out = out_dev;
+  const unsigned grid = (unsigned)std::min<i64>((n + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(k_monomial, dim3(grid), dim3(256), 0, nh_stream(stream), p);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+}  // extern "C"

@@ -516,7 +516,8 @@ class _AsCSR:
 def as_csr(integral):
     '''function.as_csr (function.py:2432-2437): evaluates to (values, rowptr, colidx);
     index arrays int64, rows/cols sorted, structural zeros retained.'''
-    if not isinstance(integral, Integral):
+    from . import factor as _factor
+    if not isinstance(integral, (Integral, _factor.FactoredMatrix)):
         raise TypeError('as_csr expects an Integral')
     return _AsCSR(integral)
 
@@ -543,3 +544,9 @@ def eval(funcs, /, arguments=None, **kwargs):
 
 
 evaluate = eval
+
+
+def factor(integral, name=None):
+    '''function.factor (function.py:2630-2642): pre-integrated form of a polynomial functional.'''
+    from . import factor as _factor
+    return _factor.factor(integral, name)

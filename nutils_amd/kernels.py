@@ -161,3 +161,17 @@ def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0.
     a.kappa = float(kappa)
     a.values_dev = device.ptr(values)
     _lib.call('nh_p1hex_laplace', ctypes.byref(a), device.stream())
+
+
+def monomial_csr(rowptr, colidx, values, x, y, alpha=1.):
+    '''y[r] += alpha * sum_k values[k] x[colidx[k]] (nh_monomial_csr).'''
+    _lib.call('nh_monomial_csr', rowptr.numel() - 1, device.ptr(rowptr), device.ptr(colidx), device.ptr(values), device.ptr(x), float(alpha), device.ptr(y),
+              device.stream())
+
+
+def monomial(values, args, indices, out, out_index=None, alpha=1.):
+    '''out[out_index[i]] += alpha values[i] prod_k args[k][indices[k][i]] (nh_monomial).'''
+    n = len(args)
+    A = (ctypes.c_void_p * max(n, 1))(*[a.data_ptr() for a in args])
+    I = (ctypes.c_void_p * max(n, 1))(*[i.data_ptr() for i in indices])
+    _lib.call('nh_monomial', values.numel(), device.ptr(values), n, A, I, device.ptr(out_index), float(alpha), device.ptr(out), device.stream())

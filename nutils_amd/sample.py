@@ -286,6 +286,9 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
 
 def evaluate(f, arguments):
     '''Evaluate one Integral / as_csr / as_coo wrapper.'''
+    from . import factor as _factor0
+    if isinstance(f, function._AsCSR) and isinstance(f.integral, _factor0.FactoredMatrix):
+        return f.integral.as_csr()
     if isinstance(f, (function._AsCSR, function._AsCOO)):
         terms = f.integral.terms
         if not terms:
@@ -296,6 +299,11 @@ def evaluate(f, arguments):
             rowidx = numpy.repeat(numpy.arange(len(rowptr) - 1, dtype=numpy.int64), numpy.diff(rowptr))
             return values, rowidx, colidx
         return values, rowptr, colidx
+    from . import factor as _factor
+    if isinstance(f, (_factor.Factored, _factor.FactoredVector)):
+        return f.eval(**arguments)
+    if isinstance(f, function._AsCSR) and isinstance(f.integral, _factor.FactoredMatrix):
+        return f.integral.as_csr()
     if not isinstance(f, function.Integral):
         raise TypeError(f'cannot evaluate {type(f).__name__}')
     kinds = {(itg.rows, itg.cols) for _, itg, _ in f.terms}
