@@ -158,7 +158,13 @@ typedef struct {
   double *values_dev;        /* [nnz of the expanded pattern] */
   const double *scale_dev;   /* optional pointwise factor of the integrand [nelems][nq] (a coefficient function evaluated at
                                 the quadrature points), NULL = 1.  With elist_dev, scale and emap are indexed by LIST position. */
+  int flags;                 /* NH_MATRIX_* bits */
 } nh_matrix_args;
+
+#define NH_MATRIX_EXCLUSIVE 1        /* no two elements of this launch touch the same CSR entry (one colour of an element
+                                        colouring): entries are added with plain loads/stores -- deterministic -- not atomics */
+#define NH_MATRIX_EMAP_BY_ELEMENT 2  /* with elist_dev: emap (and the pattern) cover ALL elements, index it by element id */
+#define NH_MATRIX_NO_MFMA 4          /* force the generic one-wave-per-element VALU kernel */
 
 int nh_assemble_matrix(const nh_matrix_args *args, void *stream);
 

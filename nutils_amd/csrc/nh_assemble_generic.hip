@@ -11,6 +11,7 @@
 //      atomicAdd into values[slot(e,m,c,n,d)] via the element map                       (K5)
 #include "nh_common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -81,8 +82,7 @@ __device__ __forceinline__ void geometry_at(const GeomK &g, i64 e, int q, int nq
   if (g.kind == NH_GEOM_ISO) {
     if (x)
       for (int i = 0; i < ND; ++i) x[i] = 0;
-    for (int a = 0; a < g.ngb; ++a) {
-      const double *X = g.verts + (i64)g.gdofs[e * g.ngb + a] * ND;
+    auto accumulate = [&](int a, const double *X) {
       const double *t = g.gT + ((i64)a * nq + q) * S;
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
@@ -91,6 +91,23 @@ __device__ __forceinline__ void geometry_at(const GeomK &g, i64 e, int q, int nq
 #pragma unroll
         for (int j = 0; j < ND; ++j) J[i][j] += xi * t[1 + j];
       }
+    };
+    if (g.ngb == (1 << ND)) {
+      // multilinear geometry: fully unrolled so that all index loads, then all vertex loads, are in flight together
+      // (two memory latencies per point instead of 2 * ngb)
+      constexpr int NG = 1 << ND;
+      int idx[NG];
+#pragma unroll
+      for (int a = 0; a < NG; ++a) idx[a] = g.gdofs[e * NG + a];
+      double X[NG][ND];
+#pragma unroll
+      for (int a = 0; a < NG; ++a)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) X[a][i] = g.verts[(i64)idx[a] * ND + i];
+#pragma unroll
+      for (int a = 0; a < NG; ++a) accumulate(a, X[a]);
+    } else {
+      for (int a = 0; a < g.ngb; ++a) accumulate(a, g.verts + (i64)g.gdofs[e * g.ngb + a] * ND);
     }
   } else {
 #pragma unroll
@@ -152,6 +169,7 @@ struct MatK {
   const double *scale;
   int qchunk;
   int maxnbt, maxnbr;
+  int emap_by_elem;
 };
 
 template <int ND>
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
     }
     __syncthreads();
     const i64 tdof0 = boff(p.test, e);
-    const i64 emap0 = p.eoff ? p.eoff[e] : ie * (i64)nbt * nbr;  // list position (== e without elist)
+    const i64 emap0 = p.eoff ? p.eoff[e] : (p.emap_by_elem ? e : ie) * (i64)nbt * nbr;  // list position unless NH_MATRIX_EMAP_BY_ELEMENT
     const int nentries = nbt * form.nct * nbr * form.ncr;
     for (int q0 = 0; q0 < p.nq; q0 += p.qchunk) {
       const int q1 = min(p.nq, q0 + p.qchunk);
@@ -213,6 +231,170 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
       }
       __syncthreads();
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MFMA path for large local matrices (p >= 2, vector fields): one WORKGROUP (4 waves) per element, the local contraction as
+// GEMMs on v_mfma_f64_16x16x4_f64.  For each test component c:
+//     A_c[m][(n,d)] = sum_{k=(q,a)} Dt[q][m][slot_a] * H_c[k][(n,d)],   H_c[k][(n,d)] = w|J|_q sum_b C[c,slot_a,d,b] Dr[q][n][b]
+// M = nbt, N = nbr*ncr, K = nq * (number of ACTIVE test slots: those a with a nonzero coefficient).  The (c, N-tile) work
+// items are dealt round-robin to the 4 waves; a wave keeps MT accumulators (16 VGPRs), forms its B fragment H on the VALU from
+// the LDS-resident D table (shared by the 4 waves) while the matrix pipe runs, and feeds all M tiles with it.  The small
+// register footprint lets 6 workgroups (24 waves) share a CU, which hides the latency of the read-modify-write scatter.
+// Operand layout of the f64 MFMA: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// D[row = (lane >> 4) + 4 r][col = lane & 15], r = 0..3.
+// Scatter: with NH_MATRIX_EXCLUSIVE (the caller launches one colour of elements that share no dof) the result is added with
+// plain loads/stores -- deterministic, at HBM rate -- otherwise with f64 atomics.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct MfmaX {
+  int nas;         // active test slots
+  int aslot[4];
+  int mt, nt, kt;  // tiles: ceil(nbt/16), ceil(nbr*ncr/16), ceil(nq*nas/4)
+  int flags;
+};
+
+template <int ND>
+__device__ __forceinline__ void fill_D_wg(double *D, const BasisK &b, i64 e, int nb, int nq, const double *Jw, int tid, int nthreads) {
+  constexpr int S = 1 + ND, JW = ND * ND + 1;
+  const i64 fn0 = bfn(b, e);
+  const int n = nq * nb;
+#pragma unroll 4
+  for (int t = tid; t < n; t += nthreads) {
+    const int q = t / nb, m = t - q * nb;
+    const double *T = b.T + ((fn0 + m) * nq + q) * S;
+    const double *Ji = Jw + q * JW;
+    double *o = D + t * S;
+    o[0] = T[0];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      double sum = 0;
+#pragma unroll
+      for (int jj = 0; jj < ND; ++jj) sum += T[1 + jj] * Ji[jj * ND + i];
+      o[1 + i] = sum;
+    }
+  }
+}
+
+template <int ND, int MT>
+__global__ __launch_bounds__(256) void k_matrix_mfma(MatK p, FormK formarg, MfmaX x) {
+  constexpr int S = 1 + ND, JW = ND * ND + 1;
+  extern __shared__ __attribute__((aligned(32))) double lds[];
+  const FormK &form = stage_form(lds, formarg, threadIdx.x & 63);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nb = p.test.nb;  // test and trial share tables on this path (p.same)
+  const int nqp = (p.nq + 3) & ~3;                 // q padded to the MFMA k-step: K index k = a * nqp + q (slot-major)
+  const int nbp = MT * 16;                         // m padded to the M tiles
+  double *Jw = lds + FORMD;                        // [nq][JW]
+  double *D = Jw + ((p.nq * JW + 3) & ~3);         // [nq][nb][S]   (32-byte aligned rows: B fragments are read as 4 doubles)
+  double *At = D + (size_t)p.nq * nb * S;          // [nas][nqp][nbp] transposed copy of the active test slots, zero padded:
+                                                   // the A fragment read A[m = li][k = lk] is conflict-free and branch-free
+  const int li = lane & 15, lk = lane >> 4;
+  const int N = p.trial.nb * form.ncr;
+  const int kq = nqp >> 2;                         // k-steps per slot
+  for (i64 ie = blockIdx.x; ie < p.nelems; ie += gridDim.x) {
+    const i64 e = p.elist ? p.elist[ie] : ie;
+    for (int q = tid; q < p.nq; q += 256) {
+      double Ji[ND][ND], det;
+      geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) Jw[q * JW + j * ND + i] = Ji[j][i];
+      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det) * (p.scale ? p.scale[ie * p.nq + q] : 1.);
+    }
+    __syncthreads();
+    fill_D_wg<ND>(D, p.test, e, nb, p.nq, Jw, tid, 256);
+    __syncthreads();
+    for (int a = 0; a < x.nas; ++a) {
+      const int sa = x.aslot[a];
+#pragma unroll 4
+      for (int t = tid; t < nqp * nbp; t += 256) {
+        const int q = t / nbp, m = t - q * nbp;  // nbp is a compile-time constant
+        At[a * nqp * nbp + t] = (m < nb && q < p.nq) ? D[(q * nb + m) * S + sa] : 0.;
+      }
+    }
+    __syncthreads();
+    const i64 tdof0 = e * (i64)nb;
+    const i64 emap0 = ((x.flags & 2) ? e : ie) * (i64)nb * p.trial.nb;
+    // per-lane row bookkeeping: this lane owns rows (lk + 4 r) of every M tile
+    i64 rbase[MT][4];
+    int rlen[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + lk + 4 * r;
+        rbase[mt][r] = -1;
+        rlen[mt][r] = 0;
+        if (m < nb) {
+          const i64 row = p.test.dofs[tdof0 + m];
+          rbase[mt][r] = p.srowptr[row];
+          rlen[mt][r] = (int)(p.srowptr[row + 1] - rbase[mt][r]);
+        }
+      }
+    for (int wi = wave; wi < form.nct * x.nt; wi += 4) {
+      const int c = wi / x.nt, nt = wi - c * x.nt;
+      const int j = nt * 16 + li;
+      const int ncol = j < N ? j / form.ncr : -1, dcol = j < N ? j - ncol * form.ncr : 0;
+      v4d acc[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = v4d{0., 0., 0., 0.};
+      for (int a = 0; a < x.nas; ++a) {
+        // coefficients of this lane's column for the (wave-uniform) test slot: registers, not LDS, inside the k loop
+        double Cc[S];
+        const double *Cp = form.C + ((c * S + x.aslot[a]) * form.ncr + dcol) * S;
+#pragma unroll
+        for (int bb = 0; bb < S; ++bb) Cc[bb] = ncol >= 0 ? Cp[bb] : 0.;
+        const double *Aa = At + (size_t)a * nqp * nbp;
+        for (int ks = 0; ks < ((x.flags & 16) ? 1 : kq); ++ks) {
+          const int q = ks * 4 + lk;
+          const int qq = q < p.nq ? q : p.nq - 1;
+          const double wq = q < p.nq ? Jw[qq * JW + ND * ND] : 0.;
+          const double *dr = D + ((size_t)qq * nb + (ncol >= 0 ? ncol : 0)) * S;
+          double b = 0.;
+#pragma unroll
+          for (int bb = 0; bb < S; ++bb) b += Cc[bb] * dr[bb];
+          b *= wq;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aa[q * nbp + mt * 16 + li], b, acc[mt], 0, 0, 0);
+        }
+      }
+      // scatter this 16-column slab: all loads of the old values first (one memory latency), then add + store
+      if (ncol >= 0 && form.mask[c][dcol] && !((x.flags & 8) && acc[0][0] != 1.2345e300)) {
+        i64 slot[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            slot[mt][r] = -1;
+            if (rbase[mt][r] >= 0) {
+              const int m = mt * 16 + lk + 4 * r;
+              slot[mt][r] = rbase[mt][r] * form.tot + (i64)rlen[mt][r] * form.cum[c] + (i64)p.emap[emap0 + m * p.trial.nb + ncol] * form.cnt[c] + form.dpos[c][dcol];
+            }
+          }
+        if (x.flags & 1) {
+          double old[MT][4];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) old[mt][r] = slot[mt][r] >= 0 ? p.values[slot[mt][r]] : 0.;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (slot[mt][r] >= 0) p.values[slot[mt][r]] = old[mt][r] + acc[mt][r];
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (slot[mt][r] >= 0) atomicAdd(p.values + slot[mt][r], acc[mt][r]);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -451,9 +633,57 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   p.eoff = (const i64 *)a->eoff_dev;
   p.values = a->values_dev;
   p.scale = a->scale_dev;
+  p.emap_by_elem = (a->flags & 2) != 0;
   NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "nh_assemble_matrix: elist with ragged bases is not supported");
   if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
   if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
+  // MFMA path: uniform shared tables, >= 16 local rows and columns, tile counts we instantiate
+  const int Nloc = a->trial.nb * a->ncr;
+  if (!(a->flags & 4) && p.same && a->test.nb >= 16 && Nloc >= 16 && !a->test.off_dev && a->ndims >= 2 && a->geom.kind != 0) {
+    MfmaX x;
+    x.nas = 0;
+    for (int sa = 0; sa < S; ++sa) {
+      bool any = false;
+      for (int c = 0; c < a->nct && !any; ++c)
+        for (int d = 0; d < a->ncr && !any; ++d)
+          for (int b = 0; b < S && !any; ++b) any = a->C_host[((c * S + sa) * a->ncr + d) * S + b] != 0.;
+      if (any) x.aslot[x.nas++] = sa;
+    }
+    x.mt = (a->test.nb + 15) / 16;
+    x.nt = (Nloc + 15) / 16;
+    x.kt = ((a->nq + 3) / 4) * x.nas;
+    x.flags = a->flags | (getenv("NH_MFMA_DEBUG") ? atoi(getenv("NH_MFMA_DEBUG")) : 0);
+    const size_t ldsm = sizeof(double) * ((size_t)FORMD + (((size_t)a->nq * JW + 3) & ~(size_t)3) + (size_t)a->nq * a->test.nb * S +
+                                          (size_t)x.nas * ((a->nq + 3) & ~3) * x.mt * 16);
+    if (x.nas > 0 && ldsm <= 160 * 1024 && x.mt <= 4) {
+      hipStream_t sm = nh_stream(stream);
+      int dev = 0, cus = 256;
+      NH_CHECK_HIP(hipGetDevice(&dev));
+      NH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(6, (160 * 1024) / ldsm));
+      dim3 gridm((unsigned)std::min<i64>(a->nelems, (i64)cus * wg_per_cu)), blockm(256);
+#define LAUNCHM(ND, MT)                                                                                                          \
+  do {                                                                                                                           \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_matrix_mfma<ND, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm)); \
+    hipLaunchKernelGGL((k_matrix_mfma<ND, MT>), gridm, blockm, ldsm, sm, p, form, x);                                            \
+  } while (0)
+      const int key = a->ndims * 10 + x.mt;
+      bool launched = true;
+      switch (key) {
+        case 21: LAUNCHM(2, 1); break;
+        case 22: LAUNCHM(2, 2); break;
+        case 31: LAUNCHM(3, 1); break;
+        case 32: LAUNCHM(3, 2); break;   // 3-D p2: 27 local scalar dofs
+        case 34: LAUNCHM(3, 4); break;   // 3-D p3: 64
+        default: launched = false;
+      }
+#undef LAUNCHM
+      if (launched) {
+        NH_LAUNCH_CHECK();
+        return NH_OK;
+      }
+    }
+  }
   const int per_q = (p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S * (int)sizeof(double);
   p.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / std::max(per_q, 1)));
   const size_t lds = sizeof(double) * ((size_t)FORMD + (size_t)a->nq * JW) + (size_t)p.qchunk * per_q;

@@ -51,8 +51,16 @@ class Pattern:
         return nnz.value
 
     def expand(self, nct=1, ncr=1, mask=None):
-        '''(rowptr, colidx) int64 device tensors of the component-expanded CSR.'''
+        '''(rowptr, colidx) int64 device tensors of the component-expanded CSR (cached: re-assemblies reuse them).'''
         m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
+        key = nct, ncr, None if m is None else m.tobytes()
+        cache = self.__dict__.setdefault('_expanded', {})
+        if key in cache:
+            return cache[key]
+        cache[key] = self._expand(nct, ncr, m)
+        return cache[key]
+
+    def _expand(self, nct, ncr, m):
         nnz = self.expanded_nnz(nct, ncr, m)
         rowptr = device.empty(self.nrows * nct + 1, 'int64')
         colidx = device.empty(nnz, 'int64')
@@ -87,7 +95,7 @@ def basis(T, dofs, nb=0, off=None, tab=None):
     return b
 
 
-def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None):
+def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0):
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.'''
     C = numpy.ascontiguousarray(C, dtype=float)
     if C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
@@ -95,7 +103,7 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
     args = _lib.MatrixArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
                            device.host_ptr(m), pattern.srowptr_ptr, ctypes.c_void_p(pattern.emap_ptr.value + 4 * emap_offset), pattern.eoff_ptr,
-                           device.ptr(values), device.ptr(scale))
+                           device.ptr(values), device.ptr(scale), int(flags))
     _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
 
 

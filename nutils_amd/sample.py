@@ -201,6 +201,29 @@ def _argument(arguments, arg):
     return u.reshape(arg.basis.ndofs, arg.ncomp)
 
 
+# Element colouring (structured bases): elements whose multi-indices are congruent modulo the dof-overlap stride share no
+# dof, so one launch per colour may add into the CSR values with plain loads/stores (NH_MATRIX_EXCLUSIVE): deterministic and
+# at HBM rate instead of memory-side f64 atomics.  Used above COLOR_THRESHOLD elements when the local matrix is large enough
+# for the MFMA kernel (below that the launch overhead of 2^d..(p+1)^d launches does not pay).
+COLOR_THRESHOLD = 4096
+
+
+def _colors(smp, basis):
+    if not isinstance(basis, StructuredBasis) or smp.elist is not None:
+        return None
+    key = 'colors', id(basis)
+    if key not in smp._tables:
+        stride = 2 if basis.btype == 'std' else basis.degree + 1
+        idx = numpy.arange(basis.nelems, dtype=numpy.int32).reshape(basis.shape)
+        lists = []
+        for off in numpy.ndindex(*(min(stride, n) for n in basis.shape)):
+            sub = idx[tuple(slice(o, None, stride) for o in off)].ravel()
+            if len(sub):
+                lists.append(device.to_dev(sub, 'int32'))
+        smp._tables[key] = lists
+    return smp._tables[key]
+
+
 def _block_mask(B):
     return (numpy.abs(B).sum(axis=(1, 3)) != 0)
 
@@ -235,10 +258,17 @@ class _MatrixPlan:
             if itg.measure is None:
                 raise NotImplementedError('integrand without J(geom): reference-space integrals are outside the accelerated path')
             tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
-            kernels.assemble_matrix(nelems=smp.nlist, ndims=smp.ndims, nq=smp.points.npoints, weights=smp._weights_dev,
-                                    geom=smp.geometry(itg.measure), test=tt.struct, trial=tr.struct, nct=nct, ncr=ncr, C=itg.B * fac,
-                                    mask=mask, pattern=smp.pattern(itg.test.basis, itg.trial.basis), values=values, elist=smp._elist_dev,
-                                    scale=smp.scale(itg.scale))
+            common = dict(ndims=smp.ndims, nq=smp.points.npoints, weights=smp._weights_dev, geom=smp.geometry(itg.measure), test=tt.struct,
+                          trial=tr.struct, nct=nct, ncr=ncr, C=itg.B * fac, mask=mask, pattern=smp.pattern(itg.test.basis, itg.trial.basis),
+                          values=values)
+            colors = None
+            if itg.test.basis is itg.trial.basis and itg.scale is None and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16:
+                colors = _colors(smp, itg.test.basis)
+            if colors:
+                for el in colors:
+                    kernels.assemble_matrix(nelems=el.numel(), elist=el, flags=1 | 2, **common)
+            else:
+                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, scale=smp.scale(itg.scale), **common)
         return values, rowptr, colidx, self.trial.basis.ndofs * ncr
 
 
