@@ -233,10 +233,14 @@ typedef struct {
   double gauss_x[2], gauss_w[2]; /* 1-D Gauss points / weights on [0,1] */
   double kappa;                  /* constant diffusivity */
   double *values_dev;
+  const double *unit_matrix_dev; /* uniform geometry only: the 8x8 element matrix from nh_p1hex_unit_matrix (computed once per
+                                    mesh, like the reference hoists it out of the loop); NULL: evaluated inside the call */
 } nh_p1hex_args;
 
 int nh_p1hex_pattern(const int *shape, int64_t row_begin, int64_t row_end, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream);
 int nh_p1hex_laplace(const nh_p1hex_args *args, void *stream);
+/* element matrix (64 doubles, row major) of the uniform cell scale[0] x scale[1] x scale[2] (verts_dev ignored) */
+int nh_p1hex_unit_matrix(const nh_p1hex_args *args, double *ke_dev, void *stream);
 
 /* ---- Monomial: evaluation of factored (pre-integrated) polynomial functionals -------------
  * replaces evaluable.Monomial (evaluable.py:5693-5751; `out = values.copy(); out *= arg[index]`

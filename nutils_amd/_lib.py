@@ -59,7 +59,8 @@ class EvalArgs(ctypes.Structure):
 class P1HexArgs(ctypes.Structure):
     _fields_ = [('shape', ctypes.c_int * 3), ('layer_begin', ctypes.c_int), ('layer_end', ctypes.c_int), ('plane_begin', ctypes.c_int),
                 ('plane_end', ctypes.c_int), ('verts_dev', vp), ('origin', ctypes.c_double * 3), ('scale', ctypes.c_double * 3),
-                ('gauss_x', ctypes.c_double * 2), ('gauss_w', ctypes.c_double * 2), ('kappa', ctypes.c_double), ('values_dev', vp)]
+                ('gauss_x', ctypes.c_double * 2), ('gauss_w', ctypes.c_double * 2), ('kappa', ctypes.c_double), ('values_dev', vp),
+                ('unit_matrix_dev', vp)]
 
 
 GEOM_ISO = 1
@@ -93,6 +94,7 @@ SIGNATURES = {
     'nh_monomial': (ctypes.c_int, [c_i64, vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, ctypes.c_double, vp, vp]),
     'nh_p1hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64, vp, vp, vp]),
     'nh_p1hex_laplace': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp]),
+    'nh_p1hex_unit_matrix': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp, vp]),
 }
 
 _lib = None

@@ -322,14 +322,11 @@ int nh_p1hex_pattern(const int *shape, int64_t row_begin, int64_t row_end, int64
   return NH_OK;
 }
 
-int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
-  NH_REQUIRE(a && a->values_dev, "nh_p1hex_laplace: NULL argument");
-  NH_REQUIRE(a->shape[0] >= 1 && a->shape[1] >= 1 && a->shape[2] >= 1, "nh_p1hex_laplace: empty mesh");
-  NH_REQUIRE(0 <= a->layer_begin && a->layer_begin <= a->layer_end && a->layer_end <= a->shape[0], "nh_p1hex_laplace: layer range");
-  NH_REQUIRE(0 <= a->plane_begin && a->plane_begin <= a->plane_end && a->plane_end <= a->shape[0] + 1, "nh_p1hex_laplace: plane range");
-  if (a->plane_begin == a->plane_end) return NH_OK;
-  constexpr int BI = 7, BJ = 7, BK = 7, NT = 512, NBUF = 2;
-  P1Args p;
+static int fill_p1args(const nh_p1hex_args *a, P1Args &p) {
+  NH_REQUIRE(a, "nh_p1hex: NULL argument");
+  NH_REQUIRE(a->shape[0] >= 1 && a->shape[1] >= 1 && a->shape[2] >= 1, "nh_p1hex: empty mesh");
+  NH_REQUIRE(0 <= a->layer_begin && a->layer_begin <= a->layer_end && a->layer_end <= a->shape[0], "nh_p1hex: layer range");
+  NH_REQUIRE(0 <= a->plane_begin && a->plane_begin <= a->plane_end && a->plane_end <= a->shape[0] + 1, "nh_p1hex: plane range");
   p.n0 = a->shape[0];
   p.n1 = a->shape[1];
   p.n2 = a->shape[2];
@@ -353,16 +350,41 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
     for (int qb = 0; qb < 2; ++qb)
       for (int qc = 0; qc < 2; ++qc) p.wk[qa][qb][qc] = a->kappa * a->gauss_w[qa] * a->gauss_w[qb] * a->gauss_w[qc];
   p.values = a->values_dev;
+  p.nbj = p.nbk = p.nboxes = 0;
+  p.debug = 0;
+  return NH_OK;
+}
+
+int nh_p1hex_unit_matrix(const nh_p1hex_args *a, double *ke_dev, void *stream) {
+  NH_REQUIRE(ke_dev, "nh_p1hex_unit_matrix: NULL output");
+  P1Args p;
+  int rc = fill_p1args(a, p);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_p1hex_unit_matrix, dim3(1), dim3(1), 0, nh_stream(stream), p, ke_dev);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
+  NH_REQUIRE(a && a->values_dev, "nh_p1hex_laplace: NULL argument");
+  P1Args p;
+  int rc = fill_p1args(a, p);
+  if (rc) return rc;
+  if (a->plane_begin == a->plane_end) return NH_OK;
+  constexpr int BI = 7, BJ = 7, BK = 7, NT = 512, NBUF = 2;
   const int nbi = (p.pl1 - p.pl0 + BI - 1) / BI;
   p.nbj = (p.n1 + 1 + BJ - 1) / BJ;
   p.nbk = (p.n2 + 1 + BK - 1) / BK;
   if (!a->verts_dev) {  // uniform geometry: unit element matrix + streaming kernel
     double *Ke = nullptr;
-    NH_CHECK_HIP(hipMallocAsync((void **)&Ke, 64 * sizeof(double), nh_stream(stream)));
-    hipLaunchKernelGGL(k_p1hex_unit_matrix, dim3(1), dim3(1), 0, nh_stream(stream), p, Ke);
-    hipLaunchKernelGGL(k_p1hex_uniform, dim3((unsigned)((p.pl1 - p.pl0) * (p.n1 + 1))), dim3(256), 0, nh_stream(stream), p, (const double *)Ke);
+    if (!a->unit_matrix_dev) {
+      NH_CHECK_HIP(hipMallocAsync((void **)&Ke, 64 * sizeof(double), nh_stream(stream)));
+      hipLaunchKernelGGL(k_p1hex_unit_matrix, dim3(1), dim3(1), 0, nh_stream(stream), p, Ke);
+    }
+    hipLaunchKernelGGL(k_p1hex_uniform, dim3((unsigned)((p.pl1 - p.pl0) * (p.n1 + 1))), dim3(256), 0, nh_stream(stream), p,
+                       a->unit_matrix_dev ? a->unit_matrix_dev : (const double *)Ke);
     NH_LAUNCH_CHECK();
-    NH_CHECK_HIP(hipFreeAsync(Ke, nh_stream(stream)));
+    if (Ke) NH_CHECK_HIP(hipFreeAsync(Ke, nh_stream(stream)));
     return NH_OK;
   }
   constexpr int ROWS = BI * BJ * BK, SETD = ROWS * 27 + ROWS + (ROWS + 1) / 2 + 1, SET = SETD + (SETD & 1);

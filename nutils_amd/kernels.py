@@ -152,8 +152,7 @@ def p1hex_pattern(shape, row_begin=0, row_end=None):
     return rowptr, colidx
 
 
-def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0., 0.), scale=(1., 1., 1.), kappa=1., layers=None, planes=None):
-    '''Write-once structured P1-hex Laplace assembly (nh_p1hex_laplace).'''
+def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix=None):
     n0 = int(shape[0])
     layers = (0, n0) if layers is None else layers
     planes = (0, n0 + 1) if planes is None else planes
@@ -168,6 +167,22 @@ def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0.
     a.gauss_w[:] = [float(x) for x in gauss_w]
     a.kappa = float(kappa)
     a.values_dev = device.ptr(values)
+    a.unit_matrix_dev = device.ptr(unit_matrix)
+    return a
+
+
+def p1hex_unit_matrix(*, shape, gauss_x, gauss_w, origin=(0., 0., 0.), scale=(1., 1., 1.), kappa=1.):
+    '''8x8 element matrix of the uniform cell (nh_p1hex_unit_matrix): computed once per mesh.'''
+    ke = device.empty(64, 'float64')
+    a = _p1hex_args(shape, None, gauss_x, gauss_w, None, origin, scale, kappa, None, None)
+    _lib.call('nh_p1hex_unit_matrix', ctypes.byref(a), device.ptr(ke), device.stream())
+    return ke
+
+
+def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0., 0.), scale=(1., 1., 1.), kappa=1., layers=None, planes=None,
+                  unit_matrix=None):
+    '''Write-once structured P1-hex Laplace assembly (nh_p1hex_laplace).'''
+    a = _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix)
     _lib.call('nh_p1hex_laplace', ctypes.byref(a), device.stream())
 
 

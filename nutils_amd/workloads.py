@@ -66,6 +66,9 @@ class PoissonSlab:
         self.nnz = int(self.colidx.numel())
         self.halo = partition.HaloPlan(self.slab, self.rowptr) if self.world > 1 else None
         self._verts_dev = device.to_dev(self.verts, 'float64') if self.verts is not None else None
+        self._ke = None
+        if self.fast and self.verts is None:  # uniform mesh: the element matrix is a per-mesh constant (hoisted, as in the reference)
+            self._ke = kernels.p1hex_unit_matrix(shape=(s.local_layers, self.n, self.n), gauss_x=self._gauss_x1(), gauss_w=self._gauss_w1())
 
     def _own_views(self):
         '''Structures restricted to the rank's own element layers (skip the ghost layer).'''
@@ -83,14 +86,12 @@ class PoissonSlab:
     def step(self, kernel_events=None, exchange=True):
         if self.fast:
             s = self.slab
-            pts = self.smp.points
-            gx = [pts.coords[0, 2], pts.coords[1, 2]]     # 1-D Gauss coordinates (last axis fastest)
-            gw = [pts.weights[0] ** (1 / 3)] * 2 if False else self._gauss_w1()
+            gx, gw = self._gauss_x1(), self._gauss_w1()
             if kernel_events:
                 kernel_events[0].record()
             kernels.p1hex_laplace(shape=(s.local_layers, self.n, self.n), values=self.values, gauss_x=gx, gauss_w=gw, verts=self._verts_dev,
                                   origin=(float(s.first_global_plane), 0., 0.), layers=(s.ghost_layers, s.local_layers),
-                                  planes=(s.ghost_layers, s.local_layers + 1))
+                                  planes=(s.ghost_layers, s.local_layers + 1), unit_matrix=self._ke)
             if kernel_events:
                 kernel_events[1].record()
             if self.halo is not None and exchange:
@@ -110,6 +111,10 @@ class PoissonSlab:
     def _gauss_w1(self):
         from . import points
         return list(points.gauss1(2)[1])
+
+    def _gauss_x1(self):
+        from . import points
+        return list(points.gauss1(2)[0])
 
     def algorithmic_bytes_per_element(self):
         '''connectivity + unique vertex coordinates + CSR values written once.'''
