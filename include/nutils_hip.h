@@ -256,6 +256,16 @@ int nh_monomial_csr(int64_t nrows, const int64_t *rowptr_dev, const int64_t *col
 int nh_monomial(int64_t n, const double *values_dev, int nargs, const double *const *args_dev, const int64_t *const *indices_dev,
                 const int64_t *out_index_dev, double alpha, double *out_dev, void *stream);
 
+/* ---- pointwise coefficient functions ------------------------------------------------------
+ * out[i] = sum_t coeffs[t] prod_v x_v[i*strides[v]]^powers[t*nvars+v]  (nvars <= 4, nterms <= 32;
+ * x_dev is a HOST array of device pointers).  Evaluates polynomial coefficient functions of field
+ * values at the quadrature points (from nh_sample_eval), e.g. psi'(phi), psi''(phi) of
+ * examples/cahnhilliard.py:175-176, once per Newton step; the result is a scale_dev array.  The
+ * reference represents such terms as rank-3/4 sparse tensors (evaluable.factor); here the
+ * integrand is re-integrated with the pointwise coefficient. */
+int nh_pointwise_poly(int64_t n, int nvars, const double *const *x_dev, const int *strides, int nterms, const double *coeffs,
+                      const int *powers, double *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

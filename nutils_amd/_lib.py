@@ -92,6 +92,8 @@ SIGNATURES = {
     'nh_sample_eval': (ctypes.c_int, [ctypes.POINTER(EvalArgs), vp]),
     'nh_monomial_csr': (ctypes.c_int, [c_i64, vp, vp, vp, vp, ctypes.c_double, vp, vp]),
     'nh_monomial': (ctypes.c_int, [c_i64, vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, ctypes.c_double, vp, vp]),
+    'nh_pointwise_poly': (ctypes.c_int, [c_i64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_int), vp, vp]),
     'nh_p1hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64, vp, vp, vp]),
     'nh_p1hex_laplace': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp]),
     'nh_p1hex_unit_matrix': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp, vp]),

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
       for (int j = 0; j < ND; ++j)
 #pragma unroll
         for (int i = 0; i < ND; ++i) Jw[q * JW + j * ND + i] = Ji[j][i];
-      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det) * (p.scale ? p.scale[ie * p.nq + q] : 1.);
+      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det) * (p.scale ? p.scale[(p.emap_by_elem ? e : ie) * p.nq + q] : 1.);
     }
     __syncthreads();
     const i64 tdof0 = boff(p.test, e);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_matrix_mfma(MatK p, FormK formarg, Mfma
       for (int j = 0; j < ND; ++j)
 #pragma unroll
         for (int i = 0; i < ND; ++i) Jw[q * JW + j * ND + i] = Ji[j][i];
-      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det) * (p.scale ? p.scale[ie * p.nq + q] : 1.);
+      Jw[q * JW + ND * ND] = p.weights[q] * fabs(det) * (p.scale ? p.scale[((x.flags & 2) ? e : ie) * p.nq + q] : 1.);
     }
     __syncthreads();
     fill_D_wg<ND>(D, p.test, e, nb, p.nq, Jw, tid, 256);
@@ -711,7 +711,7 @@ int nh_assemble_vector(const nh_vector_args *a, void *stream) {
   NH_REQUIRE((a->test.nb == 0 && !a->test.off_dev) || (a->test.T_dev && a->test.dofs_dev), "test basis tables missing");
   NH_REQUIRE((a->trial.nb == 0 && !a->trial.off_dev) || (a->trial.T_dev && a->trial.dofs_dev), "trial basis tables missing");
   NH_REQUIRE(!(a->C_host && !a->u_dev), "nh_assemble_vector: coefficient tensor given without field u");
-  NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "elist with ragged bases is not supported");
+  NH_REQUIRE(!a->elist_dev || (!a->test.off_dev && !a->trial.off_dev), "elist with ragged bases is not supported");
   int rc = check_geom(a->geom);
   if (rc) return rc;
   if (a->nelems == 0) return NH_OK;

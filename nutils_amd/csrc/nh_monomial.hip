@@ -83,3 +83,63 @@ int nh_monomial(int64_t n, const double *values_dev, int nargs, const double *co
 }
 
 }  // extern "C"
+
+// ---- pointwise polynomial of field values at the quadrature points -----------------------------------------------------
+// out[i] = sum_t coeff[t] prod_v x_v[i * stride_v]^power[t][v]: the coefficient functions g(phi, phi0, ...) of nonlinear
+// integrands (psi'(phi), psi''(phi) of a Cahn-Hilliard free energy, ...) evaluated once per Newton step; the result enters
+// the element kernels as scale_dev.  (The reference expands such terms into rank-3/4 sparse tensors with evaluable.factor;
+// here the integrand is simply re-integrated with the pointwise coefficient.)
+namespace {
+struct PolyK {
+  i64 n;
+  int nvars, nterms;
+  const double *x[4];
+  int stride[4];
+  double coeff[32];
+  unsigned char power[32][4];
+  double *out;
+};
+
+__global__ void k_pointwise_poly(PolyK p) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  double xv[4];
+  for (int v = 0; v < p.nvars; ++v) xv[v] = p.x[v][i * p.stride[v]];
+  double s = 0;
+  for (int t = 0; t < p.nterms; ++t) {
+    double m = p.coeff[t];
+    for (int v = 0; v < p.nvars; ++v)
+      for (int k = 0; k < p.power[t][v]; ++k) m *= xv[v];
+    s += m;
+  }
+  p.out[i] = s;
+}
+}  // namespace
+
+extern "C" int nh_pointwise_poly(int64_t n, int nvars, const double *const *x_dev, const int *strides, int nterms, const double *coeffs,
+                                 const int *powers, double *out_dev, void *stream) {
+  NH_REQUIRE(n >= 0 && out_dev, "nh_pointwise_poly: invalid argument");
+  NH_REQUIRE(nvars >= 0 && nvars <= 4 && nterms >= 0 && nterms <= 32, "nh_pointwise_poly: at most 4 variables and 32 terms");
+  if (!n) return NH_OK;
+  PolyK p;
+  p.n = n;
+  p.nvars = nvars;
+  p.nterms = nterms;
+  for (int v = 0; v < 4; ++v) {
+    p.x[v] = v < nvars ? x_dev[v] : nullptr;
+    p.stride[v] = v < nvars ? strides[v] : 0;
+    NH_REQUIRE(v >= nvars || p.x[v], "nh_pointwise_poly: NULL variable %d", v);
+  }
+  for (int t = 0; t < nterms; ++t) {
+    p.coeff[t] = coeffs[t];
+    for (int v = 0; v < 4; ++v) {
+      const int pw = v < nvars ? powers[t * nvars + v] : 0;
+      NH_REQUIRE(pw >= 0 && pw < 32, "nh_pointwise_poly: power out of range");
+      p.power[t][v] = (unsigned char)pw;
+    }
+  }
+  p.out = out_dev;
+  hipLaunchKernelGGL(k_pointwise_poly, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nh_stream(stream), p);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}

@@ -132,6 +132,120 @@ class PointFunc:
         return self * -1.
 
 
+class FieldPoly:
+    '''Polynomial in the POINT VALUES of scalar fields, sum_t c_t prod_v field_v^p_tv: nonlinear coefficient functions such as
+    the double-well potential psi(phi) = (phi^2-1)^2/4 of examples/cahnhilliard.py:175.  Evaluated on the device at the
+    quadrature points (nh_sample_eval + nh_pointwise_poly) and applied as a pointwise factor of the integrand; derivatives
+    with respect to a field differentiate the polynomial symbolically.'''
+
+    __array_ufunc__ = None
+
+    def __init__(self, args, terms):
+        self.args = tuple(args)
+        self.terms = {k: v for k, v in terms.items() if v != 0}
+
+    @staticmethod
+    def _merge(a, b):
+        args = list(a.args)
+        for arg in b.args:
+            if not any(arg.same(x) for x in args):
+                args.append(arg)
+        def lift(p):
+            idx = [next(i for i, x in enumerate(args) if x.same(arg)) for arg in p.args]
+            out = {}
+            for k, v in p.terms.items():
+                key = [0] * len(args)
+                for i, pw in zip(idx, k):
+                    key[i] = pw
+                out[tuple(key)] = out.get(tuple(key), 0.) + v
+            return out
+        return args, lift(a), lift(b)
+
+    @staticmethod
+    def _const(c, like):
+        return FieldPoly(like.args, {(0,) * len(like.args): float(c)})
+
+    def _coerce(self, other):
+        if isinstance(other, FieldPoly):
+            return other
+        if isinstance(other, (int, float)):
+            return FieldPoly._const(other, self)
+        return None
+
+    def __add__(self, other):
+        o = self._coerce(other)
+        if o is None:
+            return NotImplemented
+        args, a, b = FieldPoly._merge(self, o)
+        for k, v in b.items():
+            a[k] = a.get(k, 0.) + v
+        return FieldPoly(args, a)
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return FieldPoly(self.args, {k: -v for k, v in self.terms.items()})
+
+    def __sub__(self, other):
+        o = self._coerce(other)
+        return NotImplemented if o is None else self + (-o)
+
+    def __rsub__(self, other):
+        return (-self) + other
+
+    def __mul__(self, other):
+        o = self._coerce(other)
+        if o is None:
+            if isinstance(other, PointFunc):
+                return NotImplemented
+            return _as_integrand(other).with_fscale(self)
+        args, a, b = FieldPoly._merge(self, o)
+        out = {}
+        for ka, va in a.items():
+            for kb, vb in b.items():
+                k = tuple(x + y for x, y in zip(ka, kb))
+                out[k] = out.get(k, 0.) + va * vb
+        return FieldPoly(args, out)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return self * (1. / float(other))
+
+    def __pow__(self, n):
+        if not isinstance(n, int) or n < 0:
+            raise NotImplementedError('integer powers only')
+        out = FieldPoly._const(1., self)
+        for _ in range(n):
+            out = out * self
+        return out
+
+    def depends_on(self, name):
+        return any(a.name == name and any(k[i] for k in self.terms) for i, a in enumerate(self.args))
+
+    def arg_named(self, name):
+        return next(a for a in self.args if a.name == name)
+
+    def derivative(self, name):
+        out = {}
+        for i, a in enumerate(self.args):
+            if a.name != name:
+                continue
+            for k, v in self.terms.items():
+                if k[i]:
+                    kk = k[:i] + (k[i] - 1,) + k[i + 1:]
+                    out[kk] = out.get(kk, 0.) + v * k[i]
+        return FieldPoly(self.args, out)
+
+
+def value(field_operand):
+    '''Point value of a scalar field as a FieldPoly variable (to build nonlinear coefficient functions).'''
+    op = _as_operand(field_operand)
+    if op.arg.name is None or op.arg.ncomp != 1 or op.P.shape != (1, op.P.shape[-1]) or numpy.abs(op.P[0, 1:]).sum() != 0:
+        raise NotImplementedError('value() expects a plain scalar field')
+    return FieldPoly((op.arg,), {(1,): float(op.P[0, 0])})
+
+
 # ---- arguments and operands ----------------------------------------------------------
 
 class Arg:
@@ -201,7 +315,7 @@ class Operand:
         return Operand(self.arg, a * b[..., None, None], self.geom)
 
     def __mul__(self, other):
-        if isinstance(other, (Measure, PointFunc)):
+        if isinstance(other, (Measure, PointFunc, FieldPoly)):
             return other.__mul__(self)
         from .basis import Basis
         if isinstance(other, Basis):
@@ -317,16 +431,17 @@ class Integrand:
 
     __array_ufunc__ = None
 
-    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False, scale=None):
+    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False, scale=None, fscale=None):
         self.test, self.trial, self.B, self.L, self.f0 = test, trial, B, L, f0
         self.scale = scale      # PointFunc multiplying the whole integrand, or None
+        self.fscale = fscale    # FieldPoly multiplying the whole integrand, or None
         self.geom = geom        # geometry the gradients refer to
         self.measure = measure  # geometry of the measure
         self.rows, self.cols = rows, cols  # dof axis of test / trial is an array axis (else: bound to an argument value)
 
     def _copy(self, **kw):
         d = dict(test=self.test, trial=self.trial, B=self.B, L=self.L, f0=self.f0, geom=self.geom, measure=self.measure, rows=self.rows, cols=self.cols,
-                 scale=self.scale)
+                 scale=self.scale, fscale=self.fscale)
         d.update(kw)
         return Integrand(**d)
 
@@ -358,11 +473,16 @@ class Integrand:
     def with_scale(self, pf):
         return self._copy(scale=pf if self.scale is None else self.scale * pf)
 
+    def with_fscale(self, fp):
+        return self._copy(fscale=fp if self.fscale is None else self.fscale * fp)
+
     def __mul__(self, other):
         if isinstance(other, Measure):
             return self.with_measure(other.geom)
         if isinstance(other, PointFunc):
             return self.with_scale(other)
+        if isinstance(other, FieldPoly):
+            return self.with_fscale(other)
         if isinstance(other, (Operand, Integrand)):
             raise NotImplementedError('products of more than two argument-dependent factors are outside the accelerated path')
         other = numpy.asarray(other, dtype=float)
@@ -391,7 +511,7 @@ class Integrand:
             return (a is None and b is None) or (a is not None and b is not None and a.same(b))
         return same(self.test, other.test) and same(self.trial, other.trial) and self.rows == other.rows and self.cols == other.cols \
             and self.measure is other.measure and (self.B is None) == (other.B is None) and (self.L is None) == (other.L is None) \
-            and self.scale is other.scale
+            and self.scale is other.scale and self.fscale is other.fscale
 
     def __add__(self, other):
         other = _as_integrand(other)
@@ -411,6 +531,8 @@ def _as_integrand(obj):
         return Integrand(f0=numpy.ones(()), measure=obj.geom)
     if isinstance(obj, PointFunc):
         return Integrand(f0=numpy.ones(()), scale=obj)
+    if isinstance(obj, FieldPoly):
+        return Integrand(f0=numpy.ones(()), fscale=obj)
     if isinstance(obj, (int, float, numpy.ndarray)):
         return Integrand(f0=numpy.asarray(obj, dtype=float))
     op = _as_operand(obj)
@@ -485,6 +607,21 @@ def derivative(integral, name):
     exposes that argument's dof axis.  Terms that do not depend on it vanish.'''
     out = []
     for smp, itg, fac in integral.terms:
+        if itg.fscale is not None and itg.fscale.depends_on(name):
+            g = itg.fscale.derivative(name)
+            varg = itg.fscale.arg_named(name)
+            S = 1 + varg.basis.ndims
+            if g.terms:
+                if itg.B is None and itg.L is None:        # g(phi) * const  ->  linear form in the test function of phi
+                    L = numpy.zeros((1, S))
+                    L[0, 0] = float(itg.f0)
+                    out.append((smp, itg._copy(test=varg, L=L, f0=None, rows=True, fscale=g), fac))
+                elif itg.B is None and itg.rows and not itg.cols:  # g(phi) * L(test)  ->  bilinear (test x phi)
+                    B = numpy.zeros(itg.L.shape + (1, S))
+                    B[..., 0, 0] = itg.L
+                    out.append((smp, itg._copy(trial=varg, B=B, L=None, cols=True, fscale=g), fac))
+                else:
+                    raise NotImplementedError('derivative of a field-dependent coefficient in this position (rank-3 tensor)')
         t_hit = itg.test is not None and itg.test.name == name and not itg.rows
         r_hit = itg.trial is not None and itg.trial.name == name and not itg.cols
         if itg.B is not None and t_hit and r_hit:

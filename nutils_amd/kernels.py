@@ -198,3 +198,15 @@ def monomial(values, args, indices, out, out_index=None, alpha=1.):
     A = (ctypes.c_void_p * max(n, 1))(*[a.data_ptr() for a in args])
     I = (ctypes.c_void_p * max(n, 1))(*[i.data_ptr() for i in indices])
     _lib.call('nh_monomial', values.numel(), device.ptr(values), n, A, I, device.ptr(out_index), float(alpha), device.ptr(out), device.stream())
+
+
+def pointwise_poly(xs, strides, coeffs, powers, n):
+    '''out[i] = sum_t coeffs[t] prod_v xs[v][i*strides[v]]^powers[t][v] (nh_pointwise_poly).'''
+    nv, nt = len(xs), len(coeffs)
+    out = device.empty(n, 'float64')
+    X = (ctypes.c_void_p * max(nv, 1))(*[x.data_ptr() for x in xs])
+    S = (ctypes.c_int * max(nv, 1))(*[int(s) for s in strides])
+    C = (ctypes.c_double * max(nt, 1))(*[float(c) for c in coeffs])
+    P = (ctypes.c_int * max(nt * nv, 1))(*[int(p) for row in powers for p in row])
+    _lib.call('nh_pointwise_poly', n, nv, X, S, nt, C, P, device.ptr(out), device.stream())
+    return out

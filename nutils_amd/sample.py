@@ -81,15 +81,29 @@ class Sample:
             self._elist_t = device.to_dev(self.elist, 'int32')
         return self._elist_t
 
-    def scale(self, pf):
-        '''Device array [nlist][nq] of a coefficient function at the sample points (None -> None).'''
-        if pf is None:
-            return None
-        s = self._scales.get(id(pf))
-        if s is None:
-            x = self._eval_one(pf.geom, {})
-            s = self._scales[id(pf)] = (device.to_dev(pf(x), 'float64'), pf)
-        return s[0]
+    def scale(self, pf, fp=None, arguments=None):
+        '''Device array [nlist][nq]: coefficient function of x (PointFunc, cached per sample) times polynomial of field
+        values (FieldPoly, re-evaluated on the device for the current arguments); None if neither is present.'''
+        out = None
+        if pf is not None:
+            s = self._scales.get(id(pf))
+            if s is None:
+                x = self._eval_one(pf.geom, {})
+                s = self._scales[id(pf)] = (device.to_dev(pf(x), 'float64'), pf)
+            out = s[0]
+        if fp is not None:
+            nq, nd, ne = self.points.npoints, self.ndims, self.nlist
+            xs = []
+            for arg in fp.args:
+                u = _argument(arguments or {}, arg)
+                U = device.empty(ne * nq * (1 + nd), 'float64')
+                kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(_default_geometry(self.topo)), trial=self.tables(arg.basis).struct,
+                                    ncr=1, points=self._points_dev, u=device.to_dev(u, 'float64'), U=U, elist=self._elist_dev)
+                xs.append(U)
+            keys = list(fp.terms)
+            f = kernels.pointwise_poly(xs, [1 + nd] * len(xs), [fp.terms[k] for k in keys], keys, ne * nq)
+            out = f if out is None else out * f
+        return out
 
     def tables(self, basis):
         if basis.nelems != self.nelems or basis.ndims != self.ndims:
@@ -188,7 +202,9 @@ class Sample:
 
 
 def _default_geometry(topo):
-    return function.RectilinearGeometry(topo, numpy.zeros(topo.ndims), numpy.ones(topo.ndims))
+    if not hasattr(topo, '_default_geom'):
+        topo._default_geom = getattr(topo, 'geom', None) or function.RectilinearGeometry(topo, numpy.zeros(topo.ndims), numpy.ones(topo.ndims))
+    return topo._default_geom
 
 
 def _argument(arguments, arg):
@@ -248,7 +264,7 @@ class _MatrixPlan:
             self.mask |= _block_mask(itg.B)
         self.smp0 = smp0
 
-    def run(self):
+    def run(self, arguments=None):
         pat = self.smp0.pattern(self.test.basis, self.trial.basis)
         nct, ncr = self.test.ncomp, self.trial.ncomp
         mask = None if self.mask.all() else self.mask
@@ -262,13 +278,14 @@ class _MatrixPlan:
                           trial=tr.struct, nct=nct, ncr=ncr, C=itg.B * fac, mask=mask, pattern=smp.pattern(itg.test.basis, itg.trial.basis),
                           values=values)
             colors = None
-            if itg.test.basis is itg.trial.basis and itg.scale is None and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16:
+            scale = smp.scale(itg.scale, itg.fscale, arguments)
+            if itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16:
                 colors = _colors(smp, itg.test.basis)
             if colors:
                 for el in colors:
-                    kernels.assemble_matrix(nelems=el.numel(), elist=el, flags=1 | 2, **common)
+                    kernels.assemble_matrix(nelems=el.numel(), elist=el, flags=1 | 2, scale=scale, **common)
             else:
-                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, scale=smp.scale(itg.scale), **common)
+                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, scale=scale, **common)
         return values, rowptr, colidx, self.trial.basis.ndofs * ncr
 
 
@@ -281,18 +298,18 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
         tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
         if itg.rows and not itg.cols:
             u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                     nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=out)
             return
         if not itg.rows and not itg.cols:
             if itg.test.same(itg.trial):
                 u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-                kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+                kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                         nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * (2 * fac), u=u, out_scalar=scalar[0])
             else:
                 tmp = device.zeros(itg.test.basis.ndofs * itg.test.ncomp, 'float64')
                 u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-                kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+                kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                         nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=tmp)
                 # v . r for two different bound fields: O(ndofs) post-processing on the host
                 scalar[1] += float(numpy.dot(device.to_host(tmp), _argument(arguments, itg.test).ravel()))
@@ -301,16 +318,16 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
     if itg.L is not None:
         tt = smp.tables(itg.test.basis)
         if itg.rows:
-            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
+            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
                                     nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, out=out)
         else:
             u = device.to_dev(_argument(arguments, itg.test), 'float64')
-            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
+            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
                                     nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, u=u, out_scalar=scalar[0])
         return
     # constant integrand (volume-type functional): basis-free launch
     none = kernels.basis(None, None)
-    kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=none, trial=none, nct=1, ncr=1,
+    kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=none, trial=none, nct=1, ncr=1,
                             f0=float(itg.f0) * fac, out_scalar=scalar[0])
 
 
@@ -323,7 +340,7 @@ def evaluate(f, arguments):
         terms = f.integral.terms
         if not terms:
             raise ValueError('empty integral')
-        values, rowptr, colidx, ncols = _MatrixPlan(terms).run()
+        values, rowptr, colidx, ncols = _MatrixPlan(terms).run(arguments)
         values, rowptr, colidx = device.to_host(values), device.to_host(rowptr), device.to_host(colidx)
         if isinstance(f, function._AsCOO):
             rowidx = numpy.repeat(numpy.arange(len(rowptr) - 1, dtype=numpy.int64), numpy.diff(rowptr))
@@ -338,7 +355,7 @@ def evaluate(f, arguments):
         raise TypeError(f'cannot evaluate {type(f).__name__}')
     kinds = {(itg.rows, itg.cols) for _, itg, _ in f.terms}
     if kinds == {(True, True)}:
-        values, rowptr, colidx, ncols = _MatrixPlan(f.terms).run()
+        values, rowptr, colidx, ncols = _MatrixPlan(f.terms).run(arguments)
         return _matrix.assemble_csr(device.to_host(values), device.to_host(rowptr), device.to_host(colidx), ncols).export('dense')
     if (True, True) in kinds:
         raise NotImplementedError('mixing matrix and vector terms in one integral')

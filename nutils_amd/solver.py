@@ -1,19 +1,24 @@
 '''System: the caller of the assembly path, mirroring the part of
 /root/reference/src/nutils/solver.py:189-431 that orchestrates (re)assembly:
-``System(functional_or_residual, trial, test)`` builds residual and Jacobian by
-differentiation (solver.py:238,253), assembles them on the GPU, applies constraints
-on the host (NaN = free dof, solver.py:273-315) and hands the matrix to the host
-solver (``matrix.assemble_csr`` -> scipy).  Only linear problems (the class of forms
-the accelerated path represents) -- the Newton/minimize drivers stay with the
-reference.'''
+``System(functional_or_residual, trial, test)`` builds residual and Jacobian blocks by
+differentiation (solver.py:238,253), (re)assembles them on the GPU for the current
+arguments, merges the blocks (``matrix.assemble_block_csr``, matrix/__init__.py:103-151),
+applies constraints on the host (NaN = free dof, solver.py:273-315) and hands the
+matrix to the host solver (scipy).  Linear systems are solved directly, nonlinear ones
+(field-dependent coefficient functions) by plain Newton iteration (solver.py Newton
+without line search); minimisation / pseudo-time drivers stay with the reference.'''
 
 import numpy
 
-from . import function, matrix as _matrix, sample as _sample, device
+from . import function, matrix as _matrix, sample as _sample
 
 
 class SolverError(Exception):
     pass
+
+
+def _names(spec):
+    return tuple(spec.split(',')) if isinstance(spec, str) else tuple(spec)
 
 
 class System:
@@ -21,94 +26,155 @@ class System:
     def __init__(self, residual, /, trial, test=None):
         if not isinstance(residual, function.Integral):
             raise TypeError('System expects an Integral (sum of sample.integral terms)')
-        self.trials = tuple(trial.split(',')) if isinstance(trial, str) else tuple(trial)
-        if len(self.trials) != 1:
-            raise NotImplementedError('multi-field systems (block Jacobians) are not on the accelerated path yet')
-        tests = self.trials if test is None else (tuple(test.split(',')) if isinstance(test, str) else tuple(test))
+        self.trials = _names(trial)
+        tests = self.trials if test is None else _names(test)
+        if len(tests) != len(self.trials):
+            raise ValueError('as many test as trial arguments are required')
         self.is_symmetric = tests == self.trials
         self.value = residual if self.is_symmetric else None
-        self.residual = function.derivative(residual, tests[0])
-        self.jacobian = function.derivative(self.residual, self.trials[0])
-        if not self.jacobian.terms:
-            raise ValueError('the functional does not depend on the trial argument')
-        arg = self.jacobian.terms[0][1].trial
-        self.trial_arg = arg
-        self.trial_shape = (arg.basis.ndofs, arg.ncomp) if arg.ncomp > 1 else (arg.basis.ndofs,)
-        self.is_linear = True
-        self.is_constant_matrix = True
+        self.block_residual = [function.derivative(residual, t) for t in tests]
+        self.block_jacobian = [[function.derivative(r, t) for t in self.trials] for r in self.block_residual]
+        # trial argument objects: found in the Jacobian (column space) or residual terms
+        self.trial_args = []
+        for j, t in enumerate(self.trials):
+            arg = None
+            for row in self.block_jacobian:
+                for _, itg, _ in row[j].terms:
+                    arg = itg.trial
+            if arg is None:
+                raise ValueError(f'the system does not depend on trial argument {t!r}')
+            self.trial_args.append(arg)
+        self.trial_shapes = [(a.basis.ndofs, a.ncomp) if a.ncomp > 1 else (a.basis.ndofs,) for a in self.trial_args]
+        sizes = [int(numpy.prod(s)) for s in self.trial_shapes]
+        self.offsets = numpy.cumsum([0] + sizes)
+        self.size = int(self.offsets[-1])
+        # linear <=> no Jacobian term carries a coefficient function of a trial field (solver.py:255-256)
+        self.is_linear = not any(itg.fscale is not None and any(itg.fscale.depends_on(t) for t in self.trials)
+                                 for row in self.block_jacobian for blk in row for _, itg, _ in blk.terms)
+        self.is_constant_matrix = not any(itg.fscale is not None for row in self.block_jacobian for blk in row for _, itg, _ in blk.terms)
         self._jac = None
 
     # -- assembly (solver.py:318-386) --
 
-    def assemble_jacobian(self):
-        '''Constant Jacobian, cached like solver.py:321-331; terms on different samples (volume + boundary) are
-        assembled separately and added on the host.'''
-        if self._jac is None:
-            by_sample = {}
-            for term in self.jacobian.terms:
-                by_sample.setdefault(id(term[0]), []).append(term)
-            total = None
-            n = int(numpy.prod(self.trial_shape))
-            for terms in by_sample.values():
-                values, rowptr, colidx = _sample.evaluate(function.as_csr(function.Integral(terms)), {})
-                m = _matrix.assemble_csr(values, rowptr, colidx, n)
-                total = m if total is None else _matrix.ScipyMatrix(total.core + m.core)
-            self._jac = total
-        return self._jac
+    def _block_csr(self, integral, nrows, ncols, arguments):
+        '''One Jacobian block as scipy CSR; terms on different samples (volume / boundary) are assembled separately and added.'''
+        import scipy.sparse
+        total = scipy.sparse.csr_matrix((nrows, ncols))
+        by_sample = {}
+        for term in integral.terms:
+            by_sample.setdefault(id(term[0]), []).append(term)
+        for terms in by_sample.values():
+            values, rowptr, colidx = _sample.evaluate(function.as_csr(function.Integral(terms)), arguments)
+            total = total + _matrix.assemble_csr(values, rowptr, colidx, ncols).core
+        total.sort_indices()
+        return total
+
+    def assemble_jacobian(self, arguments):
+        if self._jac is not None and self.is_constant_matrix:
+            return self._jac
+        sizes = numpy.diff(self.offsets)
+        blocks = []
+        for i, row in enumerate(self.block_jacobian):
+            brow = []
+            for j, blk in enumerate(row):
+                m = self._block_csr(blk, int(sizes[i]), int(sizes[j]), arguments)
+                brow.append((m.data, m.indptr.astype(numpy.int64), m.indices.astype(numpy.int64), int(sizes[j])))
+            blocks.append(brow)
+        jac = _matrix.assemble_block_csr(blocks)
+        if self.is_constant_matrix:
+            self._jac = jac
+        return jac
 
     def assemble_residual(self, arguments):
-        '''Residual at the given trial value (linear: res(0) + jac @ x, solver.py:364-378).'''
-        zero = dict(arguments)
-        zero[self.trials[0]] = numpy.zeros(self.trial_shape)
-        res0 = numpy.zeros(int(numpy.prod(self.trial_shape)))
-        for term in self.residual.terms:
-            r = _sample.evaluate(function.Integral([term]), zero)
-            res0 += numpy.asarray(r).ravel()
-        x = numpy.asarray(arguments.get(self.trials[0], zero[self.trials[0]]), dtype=float).ravel()
-        return res0 + self.assemble_jacobian() @ x
+        parts = []
+        for r, size in zip(self.block_residual, numpy.diff(self.offsets)):
+            v = numpy.zeros(int(size))
+            for term in r.terms:
+                v += numpy.asarray(_sample.evaluate(function.Integral([term]), arguments)).ravel()
+            parts.append(v)
+        return numpy.concatenate(parts)
 
     def assemble_jacobian_residual(self, arguments):
-        return self.assemble_jacobian(), self.assemble_residual(arguments)
+        return self.assemble_jacobian(arguments), self.assemble_residual(arguments)
 
     def assemble_value(self, arguments):
         if not self.is_symmetric:
             raise Exception('value is not defined')
         return function.eval(self.value, arguments)
 
+    # -- argument packing (solver.py:273-315) --
+
+    def _pack(self, arguments, constrain):
+        x = numpy.zeros(self.size)
+        free = numpy.ones(self.size, dtype=bool)
+        for t, shape, a, b in zip(self.trials, self.trial_shapes, self.offsets, self.offsets[1:]):
+            if t in arguments:
+                x[a:b] = numpy.asarray(arguments[t], dtype=float).ravel()
+            c = (constrain or {}).get(t)
+            if c is not None:
+                c = numpy.asarray(c).ravel()
+                if c.dtype == bool:
+                    free[a:b] = ~c
+                else:
+                    fixed = ~numpy.isnan(c)
+                    x[a:b][fixed] = c[fixed]
+                    free[a:b] = ~fixed
+        return x, free
+
+    def _unpack(self, arguments, x):
+        out = dict(arguments)
+        for t, shape, a, b in zip(self.trials, self.trial_shapes, self.offsets, self.offsets[1:]):
+            out[t] = x[a:b].reshape(shape)
+        return out
+
     # -- solves --
 
-    def solve(self, *, arguments=None, constrain=None):
-        '''Direct solve of the linear system; `constrain[trial]` holds NaN for free dofs (solver.py:440-500, Direct).'''
-        arguments = dict(arguments or {})
-        t = self.trials[0]
-        cons = None if not constrain or t not in constrain else numpy.asarray(constrain[t], dtype=float).ravel()
-        x0 = numpy.zeros(int(numpy.prod(self.trial_shape)))
-        if cons is not None:
-            x0[~numpy.isnan(cons)] = cons[~numpy.isnan(cons)]
-        arguments[t] = x0.reshape(self.trial_shape)
-        jac, res = self.assemble_jacobian_residual(arguments)
-        free = numpy.ones(len(x0), dtype=bool) if cons is None else numpy.isnan(cons)
-        dx = -jac.solve(res, constrain=~free)
-        arguments[t] = (x0 + dx).reshape(self.trial_shape)
-        return arguments
+    def solve(self, *, arguments=None, constrain=None, tol=0., maxiter=25):
+        '''Direct (linear) or Newton (nonlinear) solve; `constrain[trial]` holds NaN for free dofs (solver.py:440-500).'''
+        x, free = self._pack(dict(arguments or {}), constrain)
+        args = self._unpack(dict(arguments or {}), x)
+        if not self.is_linear and tol <= 0:
+            raise ValueError('iterative solver requires a strictly positive tolerance')
+        for it in range(maxiter + 1):
+            res = self.assemble_residual(args)
+            resnorm = numpy.linalg.norm(res[free])
+            if it and (self.is_linear or resnorm <= tol):
+                break
+            if not it and not self.is_linear and resnorm <= tol:
+                break
+            if it == maxiter:
+                raise SolverError(f'failed to converge in {maxiter} iterations (residual norm {resnorm:.1e})')
+            jac = self.assemble_jacobian(args)
+            x = x - jac.solve(res, constrain=~free)
+            args = self._unpack(args, x)
+        return args
+
+    def step(self, *, arguments, suffix, timestep=None, timesteparg=None, **solveargs):
+        '''Advance a time step (solver.py:503-560): copies trial arguments to name+suffix, then solves.'''
+        arguments = dict(arguments)
+        for t in self.trials:
+            if t in arguments:
+                arguments[t + suffix] = arguments[t]
+        if timesteparg:
+            arguments[timesteparg] = timestep
+        return self.solve(arguments=arguments, **solveargs)
 
     def solve_constraints(self, *, droptol, arguments=None, constrain=None):
         '''Dirichlet constraints by boundary projection (solver.py:562-612): solve on the dofs whose matrix column has an
         entry above droptol, return NaN for all others.'''
-        arguments = dict(arguments or {})
-        t = self.trials[0]
-        n = int(numpy.prod(self.trial_shape))
-        arguments[t] = numpy.zeros(self.trial_shape)
-        jac, res = self.assemble_jacobian_residual(arguments)
+        if not self.is_linear:
+            raise ValueError('system is not linear')
+        x, free = self._pack(dict(arguments or {}), constrain)
+        args = self._unpack(dict(arguments or {}), x)
+        jac, res = self.assemble_jacobian_residual(args)
         data, colidx, _ = jac.export('csr')
-        mycons = numpy.ones(n, dtype=bool)
+        mycons = numpy.ones(self.size, dtype=bool)
         mycons[colidx[abs(data) > droptol]] = False
-        x = -jac.solve(res, constrain=mycons)
-        x[mycons] = numpy.nan
+        mycons |= ~free
+        dx = -jac.solve(res, constrain=mycons)
+        x = x + dx
+        x[mycons & free] = numpy.nan
         out = dict(constrain or {})
-        prev = out.get(t)
-        if prev is not None:
-            prev = numpy.asarray(prev, dtype=float).ravel()
-            x = numpy.where(numpy.isnan(prev), x, prev)
-        out[t] = x.reshape(self.trial_shape)
+        for t, shape, a, b in zip(self.trials, self.trial_shapes, self.offsets, self.offsets[1:]):
+            out[t] = x[a:b].reshape(shape)
         return out

@@ -104,6 +104,17 @@ class _Boundary:
         self.parent = parent
         self._cache = {}
 
+    def sides(self):
+        return [self[n] for names in _BNAMES[:self.parent.ndims] for n in names]
+
+    def integral(self, func, degree):
+        '''Integral over the whole boundary (domain.boundary.integral): sum over the sides.'''
+        total = None
+        for side in self.sides():
+            term = side.integral(func, degree)
+            total = term if total is None else total + term
+        return total
+
     def __getitem__(self, name):
         if name not in self._cache:
             for axis, names in enumerate(_BNAMES[:self.parent.ndims]):

@@ -194,6 +194,49 @@ def hierarchical_case(name, ndim):
     save(name, **data)
 
 
+def cahnhilliard_case(name, nelems, degree=2, seed=3):
+    '''Cahn-Hilliard free-energy functional of examples/cahnhilliard.py:163-184 (unit-free restatement: the shipped example
+    imports nutils.units, which is not in the reference tree): residual blocks, Jacobian blocks and energy at a random state,
+    and the result of one implicit time step (Newton solve).'''
+    from nutils.solver import System
+    rng = numpy.random.default_rng(seed)
+    size, epsilon, mobility, stens, wtensn, wtensp, dt = 10., 1., 1., 50., 30., 20., .5
+    domain, geom = mesh.unitsquare(nelems, 'square')
+    ns = Namespace()
+    ns.x = geom * size
+    ns.define_for('x', gradient='∇', normal='n', jacobians=('dV', 'dS'))
+    ns.φ = domain.field('φ', btype='std', degree=degree)
+    ns.dφ = ns.φ - function.replace_arguments(ns.φ, 'φ:φ0')
+    ns.η = domain.field('η', btype='std', degree=degree) * (stens / epsilon)
+    ns.dt = dt
+    ns.ε = epsilon
+    ns.σ = stens
+    ns.σmean = (wtensp + wtensn) / 2
+    ns.σdiff = (wtensp - wtensn) / 2
+    ns.σwall = 'σmean + φ σdiff'
+    ns.ψ = '.25 (φ^2 - 1)^2'
+    ns.δψ = '.25 dφ^2 (1 - φ^2 + 2 φ dφ / 3 - dφ^2 / 6)'
+    ns.M = mobility
+    ns.J_i = '-M ∇_i(η)'
+    nrg = domain.integral('(ψ σ / ε + .5 σ ε ∇_k(φ) ∇_k(φ) + δψ σ / ε - η dφ + .5 dt J_k ∇_k(η)) dV' @ ns, degree=degree * 4) \
+        + domain.boundary.integral('σwall dS' @ ns, degree=degree * 2)
+    basis = domain.basis('std', degree=degree)
+    n = len(basis)
+    args = dict(φ=rng.normal(0, .5, n), φ0=rng.normal(0, .5, n), η=rng.normal(0, .1, n))
+    data = dict(nelems=nelems, degree=degree, params=numpy.array([size, epsilon, mobility, stens, wtensn, wtensp, dt]), **{'arg_' + k: v for k, v in args.items()})
+    data['energy'] = function.eval(nrg, args)
+    for a in 'φη':
+        ra = function.derivative(nrg, a)
+        data['res_' + a] = function.eval(ra, args)
+        for b in 'φη':
+            v, rp, ci = function.eval(function.as_csr(function.derivative(ra, b)), args)
+            data[f'jac_{a}{b}_values'], data[f'jac_{a}{b}_rowptr'], data[f'jac_{a}{b}_colidx'] = v, rp, ci
+    sol = System(nrg, trial='φ,η').solve(arguments=dict(φ=args['φ0'], φ0=args['φ0'], η=numpy.zeros(n)), tol=1e-8)
+    data['step_φ'] = sol['φ']
+    data['step_η'] = sol['η']
+    save(name, **data)
+
+
 def example_vectors():
     '''Decoded assertAlmostEqual64 payloads of the reference examples
     (examples/laplace.py:111-152, examples/elasticity.py:89-146): the embedded
@@ -235,6 +278,7 @@ if __name__ == '__main__':
     elasticity_case('elast3d_p1_2_iso', (2, 2, 2), 1, iso=True)
     elasticity_case('elast3d_p2_2', (2, 2, 2), 2, iso=False)
     elasticity_case('elast3d_p2_2_iso', (2, 2, 2), 2, iso=True)
+    cahnhilliard_case('cahnhilliard_p2_4', 4)
     hierarchical_case('hier_spline2_1d', 1)
     hierarchical_case('hier_spline2_2d', 2)
     example_vectors()
