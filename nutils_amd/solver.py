@@ -56,31 +56,48 @@ class System:
 
     # -- assembly (solver.py:318-386) --
 
-    def _block_csr(self, integral, nrows, ncols, arguments):
-        '''One Jacobian block as scipy CSR; terms on different samples (volume / boundary) are assembled separately and added.'''
-        import scipy.sparse
-        total = scipy.sparse.csr_matrix((nrows, ncols))
-        by_sample = {}
-        for term in integral.terms:
-            by_sample.setdefault(id(term[0]), []).append(term)
-        for terms in by_sample.values():
-            values, rowptr, colidx = _sample.evaluate(function.as_csr(function.Integral(terms)), arguments)
-            total = total + _matrix.assemble_csr(values, rowptr, colidx, ncols).core
-        total.sort_indices()
-        return total
+    def _build_merge_plan(self, arguments):
+        '''Symbolic block merge, ONCE per system (the patterns do not change between Newton steps): every (block, sample)
+        group of matrix terms is one device assembly; the position of each of its CSR entries in the merged block matrix is
+        precomputed, so a re-assembly is device launches + one scatter-add per group (nh_monomial with an output index) + one
+        D2H copy of the merged values.  Replaces the per-row Python loop of matrix.assemble_block_csr
+        (matrix/__init__.py:141-147) on the per-step path.'''
+        from . import device
+        groups, keys = [], []
+        for i, row in enumerate(self.block_jacobian):
+            for j, blk in enumerate(row):
+                by_sample = {}
+                for term in blk.terms:
+                    by_sample.setdefault(id(term[0]), []).append(term)
+                for terms in by_sample.values():
+                    plan = _sample._MatrixPlan(terms)
+                    values, rowptr, colidx, ncols = plan.run(arguments)
+                    rp, ci = device.to_host(rowptr), device.to_host(colidx)
+                    rows = numpy.repeat(numpy.arange(len(rp) - 1, dtype=numpy.int64), numpy.diff(rp)) + int(self.offsets[i])
+                    key = rows * self.size + ci + int(self.offsets[j])
+                    constant = not any(itg.fscale is not None for _, itg, _ in terms)
+                    groups.append(dict(plan=plan, constant=constant, values=values if constant else None, n=len(key)))
+                    keys.append(key)
+        allkeys = numpy.concatenate(keys) if keys else numpy.zeros(0, dtype=numpy.int64)
+        ukeys = numpy.unique(allkeys)
+        rows, cols = numpy.divmod(ukeys, self.size)
+        self._merged_rowptr = numpy.searchsorted(rows, numpy.arange(self.size + 1)).astype(numpy.int64)
+        self._merged_colidx = cols.astype(numpy.int64)
+        for grp, key in zip(groups, keys):
+            grp['slot'] = device.to_dev(numpy.searchsorted(ukeys, key), 'int64')
+        self._groups = groups
 
     def assemble_jacobian(self, arguments):
+        from . import device, kernels
         if self._jac is not None and self.is_constant_matrix:
             return self._jac
-        sizes = numpy.diff(self.offsets)
-        blocks = []
-        for i, row in enumerate(self.block_jacobian):
-            brow = []
-            for j, blk in enumerate(row):
-                m = self._block_csr(blk, int(sizes[i]), int(sizes[j]), arguments)
-                brow.append((m.data, m.indptr.astype(numpy.int64), m.indices.astype(numpy.int64), int(sizes[j])))
-            blocks.append(brow)
-        jac = _matrix.assemble_block_csr(blocks)
+        if not hasattr(self, '_groups'):
+            self._build_merge_plan(arguments)
+        merged = device.zeros(len(self._merged_colidx), 'float64')
+        for grp in self._groups:
+            values = grp['values'] if grp['constant'] else grp['plan'].run(arguments)[0]
+            kernels.monomial(values, [], [], merged, out_index=grp['slot'])
+        jac = _matrix.assemble_csr(device.to_host(merged), self._merged_rowptr, self._merged_colidx, self.size)
         if self.is_constant_matrix:
             self._jac = jac
         return jac
