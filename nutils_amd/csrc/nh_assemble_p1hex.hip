@@ -107,33 +107,79 @@ __device__ __forceinline__ bool load_element(const P1Args &p, int box, int tid, 
   return true;
 }
 
-template <int BI, int BJ, int BK, int NT, int NBUF>
+// Cooperative load of the (BI+2)(BJ+2)(BK+2) vertex block of box `box` into registers: thread t owns block vertices t + k*NT.
+// Issued one box ahead (after the scatter, before the barrier) so that the HBM/L2 latency hides behind barrier + flush; the
+// block is then staged in LDS and every element thread reads its 8 vertices from there.
+template <int BI, int BJ, int BK, int NT, int VPT>
+__device__ __forceinline__ void load_vertex_block(const P1Args &p, int box, int tid, double (&V)[VPT][3]) {
+  constexpr int VI = BI + 2, VJ = BJ + 2, VK = BK + 2;
+  const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
+  int b = box;
+  const int bk = b % p.nbk; b /= p.nbk;
+  const int bj = b % p.nbj;
+  const int bi = b / p.nbj;
+  const int I0 = p.pl0 + bi * BI - 1, J0 = bj * BJ - 1, K0 = bk * BK - 1;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int v = tid + k * NT;
+    const int c = v % VK, bb = (v / VK) % VJ, a = v / (VK * VJ);
+    const int I = I0 + a, J = J0 + bb, K = K0 + c;
+    const bool ok = box < p.nboxes && v < VI * VJ * VK && I >= 0 && I < N0 && J >= 0 && J < N1 && K >= 0 && K < N2;
+    if (ok && p.verts) {
+      const double *src = p.verts + (((i64)I * N1 + J) * N2 + K) * 3;
+      V[k][0] = src[0];
+      V[k][1] = src[1];
+      V[k][2] = src[2];
+    } else {
+      V[k][0] = p.origin[0] + p.scale[0] * I;
+      V[k][1] = p.origin[1] + p.scale[1] * J;
+      V[k][2] = p.origin[2] + p.scale[2] * K;
+    }
+  }
+}
+
+template <int BI, int BJ, int BK, int NT, int NBUF, int EPT>
 __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
   constexpr int ROWS = BI * BJ * BK;
   constexpr int EI = BI + 1, EJ = BJ + 1, EK = BK + 1;
-  static_assert(EI * EJ * EK <= NT, "one thread per element");
+  static_assert(EI * EJ * EK <= NT * EPT, "EPT elements per thread");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   // two accumulator sets (double buffering across consecutive boxes of this persistent workgroup):
   //   acc [ROWS][27] f64, rowbase [ROWS] i64 (CSR offset of the row, -1 = not written), rowflag [ROWS] i32
   constexpr int SETD = ROWS * 27 + ROWS + (ROWS + 1) / 2 + 1;  // doubles per set (kept even for 16-byte alignment)
   constexpr int SET = SETD + (SETD & 1);
+  constexpr int VI = BI + 2, VJ = BJ + 2, VK = BK + 2, NV = VI * VJ * VK, VPT = (NV + NT - 1) / NT;
+  double *vbuf = lds + NBUF * SET;  // [NV][3] vertex block of the current box
   const int tid = threadIdx.x;
   const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
   for (int t = tid; t < NBUF * SET; t += NT) lds[t] = 0.;
+  double V[VPT][3];
+  load_vertex_block<BI, BJ, BK, NT, VPT>(p, blockIdx.x, tid, V);
   __syncthreads();
 
   for (int box = blockIdx.x, it = 0; box < p.nboxes; box += gridDim.x, ++it) {
   double *acc = lds + (NBUF == 2 ? (it & 1) : 0) * SET;
-  i64 *rowbase = reinterpret_cast<i64 *>(acc + ROWS * 27);
-  int *rowflag = reinterpret_cast<int *>(rowbase + ROWS);
+  // the row table alternates between two copies even with a single accumulator set: fast waves write the table of box k+1
+  // while slow waves still flush box k
+  i64 *rowbase = reinterpret_cast<i64 *>(vbuf + NV * 3 + (NV & 1)) + (it & 1) * ROWS;
+  int *rowflag = reinterpret_cast<int *>(reinterpret_cast<i64 *>(vbuf + NV * 3 + (NV & 1)) + 2 * ROWS) + (it & 1) * ROWS;
   int b = box;
   const int bk = b % p.nbk; b /= p.nbk;
   const int bj = b % p.nbj;
   const int bi = b / p.nbj;
   const int I0 = p.pl0 + bi * BI, J0 = bj * BJ, K0 = bk * BK;
 
-  if (tid < ROWS) {  // closed-form CSR row offsets, once per row (not once per entry)
-    const int lk = tid % BK, lj = (tid / BK) % BJ, li = tid / (BK * BJ);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int v = tid + k * NT;
+    if (v < NV) {
+      vbuf[v * 3 + 0] = V[k][0];
+      vbuf[v * 3 + 1] = V[k][1];
+      vbuf[v * 3 + 2] = V[k][2];
+    }
+  }
+  for (int rr = tid; rr < ROWS; rr += NT) {  // closed-form CSR row offsets, once per row (not once per entry)
+    const int lk = rr % BK, lj = (rr / BK) % BJ, li = rr / (BK * BJ);
     const int I = I0 + li, J = J0 + lj, Kk = K0 + lk;
     i64 base = -1;
     int flag = 0;
@@ -142,14 +188,29 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
       base = cum_of(I, N0) * T1 * T2 + len_of(I, N0) * (cum_of(J, N1) * T2 + (i64)len_of(J, N1) * cum_of(Kk, N2));
       flag = (I > 0) | (J > 0) << 1 | (Kk > 0) << 2 | (I < N0 - 1) << 3 | (J < N1 - 1) << 4 | (Kk < N2 - 1) << 5;
     }
-    rowbase[tid] = base;
-    rowflag[tid] = flag;
+    rowbase[rr] = base;
+    rowflag[rr] = flag;
   }
+  __syncthreads();  // vertex block + row table visible; the previous flush (which zeroed acc) is complete
 
-  {
-    const int ek = tid % EK, ej = (tid / EK) % EJ, ei = tid / (EK * EJ);
+#pragma unroll 1
+  for (int ke = 0; ke < EPT; ++ke) {
+    const int el = tid + ke * NT;
+    const int ek = el % EK, ej = (el / EK) % EJ, ei = el / (EK * EJ);
     double X[2][2][2][3];
-    if (load_element<BI, BJ, BK>(p, box, tid, X)) {
+    const int gi = I0 - 1 + ei, gj = J0 - 1 + ej, gk = K0 - 1 + ek;
+    if (el < EI * EJ * EK && gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2 && !(DEBUG(p) & 4)) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const double *src = vbuf + (((ei + a) * VJ + (ej + bb)) * VK + (ek + c)) * 3;
+            X[a][bb][c][0] = src[0];
+            X[a][bb][c][1] = src[1];
+            X[a][bb][c][2] = src[2];
+          }
       double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3];
 #include "nh_p1hex_math.inc"
       // ---- form K[a][b] (a <= b) entry by entry and reduce it into the LDS row accumulators ---------------
@@ -183,6 +244,7 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
       }
     }
   }
+  load_vertex_block<BI, BJ, BK, NT, VPT>(p, box + gridDim.x, tid, V);  // next box: in flight during barrier + flush
   __syncthreads();
 
   // ---- stream the finished rows to HBM: 32 lanes per row (27 slots), NT/32 rows per pass ------------------
@@ -205,7 +267,6 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
       }
     }
   }
-  if (NBUF == 1) __syncthreads();
   }  // persistent loop over boxes: with NBUF == 2, ONE barrier per box; the stores of this box drain while the next box computes
 }
 
@@ -371,7 +432,7 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
   int rc = fill_p1args(a, p);
   if (rc) return rc;
   if (a->plane_begin == a->plane_end) return NH_OK;
-  constexpr int BI = 7, BJ = 7, BK = 7, NT = 512, NBUF = 2;
+  constexpr int BI = 7, BJ = 7, BK = 7, NT = 512, NBUF = 1, EPT = 1;
   const int nbi = (p.pl1 - p.pl0 + BI - 1) / BI;
   p.nbj = (p.n1 + 1 + BJ - 1) / BJ;
   p.nbk = (p.n2 + 1 + BK - 1) / BK;
@@ -388,15 +449,15 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
     return NH_OK;
   }
   constexpr int ROWS = BI * BJ * BK, SETD = ROWS * 27 + ROWS + (ROWS + 1) / 2 + 1, SET = SETD + (SETD & 1);
-  const size_t lds = sizeof(double) * NBUF * SET;
+  const size_t lds = sizeof(double) * (NBUF * SET + (BI + 2) * (BJ + 2) * (BK + 2) * 3 + 1 + 2 * ROWS + ROWS + 2);
   p.nboxes = nbi * p.nbj * p.nbk;
   p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
   int dev = 0, cus = 256;
   NH_CHECK_HIP(hipGetDevice(&dev));
   NH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  auto kern = k_p1hex_laplace<BI, BJ, BK, NT, NBUF>;
+  auto kern = k_p1hex_laplace<BI, BJ, BK, NT, NBUF, EPT>;
   NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)std::min(p.nboxes, cus)), dim3(NT), lds, nh_stream(stream), p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min(p.nboxes, cus * (NT == 256 ? 2 : 1))), dim3(NT), lds, nh_stream(stream), p);
   NH_LAUNCH_CHECK();
   return NH_OK;
 }
