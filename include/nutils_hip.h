@@ -111,6 +111,8 @@ int nh_pattern_expand(const nh_pattern *p, int nct, int ncr, const unsigned char
  * (function.py:1162-1181,1284-1295; evaluable.py:1403-1490; numeric.py:221-241). */
 #define NH_GEOM_ISO 1    /* x = sum_a N_a(xi) X[gdofs[e][a]]; gT = tabulated geometry basis [ngb][nq][S] */
 #define NH_GEOM_BOX 2    /* x = origin[e] + size[e] * xi  (axis aligned; rectilinear + hierarchical refinements) */
+#define NH_GEOM_TAB 3    /* Jacobian (and coordinates) tabulated per element and point by the producer of the mesh: geometries
+                            the kernels do not evaluate themselves (NURBS maps through transform chains, trimmed cells ...) */
 
 typedef struct {
   int kind;
@@ -120,6 +122,8 @@ typedef struct {
   const double *verts_dev;   /* ISO: [nverts][ndims] */
   const double *origin_dev;  /* BOX: [nelems][ndims] */
   const double *size_dev;    /* BOX: [nelems][ndims] */
+  const double *jac_dev;     /* TAB: [nelems][nq][ndims][ndims]  d x_i / d xi_j */
+  const double *x_dev;       /* TAB: [nelems][nq][ndims] or NULL (only needed by nh_sample_eval) */
   int bnd_axis;              /* -1: volume measure |det J|.  a >= 0: the points lie on the reference face xi_a = const and the
                                 measure is the surface measure |det J| |J^-T e_a| (boundary integrals, topology.boundary) */
 } nh_geometry;
@@ -265,6 +269,15 @@ int nh_monomial(int64_t n, const double *values_dev, int nargs, const double *co
  * integrand is re-integrated with the pointwise coefficient. */
 int nh_pointwise_poly(int64_t n, int nvars, const double *const *x_dev, const int *strides, int nterms, const double *coeffs,
                       const int *powers, double *out_dev, void *stream);
+
+/* ---- rational bases (NURBS) ------------------------------------------------------------------
+ * In-place transform of per-element tabulated functions T[(e, i)][q][S] (function (e,i) = e*nb+i, or off[e]+i for ragged bases)
+ * into N_i = w_i B_i / W,  dN_i = w_i (dB_i W - B_i dW) / W^2  with the dof weights w[dofs[e][i]] and the weight function W
+ * either tabulated (W_dev [nelems][nq], dW_dev [nelems][nq][ndims], derivatives w.r.t. the element coordinates) or, if
+ * W_dev is NULL, W = sum_j w_j B_j of the element itself.  Replaces the symbolic quotient
+ * `bsplinebasis * controlweights / weightfunc` (examples/platewithhole.py:71-72,85) evaluated inside the generated loop. */
+int nh_rationalize(double *T_dev, int64_t nelems, int nb, const int64_t *off_dev, const int32_t *dofs_dev, const double *weights_dev,
+                   const double *W_dev, const double *dW_dev, int nq, int ndims, void *stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ class NutilsHipError(RuntimeError):
 
 class Geometry(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int), ('ngb', ctypes.c_int), ('gT_dev', vp), ('gdofs_dev', vp), ('verts_dev', vp),
-                ('origin_dev', vp), ('size_dev', vp), ('bnd_axis', ctypes.c_int)]
+                ('origin_dev', vp), ('size_dev', vp), ('jac_dev', vp), ('x_dev', vp), ('bnd_axis', ctypes.c_int)]
 
 
 class Basis(ctypes.Structure):
@@ -65,6 +65,7 @@ class P1HexArgs(ctypes.Structure):
 
 GEOM_ISO = 1
 GEOM_BOX = 2
+GEOM_TAB = 3
 
 # name -> (restype, argtypes); kept in step with include/nutils_hip.h (tests/test_abi.py parses the header)
 SIGNATURES = {
@@ -94,6 +95,7 @@ SIGNATURES = {
     'nh_monomial': (ctypes.c_int, [c_i64, vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, ctypes.c_double, vp, vp]),
     'nh_pointwise_poly': (ctypes.c_int, [c_i64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int), vp, vp]),
+    'nh_rationalize': (ctypes.c_int, [vp, c_i64, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     'nh_p1hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64, vp, vp, vp]),
     'nh_p1hex_laplace': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp]),
     'nh_p1hex_unit_matrix': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp, vp]),

@@ -212,3 +212,28 @@ class PlainBasis(Basis):
     def concatenated(self):
         return (numpy.concatenate(self._dofs) if self._dofs else numpy.zeros(0, numpy.int64),
                 numpy.concatenate(self._coeffs, axis=0) if self._coeffs else numpy.zeros((0, self.ncoeffs)))
+
+
+class RationalBasis(Basis):
+    '''NURBS-type basis  N_i = w_i B_i / W  over a polynomial parent basis (examples/platewithhole.py:71-72,85:
+    ``bsplinebasis * controlweights / weightfunc``).  `weights` are the dof weights w.  The weight function W is either the
+    parent combination sum_j w_j B_j itself (W=None) or supplied by the mesh producer at the points of ONE sample:
+    W[nelems][nq] and dW[nelems][nq][ndims] (derivatives w.r.t. the element coordinates), e.g. a coarse-level weight function
+    seen through refinement transforms.  Tables are per element (nh_rationalize on the device).'''
+
+    def __init__(self, parent, weights, W=None, dW=None):
+        weights = numpy.asarray(weights, dtype=float)
+        if weights.shape != (parent.ndofs,):
+            raise ValueError('one weight per dof expected')
+        if (W is None) != (dW is None):
+            raise ValueError('W and dW go together')
+        self.parent, self.weights = parent, weights
+        self.W = None if W is None else numpy.ascontiguousarray(W, dtype=float)
+        self.dW = None if dW is None else numpy.ascontiguousarray(dW, dtype=float)
+        self.ndofs, self.nelems, self.ndims = parent.ndofs, parent.nelems, parent.ndims
+
+    def get_dofs(self, ielem):
+        return self.parent.get_dofs(ielem)
+
+    def get_coefficients(self, ielem):
+        raise NotImplementedError('a rational basis has no polynomial coefficients; see parent.get_coefficients and weights')

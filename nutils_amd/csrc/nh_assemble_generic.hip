@@ -109,6 +109,14 @@ __device__ __forceinline__ void geometry_at(const GeomK &g, i64 e, int q, int nq
     } else {
       for (int a = 0; a < g.ngb; ++a) accumulate(a, g.verts + (i64)g.gdofs[e * g.ngb + a] * ND);
     }
+  } else if (g.kind == NH_GEOM_TAB) {
+    const double *Jt = g.jac + ((i64)e * nq + q) * ND * ND;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+#pragma unroll
+      for (int j = 0; j < ND; ++j) J[i][j] = Jt[i * ND + j];
+      if (x) x[i] = g.x ? g.x[((i64)e * nq + q) * ND + i] : 0.;
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
@@ -576,6 +584,8 @@ int make_form(int nd, int nct, int ncr, const double *C, const double *f, const 
 int check_geom(const nh_geometry &g) {
   if (g.kind == NH_GEOM_ISO) {
     NH_REQUIRE(g.ngb > 0 && g.gT_dev && g.gdofs_dev && g.verts_dev, "isoparametric geometry needs ngb, gT, gdofs, verts");
+  } else if (g.kind == NH_GEOM_TAB) {
+    NH_REQUIRE(g.jac_dev, "tabulated geometry needs jac_dev");
   } else if (g.kind == NH_GEOM_BOX) {
     NH_REQUIRE(g.origin_dev && g.size_dev, "box geometry needs origin and size");
   } else {

@@ -44,6 +44,8 @@ struct GeomK {
   const double *verts;
   const double *origin;
   const double *size;
+  const double *jac;
+  const double *x;
   int bnd_axis;
 };
 
@@ -55,5 +57,5 @@ struct BasisK {
   const int32_t *tab;
 };
 
-static inline GeomK to_k(const nh_geometry &g) { return GeomK{g.kind, g.ngb, g.gT_dev, g.gdofs_dev, g.verts_dev, g.origin_dev, g.size_dev, g.bnd_axis}; }
+static inline GeomK to_k(const nh_geometry &g) { return GeomK{g.kind, g.ngb, g.gT_dev, g.gdofs_dev, g.verts_dev, g.origin_dev, g.size_dev, g.jac_dev, g.x_dev, g.bnd_axis}; }
 static inline BasisK to_k(const nh_basis &b) { return BasisK{b.nb, b.T_dev, b.dofs_dev, b.off_dev, b.tab_dev}; }

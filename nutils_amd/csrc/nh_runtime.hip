@@ -286,3 +286,57 @@ extern "C" int nh_structured_dofs(int ndims, const int *shape, const int *nloc, 
   NH_LAUNCH_CHECK();
   return NH_OK;
 }
+
+// ---------------------------------------------------------------------------------
+// Rational (NURBS) bases: N_i = w_i B_i / W in place on per-element tables.
+// ---------------------------------------------------------------------------------
+template <int ND>
+__global__ void k_rationalize(double *T, i64 nelems, int nb, const i64 *off, const int32_t *dofs, const double *w, const double *W, const double *dW,
+                              int nq) {
+  constexpr int S = 1 + ND;
+  const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nelems * nq) return;
+  const i64 e = t / nq;
+  const int q = (int)(t % nq);
+  const i64 f0 = off ? off[e] : e * (i64)nb;
+  const int n = off ? (int)(off[e + 1] - off[e]) : nb;
+  double Wq, dWq[ND];
+  if (W) {
+    Wq = W[t];
+    for (int k = 0; k < ND; ++k) dWq[k] = dW[t * ND + k];
+  } else {
+    Wq = 0;
+    for (int k = 0; k < ND; ++k) dWq[k] = 0;
+    for (int i = 0; i < n; ++i) {
+      const double wi = w[dofs[f0 + i]];
+      const double *Ti = T + ((f0 + i) * nq + q) * S;
+      Wq += wi * Ti[0];
+      for (int k = 0; k < ND; ++k) dWq[k] += wi * Ti[1 + k];
+    }
+  }
+  const double r = 1. / Wq;
+  for (int i = 0; i < n; ++i) {
+    const double wi = w[dofs[f0 + i]] * r;
+    double *Ti = T + ((f0 + i) * nq + q) * S;
+    const double B = Ti[0];
+    Ti[0] = wi * B;
+    for (int k = 0; k < ND; ++k) Ti[1 + k] = wi * (Ti[1 + k] - B * dWq[k] * r);
+  }
+}
+
+extern "C" int nh_rationalize(double *T_dev, int64_t nelems, int nb, const int64_t *off_dev, const int32_t *dofs_dev, const double *weights_dev,
+                              const double *W_dev, const double *dW_dev, int nq, int ndims, void *stream) {
+  NH_REQUIRE(T_dev && dofs_dev && weights_dev, "nh_rationalize: NULL argument");
+  NH_REQUIRE(ndims >= 1 && ndims <= 3, "nh_rationalize: ndims must be 1..3");
+  NH_REQUIRE((nb > 0) != (off_dev != nullptr), "nh_rationalize: give either nb or off_dev");
+  NH_REQUIRE(!W_dev || dW_dev, "nh_rationalize: W_dev without dW_dev");
+  const i64 n = (i64)nelems * nq;
+  if (!n) return NH_OK;
+  dim3 grid((unsigned)((n + 127) / 128)), block(128);
+  hipStream_t s = nh_stream(stream);
+  if (ndims == 1) hipLaunchKernelGGL(k_rationalize<1>, grid, block, 0, s, T_dev, (i64)nelems, nb, (const i64 *)off_dev, dofs_dev, weights_dev, W_dev, dW_dev, nq);
+  if (ndims == 2) hipLaunchKernelGGL(k_rationalize<2>, grid, block, 0, s, T_dev, (i64)nelems, nb, (const i64 *)off_dev, dofs_dev, weights_dev, W_dev, dW_dev, nq);
+  if (ndims == 3) hipLaunchKernelGGL(k_rationalize<3>, grid, block, 0, s, T_dev, (i64)nelems, nb, (const i64 *)off_dev, dofs_dev, weights_dev, W_dev, dW_dev, nq);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}

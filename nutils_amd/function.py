@@ -67,6 +67,19 @@ class IsoGeometry(Geometry):
         self.ndims = basis.ndims
 
 
+class TabulatedGeometry(Geometry):
+    '''Geometry known at the points of ONE sample only: coordinates x[nelems][nq][ndims] and Jacobians
+    J[nelems][nq][ndims][ndims] = d x_i / d xi_j w.r.t. the element coordinates, supplied by the mesh producer (NURBS maps
+    seen through refinement transforms, examples/platewithhole.py:74-79; any map the kernels do not evaluate themselves).'''
+
+    def __init__(self, x, J):
+        self.x = numpy.ascontiguousarray(x, dtype=float)
+        self.jac = numpy.ascontiguousarray(J, dtype=float)
+        if self.jac.shape != self.x.shape + self.x.shape[-1:]:
+            raise ValueError('J must have shape x.shape + (ndims,)')
+        self.ndims = self.x.shape[-1]
+
+
 def dot_basis(basis, values):
     '''``basis @ values``: geometry if values is (ndofs, ndims), else a scalar/vector field value.'''
     values = numpy.asarray(values, dtype=float)

@@ -78,15 +78,27 @@ class Pattern:
 
 
 def geometry_iso(ngb, gT, gdofs, verts, bnd_axis=-1):
-    g = _lib.Geometry(_lib.GEOM_ISO, ngb, device.ptr(gT), device.ptr(gdofs), device.ptr(verts), None, None, bnd_axis)
+    g = _lib.Geometry(_lib.GEOM_ISO, ngb, device.ptr(gT), device.ptr(gdofs), device.ptr(verts), None, None, None, None, bnd_axis)
     g._keep = (gT, gdofs, verts)
     return g
 
 
 def geometry_box(origin, size, bnd_axis=-1):
-    g = _lib.Geometry(_lib.GEOM_BOX, 0, None, None, None, device.ptr(origin), device.ptr(size), bnd_axis)
+    g = _lib.Geometry(_lib.GEOM_BOX, 0, None, None, None, device.ptr(origin), device.ptr(size), None, None, bnd_axis)
     g._keep = (origin, size)
     return g
+
+
+def geometry_tab(jac, x=None, bnd_axis=-1):
+    g = _lib.Geometry(_lib.GEOM_TAB, 0, None, None, None, None, None, device.ptr(jac), device.ptr(x), bnd_axis)
+    g._keep = (jac, x)
+    return g
+
+
+def rationalize(T, nelems, nb, dofs, weights, nq, ndims, W=None, dW=None, off=None):
+    '''N_i = w_i B_i / W in place on per-element tables (nh_rationalize).'''
+    _lib.call('nh_rationalize', device.ptr(T), nelems, nb, device.ptr(off), device.ptr(dofs), device.ptr(weights), device.ptr(W), device.ptr(dW), nq, ndims,
+              device.stream())
 
 
 def basis(T, dofs, nb=0, off=None, tab=None):

@@ -12,7 +12,7 @@ libnutils_hip.so.  No CPU fallback.
 import numpy
 
 from . import device, function, kernels, matrix as _matrix
-from .basis import StructuredBasis, PlainBasis
+from .basis import StructuredBasis, PlainBasis, RationalBasis
 
 
 class _BasisTables:
@@ -37,6 +37,27 @@ class _BasisTables:
             self.off = device.to_dev(basis.offsets, 'int64')
             self.tab = None
             self.nb = 0
+        elif isinstance(basis, RationalBasis):
+            pt = smp.tables(basis.parent)
+            ne = basis.nelems
+            w = device.to_dev(basis.weights, 'float64')
+            W = dW = None
+            if basis.W is not None:
+                if basis.W.shape != (ne, nq) or basis.dW.shape != (ne, nq, nd):
+                    raise ValueError('weight function tables do not match this sample')
+                W, dW = device.to_dev(basis.W, 'float64'), device.to_dev(basis.dW, 'float64')
+            if pt.off is None:  # uniform nb: expand the class tables to per-element tables, then transform in place
+                S = 1 + nd
+                cls = pt.tab.long() if pt.tab is not None else device.torch().zeros(ne, dtype=device.torch().long, device='cuda')
+                self.T = pt.T.view(-1, pt.nb * nq * S)[cls].reshape(-1).contiguous()
+                self.tab = device.to_dev(numpy.arange(ne), 'int32')
+                self.off, self.nb = None, pt.nb
+                kernels.rationalize(self.T, ne, pt.nb, pt.dofs, w, nq, nd, W, dW)
+            else:
+                self.T = pt.T.clone()
+                self.tab, self.off, self.nb = None, pt.off, 0
+                kernels.rationalize(self.T, ne, 0, pt.dofs, w, nq, nd, W, dW, off=pt.off)
+            self.dofs = pt.dofs
         else:
             raise TypeError(f'unsupported basis type {type(basis).__name__}')
         self.struct = kernels.basis(self.T, self.dofs, nb=self.nb, off=self.off, tab=self.tab)
@@ -124,6 +145,10 @@ class Sample:
                 if len(origin) != self.nelems:
                     raise ValueError('geometry does not match the sample')
                 g = kernels.geometry_box(device.to_dev(origin, 'float64'), device.to_dev(size, 'float64'), self.bnd_axis)
+            elif isinstance(geom, function.TabulatedGeometry):
+                if geom.x.shape[:2] != (self.nelems, self.points.npoints):
+                    raise ValueError('tabulated geometry does not match this sample')
+                g = kernels.geometry_tab(device.to_dev(geom.jac, 'float64'), device.to_dev(geom.x, 'float64'), self.bnd_axis)
             else:
                 raise TypeError(f'unsupported geometry {type(geom).__name__}')
             self._geoms[id(geom)] = g

@@ -237,6 +237,65 @@ def cahnhilliard_case(name, nelems, degree=2, seed=3):
     save(name, **data)
 
 
+def nurbs_case(name, nrefine=2, radius=.5, poisson=.3, seed=4):
+    '''BASELINE.json configs[4] ingredient: the NURBS mode of examples/platewithhole.py:66-86 -- rational basis
+    bspline_i w_i / W(xi) on a refined structured topology, NURBS geometry -- and the plane-strain elasticity stiffness
+    matrix / residual of :126-153.  Pointwise data of the coarse-level weight function W and geometry map are stored at the
+    Gauss points (they are inputs of the hot path, produced by the reference's transform chains).'''
+    from nutils.solver import System
+    rng = numpy.random.default_rng(seed)
+    topo, geom0 = mesh.rectilinear([1, 2])
+    bsplinebasis = topo.basis('spline', degree=2)
+    controlweights = numpy.ones(12)
+    controlweights[1:3] = .5 + .25 * numpy.sqrt(2)
+    weightfunc = bsplinebasis @ controlweights
+    nurbsbasis = bsplinebasis * controlweights / weightfunc
+    A = 0, 0, 0
+    B = (2**.5 - 1) * radius, .3 * (radius + 1) / 2, 1
+    C = radius, (radius + 1) / 2, 1
+    controlpoints = numpy.array([[A, B, C, C], [C, C, B, A]]).T.reshape(-1, 2)
+    geom = nurbsbasis @ controlpoints
+    topo = topo.refine(nrefine)
+    bsplinebasis = topo.basis('spline', degree=2)
+    sqr = topo.integral((function.field('w', bsplinebasis) - weightfunc)**2, degree=9)
+    controlweights = System(sqr, trial='w').solve()['w']
+    nurbsbasis = bsplinebasis * controlweights / weightfunc
+    degree = 5
+    smp = topo.sample('gauss', degree * 2)
+    nelems = len(topo)
+    data = dict(shape=numpy.array([2**nrefine, 2 * 2**nrefine]), nrefine=nrefine, weights=controlweights, lam=2 * poisson, mu=1 - poisson)
+    data.update(basis_tables(bsplinebasis, nelems))
+    pts = smp.points[0]
+    data['gauss_coords'] = numpy.asarray(pts.coords, dtype=float)
+    data['gauss_weights'] = numpy.asarray(pts.weights, dtype=float)
+    nq = len(pts.weights)
+    data['W'] = smp.eval(weightfunc).reshape(nelems, nq)
+    data['dW_dparam'] = smp.eval(function.grad(weightfunc, geom0)).reshape(nelems, nq, 2)
+    data['x'] = smp.eval(geom).reshape(nelems, nq, 2)
+    data['dx_dparam'] = smp.eval(function.grad(geom, geom0)).reshape(nelems, nq, 2, 2)
+    data['param'] = smp.eval(geom0).reshape(nelems, nq, 2)
+    ns = Namespace()
+    ns.δ = function.eye(2)
+    ns.x = geom
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    ns.λ = 2 * poisson
+    ns.μ = 1 - poisson
+    ns.u = function.field('u', nurbsbasis, shape=[2])
+    ns.v = function.field('v', nurbsbasis, shape=[2])
+    ns.ε_ij = '(∇_j(u_i) + ∇_i(u_j)) / 2'
+    ns.σ_ij = 'λ ε_kk δ_ij + 2 μ ε_ij'
+    res = smp.integral('∇_j(v_i) σ_ij dV' @ ns)
+    n = len(bsplinebasis)
+    u = rng.normal(size=(n, 2))
+    data['u'] = u
+    jac = function.derivative(function.derivative(res, 'v'), 'u')
+    jac2 = function.Array.cast(numpy.reshape(function.Array.cast(jac), (n * 2, n * 2)))
+    data.update(csr('K', jac2, dict(u=u * 0, v=u * 0)))
+    data['res'] = numpy.asarray(function.eval(function.derivative(res, 'v'), dict(u=u, v=u * 0)))
+    data['area'] = smp.integrate('dV' @ ns)
+    save(name, **data)
+
+
 def example_vectors():
     '''Decoded assertAlmostEqual64 payloads of the reference examples
     (examples/laplace.py:111-152, examples/elasticity.py:89-146): the embedded
@@ -279,6 +338,7 @@ if __name__ == '__main__':
     elasticity_case('elast3d_p2_2', (2, 2, 2), 2, iso=False)
     elasticity_case('elast3d_p2_2_iso', (2, 2, 2), 2, iso=True)
     cahnhilliard_case('cahnhilliard_p2_4', 4)
+    nurbs_case('nurbs_plate_r2')
     hierarchical_case('hier_spline2_1d', 1)
     hierarchical_case('hier_spline2_2d', 2)
     example_vectors()
