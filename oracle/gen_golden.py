@@ -194,6 +194,37 @@ def hierarchical_case(name, ndim):
     save(name, **data)
 
 
+def hierarchical_p3_case(name, levels=4):
+    '''Ragged nbasis-per-element at p=3 over several hierarchical refinement levels (BASELINE.json configs[4]:
+    "p=3 ... hierarchical-refinement levels"; refinement loop as in examples/adaptivity.py:60-70, towards one corner).'''
+    topo, geom = mesh.rectilinear([4, 4])
+    for lvl in range(levels):
+        n = len(topo)
+        # refine the elements touching the origin corner region
+        bez = topo.sample('gauss', 1).eval(geom).reshape(n, 2)
+        sel = [i for i, x in enumerate(bez) if x.max() < 4 * .5 ** lvl]
+        topo = topo.refined_by(sel)
+    nelems = len(topo)
+    data = dict(ndim=2, levels=levels)
+    smp = topo.sample('gauss', 6)
+    pts = smp.points[0]
+    data['gauss_coords'] = numpy.asarray(pts.coords, dtype=float)
+    data['gauss_weights'] = numpy.asarray(pts.weights, dtype=float)
+    x_el = topo.sample('bezier', 2).eval(geom).reshape(nelems, 4, 2)
+    data['elem_origin'] = x_el.min(axis=1)
+    data['elem_size'] = x_el.max(axis=1) - x_el.min(axis=1)
+    ns = Namespace()
+    ns.x = geom
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    basis = topo.basis('th-spline', degree=3)
+    tb = basis_tables(basis, nelems)
+    data['t_dofs'], data['t_dof_offsets'], data['t_coeffs'], data['t_ndofs'] = tb['dofs'], tb['dof_offsets'], tb['coeffs'], len(basis)
+    ns.b = basis
+    data.update(csr('tK', smp.integral('∇_k(b_i) ∇_k(b_j) dV' @ ns)))
+    data.update(csr('tM', smp.integral('b_i b_j dV' @ ns)))
+    save(name, **data)
+
+
 def cahnhilliard_case(name, nelems, degree=2, seed=3):
     '''Cahn-Hilliard free-energy functional of examples/cahnhilliard.py:163-184 (unit-free restatement: the shipped example
     imports nutils.units, which is not in the reference tree): residual blocks, Jacobian blocks and energy at a random state,
@@ -339,6 +370,7 @@ if __name__ == '__main__':
     elasticity_case('elast3d_p2_2_iso', (2, 2, 2), 2, iso=True)
     cahnhilliard_case('cahnhilliard_p2_4', 4)
     nurbs_case('nurbs_plate_r2')
+    hierarchical_p3_case('hier_thspline3_2d_l4')
     hierarchical_case('hier_spline2_1d', 1)
     hierarchical_case('hier_spline2_2d', 2)
     example_vectors()

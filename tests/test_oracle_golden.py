@@ -121,3 +121,11 @@ def test_known_answers():
         assert len(v) == (3 * n + 1) ** 3
         assert abs(v[0] - 1 / 3) < 1e-15
         assert abs(v.sum()) < 1e-12
+
+
+def test_hierarchical_p3(golden):
+    g = golden('hier_thspline3_2d_l4')
+    v, rp, ci = oa.ragged_stiffness(g['t_dofs'], g['t_dof_offsets'], g['t_coeffs'], g['elem_origin'], g['elem_size'], g['gauss_coords'], g['gauss_weights'],
+                                    int(g['t_ndofs']))
+    assert numpy.array_equal(rp, g['tK_rowptr']) and numpy.array_equal(ci, g['tK_colidx'])
+    close(v, g['tK_values'])
