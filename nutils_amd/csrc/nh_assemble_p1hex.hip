@@ -3,17 +3,16 @@
 // Gauss per axis, isoparametric P1 geometry (or the uniform box geometry).
 //
 // WRITE-ONCE design (no global atomics, no zero-fill, CSR values stored exactly once):
-//   * a workgroup OWNS a box of BI x BJ x BK dof rows;
-//   * its threads (one per element) recompute the local matrices of all elements that touch
-//     the box -- (BI+1)(BJ+1)(BK+1), i.e. a one-element halo is recomputed instead of
-//     communicated;
+//   * a persistent workgroup (one per CU) OWNS one box of BI x BJ x BK dof rows at a time;
+//   * its threads (one per element) recompute the local matrices of all elements that touch the box --
+//     (BI+1)(BJ+1)(BK+1), i.e. a one-element halo is recomputed instead of communicated; the vertex block of the NEXT box
+//     is prefetched during barrier + flush and staged in LDS;
 //   * contributions are reduced in LDS (ds_add_f64) into a [rows][27] slot array
 //     (slot = 9(dI+1) + 3(dJ+1) + (dK+1): column offset relative to the row dof);
-//   * the finished rows are streamed to HBM, coalesced, at closed-form CSR offsets: for the
-//     reference's structured dof numbering the sorted-unique pattern (evaluable.py:588-616)
-//     is the tensor product of per-axis ranges [max(X-1,0), min(X+1,N-1)], so
-//     rowptr(I,J,K) and the position of a column inside its row are pure arithmetic.
-// HBM traffic = vertex coordinates (L2-shared between neighbouring threads) + values.
+//   * the finished rows are streamed to HBM, coalesced, at closed-form CSR offsets: for the reference's structured dof
+//     numbering the sorted-unique pattern (evaluable.py:588-616) is the tensor product of per-axis ranges
+//     [max(X-1,0), min(X+1,N-1)], so rowptr(I,J,K) and the position of a column inside its row are pure arithmetic.
+// HBM traffic = vertex coordinates (each box re-reads its halo) + values.  Uniform meshes take k_p1hex_uniform instead.
 #include "nh_common.h"
 #include <algorithm>
 #include <cstdlib>
@@ -74,39 +73,6 @@ __device__ __forceinline__ double element_entry(const ElemTables &T, int a, int 
          s02 * T.W02[b0][a2][p1] + s20 * T.W02[a0][b2][p1] + s12 * T.W12[b1][a2][p0] + s21 * T.W12[a1][b2][p0];
 }
 
-// Vertex coordinates of the element handled by thread `tid` in box `box` (or false if the thread has no element there).
-template <int BI, int BJ, int BK>
-__device__ __forceinline__ bool load_element(const P1Args &p, int box, int tid, double (&X)[2][2][2][3]) {
-  constexpr int EI = BI + 1, EJ = BJ + 1, EK = BK + 1;
-  if (box >= p.nboxes || tid >= EI * EJ * EK) return false;
-  const int N1 = p.n1 + 1, N2 = p.n2 + 1;
-  int b = box;
-  const int bk = b % p.nbk; b /= p.nbk;
-  const int bj = b % p.nbj;
-  const int bi = b / p.nbj;
-  const int ek = tid % EK, ej = (tid / EK) % EJ, ei = tid / (EK * EJ);
-  const int gi = p.pl0 + bi * BI - 1 + ei, gj = bj * BJ - 1 + ej, gk = bk * BK - 1 + ek;
-  if (!(gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2) || (DEBUG(p) & 4)) return false;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (p.verts) {
-          const double *v = p.verts + (((i64)(gi + a) * N1 + (gj + bb)) * N2 + (gk + c)) * 3;
-          X[a][bb][c][0] = v[0];
-          X[a][bb][c][1] = v[1];
-          X[a][bb][c][2] = v[2];
-        } else {
-          X[a][bb][c][0] = p.origin[0] + p.scale[0] * (gi + a);
-          X[a][bb][c][1] = p.origin[1] + p.scale[1] * (gj + bb);
-          X[a][bb][c][2] = p.origin[2] + p.scale[2] * (gk + c);
-        }
-      }
-  return true;
-}
-
 // Cooperative load of the (BI+2)(BJ+2)(BK+2) vertex block of box `box` into registers: thread t owns block vertices t + k*NT.
 // Issued one box ahead (after the scatter, before the barrier) so that the HBM/L2 latency hides behind barrier + flush; the
 // block is then staged in LDS and every element thread reads its 8 vertices from there.
@@ -125,15 +91,12 @@ __device__ __forceinline__ void load_vertex_block(const P1Args &p, int box, int 
     const int c = v % VK, bb = (v / VK) % VJ, a = v / (VK * VJ);
     const int I = I0 + a, J = J0 + bb, K = K0 + c;
     const bool ok = box < p.nboxes && v < VI * VJ * VK && I >= 0 && I < N0 && J >= 0 && J < N1 && K >= 0 && K < N2;
-    if (ok && p.verts) {
+    V[k][0] = V[k][1] = V[k][2] = 0.;
+    if (ok) {  // the box kernel is only launched with a vertex array (uniform meshes take k_p1hex_uniform)
       const double *src = p.verts + (((i64)I * N1 + J) * N2 + K) * 3;
       V[k][0] = src[0];
       V[k][1] = src[1];
       V[k][2] = src[2];
-    } else {
-      V[k][0] = p.origin[0] + p.scale[0] * I;
-      V[k][1] = p.origin[1] + p.scale[1] * J;
-      V[k][2] = p.origin[2] + p.scale[2] * K;
     }
   }
 }
@@ -213,13 +176,12 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
           }
       double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3];
 #include "nh_p1hex_math.inc"
-      // ---- form K[a][b] (a <= b) entry by entry and reduce it into the LDS row accumulators ---------------
+      // ---- form the 36 upper-triangle entries, then reduce row by row: ONE exec-mask region per row vertex (8 per element)
+      // instead of one per (row, column) pair (64) -- the scalar mask bookkeeping was ~8 % of the instruction stream
+      double Kt[36];
 #pragma unroll
       for (int a = 0; a < 8; ++a) {
         const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
-        const int ra0 = ei - 1 + a0, ra1 = ej - 1 + a1, ra2 = ek - 1 + a2;  // row of vertex a relative to the box
-        const bool ina = ra0 >= 0 && ra0 < BI && ra1 >= 0 && ra1 < BJ && ra2 >= 0 && ra2 < BK;
-        const int rowa = ((ra0 * BJ + ra1) * BK + ra2) * 27;
 #pragma unroll
         for (int bb = a; bb < 8; ++bb) {
           const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
@@ -228,20 +190,27 @@ __global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
           const double s01 = (a0 == b1) ? 1. : -1., s10 = (b0 == a1) ? 1. : -1.;
           const double s02 = (a0 == b2) ? 1. : -1., s20 = (b0 == a2) ? 1. : -1.;
           const double s12 = (a1 == b2) ? 1. : -1., s21 = (b1 == a2) ? 1. : -1.;
-          const double Kab = s00 * R0[p1][p2] + s11 * R1[p0][p2] + s22 * R2[p0][p1]
-                           + s01 * W01[b0][a1][p2] + s10 * W01[a0][b1][p2]
-                           + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1]
-                           + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
-          const int d0 = b0 - a0, d1 = b1 - a1, d2 = b2 - a2;
-          if (ina && !(DEBUG(p) & 1)) atomicAdd(&acc[rowa + (d0 + 1) * 9 + (d1 + 1) * 3 + (d2 + 1)], Kab);
-          if ((DEBUG(p) & 1) && Kab == 1.2345e300) acc[0] = Kab;
-          if (bb != a) {
-            const int rb0 = ei - 1 + b0, rb1 = ej - 1 + b1, rb2 = ek - 1 + b2;
-            const bool inb = rb0 >= 0 && rb0 < BI && rb1 >= 0 && rb1 < BJ && rb2 >= 0 && rb2 < BK;
-            if (inb && !(DEBUG(p) & 1)) atomicAdd(&acc[((rb0 * BJ + rb1) * BK + rb2) * 27 + (1 - d0) * 9 + (1 - d1) * 3 + (1 - d2)], Kab);
+          Kt[a * 8 - a * (a - 1) / 2 + (bb - a)] = s00 * R0[p1][p2] + s11 * R1[p0][p2] + s22 * R2[p0][p1]
+                                                 + s01 * W01[b0][a1][p2] + s10 * W01[a0][b1][p2]
+                                                 + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1]
+                                                 + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
+        const int ra0 = ei - 1 + a0, ra1 = ej - 1 + a1, ra2 = ek - 1 + a2;  // row of vertex a relative to the box
+        if (ra0 >= 0 && ra0 < BI && ra1 >= 0 && ra1 < BJ && ra2 >= 0 && ra2 < BK && !(DEBUG(p) & 1)) {
+          double *row = acc + ((ra0 * BJ + ra1) * BK + ra2) * 27;
+#pragma unroll
+          for (int bb = 0; bb < 8; ++bb) {
+            const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
+            const int lo = a < bb ? a : bb, hi = a < bb ? bb : a;
+            atomicAdd(&row[(b0 - a0 + 1) * 9 + (b1 - a1 + 1) * 3 + (b2 - a2 + 1)], Kt[lo * 8 - lo * (lo - 1) / 2 + (hi - lo)]);
           }
         }
       }
+      if ((DEBUG(p) & 1) && Kt[0] == 1.2345e300) acc[0] = Kt[0];
     }
   }
   load_vertex_block<BI, BJ, BK, NT, VPT>(p, box + gridDim.x, tid, V);  // next box: in flight during barrier + flush

@@ -235,3 +235,30 @@ def test_p1hex_fast_vs_generic(shape, iso):
     r0, r1 = nplane, min(3, shape[0] + 1) * nplane
     rps, cis = kernels.p1hex_pattern(shape, r0, r1)
     assert numpy.array_equal(device.to_host(rps), rp[r0:r1 + 1] - rp[r0]) and numpy.array_equal(device.to_host(cis), ci[rp[r0]:rp[r1]])
+
+
+def test_error_paths_on_device():
+    '''Invalid arguments come back as status codes + nh_last_error -> NutilsHipError, never a crash or a silent result.'''
+    import ctypes
+    from nutils_amd import _lib, device, kernels
+    device.require_gpu()
+    pts = device.to_dev(numpy.zeros((2, 3)), 'float64')
+    co = device.to_dev(numpy.zeros((4, 7)), 'float64')
+    with pytest.raises(_lib.NutilsHipError, match='not a valid coefficient count'):
+        kernels.tabulate(co, 4, 7, pts, 2, 3)
+    with pytest.raises(_lib.NutilsHipError, match='ndims must be 1..3'):
+        kernels.tabulate(co, 4, 7, pts, 2, 4)
+    d = device.to_dev(numpy.arange(8), 'int32')
+    with pytest.raises(_lib.NutilsHipError, match='give either nbt or toff_dev'):
+        kernels.Pattern(1, 8, 8, d, d)
+    pat = kernels.Pattern(1, 8, 8, d, d, nbt=8, nbr=8)
+    with pytest.raises(_lib.NutilsHipError, match='component counts'):
+        pat.expand(9, 1)
+    with pytest.raises(ValueError, match='coefficient tensor has shape'):
+        kernels.assemble_matrix(nelems=1, ndims=3, nq=2, weights=pts, geom=kernels.geometry_box(pts, pts), test=kernels.basis(co, d, nb=8),
+                                trial=kernels.basis(co, d, nb=8), nct=1, ncr=1, C=numpy.zeros((1, 3, 1, 3)), mask=None, pattern=pat, values=co)
+    g = _lib.Geometry(7, 0, None, None, None, None, None, None, None, -1)
+    with pytest.raises(_lib.NutilsHipError, match='unknown geometry kind'):
+        kernels.sample_eval(nelems=1, ndims=3, nq=2, geom=g, points=pts, detj=co)
+    with pytest.raises(_lib.NutilsHipError, match='layer range'):
+        kernels.p1hex_laplace(shape=(2, 2, 2), values=co, gauss_x=[.2, .8], gauss_w=[.5, .5], layers=(0, 3))
