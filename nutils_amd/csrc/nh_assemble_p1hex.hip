@@ -3,18 +3,17 @@
 // Gauss per axis, isoparametric P1 geometry (or the uniform box geometry).
 //
 // WRITE-ONCE design (no global atomics, no zero-fill, CSR values stored exactly once):
-//   * a persistent workgroup (one per CU) OWNS one box of BI x BJ x BK dof rows at a time;
-//   * its threads (one per element) recompute the local matrices of all elements that touch the box --
-//     (BI+1)(BJ+1)(BK+1), i.e. a one-element halo is recomputed instead of communicated; the vertex block of the NEXT box
-//     is prefetched during barrier + flush and staged in LDS;
-//   * contributions are reduced in LDS (ds_add_f64) into a [rows][27] slot array
-//     (slot = 9(dI+1) + 3(dJ+1) + (dK+1): column offset relative to the row dof);
+//   * a persistent workgroup (one per CU) OWNS a column tile of dof rows and marches through it along axis 0 (k_p1hex_march);
+//   * its threads (one per element) recompute the local matrices of all elements that touch the owned rows, i.e. a one-element
+//     lateral halo is recomputed instead of communicated; the vertex tile of the NEXT step is prefetched and staged in LDS;
+//   * contributions are reduced in LDS (ds_add_f64) into per-row slot arrays (slot = column offset relative to the row dof);
 //   * the finished rows are streamed to HBM, coalesced, at closed-form CSR offsets: for the reference's structured dof
 //     numbering the sorted-unique pattern (evaluable.py:588-616) is the tensor product of per-axis ranges
 //     [max(X-1,0), min(X+1,N-1)], so rowptr(I,J,K) and the position of a column inside its row are pure arithmetic.
-// HBM traffic = vertex coordinates (each box re-reads its halo) + values.  Uniform meshes take k_p1hex_uniform instead.
+// HBM traffic = vertex coordinates (each tile re-reads its lateral halo) + values.  Uniform meshes take k_p1hex_uniform instead.
 #include "nh_common.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -38,6 +37,7 @@ struct P1Args {
   double *values;
   int nbj, nbk;            // boxes per axis (j, k)
   int nboxes;
+  long long *tdbg;         // phase timers (ablation builds)
   int debug;               // ablation switches (NH_P1HEX_DEBUG env): 1 = no LDS reduction, 2 = no HBM stores, 4 = no element math
 };
 
@@ -52,6 +52,12 @@ __device__ __forceinline__ double fast_rcp(double d) {
   r = fma(fma(-d, r, 1.), r, r);
   return r;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release/acquire fence over ALL address
+// spaces, i.e. s_waitcnt vmcnt(0): every wave would sit at the barrier until its prefetch loads have returned and its CSR stores
+// have been acknowledged by L2/HBM.  The kernels below never read back what they store and consume prefetched registers behind
+// the compiler's own vmcnt wait, so only the LDS accumulators need to be ordered.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct ElemTables {
   double R0[3][3], R1[3][3], R2[3][3];             // diagonal (j == k) terms, indexed by the pair classes p = a_d + b_d
@@ -73,26 +79,27 @@ __device__ __forceinline__ double element_entry(const ElemTables &T, int a, int 
          s02 * T.W02[b0][a2][p1] + s20 * T.W02[a0][b2][p1] + s12 * T.W12[b1][a2][p0] + s21 * T.W12[a1][b2][p0];
 }
 
-// Cooperative load of the (BI+2)(BJ+2)(BK+2) vertex block of box `box` into registers: thread t owns block vertices t + k*NT.
-// Issued one box ahead (after the scatter, before the barrier) so that the HBM/L2 latency hides behind barrier + flush; the
-// block is then staged in LDS and every element thread reads its 8 vertices from there.
-template <int BI, int BJ, int BK, int NT, int VPT>
-__device__ __forceinline__ void load_vertex_block(const P1Args &p, int box, int tid, double (&V)[VPT][3]) {
-  constexpr int VI = BI + 2, VJ = BJ + 2, VK = BK + 2;
+// ---- marching kernel: a workgroup owns a COLUMN tile of (TJ-1) x (TK-1) dofs and marches along axis 0, L element layers per
+// step, carrying the partially summed dof plane in LDS, so that elements are recomputed only across the two lateral tile faces
+// (TJ TK / (TJ-1)(TK-1), 1.14 for 16 x 16) instead of across all six box faces (1.49 for 7^3 boxes).  The local matrix is
+// symmetric and local vertex order equals global dof order, so only the 36 entries a <= b are reduced, into [rows][14] slots
+// (column offset >= 0, lexicographically); a row's 13 "lower" entries are read at flush time from the upper slots of the
+// neighbouring rows -- which is why the accumulated rows of a plane are ALL (TJ+1)(TK+1) tile vertices (owned dofs + a halo line
+// on either side) and one extra plane is kept.
+// The circular plane buffer holds L + 2 planes: the previous plane (source of the dI = -1 entries), the L planes completed by this
+// step, and the partially summed plane carried to the next step.  Work is split over workgroups by (column, plane) units; every
+// contiguous run of planes inside a column costs one extra element layer at its start.
+template <int TJ, int TK, int L, int VPT>
+__device__ __forceinline__ void load_vertex_tile(const P1Args &p, bool valid, int J0, int K0, int L0, int tid, double (&V)[VPT][3]) {
+  constexpr int NT = L * TJ * TK, VJ = TJ + 1, VK = TK + 1, NV = (L + 1) * VJ * VK;
   const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
-  int b = box;
-  const int bk = b % p.nbk; b /= p.nbk;
-  const int bj = b % p.nbj;
-  const int bi = b / p.nbj;
-  const int I0 = p.pl0 + bi * BI - 1, J0 = bj * BJ - 1, K0 = bk * BK - 1;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int v = tid + k * NT;
     const int c = v % VK, bb = (v / VK) % VJ, a = v / (VK * VJ);
-    const int I = I0 + a, J = J0 + bb, K = K0 + c;
-    const bool ok = box < p.nboxes && v < VI * VJ * VK && I >= 0 && I < N0 && J >= 0 && J < N1 && K >= 0 && K < N2;
+    const int I = L0 + a, J = J0 - 1 + bb, K = K0 - 1 + c;
     V[k][0] = V[k][1] = V[k][2] = 0.;
-    if (ok) {  // the box kernel is only launched with a vertex array (uniform meshes take k_p1hex_uniform)
+    if (valid && v < NV && I >= 0 && I < N0 && J >= 0 && J < N1 && K >= 0 && K < N2) {
       const double *src = p.verts + (((i64)I * N1 + J) * N2 + K) * 3;
       V[k][0] = src[0];
       V[k][1] = src[1];
@@ -101,143 +108,203 @@ __device__ __forceinline__ void load_vertex_block(const P1Args &p, int box, int 
   }
 }
 
-template <int BI, int BJ, int BK, int NT, int NBUF, int EPT>
-__global__ __launch_bounds__(NT) void k_p1hex_laplace(P1Args p) {
-  constexpr int ROWS = BI * BJ * BK;
-  constexpr int EI = BI + 1, EJ = BJ + 1, EK = BK + 1;
-  static_assert(EI * EJ * EK <= NT * EPT, "EPT elements per thread");
+template <int TJ, int TK, int L>
+__global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
+#ifdef NH_ABLATION
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#define NH_TICK(i) { const long long tnow = clock64(); tacc[i] += tnow - tprev; tprev = tnow; }
+#else
+#define NH_TICK(i)
+#endif
+  constexpr int NT = L * TJ * TK, NP = L + 2, OJ = TJ - 1, OK = TK - 1;
+  constexpr int NS = 15;  // 14 slots + 1 pad: an odd row stride (in doubles) spreads the 64 lanes of a ds_add_f64 over all LDS banks
+  constexpr int VJ = TJ + 1, VK = TK + 1, RP = VJ * VK, PS = (RP * NS + 1) & ~1, NV = (L + 1) * VJ * VK, VPT = (NV + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  // two accumulator sets (double buffering across consecutive boxes of this persistent workgroup):
-  //   acc [ROWS][27] f64, rowbase [ROWS] i64 (CSR offset of the row, -1 = not written), rowflag [ROWS] i32
-  constexpr int SETD = ROWS * 27 + ROWS + (ROWS + 1) / 2 + 1;  // doubles per set (kept even for 16-byte alignment)
-  constexpr int SET = SETD + (SETD & 1);
-  constexpr int VI = BI + 2, VJ = BJ + 2, VK = BK + 2, NV = VI * VJ * VK, VPT = (NV + NT - 1) / NT;
-  double *vbuf = lds + NBUF * SET;  // [NV][3] vertex block of the current box
+  double *acc = lds;             // [NP][RP][NS], plane stride PS
+  double *vbuf = lds + NP * PS;  // [L+1][VJ][VK][3]
   const int tid = threadIdx.x;
   const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
-  for (int t = tid; t < NBUF * SET; t += NT) lds[t] = 0.;
+  const int NPL = p.pl1 - p.pl0;
+  const i64 U = (i64)p.nbj * p.nbk * NPL;
+  i64 u = U * blockIdx.x / gridDim.x;
+  const i64 u1 = U * (blockIdx.x + 1) / gridDim.x;
+  if (u >= u1) return;
+  auto slot_of = [](int P) { return (int)((unsigned)(P + 2 * NP) % NP) * PS; };  // P >= -2
+  // current run: planes [A, B) of column (cj, ck); current step: element layers [L0, L0 + L)
+  int col = (int)(u / NPL), A = p.pl0 + (int)(u % NPL), B = (int)min((i64)p.pl1, A + (u1 - u)), L0 = A - 1;
   double V[VPT][3];
-  load_vertex_block<BI, BJ, BK, NT, VPT>(p, blockIdx.x, tid, V);
-  __syncthreads();
-
-  for (int box = blockIdx.x, it = 0; box < p.nboxes; box += gridDim.x, ++it) {
-  double *acc = lds + (NBUF == 2 ? (it & 1) : 0) * SET;
-  // the row table alternates between two copies even with a single accumulator set: fast waves write the table of box k+1
-  // while slow waves still flush box k
-  i64 *rowbase = reinterpret_cast<i64 *>(vbuf + NV * 3 + (NV & 1)) + (it & 1) * ROWS;
-  int *rowflag = reinterpret_cast<int *>(reinterpret_cast<i64 *>(vbuf + NV * 3 + (NV & 1)) + 2 * ROWS) + (it & 1) * ROWS;
-  int b = box;
-  const int bk = b % p.nbk; b /= p.nbk;
-  const int bj = b % p.nbj;
-  const int bi = b / p.nbj;
-  const int I0 = p.pl0 + bi * BI, J0 = bj * BJ, K0 = bk * BK;
-
+  load_vertex_tile<TJ, TK, L, VPT>(p, true, (col / p.nbk) * OJ, (col % p.nbk) * OK, L0, tid, V);
+  for (int t = tid; t < NP * PS / 2; t += NT) reinterpret_cast<double2 *>(acc)[t] = make_double2(0., 0.);
+  auto stage_vertex_tile = [&]() {
 #pragma unroll
-  for (int k = 0; k < VPT; ++k) {
-    const int v = tid + k * NT;
-    if (v < NV) {
-      vbuf[v * 3 + 0] = V[k][0];
-      vbuf[v * 3 + 1] = V[k][1];
-      vbuf[v * 3 + 2] = V[k][2];
+    for (int k = 0; k < VPT; ++k) {
+      const int v = tid + k * NT;
+      if (v < NV) {
+        vbuf[v * 3 + 0] = V[k][0];
+        vbuf[v * 3 + 1] = V[k][1];
+        vbuf[v * 3 + 2] = V[k][2];
+      }
     }
-  }
-  for (int rr = tid; rr < ROWS; rr += NT) {  // closed-form CSR row offsets, once per row (not once per entry)
-    const int lk = rr % BK, lj = (rr / BK) % BJ, li = rr / (BK * BJ);
-    const int I = I0 + li, J = J0 + lj, Kk = K0 + lk;
-    i64 base = -1;
-    int flag = 0;
-    if (I < p.pl1 && J < N1 && Kk < N2) {
-      const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;  // sum of len over an axis
-      base = cum_of(I, N0) * T1 * T2 + len_of(I, N0) * (cum_of(J, N1) * T2 + (i64)len_of(J, N1) * cum_of(Kk, N2));
-      flag = (I > 0) | (J > 0) << 1 | (Kk > 0) << 2 | (I < N0 - 1) << 3 | (J < N1 - 1) << 4 | (Kk < N2 - 1) << 5;
-    }
-    rowbase[rr] = base;
-    rowflag[rr] = flag;
-  }
-  __syncthreads();  // vertex block + row table visible; the previous flush (which zeroed acc) is complete
+  };
+  stage_vertex_tile();
 
-#pragma unroll 1
-  for (int ke = 0; ke < EPT; ++ke) {
-    const int el = tid + ke * NT;
-    const int ek = el % EK, ej = (el / EK) % EJ, ei = el / (EK * EJ);
-    double X[2][2][2][3];
-    const int gi = I0 - 1 + ei, gj = J0 - 1 + ej, gk = K0 - 1 + ek;
-    if (el < EI * EJ * EK && gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2 && !(DEBUG(p) & 4)) {
+  for (;;) {
+    const int J0 = (col / p.nbk) * OJ, K0 = (col % p.nbk) * OK;
+    // next step (or next run): its vertex loads are issued at the head of the element phase and land in LDS right after it
+    int ncol = col, nA = A, nB = B, nL0 = L0 + L;
+    bool last = false, fresh = false;
+    if (nL0 >= B) {
+      u += B - A;
+      if (u >= u1) last = true;
+      else {
+        ncol = (int)(u / NPL), nA = p.pl0 + (int)(u % NPL), nB = (int)min((i64)p.pl1, nA + (u1 - u)), nL0 = nA - 1;
+        fresh = true;
+      }
+    }
+    NH_TICK(0)
+    lds_barrier();  // vertex tile staged, plane slots zeroed
+    NH_TICK(1)
+    load_vertex_tile<TJ, TK, L, VPT>(p, !last, (ncol / p.nbk) * OJ, (ncol % p.nbk) * OK, nL0, tid, V);
+
+    {
+      const int lay = tid / (TJ * TK), el = tid % (TJ * TK), ej = el / TK, ek = el % TK;
+      const int gi = L0 + lay, gj = J0 - 1 + ej, gk = K0 - 1 + ek;
+      if (gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2 && !(DEBUG(p) & 4)) {
+        double X[2][2][2][3];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
+          for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const double *src = vbuf + (((ei + a) * VJ + (ej + bb)) * VK + (ek + c)) * 3;
-            X[a][bb][c][0] = src[0];
-            X[a][bb][c][1] = src[1];
-            X[a][bb][c][2] = src[2];
-          }
-      double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3];
+            for (int c = 0; c < 2; ++c) {
+              const double *src = vbuf + (((lay + a) * VJ + (ej + bb)) * VK + (ek + c)) * 3;
+              X[a][bb][c][0] = src[0];
+              X[a][bb][c][1] = src[1];
+              X[a][bb][c][2] = src[2];
+            }
+        double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3];
 #include "nh_p1hex_math.inc"
-      // ---- form the 36 upper-triangle entries, then reduce row by row: ONE exec-mask region per row vertex (8 per element)
-      // instead of one per (row, column) pair (64) -- the scalar mask bookkeeping was ~8 % of the instruction stream
-      double Kt[36];
+        double Kt[36];
 #pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
+        for (int a = 0; a < 8; ++a) {
+          const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
 #pragma unroll
-        for (int bb = a; bb < 8; ++bb) {
-          const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
-          const int p0 = a0 + b0, p1 = a1 + b1, p2 = a2 + b2;
-          const double s00 = (a0 == b0) ? 1. : -1., s11 = (a1 == b1) ? 1. : -1., s22 = (a2 == b2) ? 1. : -1.;
-          const double s01 = (a0 == b1) ? 1. : -1., s10 = (b0 == a1) ? 1. : -1.;
-          const double s02 = (a0 == b2) ? 1. : -1., s20 = (b0 == a2) ? 1. : -1.;
-          const double s12 = (a1 == b2) ? 1. : -1., s21 = (b1 == a2) ? 1. : -1.;
-          Kt[a * 8 - a * (a - 1) / 2 + (bb - a)] = s00 * R0[p1][p2] + s11 * R1[p0][p2] + s22 * R2[p0][p1]
-                                                 + s01 * W01[b0][a1][p2] + s10 * W01[a0][b1][p2]
-                                                 + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1]
-                                                 + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
-        const int ra0 = ei - 1 + a0, ra1 = ej - 1 + a1, ra2 = ek - 1 + a2;  // row of vertex a relative to the box
-        if (ra0 >= 0 && ra0 < BI && ra1 >= 0 && ra1 < BJ && ra2 >= 0 && ra2 < BK && !(DEBUG(p) & 1)) {
-          double *row = acc + ((ra0 * BJ + ra1) * BK + ra2) * 27;
-#pragma unroll
-          for (int bb = 0; bb < 8; ++bb) {
+          for (int bb = a; bb < 8; ++bb) {
             const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
-            const int lo = a < bb ? a : bb, hi = a < bb ? bb : a;
-            atomicAdd(&row[(b0 - a0 + 1) * 9 + (b1 - a1 + 1) * 3 + (b2 - a2 + 1)], Kt[lo * 8 - lo * (lo - 1) / 2 + (hi - lo)]);
+            const int p0 = a0 + b0, p1 = a1 + b1, p2 = a2 + b2;
+            const double s00 = (a0 == b0) ? 1. : -1., s11 = (a1 == b1) ? 1. : -1., s22 = (a2 == b2) ? 1. : -1.;
+            const double s01 = (a0 == b1) ? 1. : -1., s10 = (b0 == a1) ? 1. : -1.;
+            const double s02 = (a0 == b2) ? 1. : -1., s20 = (b0 == a2) ? 1. : -1.;
+            const double s12 = (a1 == b2) ? 1. : -1., s21 = (b1 == a2) ? 1. : -1.;
+            Kt[a * 8 - a * (a - 1) / 2 + (bb - a)] = s00 * R0[p1][p2] + s11 * R1[p0][p2] + s22 * R2[p0][p1]
+                                                   + s01 * W01[b0][a1][p2] + s10 * W01[a0][b1][p2]
+                                                   + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1]
+                                                   + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
+          }
+        }
+        // reduce: the accumulated rows of a plane are the vertices of the tile, so every local vertex has a row (no masking)
+        double *const pl[2] = {acc + slot_of(gi) + (ej * VK + ek) * NS, acc + slot_of(gi + 1) + (ej * VK + ek) * NS};
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
+          double *row = pl[a0] + (a1 * VK + a2) * NS;
+          if (DEBUG(p) & 1) { if (Kt[a] == 1.2345e300) row[0] = 1.; continue; }
+#pragma unroll
+          for (int bb = a; bb < 8; ++bb) {
+            const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
+            atomicAdd(&row[(b0 - a0) * 9 + (b1 - a1) * 3 + (b2 - a2)], Kt[a * 8 - a * (a - 1) / 2 + (bb - a)]);
           }
         }
       }
-      if ((DEBUG(p) & 1) && Kt[0] == 1.2345e300) acc[0] = Kt[0];
     }
-  }
-  load_vertex_block<BI, BJ, BK, NT, VPT>(p, box + gridDim.x, tid, V);  // next box: in flight during barrier + flush
-  __syncthreads();
+    NH_TICK(2)
+    lds_barrier();  // all contributions of this step are in LDS, all vertex reads done
+    NH_TICK(3)
+    if (!last) stage_vertex_tile();
 
-  // ---- stream the finished rows to HBM: 32 lanes per row (27 slots), NT/32 rows per pass ------------------
-  {
-    const int sl = tid & 31, rsub = tid >> 5;
-    const int dI = sl / 9 - 1, dJ = (sl / 3) % 3 - 1, dK = sl % 3 - 1;
-    // slot is stored iff the column exists: a -1 offset needs the lo flag, a +1 offset the hi flag
-    const int need = (dI < 0 ? 1 : dI > 0 ? 8 : 0) | (dJ < 0 ? 2 : dJ > 0 ? 16 : 0) | (dK < 0 ? 4 : dK > 0 ? 32 : 0);
-    if (sl < 27) {
-      for (int r = rsub; r < ROWS; r += NT / 32) {
-        const i64 base = rowbase[r];
-        const int flag = rowflag[r];
-        if (base >= 0 && (flag & need) == need && !(DEBUG(p) & 2)) {
-          const int loI = flag & 1, loJ = (flag >> 1) & 1, loK = (flag >> 2) & 1;
-          const int lenJ = loJ + 1 + ((flag >> 4) & 1), lenK = loK + 1 + ((flag >> 5) & 1);
-          const int pos = ((dI + loI) * lenJ + (dJ + loJ)) * lenK + (dK + loK);
-          p.values[base + pos] = acc[r * 27 + sl];
+    // ---- stream the completed planes to HBM ---------------------------------------------------------------------------------
+    const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;
+    const int Pb = max(L0, A), Pe = (DEBUG(p) & 2) ? Pb : min(L0 + L, B);
+    {
+      // 32 lanes per row (27 slots), one K line (or part of it) per pass.  (A variant with two entries per lane and 16-byte stores was
+      // measured slower: 0.279 vs 0.252 ms.)
+      constexpr int RPP = NT / 32, KP = (OK + RPP - 1) / RPP;  // rows per flush pass, passes per K line
+      const int sl = tid & 31, rsub = tid >> 5;
+      const int dI = sl / 9 - 1, dJ = (sl / 3) % 3 - 1, dK = sl % 3 - 1;
+      const bool upper = sl >= 13;
+      const int need = (dI < 0 ? 1 : dI > 0 ? 8 : 0) | (dJ < 0 ? 2 : dJ > 0 ? 16 : 0) | (dK < 0 ? 4 : dK > 0 ? 32 : 0);
+      constexpr int C = OJ % 5 == 0 ? 5 : OJ % 7 == 0 ? 7 : OJ % 3 == 0 ? 3 : 1;  // LDS reads in flight per lane
+      const int cumJ0 = J0 == 0 ? 0 : 3 * J0 - 1;
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp) {
+        const int ok = kp * RPP + rsub, Kk = K0 + ok;
+        const bool kact = sl < 27 && ok < OK && Kk < N2;
+        const int loK = Kk > 0, hiK = Kk < N2 - 1, lenK = loK + 1 + hiK, cumK = Kk == 0 ? 0 : 3 * Kk - 1;
+        // LDS source relative to (plane, line vj = 1): own upper slot, or the mirrored upper slot of the neighbouring row
+        const int srow = (VK + ok + 1) * NS + (upper ? sl - 13 : (dJ * VK + dK) * NS + 13 - sl);
+        for (int P = Pb; P < Pe; ++P) {
+          const int loI = P > 0, hiI = P < N0 - 1, lenI = loI + 1 + hiI;
+          const double *src = acc + ((!upper && dI < 0) ? slot_of(P - 1) : slot_of(P)) + srow;
+          // CSR offset of row (P, J, 0): uniform, advanced line by line
+          double *line = p.values + ((P == 0 ? 0 : 3 * (i64)P - 1) * T1 * T2 + lenI * (cumJ0 * T2));
+          if (J0 > 0 && J0 + OJ < N1) {
+            // all OJ lines exist and are interior along J: lane offset and mask are loop invariants, the loop is straight-line
+            const int flag = loI | 2 | loK << 2 | hiI << 3 | 16 | hiK << 5;
+            const unsigned voff = (unsigned)(lenI * 3 * cumK + ((dI + loI) * 3 + (dJ + 1)) * lenK + (dK + loK));
+            const int stride = lenI * 3 * (int)T2;
+            if (kact && (flag & need) == need) {
+              double v[OJ];  // all LDS reads of the pass in flight before the first store
+#pragma unroll
+              for (int oj = 0; oj < OJ; ++oj) v[oj] = src[oj * (VK * NS)];
+#pragma unroll
+              for (int oj = 0; oj < OJ; ++oj) {
+                line[voff] = v[oj];
+                line += stride;
+              }
+            }
+          } else {
+            // boundary lines: the same, branch-free per line (flags recomputed on the scalar unit)
+#pragma unroll 1
+            for (int oj = 0; oj < OJ; oj += C) {
+              double v[C];
+#pragma unroll
+              for (int q = 0; q < C; ++q) v[q] = src[(oj + q) * (VK * NS)];
+#pragma unroll
+              for (int q = 0; q < C; ++q) {
+                const int J = J0 + oj + q;
+                const int loJ = J > 0, hiJ = J < N1 - 1, lenJ = loJ + 1 + hiJ;
+                const int flag = loI | loJ << 1 | loK << 2 | hiI << 3 | hiJ << 4 | hiK << 5;
+                const unsigned voff = (unsigned)(lenI * lenJ * cumK + ((dI + loI) * lenJ + (dJ + loJ)) * lenK + (dK + loK));
+                if (kact && J < N1 && (flag & need) == need) line[voff] = v[q];
+                line += lenI * lenJ * (int)T2;
+              }
+            }
+          }
         }
-        acc[r * 27 + sl] = 0.;  // ready for the box after next; ordered by the barrier of the next box
       }
     }
+    NH_TICK(4)
+    if (last) break;
+    lds_barrier();  // flush reads done: recycle plane slots
+    NH_TICK(5)
+    if (fresh) {
+      for (int t = tid; t < NP * PS / 2; t += NT) reinterpret_cast<double2 *>(acc)[t] = make_double2(0., 0.);
+    } else {
+#pragma unroll
+      for (int P = L0 - 1; P < L0 + L - 1; ++P) {
+        double2 *z = reinterpret_cast<double2 *>(acc + slot_of(P));
+        for (int t = tid; t < PS / 2; t += NT) z[t] = make_double2(0., 0.);
+      }
+    }
+    col = ncol, A = nA, B = nB, L0 = nL0;
+    NH_TICK(6)
   }
-  }  // persistent loop over boxes: with NBUF == 2, ONE barrier per box; the stores of this box drain while the next box computes
+#ifdef NH_ABLATION
+  if (p.tdbg && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
+#endif
 }
+#undef NH_TICK
 
 // ---- uniform geometry: all element matrices are equal (the reference hoists them out of the loop too) -------------
 // One thread evaluates the element matrix of the unit cell; the assembly is then a pure streaming kernel: every CSR entry is the
@@ -382,6 +449,7 @@ static int fill_p1args(const nh_p1hex_args *a, P1Args &p) {
   p.values = a->values_dev;
   p.nbj = p.nbk = p.nboxes = 0;
   p.debug = 0;
+  p.tdbg = nullptr;
   return NH_OK;
 }
 
@@ -401,10 +469,6 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
   int rc = fill_p1args(a, p);
   if (rc) return rc;
   if (a->plane_begin == a->plane_end) return NH_OK;
-  constexpr int BI = 7, BJ = 7, BK = 7, NT = 512, NBUF = 1, EPT = 1;
-  const int nbi = (p.pl1 - p.pl0 + BI - 1) / BI;
-  p.nbj = (p.n1 + 1 + BJ - 1) / BJ;
-  p.nbk = (p.n2 + 1 + BK - 1) / BK;
   if (!a->verts_dev) {  // uniform geometry: unit element matrix + streaming kernel
     double *Ke = nullptr;
     if (!a->unit_matrix_dev) {
@@ -417,18 +481,40 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
     if (Ke) NH_CHECK_HIP(hipFreeAsync(Ke, nh_stream(stream)));
     return NH_OK;
   }
-  constexpr int ROWS = BI * BJ * BK, SETD = ROWS * 27 + ROWS + (ROWS + 1) / 2 + 1, SET = SETD + (SETD & 1);
-  const size_t lds = sizeof(double) * (NBUF * SET + (BI + 2) * (BJ + 2) * (BK + 2) * 3 + 1 + 2 * ROWS + ROWS + 2);
-  p.nboxes = nbi * p.nbj * p.nbk;
+#ifdef NH_ABLATION
   p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
-  int dev = 0, cus = 256;
-  NH_CHECK_HIP(hipGetDevice(&dev));
-  NH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  auto kern = k_p1hex_laplace<BI, BJ, BK, NT, NBUF, EPT>;
-  NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)std::min(p.nboxes, cus * (NT == 256 ? 2 : 1))), dim3(NT), lds, nh_stream(stream), p);
-  NH_LAUNCH_CHECK();
-  return NH_OK;
+#endif
+  {
+    constexpr int TJ = 16, TK = 16, L = 2, NTM = L * TJ * TK;
+    int dev = 0, cus = 256;
+    NH_CHECK_HIP(hipGetDevice(&dev));
+    NH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    p.nbj = (p.n1 + 1 + TJ - 2) / (TJ - 1);
+    p.nbk = (p.n2 + 1 + TK - 2) / (TK - 1);
+    const size_t ldsm = sizeof(double) * ((L + 2) * (((TJ + 1) * (TK + 1) * 15 + 1) & ~1) + (L + 1) * (TJ + 1) * (TK + 1) * 3 + 2);
+    const i64 units = (i64)p.nbj * p.nbk * (p.pl1 - p.pl0);
+    const unsigned grid = (unsigned)std::min<i64>(units, cus);
+    auto kern = k_p1hex_march<TJ, TK, L>;
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+#ifdef NH_ABLATION
+    static long long *tdbg = nullptr;
+    if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, 16 * sizeof(long long)));
+    NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, 16 * sizeof(long long), nh_stream(stream)));
+    p.tdbg = getenv("NH_P1HEX_TIMERS") ? tdbg : nullptr;
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTM), ldsm, nh_stream(stream), p);
+    NH_LAUNCH_CHECK();
+#ifdef NH_ABLATION
+    if (p.tdbg) {
+      long long h[16];
+      NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
+      const double nw = (double)grid * (NTM / 64);
+      fprintf(stderr, "p1hex_march cycles per wave: stage+next %.0f | B1 %.0f | load+math %.0f | B2 %.0f | stage+flush %.0f | B3 %.0f | zero %.0f\n", h[0] / nw, h[1] / nw,
+              h[2] / nw, h[3] / nw, h[4] / nw, h[5] / nw, h[6] / nw);
+    }
+#endif
+    return NH_OK;
+  }
 }
 
 }  // extern "C"
