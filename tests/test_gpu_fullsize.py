@@ -1,0 +1,94 @@
+'''Parity at BASELINE.json's FULL sizes through size-independent properties (and, where the C port of the oracle finishes in
+seconds, entry by entry): C2 = 128^3 P1 hex Poisson stiffness, C3 = 64^3 P2 vector elasticity.'''
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr_matvec(values, rowptr, colidx, x, transpose=False):
+    import torch
+    rows = torch.repeat_interleave(torch.arange(len(rowptr) - 1, device=values.device), rowptr[1:] - rowptr[:-1])
+    src, dst = (rows, colidx) if transpose else (colidx, rows)
+    return torch.zeros_like(x).index_add_(0, dst, values * x[src])
+
+
+@pytest.mark.parametrize('variant', ['iso', 'uniform'])
+def test_c2_full_size(variant):
+    '''128^3 elements (57 066 625 nonzeros): index arrays bit-exact and values to 1e-13 against the oracle's C port run on the host
+    cores, plus the known answers of SURVEY 8c (nnz law, K 1 = 0, symmetry, strictly increasing columns).'''
+    import torch
+    from nutils_amd import workloads
+    n = 128
+    wl = workloads.PoissonSlab(n=n, rank=0, world=1, variant=variant)
+    wl.setup()
+    wl.build_pattern()
+    wl.values.fill_(float('nan'))  # write-once kernels: every entry must be stored
+    assert wl.self_check() < 1e-13
+    values, rowptr, colidx = wl.values, wl.rowptr, wl.colidx
+    assert values.numel() == (3 * n + 1) ** 3 == int(rowptr[-1])
+    assert rowptr.dtype == colidx.dtype == torch.int64
+    inner = torch.ones(values.numel() - 1, dtype=torch.bool, device=values.device)
+    inner[rowptr[1:-1] - 1] = False  # positions where a new row starts
+    assert bool(((colidx[1:] - colidx[:-1])[inner] > 0).all())
+    scale = float(values.abs().max())
+    ones = torch.ones(len(rowptr) - 1, dtype=torch.float64, device=values.device)
+    assert float(_csr_matvec(values, rowptr, colidx, ones).abs().max()) < 1e-12 * scale
+    x = torch.rand(len(rowptr) - 1, dtype=torch.float64, device=values.device, generator=torch.Generator(device=values.device).manual_seed(1))
+    y, yt = _csr_matvec(values, rowptr, colidx, x), _csr_matvec(values, rowptr, colidx, x, transpose=True)
+    assert float((y - yt).abs().max()) < 1e-12 * scale
+    if variant == 'uniform':
+        assert abs(float(values[0]) - 1 / 3) < 1e-15
+
+
+def test_c3_full_size_rigid_body_modes():
+    '''64^3 P2 vector elasticity (6 440 067 dofs, 1.2e9 nonzeros) on the perturbed (isoparametric) mesh: the stiffness matrix
+    annihilates the six rigid body modes -- translations and (for the interpolated P2 coordinates) rotations --, is symmetric,
+    and obeys the nnz bound 9 (8 n + 1)^3 of SURVEY 8a; values come from the MFMA kernel with the colour-wise scatter.'''
+    import torch
+    from nutils_amd import mesh, function, sample, device
+    n = 64
+    domain, geom = mesh.rectilinear([n] * 3)
+    gb = domain.basis('std', degree=1)
+    rng = numpy.random.default_rng(0)
+    verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.)] * 3, indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, (len(gb), 3))
+    geom = gb @ verts
+    u = domain.field('u', btype='std', degree=2, shape=[3])
+    v = domain.field('v', btype='std', degree=2, shape=[3])
+    lam, mu = 1., .5 / .3 - 1
+    eps = lambda w: function.symgrad(w, geom)
+    sigma = lam * function.div(u, geom) * function.eye(3) + 2 * mu * eps(u)
+    res = domain.integral(function.inner(eps(v), sigma) * function.J(geom), degree=4)
+    jac = function.derivative(function.derivative(res, 'v'), 'u')
+    values, rowptr, colidx, ncols = sample._MatrixPlan(jac.terms).run()
+    ndofs = 3 * (2 * n + 1) ** 3
+    assert ncols == ndofs == len(rowptr) - 1
+    assert values.numel() == int(rowptr[-1]) <= 9 * (8 * n + 1) ** 3
+    assert bool(torch.isfinite(values).all())
+    scale = float(values.abs().max())
+    # P2 nodal coordinates of the isoparametric map: the P1 geometry evaluated at the P2 nodes (midpoints are averages)
+    X = torch.as_tensor(verts.reshape(n + 1, n + 1, n + 1, 3), device=values.device)
+    for ax in range(3):
+        lo, hi = X.narrow(ax, 0, n), X.narrow(ax, 1, n)
+        shape = list(X.shape)
+        shape[ax] = 2 * n + 1
+        Y = torch.empty(shape, dtype=X.dtype, device=X.device)
+        Y.index_copy_(ax, torch.arange(0, 2 * n + 1, 2, device=X.device), X)
+        Y.index_copy_(ax, torch.arange(1, 2 * n, 2, device=X.device), .5 * (lo + hi))
+        X = Y
+    X = X.reshape(-1, 3)
+    modes = []
+    for c in range(3):
+        t = torch.zeros_like(X)
+        t[:, c] = 1.
+        modes.append(t)
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        r = torch.zeros_like(X)
+        r[:, a], r[:, b] = -X[:, b], X[:, a]
+        modes.append(r)
+    for m in modes:  # std P2 (Bernstein) coefficients of a LINEAR field are its values at the control points = nodal coordinates
+        y = _csr_matvec(values, rowptr, colidx, m.reshape(-1))
+        assert float(y.abs().max()) < 1e-10 * scale * float(m.abs().max()), float(y.abs().max())
+    x = torch.rand(ndofs, dtype=torch.float64, device=values.device, generator=torch.Generator(device=values.device).manual_seed(2))
+    y, yt = _csr_matvec(values, rowptr, colidx, x), _csr_matvec(values, rowptr, colidx, x, transpose=True)
+    assert float((y - yt).abs().max()) < 1e-11 * scale
