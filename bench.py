@@ -167,6 +167,23 @@ def main():
     torch.cuda.synchronize()
     elapsed, kernel_ms, launch = timed_steps(wl, a.steps, world, dist if world > 1 else None, a.graph)
 
+    # size-independent check of the assembled matrix on every rank (rows it owns are complete after the interface reduce):
+    # K 1 = 0, i.e. every owned row sums to zero; catches a lost or doubled halo contribution without moving the matrix
+    wl.finish()
+    s = wl.slab
+    a_row, b_row = s.own_plane_begin * s.plane, s.own_plane_end * s.plane
+    lens = wl.rowptr[a_row + 1:b_row + 1] - wl.rowptr[a_row:b_row]
+    rows = torch.repeat_interleave(torch.arange(b_row - a_row, device=wl.values.device), lens)
+    owned = wl.values[int(wl.rowptr[a_row]):int(wl.rowptr[b_row])]
+    rowsum = torch.zeros(b_row - a_row, dtype=torch.float64, device=wl.values.device).index_add_(0, rows, owned)
+    check = torch.stack([rowsum.abs().max() / owned.abs().max()])
+    del rows, rowsum
+    if world > 1:
+        dist.all_reduce(check, op=dist.ReduceOp.MAX)
+    row_sum_rel = float(check.item())
+    if not row_sum_rel < 1e-10:
+        print(f'WARNING: owned rows do not sum to zero (relative {row_sum_rel:.2e}): the assembled matrix is wrong', file=sys.stderr)
+
     if rank == 0:
         nelems_total = wl.nelems * world
         value = nelems_total * a.steps / elapsed
@@ -181,7 +198,7 @@ def main():
                        'parallelism': f'element slabs x{world}, halo-plane reduce' if world > 1 else 'single GPU', 'launch': launch},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': measured_traffic(wl.kernel_name, a.n) if world == 1 else None, 'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bytes_per_elem},
-            'pattern_ms': pattern_ms, 'setup_s': setup_s,
+            'pattern_ms': pattern_ms, 'setup_s': setup_s, 'checks': {'owned_row_sums_rel': row_sum_rel},
         }
         if world == 1 and a.variant == 'iso':
             # secondary variant of the same config: exact-uniform mesh (what mesh.rectilinear gives the reference; there the
