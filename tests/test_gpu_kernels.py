@@ -209,9 +209,11 @@ def test_p1hex_fast_path_golden(golden, name):
     close(device.to_host(values), g['K_values'])
 
 
-@pytest.mark.parametrize('shape,iso', [((17, 9, 23), True), ((7, 7, 7), False), ((1, 1, 1), True), ((1, 20, 3), True), ((30, 2, 1), False)])
+@pytest.mark.parametrize('shape,iso', [((17, 9, 23), True), ((7, 7, 7), False), ((1, 1, 1), True), ((1, 20, 3), True), ((30, 2, 1), False),
+                                       ((40, 33, 70), True), ((3, 100, 100), True), ((100, 16, 15), False), ((65, 1, 130), True)])
 def test_p1hex_fast_vs_generic(shape, iso):
-    '''Box-boundary / ragged-edge coverage: sizes that are not multiples of the 7^3 dof box, compared with the generic kernel
+    '''Tile-boundary / ragged-edge coverage: sizes that are not multiples of the 15 x 15 dof column tile or of the two-layer step,
+    several tiles per axis, meshes smaller than one tile; compared with the generic kernel
     (itself pinned to the golden vectors above).'''
     from nutils_amd import mesh, function, device, kernels, points
     rng = numpy.random.default_rng(3)
