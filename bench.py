@@ -33,7 +33,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--n', type=int, default=128, help='elements per axis per GPU')
+    ap.add_argument('--n', '--elements-per-axis', dest='n', type=int, default=128,
+                    help='elements per axis per GPU (use the long form behind torch.distributed.run, whose parser claims --n)')
     ap.add_argument('--variant', choices=['iso', 'uniform'], default='iso')
     ap.add_argument('--kernel', choices=['auto', 'generic', 'fast'], default='auto')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
@@ -143,10 +144,17 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    # test hook (tests/test_gpu_partition.py): all ranks on ONE GPU with gloo transport, to run the multi-process path on a 1-GPU box
+    one_gpu = os.environ.get('NUTILS_AMD_BENCH_ONE_GPU') == '1'
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     from nutils_amd import workloads
     wl = workloads.PoissonSlab(n=a.n, rank=rank, world=world, variant=a.variant, kernel=a.kernel)

@@ -64,6 +64,13 @@ def host_ptr(array):
 
 
 def to_host(tensor):
+    '''Fresh host (numpy) copy.  Large arrays go through page-locked memory from torch's caching host allocator (a pageable
+    `.cpu()` copy of the 0.2 GB C4 Jacobian runs at ~8 GB/s, the pinned one at PCIe speed); the block returns to the cache when
+    the numpy array is released.'''
+    if tensor.is_cuda and tensor.numel() * tensor.element_size() >= 1 << 20:
+        host = torch().empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+        host.copy_(tensor)
+        return host.numpy()
     return tensor.cpu().numpy()
 
 

@@ -73,6 +73,17 @@ class _ScipyBackend:
         import scipy.sparse
         return ScipyMatrix(scipy.sparse.csr_matrix((values, colidx, rowptr), (len(rowptr) - 1, ncols)))
 
+    @staticmethod
+    def assemble_trusted(values, rowptr, colidx, ncols):
+        '''Same matrix for an index pair that has been through `assemble_csr` before (re-assembly of a Newton step: only the values
+        are new): skips scipy's O(nnz) index scans and the copy it makes of the index arrays.'''
+        import scipy.sparse
+        core = scipy.sparse.csr_matrix((len(rowptr) - 1, ncols), dtype=values.dtype)
+        core.data, core.indices, core.indptr = values, colidx, rowptr
+        core.has_sorted_indices = True
+        core.has_canonical_format = True
+        return ScipyMatrix(core)
+
 
 class _Backend:
     '''``matrix.backend`` selector: any object with ``.assemble(values, rowptr,
@@ -118,6 +129,17 @@ def assemble_csr(values, rowptr, colidx, ncols):
     if not increasing.all():
         raise MatrixError('column indices are not stricty increasing')
     return backend.current.assemble(values, rowptr, colidx, ncols)
+
+
+def reassemble_csr(values, rowptr, colidx, ncols):
+    '''`assemble_csr` for a (rowptr, colidx) pair that a previous `assemble_csr` call has validated -- the situation of every
+    re-assembly inside a Newton or time loop, where the reference repeats the O(nnz) checks (matrix/__init__.py:47-69).
+    Only the values are checked; backends without a trusted entry point get the ordinary one.'''
+    values = numpy.asarray(values)
+    if not (values.ndim == 1 and len(values) == len(colidx)):
+        raise MatrixError('assemble received invalid values')
+    trusted = getattr(backend.current, 'assemble_trusted', None)
+    return trusted(values, rowptr, colidx, ncols) if trusted else backend.current.assemble(values, rowptr, colidx, ncols)
 
 
 def compress_indices(indices, length):

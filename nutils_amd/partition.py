@@ -70,15 +70,23 @@ class HaloPlan:
     def exchange(self, values):
         import torch.distributed as dist
         s = self.slab
+        staged = values.is_cuda and dist.get_backend() == 'gloo'  # gloo moves host memory only (tests on a 1-GPU box)
+        send = values[self.send_a:self.send_b] if s.sends else None
+        recv = self.recv_buf if s.recvs else None
+        if staged:
+            send = send.cpu() if s.sends else None
+            recv = recv.cpu() if s.recvs else None
         ops = []
         if s.sends:
-            ops.append(dist.P2POp(dist.isend, values[self.send_a:self.send_b], s.rank + 1))
+            ops.append(dist.P2POp(dist.isend, send, s.rank + 1))
         if s.recvs:
-            ops.append(dist.P2POp(dist.irecv, self.recv_buf, s.rank - 1))
+            ops.append(dist.P2POp(dist.irecv, recv, s.rank - 1))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if s.recvs:
+            if staged:
+                self.recv_buf.copy_(recv)
             values.index_add_(0, self.recv_idx, self.recv_buf)
 
 

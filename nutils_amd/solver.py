@@ -97,7 +97,11 @@ class System:
         for grp in self._groups:
             values = grp['values'] if grp['constant'] else grp['plan'].run(arguments)[0]
             kernels.monomial(values, [], [], merged, out_index=grp['slot'])
-        jac = _matrix.assemble_csr(device.to_host(merged), self._merged_rowptr, self._merged_colidx, self.size)
+        if getattr(self, '_pattern_validated', False):
+            jac = _matrix.reassemble_csr(device.to_host(merged), self._merged_rowptr, self._merged_colidx, self.size)
+        else:
+            jac = _matrix.assemble_csr(device.to_host(merged), self._merged_rowptr, self._merged_colidx, self.size)
+            self._pattern_validated = True
         if self.is_constant_matrix:
             self._jac = jac
         return jac
@@ -105,9 +109,12 @@ class System:
     def assemble_residual(self, arguments):
         parts = []
         for r, size in zip(self.block_residual, numpy.diff(self.offsets)):
-            v = numpy.zeros(int(size))
-            for term in r.terms:
-                v += numpy.asarray(_sample.evaluate(function.Integral([term]), arguments)).ravel()
+            try:  # all terms of a block share the test space: one device accumulator, one copy back
+                v = numpy.asarray(_sample.evaluate(r, arguments), dtype=float).ravel() if r.terms else numpy.zeros(int(size))
+            except NotImplementedError:
+                v = numpy.zeros(int(size))
+                for term in r.terms:
+                    v += numpy.asarray(_sample.evaluate(function.Integral([term]), arguments)).ravel()
             parts.append(v)
         return numpy.concatenate(parts)
 

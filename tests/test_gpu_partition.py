@@ -84,3 +84,24 @@ def test_pipelined_exchange_matches_serial():
     for got in (pa, pb, plast):
         assert float((got - sa).abs().max()) <= 1e-13 * scale
     assert plast.data_ptr() != 0
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_bench_multiprocess_on_one_gpu(world):
+    '''`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank), except that all ranks
+    share the one GPU of this box and the interface rows travel through gloo (host staging) instead of RCCL: exercises rank
+    bookkeeping, ghost layers, the pipelined exchange, the timing protocol and the owned-row-sum check of every rank.'''
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NUTILS_AMD_BENCH_ONE_GPU='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1', '--master-port', str(29500 + world),
+           'bench.py', '--gpus', str(world), '--steps', '4', '--warmup', '2', '--elements-per-axis', '32', '--no-cpu']
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == world and rec['steps'] == 4 and rec['scaling'] == 'weak'
+    assert rec['config']['nelems_per_gpu'] == 32 ** 3 and rec['value'] > 0
+    assert rec['checks']['owned_row_sums_rel'] < 1e-12
+    assert 'WARNING' not in out.stderr

@@ -123,3 +123,29 @@ def test_no_cpu_fallback():
     K = domain.integral(function.outer(function.grad(basis, geom)).sum(-1) * function.J(geom), degree=2)
     with pytest.raises(_lib.NutilsHipError):
         function.eval(function.as_csr(K))
+
+
+def test_reassemble_csr_matches_assemble_csr():
+    '''Trusted re-assembly (values only) gives the same matrix as the validating entry point, and still rejects a wrong length.'''
+    from nutils_amd import matrix
+    rowptr = numpy.array([0, 2, 3, 5], dtype=numpy.int64)
+    colidx = numpy.array([0, 2, 1, 0, 2], dtype=numpy.int64)
+    vals = numpy.array([4., 1., 3., 1., 5.])
+    a = matrix.assemble_csr(vals, rowptr, colidx, 3)
+    b = matrix.reassemble_csr(vals * 2, rowptr, colidx, 3)
+    assert numpy.array_equal(b.export('dense'), 2 * a.export('dense'))
+    x = numpy.array([1., 2., 3.])
+    assert numpy.allclose(b @ x, 2 * (a @ x))
+    assert numpy.allclose(b.solve(numpy.ones(3), constrain=numpy.array([numpy.nan, numpy.nan, 1.])),
+                          matrix.assemble_csr(vals * 2, rowptr, colidx, 3).solve(numpy.ones(3), constrain=numpy.array([numpy.nan, numpy.nan, 1.])))
+    with pytest.raises(matrix.MatrixError):
+        matrix.reassemble_csr(numpy.arange(4.), rowptr, colidx, 3)
+    calls = []
+
+    class Fake:  # backends without the trusted entry point still work (fake-backend precedent, reference tests/test_matrix.py:6-23)
+        @staticmethod
+        def assemble(values, rowptr, colidx, ncols):
+            calls.append(len(values))
+            return 'fake'
+    with matrix.backend(Fake):
+        assert matrix.reassemble_csr(numpy.arange(5.), rowptr, colidx, 3) == 'fake' and calls == [5]
