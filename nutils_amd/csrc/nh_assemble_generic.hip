@@ -178,6 +178,7 @@ struct MatK {
   int qchunk;
   int maxnbt, maxnbr;
   int emap_by_elem;
+  int exclusive;  // NH_MATRIX_EXCLUSIVE: no two elements of this launch share a matrix entry -> plain read-modify-write (deterministic)
 };
 
 template <int ND>
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
         const i64 row = p.test.dofs[tdof0 + m];
         const i64 a0 = p.srowptr[row], len = p.srowptr[row + 1] - a0;
         const i64 slot = a0 * form.tot + len * form.cum[c] + (i64)p.emap[emap0 + m * nbr + n] * form.cnt[c] + form.dpos[c][d];
-        atomicAdd(p.values + slot, acc);
+        if (p.exclusive) p.values[slot] += acc;
+        else atomicAdd(p.values + slot, acc);
       }
       __syncthreads();
     }
@@ -644,6 +646,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   p.values = a->values_dev;
   p.scale = a->scale_dev;
   p.emap_by_elem = (a->flags & 2) != 0;
+  p.exclusive = (a->flags & 1) != 0;
   NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "nh_assemble_matrix: elist with ragged bases is not supported");
   if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
   if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;

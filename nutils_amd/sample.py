@@ -9,6 +9,8 @@ runs a generated Python loop, this class keeps the per-sample device tables
 libnutils_hip.so.  No CPU fallback.
 '''
 
+import os
+
 import numpy
 
 from . import device, function, kernels, matrix as _matrix
@@ -289,7 +291,59 @@ class _MatrixPlan:
             self.mask |= _block_mask(itg.B)
         self.smp0 = smp0
 
+    def _p1hex_laplace(self):
+        '''Recognise the headline form -- scalar Laplace stiffness `kappa grad(phi_m) . grad(phi_n) J(geom)` on the trilinear 'std'
+        basis of a full 3-D structured topology, 2-point Gauss per axis, geometry either rectilinear or the isoparametric P1
+        map -- and assemble it with the write-once structured kernel (nh_p1hex_pattern / nh_p1hex_laplace) instead of the
+        generic one.  Anything else (other bases, coefficients, samples, extra terms) returns None.'''
+        from . import points as _points
+        basis, smp = self.test.basis, self.smp0
+        if not (basis is self.trial.basis and isinstance(basis, StructuredBasis) and basis.btype == 'std' and basis.degree == 1
+                and basis.ndims == 3 and basis.dofs_shape == tuple(n + 1 for n in basis.shape) and self.test.ncomp == self.trial.ncomp == 1):
+            return None
+        if smp.elist is not None or smp.bnd_axis >= 0 or smp.points.npoints != 8 or os.environ.get('NUTILS_AMD_NO_FAST_PATH'):
+            return None
+        x1, w1 = _points.gauss1(2)
+        ref = _points.gauss(2, 3) if hasattr(_points, 'gauss') else None
+        if ref is None or not (numpy.array_equal(smp.points.coords, ref.coords) and numpy.array_equal(smp.points.weights, ref.weights)):
+            return None
+        kappa, geom = 0., None
+        for _, itg, fac in self.terms:
+            B = numpy.asarray(itg.B, dtype=float) * fac
+            if itg.scale is not None or itg.fscale is not None or B.shape != (1, 4, 1, 4):
+                return None
+            B = B[0, :, 0, :]
+            k = B[1, 1]
+            if not numpy.array_equal(B, numpy.diag([0., k, k, k])):
+                return None
+            if geom is not None and itg.measure is not geom:
+                return None
+            kappa, geom = kappa + k, itg.measure
+        verts, origin, scale = None, (0., 0., 0.), (1., 1., 1.)
+        if isinstance(geom, function.IsoGeometry):
+            g = geom.basis
+            if not (isinstance(g, StructuredBasis) and g.btype == 'std' and g.degree == 1 and g.shape == basis.shape and g.dofs_shape == basis.dofs_shape):
+                return None
+            key = 'p1hex_verts', id(geom)
+            if key not in smp._tables:
+                smp._tables[key] = device.to_dev(geom.verts, 'float64')
+            verts = smp._tables[key]
+        elif isinstance(geom, function.RectilinearGeometry) and geom.topo.shape == basis.shape:
+            origin, scale = tuple(geom.offset), tuple(geom.scale)
+        else:
+            return None
+        key = 'p1hex_pattern', basis.shape
+        if key not in smp._tables:
+            smp._tables[key] = kernels.p1hex_pattern(basis.shape)
+        rowptr, colidx = smp._tables[key]
+        values = device.empty(colidx.numel(), 'float64')  # write-once kernel: no zero-fill
+        kernels.p1hex_laplace(shape=basis.shape, values=values, gauss_x=list(x1), gauss_w=list(w1), verts=verts, origin=origin, scale=scale, kappa=kappa)
+        return values, rowptr, colidx, basis.ndofs
+
     def run(self, arguments=None):
+        fast = self._p1hex_laplace()
+        if fast is not None:
+            return fast
         pat = self.smp0.pattern(self.test.basis, self.trial.basis)
         nct, ncr = self.test.ncomp, self.trial.ncomp
         mask = None if self.mask.all() else self.mask
@@ -304,7 +358,7 @@ class _MatrixPlan:
                           values=values)
             colors = None
             scale = smp.scale(itg.scale, itg.fscale, arguments)
-            if itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16:
+            if itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and (tt.nb >= 16 or os.environ.get('NUTILS_AMD_COLOR_SMALL')):
                 colors = _colors(smp, itg.test.basis)
             if colors:
                 for el in colors:

@@ -92,3 +92,30 @@ def test_c3_full_size_rigid_body_modes():
     x = torch.rand(ndofs, dtype=torch.float64, device=values.device, generator=torch.Generator(device=values.device).manual_seed(2))
     y, yt = _csr_matvec(values, rowptr, colidx, x), _csr_matvec(values, rowptr, colidx, x, transpose=True)
     assert float((y - yt).abs().max()) < 1e-11 * scale
+
+
+def test_c2_full_size_through_the_api():
+    '''The same 128^3 isoparametric Poisson stiffness written as a user script writes it (mesh.rectilinear, basis, `basis @ verts`,
+    domain.integral, function.eval(as_csr)): the front end recognises the form and takes the write-once kernel; indices and values
+    must equal the slab workload that bench.py times.'''
+    import time
+    import torch
+    from nutils_amd import mesh, function, workloads, device
+    n = 128
+    wl = workloads.PoissonSlab(n=n, rank=0, world=1, variant='iso')
+    wl.setup()
+    wl.build_pattern()
+    wl.step()
+    domain, geom = mesh.rectilinear([n] * 3)
+    basis = domain.basis('std', degree=1)
+    X = basis @ wl.verts
+    K = domain.integral(function.outer(function.grad(basis, X)).sum(-1) * function.J(X), degree=2)
+    function.eval(function.as_csr(K))  # first call: tables, pattern, upload of the vertices
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    values, rowptr, colidx = function.eval(function.as_csr(K))
+    dt = time.perf_counter() - t0
+    assert numpy.array_equal(rowptr, device.to_host(wl.rowptr)) and numpy.array_equal(colidx, device.to_host(wl.colidx))
+    ref = device.to_host(wl.values)
+    assert numpy.abs(values - ref).max() <= 1e-13 * numpy.abs(ref).max()
+    assert dt < 2., dt  # device assembly 0.25 ms; the rest is the copy of 1.4 GB of CSR arrays to the host

@@ -211,7 +211,7 @@ def test_p1hex_fast_path_golden(golden, name):
 
 @pytest.mark.parametrize('shape,iso', [((17, 9, 23), True), ((7, 7, 7), False), ((1, 1, 1), True), ((1, 20, 3), True), ((30, 2, 1), False),
                                        ((40, 33, 70), True), ((3, 100, 100), True), ((100, 16, 15), False), ((65, 1, 130), True)])
-def test_p1hex_fast_vs_generic(shape, iso):
+def test_p1hex_fast_vs_generic(shape, iso, monkeypatch):
     '''Tile-boundary / ragged-edge coverage: sizes that are not multiples of the 15 x 15 dof column tile or of the two-layer step,
     several tiles per axis, meshes smaller than one tile; compared with the generic kernel
     (itself pinned to the golden vectors above).'''
@@ -224,7 +224,12 @@ def test_p1hex_fast_vs_generic(shape, iso):
         verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, (len(basis), 3))
         geom = basis @ verts
     K = domain.integral(function.outer(function.grad(basis, geom)).sum(-1) * function.J(geom), degree=2)
+    monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')  # reference values from the generic kernel
     vref, rp, ci = function.eval(function.as_csr(K))
+    monkeypatch.delenv('NUTILS_AMD_NO_FAST_PATH')
+    vapi, rpa, cia = function.eval(function.as_csr(2.5 * K))  # the same integral through the API takes the fast path on its own
+    assert numpy.array_equal(rpa, rp) and numpy.array_equal(cia, ci)
+    close(vapi, 2.5 * vref)
     rowptr, colidx = kernels.p1hex_pattern(shape)
     assert numpy.array_equal(device.to_host(rowptr), rp) and numpy.array_equal(device.to_host(colidx), ci)
     values = device.empty(colidx.numel(), 'float64')
