@@ -39,7 +39,6 @@ def parse():
     ap.add_argument('--kernel', choices=['auto', 'generic', 'fast'], default='auto')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-graph', dest='graph', action='store_false', help='launch every step eagerly instead of replaying a captured HIP graph')
-    ap.add_argument('--check', action='store_true', help='verify the result against the oracle port on a small mesh first')
     return ap.parse_args()
 
 
@@ -166,9 +165,6 @@ def main():
     wl.build_pattern()
     torch.cuda.synchronize()
     pattern_ms = (time.perf_counter() - t0) * 1e3
-
-    if a.check and rank == 0:
-        wl.self_check()
 
     for _ in range(a.warmup):
         wl.step()

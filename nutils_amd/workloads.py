@@ -180,18 +180,3 @@ class PoissonSlab:
         '''(values, rowptr, colidx) of the rows this rank owns, global numbering, on the host.'''
         self.finish()
         return partition.owned_rows(self.slab, device.to_host(self.values), device.to_host(self.rowptr), device.to_host(self.colidx))
-
-    def self_check(self):
-        from oracle import assemble as oa, port
-        pts, w = oa.gauss(2, 3)
-        _, coeffs, _ = oa.structured_basis((1, 1, 1), 'std', 1)
-        N, dN = oa.tabulate(coeffs[0], pts)
-        T = numpy.concatenate([N.T[:, :, None], dN.transpose(1, 0, 2)], axis=2)
-        s = self.slab
-        self.step()
-        v, rp, ci, _ = port.laplace3d((s.local_layers, self.n, self.n), 1, T, T, w, self.verts)
-        assert numpy.array_equal(device.to_host(self.rowptr), rp) and numpy.array_equal(device.to_host(self.colidx), ci)
-        got = device.to_host(self.values)
-        err = numpy.abs(got - v).max() / numpy.abs(v).max()
-        assert err < 1e-13, err
-        return err
