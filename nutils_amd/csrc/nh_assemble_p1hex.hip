@@ -247,23 +247,30 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
           const double *src = acc + ((!upper && dI < 0) ? slot_of(P - 1) : slot_of(P)) + srow;
           // CSR offset of row (P, J, 0): uniform, advanced line by line
           double *line = p.values + ((P == 0 ? 0 : 3 * (i64)P - 1) * T1 * T2 + lenI * (cumJ0 * T2));
-          if (J0 > 0 && J0 + OJ < N1) {
-            // all OJ lines exist and are interior along J: lane offset and mask are loop invariants, the loop is straight-line
-            const int flag = loI | 2 | loK << 2 | hiI << 3 | 16 | hiK << 5;
-            const unsigned voff = (unsigned)(lenI * 3 * cumK + ((dI + loI) * 3 + (dJ + 1)) * lenK + (dK + loK));
-            const int stride = lenI * 3 * (int)T2;
-            if (kact && (flag & need) == need) {
-              double v[OJ];  // all LDS reads of the pass in flight before the first store
+          const bool lowJ = J0 == 0, highJ = J0 + OJ >= N1;
+          if (!(lowJ && highJ)) {
+            // straight-line: lane offset and mask are loop invariants, with a second set for the ONE line of a tile that can
+            // touch the J boundary (J = 0 in the first tile, J = N1 - 1 in the last; lines beyond it do not exist)
+            const int jb = lowJ ? 0 : highJ ? N1 - 1 - J0 : -1, nlines = highJ ? N1 - J0 : OJ;
+            const int flag3 = loI | 2 | loK << 2 | hiI << 3 | 16 | hiK << 5;
+            const unsigned voff3 = (unsigned)(lenI * 3 * cumK + ((dI + loI) * 3 + (dJ + 1)) * lenK + (dK + loK));
+            const bool act3 = kact && (flag3 & need) == need;
+            const int loJb = lowJ ? 0 : 1, flagb = loI | loJb << 1 | loK << 2 | hiI << 3 | (lowJ ? 16 : 0) | hiK << 5;
+            const unsigned voffb = (unsigned)(lenI * 2 * cumK + ((dI + loI) * 2 + (dJ + loJb)) * lenK + (dK + loK));
+            const bool actb = kact && (flagb & need) == need;
+            double v[OJ];  // all LDS reads of the pass in flight before the first store
 #pragma unroll
-              for (int oj = 0; oj < OJ; ++oj) v[oj] = src[oj * (VK * NS)];
+            for (int oj = 0; oj < OJ; ++oj) v[oj] = src[oj * (VK * NS)];
 #pragma unroll
-              for (int oj = 0; oj < OJ; ++oj) {
-                line[voff] = v[oj];
-                line += stride;
+            for (int oj = 0; oj < OJ; ++oj) {
+              if (oj < nlines) {  // uniform
+                const bool bnd = oj == jb;
+                if (bnd ? actb : act3) line[bnd ? voffb : voff3] = v[oj];
+                line += lenI * (bnd ? 2 : 3) * (int)T2;
               }
             }
           } else {
-            // boundary lines: the same, branch-free per line (flags recomputed on the scalar unit)
+            // meshes with a single tile along J: per-line flags recomputed on the scalar unit
 #pragma unroll 1
             for (int oj = 0; oj < OJ; oj += C) {
               double v[C];
