@@ -13,6 +13,7 @@
 // HBM traffic = vertex coordinates (each tile re-reads its lateral halo) + values.  Uniform meshes take k_p1hex_uniform instead.
 #include "nh_common.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -242,13 +243,16 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
         const int loK = Kk > 0, hiK = Kk < N2 - 1, lenK = loK + 1 + hiK, cumK = Kk == 0 ? 0 : 3 * Kk - 1;
         // LDS source relative to (plane, line vj = 1): own upper slot, or the mirrored upper slot of the neighbouring row
         const int srow = (VK + ok + 1) * NS + (upper ? sl - 13 : (dJ * VK + dK) * NS + 13 - sl);
+        const bool lowJ = J0 == 0, highJ = J0 + OJ >= N1;
+        // one plane loop per tile kind (the kind is decided OUTSIDE the loop: otherwise the loop invariants of the rarer kinds are
+        // hoisted in front of the common one and executed on every step)
+        auto planes = [&](auto kind) {
         for (int P = Pb; P < Pe; ++P) {
           const int loI = P > 0, hiI = P < N0 - 1, lenI = loI + 1 + hiI;
           const double *src = acc + ((!upper && dI < 0) ? slot_of(P - 1) : slot_of(P)) + srow;
           // CSR offset of row (P, J, 0): uniform, advanced line by line
           double *line = p.values + ((P == 0 ? 0 : 3 * (i64)P - 1) * T1 * T2 + lenI * (cumJ0 * T2));
-          const bool lowJ = J0 == 0, highJ = J0 + OJ >= N1;
-          if (!lowJ && !highJ) {
+          if constexpr (decltype(kind)::value == 0) {
             // all OJ lines exist and are interior along J (7 of 9 tiles at 128^3): lane offset and mask are loop invariants and the
             // whole pass is ONE exec region of straight-line code -- per store one global_store (uniform line pointer + 32-bit lane
             // byte offset) and one scalar pointer bump.  In this phase nothing else runs on the CU, so every instruction around
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
                 lp += stride8;
               }
             }
-          } else if (!(lowJ && highJ)) {
+          } else if constexpr (decltype(kind)::value == 1) {
             // straight-line: lane offset and mask are loop invariants, with a second set for the ONE line of a tile that can
             // touch the J boundary (J = 0 in the first tile, J = N1 - 1 in the last; lines beyond it do not exist)
             const int jb = lowJ ? 0 : highJ ? N1 - 1 - J0 : -1, nlines = highJ ? N1 - J0 : OJ;
@@ -307,6 +311,10 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
             }
           }
         }
+        };
+        if (!lowJ && !highJ) planes(std::integral_constant<int, 0>{});
+        else if (!(lowJ && highJ)) planes(std::integral_constant<int, 1>{});
+        else planes(std::integral_constant<int, 2>{});
       }
     }
     NH_TICK(4)
