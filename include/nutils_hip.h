@@ -220,7 +220,7 @@ int nh_sample_eval(const nh_eval_args *args, void *stream);
  * Same result as nh_pattern_* + nh_assemble_matrix for the 3-D trilinear 'std' basis on
  * mesh.rectilinear (mesh.py:34-60; StructuredBasis function.py:3080-3100) with 2-point
  * Gauss per axis and isoparametric P1 (or uniform) geometry, but WRITE-ONCE: each
- * workgroup owns a box of dof rows, recomputes the element matrices that touch it,
+ * workgroup owns a column tile of dof rows, recomputes the element matrices that touch it,
  * reduces them in LDS and streams the finished CSR rows to HBM -- no global atomics, no
  * zero-fill, no element map.  The pattern is the reference's (sorted unique, structural
  * zeros kept; (3n+1)^3 law) in closed form: nh_p1hex_pattern writes rowptr (re-based to
@@ -239,6 +239,9 @@ typedef struct {
   double *values_dev;
   const double *unit_matrix_dev; /* uniform geometry only: the 8x8 element matrix from nh_p1hex_unit_matrix (computed once per
                                     mesh, like the reference hoists it out of the loop); NULL: evaluated inside the call */
+  const double *qscale_dev;      /* NULL, or [nelems][8]: coefficient at the Gauss points of every element (element index last
+                                    axis fastest, points first coordinate slowest) multiplying kappa -- a scale_dev array of
+                                    nh_assemble_matrix (variable or field-dependent diffusivity).  Needs verts_dev. */
 } nh_p1hex_args;
 
 int nh_p1hex_pattern(const int *shape, int64_t row_begin, int64_t row_end, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream);

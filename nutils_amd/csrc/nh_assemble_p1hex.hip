@@ -36,6 +36,7 @@ struct P1Args {
   double c[3][2];          // c[x+y][q] = n[x][q] n[y][q]
   double wk[2][2][2];      // kappa w_qa w_qb w_qc
   double *values;
+  const double *qscale;    // NULL or [nelems][8] coefficient at the Gauss points
   int nbj, nbk;            // boxes per axis (j, k)
   int nboxes;
   long long *tdbg;         // phase timers (ablation builds)
@@ -183,8 +184,18 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
               X[a][bb][c][1] = src[1];
               X[a][bb][c][2] = src[2];
             }
+        double qs[8];  // coefficient at the Gauss points (1 without a coefficient array)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) qs[q] = 1.;
+        if (p.qscale) {
+          const double *src = p.qscale + (((i64)gi * p.n1 + gj) * p.n2 + gk) * 8;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) qs[q] = src[q];
+        }
         double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3];
+#define NH_P1HEX_QS(q) qs[q]
 #include "nh_p1hex_math.inc"
+#undef NH_P1HEX_QS
         double Kt[36];
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
@@ -356,7 +367,9 @@ __global__ void k_p1hex_unit_matrix(P1Args p, double *Ke) {
   {
     double (&R0)[3][3] = T.R0, (&R1)[3][3] = T.R1, (&R2)[3][3] = T.R2;
     double (&W01)[2][2][3] = T.W01, (&W02)[2][2][3] = T.W02, (&W12)[2][2][3] = T.W12;
+#define NH_P1HEX_QS(q) 1.
 #include "nh_p1hex_math.inc"
+#undef NH_P1HEX_QS
   }
 #pragma unroll
   for (int a = 0; a < 8; ++a)
@@ -481,6 +494,7 @@ static int fill_p1args(const nh_p1hex_args *a, P1Args &p) {
     for (int qb = 0; qb < 2; ++qb)
       for (int qc = 0; qc < 2; ++qc) p.wk[qa][qb][qc] = a->kappa * a->gauss_w[qa] * a->gauss_w[qb] * a->gauss_w[qc];
   p.values = a->values_dev;
+  p.qscale = a->qscale_dev;
   p.nbj = p.nbk = p.nboxes = 0;
   p.debug = 0;
   p.tdbg = nullptr;
@@ -503,6 +517,7 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
   int rc = fill_p1args(a, p);
   if (rc) return rc;
   if (a->plane_begin == a->plane_end) return NH_OK;
+  NH_REQUIRE(!a->qscale_dev || a->verts_dev, "nh_p1hex_laplace: a coefficient array needs explicit vertices");
   if (!a->verts_dev) {  // uniform geometry: unit element matrix + streaming kernel
     double *Ke = nullptr;
     if (!a->unit_matrix_dev) {

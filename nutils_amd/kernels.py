@@ -164,7 +164,7 @@ def p1hex_pattern(shape, row_begin=0, row_end=None):
     return rowptr, colidx
 
 
-def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix=None):
+def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix=None, qscale=None):
     n0 = int(shape[0])
     layers = (0, n0) if layers is None else layers
     planes = (0, n0 + 1) if planes is None else planes
@@ -180,6 +180,9 @@ def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, la
     a.kappa = float(kappa)
     a.values_dev = device.ptr(values)
     a.unit_matrix_dev = device.ptr(unit_matrix)
+    if qscale is not None and qscale.numel() != 8 * int(shape[0]) * int(shape[1]) * int(shape[2]):
+        raise ValueError('qscale must hold 8 values per element')
+    a.qscale_dev = device.ptr(qscale)
     return a
 
 
@@ -192,9 +195,9 @@ def p1hex_unit_matrix(*, shape, gauss_x, gauss_w, origin=(0., 0., 0.), scale=(1.
 
 
 def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0., 0.), scale=(1., 1., 1.), kappa=1., layers=None, planes=None,
-                  unit_matrix=None):
+                  unit_matrix=None, qscale=None):
     '''Write-once structured P1-hex Laplace assembly (nh_p1hex_laplace).'''
-    a = _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix)
+    a = _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix, qscale)
     _lib.call('nh_p1hex_laplace', ctypes.byref(a), device.stream())
 
 

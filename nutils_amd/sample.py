@@ -291,7 +291,7 @@ class _MatrixPlan:
             self.mask |= _block_mask(itg.B)
         self.smp0 = smp0
 
-    def _p1hex_laplace(self):
+    def _p1hex_laplace(self, arguments=None):
         '''Recognise the headline form -- scalar Laplace stiffness `kappa grad(phi_m) . grad(phi_n) J(geom)` on the trilinear 'std'
         basis of a full 3-D structured topology, 2-point Gauss per axis, geometry either rectilinear or the isoparametric P1
         map -- and assemble it with the write-once structured kernel (nh_p1hex_pattern / nh_p1hex_laplace) instead of the
@@ -307,10 +307,10 @@ class _MatrixPlan:
         ref = _points.gauss(2, 3) if hasattr(_points, 'gauss') else None
         if ref is None or not (numpy.array_equal(smp.points.coords, ref.coords) and numpy.array_equal(smp.points.weights, ref.weights)):
             return None
-        kappa, geom = 0., None
+        kappa, geom, qscale = 0., None, None
         for _, itg, fac in self.terms:
             B = numpy.asarray(itg.B, dtype=float) * fac
-            if itg.scale is not None or itg.fscale is not None or B.shape != (1, 4, 1, 4):
+            if B.shape != (1, 4, 1, 4):
                 return None
             B = B[0, :, 0, :]
             k = B[1, 1]
@@ -318,7 +318,16 @@ class _MatrixPlan:
                 return None
             if geom is not None and itg.measure is not geom:
                 return None
-            kappa, geom = kappa + k, itg.measure
+            geom = itg.measure
+            if itg.scale is None and itg.fscale is None:
+                kappa += k
+            else:  # coefficient function (of position, or of a field): values at the Gauss points, summed over the terms
+                sc = smp.scale(itg.scale, itg.fscale, arguments)
+                qscale = sc * k if qscale is None else qscale.add_(sc, alpha=k)
+        if qscale is not None:
+            if kappa:
+                qscale = qscale + kappa
+            kappa = 1.
         verts, origin, scale = None, (0., 0., 0.), (1., 1., 1.)
         if isinstance(geom, function.IsoGeometry):
             g = geom.basis
@@ -330,6 +339,12 @@ class _MatrixPlan:
             verts = smp._tables[key]
         elif isinstance(geom, function.RectilinearGeometry) and geom.topo.shape == basis.shape:
             origin, scale = tuple(geom.offset), tuple(geom.scale)
+            if qscale is not None:  # element matrices differ: explicit vertices for the isoparametric kernel
+                key = 'p1hex_verts', id(geom)
+                if key not in smp._tables:
+                    idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in basis.shape], indexing='ij'), -1).reshape(-1, 3)
+                    smp._tables[key] = device.to_dev(geom.offset + geom.scale * idx, 'float64')
+                verts = smp._tables[key]
         else:
             return None
         key = 'p1hex_pattern', basis.shape
@@ -337,11 +352,12 @@ class _MatrixPlan:
             smp._tables[key] = kernels.p1hex_pattern(basis.shape)
         rowptr, colidx = smp._tables[key]
         values = device.empty(colidx.numel(), 'float64')  # write-once kernel: no zero-fill
-        kernels.p1hex_laplace(shape=basis.shape, values=values, gauss_x=list(x1), gauss_w=list(w1), verts=verts, origin=origin, scale=scale, kappa=kappa)
+        kernels.p1hex_laplace(shape=basis.shape, values=values, gauss_x=list(x1), gauss_w=list(w1), verts=verts, origin=origin, scale=scale, kappa=kappa,
+                              qscale=qscale)
         return values, rowptr, colidx, basis.ndofs
 
     def run(self, arguments=None):
-        fast = self._p1hex_laplace()
+        fast = self._p1hex_laplace(arguments)
         if fast is not None:
             return fast
         pat = self.smp0.pattern(self.test.basis, self.trial.basis)

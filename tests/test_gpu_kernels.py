@@ -269,3 +269,43 @@ def test_error_paths_on_device():
         kernels.sample_eval(nelems=1, ndims=3, nq=2, geom=g, points=pts, detj=co)
     with pytest.raises(_lib.NutilsHipError, match='layer range'):
         kernels.p1hex_laplace(shape=(2, 2, 2), values=co, gauss_x=[.2, .8], gauss_w=[.5, .5], layers=(0, 3))
+
+
+@pytest.mark.parametrize('iso', [True, False])
+def test_p1hex_fast_path_with_coefficients(iso, monkeypatch):
+    '''Variable and field-dependent diffusivity through the front end: kappa(x) grad.grad + (1 + u^2) grad.grad + 0.5 grad.grad on
+    the trilinear basis takes the write-once kernel with a per-Gauss-point coefficient array (qscale_dev); values must equal the
+    generic kernel's, the Jacobian-type re-assembly must follow a change of the field.'''
+    from nutils_amd import mesh, function
+    shape = (9, 20, 17)
+    rng = numpy.random.default_rng(5)
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1.8, shape[0] + 1), numpy.linspace(0, 2., shape[1] + 1), numpy.linspace(-1, 0.7, shape[2] + 1)])
+    basis = domain.basis('std', degree=1)
+    if iso:
+        verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3) * .1 + rng.uniform(-.02, .02, (len(basis), 3))
+        geom = basis @ verts
+    kappa = function.PointFunc(lambda x: 1.5 + numpy.sin(3 * x[:, 0]) * x[:, 1] + x[:, 2] ** 2, geom)
+    u = function.value(domain.field('u', btype='std', degree=1))
+    gg = function.outer(function.grad(basis, geom)).sum(-1)
+    dV = function.J(geom)
+    K = domain.integral(kappa * gg * dV, degree=2) + domain.integral((1 + u ** 2) * gg * dV, degree=2) + domain.integral(.5 * gg * dV, degree=2)
+    from nutils_amd import kernels
+    calls = []
+    orig = kernels.p1hex_laplace
+    monkeypatch.setattr(kernels, 'p1hex_laplace', lambda **kw: (calls.append(kw.get('qscale') is not None), orig(**kw))[1])
+    results = {}
+    for mode in ('generic', 'fast'):
+        if mode == 'generic':
+            monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')
+        else:
+            monkeypatch.delenv('NUTILS_AMD_NO_FAST_PATH')
+        for tag, scale in (('a', 1.), ('b', -2.)):
+            args = {'u': scale * numpy.cos(numpy.arange(len(basis)) * .37)}
+            results[mode, tag] = function.eval(function.as_csr(K), arguments=args)
+    for tag in 'ab':
+        vg, rpg, cig = results['generic', tag]
+        vf, rpf, cif = results['fast', tag]
+        assert numpy.array_equal(rpg, rpf) and numpy.array_equal(cig, cif)
+        close(vf, vg)
+    assert numpy.abs(results['fast', 'a'][0] - results['fast', 'b'][0]).max() > 1e-3  # the field really enters
+    assert calls == [True, True]  # the write-once kernel ran exactly for the two 'fast' evaluations, with a coefficient array
