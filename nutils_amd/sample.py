@@ -374,7 +374,7 @@ class _MatrixPlan:
                           values=values)
             colors = None
             scale = smp.scale(itg.scale, itg.fscale, arguments)
-            if itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and (tt.nb >= 16 or os.environ.get('NUTILS_AMD_COLOR_SMALL')):
+            if itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16:  # (small local matrices: 8 coloured launches measured slower than atomics, 4.7 vs 4.0 ms)
                 colors = _colors(smp, itg.test.basis)
             if colors:
                 for el in colors:
