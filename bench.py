@@ -31,8 +31,9 @@ HBM_PEAK_GBS = 8000.  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.m
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--settle', type=int, default=300, help='untimed steps before the warm-up: the first ~50 launches after idle run ~10 %% slower (clock ramp)')
     ap.add_argument('--n', '--elements-per-axis', dest='n', type=int, default=128,
                     help='elements per axis per GPU (use the long form behind torch.distributed.run, whose parser claims --n)')
     ap.add_argument('--variant', choices=['iso', 'uniform'], default='iso')
@@ -166,8 +167,8 @@ def main():
     torch.cuda.synchronize()
     pattern_ms = (time.perf_counter() - t0) * 1e3
 
-    for _ in range(a.warmup):
-        wl.step()
+    for _ in range(a.settle + a.warmup):  # settle: bring the GPU out of its idle power state (0.236 ms per step over the first 20
+        wl.step()                          # launches, 0.215 ms in steady state); then the W warm-up steps of the contract
     torch.cuda.synchronize()
     elapsed, kernel_ms, launch = timed_steps(wl, a.steps, world, dist if world > 1 else None, a.graph)
 
@@ -199,7 +200,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'3D Poisson stiffness, {a.n}^3 structured hex per GPU, p=1, 2x2x2 Gauss, {a.variant} geometry '
                                    f'(BASELINE.json configs[1])', 'nelems_per_gpu': wl.nelems, 'nnz_per_gpu': wl.nnz, 'kernel': wl.kernel_name,
-                       'parallelism': f'element slabs x{world}, halo-plane reduce' if world > 1 else 'single GPU', 'launch': launch},
+                       'parallelism': f'element slabs x{world}, halo-plane reduce' if world > 1 else 'single GPU', 'launch': launch,
+                       'settle_steps': a.settle},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': measured_traffic(wl.kernel_name, a.n) if world == 1 else None, 'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bytes_per_elem},
             'pattern_ms': pattern_ms, 'setup_s': setup_s, 'checks': {'owned_row_sums_rel': row_sum_rel},
@@ -210,7 +212,7 @@ def main():
             w2 = workloads.PoissonSlab(n=a.n, rank=0, world=1, variant='uniform', kernel=a.kernel)
             w2.setup()
             w2.build_pattern()
-            for _ in range(a.warmup):
+            for _ in range(a.settle + a.warmup):
                 w2.step()
             torch.cuda.synchronize()
             el2, kms, _ = timed_steps(w2, a.steps, 1, None, a.graph)
