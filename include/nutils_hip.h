@@ -242,6 +242,9 @@ typedef struct {
   const double *qscale_dev;      /* NULL, or [nelems][8]: coefficient at the Gauss points of every element (element index last
                                     axis fastest, points first coordinate slowest) multiplying kappa -- a scale_dev array of
                                     nh_assemble_matrix (variable or field-dependent diffusivity).  Needs verts_dev. */
+  int max_workgroups;            /* 0: one persistent workgroup per CU.  > 0: upper bound -- a multi-GPU caller leaves a few CUs to
+                                    the RCCL send/recv kernels that run concurrently (a workgroup here takes a whole CU's LDS,
+                                    so nothing else can start on a CU it occupies) */
 } nh_p1hex_args;
 
 int nh_p1hex_pattern(const int *shape, int64_t row_begin, int64_t row_end, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream);

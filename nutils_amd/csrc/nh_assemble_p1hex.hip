@@ -542,7 +542,8 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
     p.nbk = (p.n2 + 1 + TK - 2) / (TK - 1);
     const size_t ldsm = sizeof(double) * ((L + 2) * (((TJ + 1) * (TK + 1) * 15 + 1) & ~1) + (L + 1) * (TJ + 1) * (TK + 1) * 3 + 2);
     const i64 units = (i64)p.nbj * p.nbk * (p.pl1 - p.pl0);
-    const unsigned grid = (unsigned)std::min<i64>(units, cus);
+    NH_REQUIRE(a->max_workgroups >= 0, "nh_p1hex_laplace: negative max_workgroups");
+    const unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
     auto kern = k_p1hex_march<TJ, TK, L>;
     NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
 #ifdef NH_ABLATION

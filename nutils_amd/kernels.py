@@ -164,7 +164,7 @@ def p1hex_pattern(shape, row_begin=0, row_end=None):
     return rowptr, colidx
 
 
-def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix=None, qscale=None):
+def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix=None, qscale=None, max_workgroups=0):
     n0 = int(shape[0])
     layers = (0, n0) if layers is None else layers
     planes = (0, n0 + 1) if planes is None else planes
@@ -183,6 +183,7 @@ def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, la
     if qscale is not None and qscale.numel() != 8 * int(shape[0]) * int(shape[1]) * int(shape[2]):
         raise ValueError('qscale must hold 8 values per element')
     a.qscale_dev = device.ptr(qscale)
+    a.max_workgroups = int(max_workgroups)
     return a
 
 
@@ -195,9 +196,9 @@ def p1hex_unit_matrix(*, shape, gauss_x, gauss_w, origin=(0., 0., 0.), scale=(1.
 
 
 def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0., 0.), scale=(1., 1., 1.), kappa=1., layers=None, planes=None,
-                  unit_matrix=None, qscale=None):
+                  unit_matrix=None, qscale=None, max_workgroups=0):
     '''Write-once structured P1-hex Laplace assembly (nh_p1hex_laplace).'''
-    a = _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix, qscale)
+    a = _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix, qscale, max_workgroups)
     _lib.call('nh_p1hex_laplace', ctypes.byref(a), device.stream())
 
 

@@ -67,6 +67,12 @@ class PoissonSlab:
         self.values = device.zeros(self.colidx.numel(), 'float64')  # rows of a ghost plane are never written: keep them zero
         self.nnz = int(self.colidx.numel())
         self.halo = partition.HaloPlan(self.slab, self.rowptr) if self.world > 1 else None
+        # with an exchange in flight next to the kernel, 8 CUs are left to the RCCL send/recv workgroups: a marching workgroup takes
+        # the whole LDS of its CU, so on a fully occupied chip the transfer could only start when the assembly has finished
+        self._max_wg = 0
+        if self.halo is not None:
+            import torch
+            self._max_wg = max(1, torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count - 8)
         self._vals = None
         if self.halo is not None and not os.environ.get('NUTILS_AMD_SERIAL_EXCHANGE'):
             self.enable_pipeline()
@@ -144,7 +150,7 @@ class PoissonSlab:
                 kernel_events[0].record()
             kernels.p1hex_laplace(shape=(s.local_layers, self.n, self.n), values=self.values, gauss_x=gx, gauss_w=gw, verts=self._verts_dev,
                                   origin=(float(s.first_global_plane), 0., 0.), layers=(s.ghost_layers, s.local_layers),
-                                  planes=(s.ghost_layers, s.local_layers + 1), unit_matrix=self._ke)
+                                  planes=(s.ghost_layers, s.local_layers + 1), unit_matrix=self._ke, max_workgroups=self._max_wg)
             if kernel_events:
                 kernel_events[1].record()
             self._end_step(slot, exchange)
