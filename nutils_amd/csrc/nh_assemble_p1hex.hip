@@ -378,50 +378,72 @@ __global__ void k_p1hex_unit_matrix(P1Args p, double *Ke) {
 }
 
 __global__ __launch_bounds__(256) void k_p1hex_uniform(P1Args p, const double *KeG) {
-  // one workgroup per (I, J) dof line; 32 lanes per row (27 slots), 8 rows per pass along K
-  __shared__ double Ke[64];
+  // One workgroup per (I, J) dof line.  Along K the rows of a line repeat: [first row: R2 entries][N2 - 2 interior rows with the
+  // SAME R3 = lenI lenJ 3 values each][last row: R2 = lenI lenJ 2 entries], contiguous in the CSR array.  27 threads build the three
+  // small tables in LDS; then all 256 threads stream the line as a periodic fill with 16-byte stores (two entries per lane).
+  __shared__ double Ke[64], tabI[2 * 27], tabF[18], tabL[18];
   if (threadIdx.x < 64) Ke[threadIdx.x] = KeG[threadIdx.x];
   __syncthreads();
   const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
   const int I = p.pl0 + blockIdx.x / N1, J = blockIdx.x % N1;
   const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;
-  const int lenI = len_of(I, N0), lenJ = len_of(J, N1);
-  const i64 line = cum_of(I, N0) * T1 * T2 + lenI * (cum_of(J, N1) * T2);  // CSR offset of row (I, J, 0)
-  const int sl = threadIdx.x & 31, rsub = threadIdx.x >> 5;
-  if (sl >= 27) return;
-  const int dI = sl / 9 - 1, dJ = (sl / 3) % 3 - 1, dK = sl % 3 - 1;
-  const int cI = I + dI, cJ = J + dJ;
-  if (cI < 0 || cI >= N0 || cJ < 0 || cJ >= N1) return;
-  // per-thread constants: which of the (<= 4) element columns (i, j) around the dof line contribute, with their local vertices
-  double w[2][2][2];  // [ok][a2][b2] summed over the valid (oi, oj): entry of sum_{oi,oj} Ke[(a0,a1,a2)][(b0,b1,b2)]
+  const int lenI = len_of(I, N0), lenJ = len_of(J, N1), R3 = lenI * lenJ * 3, R2 = lenI * lenJ * 2;
+  double *const line = p.values + (cum_of(I, N0) * T1 * T2 + lenI * (cum_of(J, N1) * T2));  // CSR position of row (I, J, 0)
+  const int sl = threadIdx.x;
+  if (sl < 27) {
+    const int dI = sl / 9 - 1, dJ = (sl / 3) % 3 - 1, dK = sl % 3 - 1;
+    const int cI = I + dI, cJ = J + dJ;
+    if (cI >= 0 && cI < N0 && cJ >= 0 && cJ < N1) {
+      // w[a2][b2]: sum over the (<= 4) element columns (i, j) around the dof line of Ke[(a0,a1,a2)][(b0,b1,b2)]
+      double w[2][2];
 #pragma unroll
-  for (int a2 = 0; a2 < 2; ++a2)
+      for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-    for (int b2 = 0; b2 < 2; ++b2) {
-      double v = 0.;
+        for (int b2 = 0; b2 < 2; ++b2) {
+          double v = 0.;
 #pragma unroll
-      for (int oi = -1; oi <= 0; ++oi) {
-        const int i = I + oi, a0 = -oi, b0 = a0 + dI;
-        if (b0 < 0 || b0 > 1 || i < p.lay0 || i >= p.lay1) continue;
+          for (int oi = -1; oi <= 0; ++oi) {
+            const int i = I + oi, a0 = -oi, b0 = a0 + dI;
+            if (b0 < 0 || b0 > 1 || i < p.lay0 || i >= p.lay1) continue;
 #pragma unroll
-        for (int oj = -1; oj <= 0; ++oj) {
-          const int j = J + oj, a1 = -oj, b1 = a1 + dJ;
-          if (b1 < 0 || b1 > 1 || j < 0 || j >= p.n1) continue;
-          v += Ke[((a0 * 2 + a1) * 2 + a2) * 8 + (b0 * 2 + b1) * 2 + b2];
+            for (int oj = -1; oj <= 0; ++oj) {
+              const int j = J + oj, a1 = -oj, b1 = a1 + dJ;
+              if (b1 < 0 || b1 > 1 || j < 0 || j >= p.n1) continue;
+              v += Ke[((a0 * 2 + a1) * 2 + a2) * 8 + (b0 * 2 + b1) * 2 + b2];
+            }
+          }
+          w[a2][b2] = v;
         }
-      }
-      w[0][a2][b2] = v;
+      const int prefix = (dI + (I > 0)) * lenJ + (dJ + (J > 0));
+      // a row K gets element k = K - 1 (local a2 = 1) and element k = K (a2 = 0); b2 = a2 + dK
+      double v = 0.;
+      if (dK <= 0) v += w[1][1 + dK];
+      if (dK >= 0) v += w[0][dK];
+      tabI[prefix * 3 + (dK + 1)] = v;
+      tabI[R3 + prefix * 3 + (dK + 1)] = v;                      // second period: pairs may wrap around
+      if (dK >= 0) tabF[prefix * 2 + dK] = w[0][dK];            // K = 0: element 0 only, columns K and K + 1
+      if (dK <= 0) tabL[prefix * 2 + (dK + 1)] = w[1][1 + dK];  // K = N2 - 1: element N2 - 2 only, columns K - 1 and K
     }
-  const int prefix = ((dI + (I > 0)) * lenJ + (dJ + (J > 0)));
-  for (int Kk = rsub; Kk < N2; Kk += 8) {
-    const int cK = Kk + dK;
-    if (cK < 0 || cK >= N2) continue;
-    double v = 0.;
-    // elements k = Kk - 1 (a2 = 1) and k = Kk (a2 = 0); b2 = a2 + dK
-    if (Kk >= 1 && dK <= 0) v += w[0][1][1 + dK];
-    if (Kk < p.n2 && dK >= 0) v += w[0][0][dK];
-    const int lenK = len_of(Kk, N2);
-    p.values[line + (i64)lenI * lenJ * cum_of(Kk, N2) + (prefix * lenK + (dK + (Kk > 0)))] = v;
+  }
+  __syncthreads();
+  const int ninner = (N2 - 2) * R3;
+  double *const inner = line + R2;
+  // 16-byte stores need 16-byte alignment to be worth it: one scalar entry first if the run starts on an odd double
+  const int head = (int)((reinterpret_cast<size_t>(inner) >> 3) & 1);
+  const int npairs = (ninner - head) / 2;
+  int r = (head + 2 * (int)threadIdx.x) % R3;
+  const int step = 512 % R3;
+  double2 *const dst = reinterpret_cast<double2 *>(inner + head);
+  for (int e = threadIdx.x; e < npairs; e += 256) {
+    dst[e] = make_double2(tabI[r], tabI[r + 1]);
+    r += step;
+    r -= r >= R3 ? R3 : 0;
+  }
+  if (threadIdx.x == 0 && head) inner[0] = tabI[0];
+  if (threadIdx.x == 1 && ((ninner - head) & 1)) inner[ninner - 1] = tabI[(ninner - 1) % R3];
+  if (threadIdx.x < R2) {
+    line[threadIdx.x] = tabF[threadIdx.x];
+    line[R2 + ninner + threadIdx.x] = tabL[threadIdx.x];
   }
 }
 
