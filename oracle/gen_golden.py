@@ -371,6 +371,7 @@ if __name__ == '__main__':
     cahnhilliard_case('cahnhilliard_p2_4', 4)
     nurbs_case('nurbs_plate_r2')
     hierarchical_p3_case('hier_thspline3_2d_l4')
+    hierarchical_p3_case('hier_thspline3_2d_l10', levels=10)  # BASELINE.json configs[4]: ten refinement levels
     hierarchical_case('hier_spline2_1d', 1)
     hierarchical_case('hier_spline2_2d', 2)
     example_vectors()

@@ -123,8 +123,9 @@ def test_known_answers():
         assert abs(v.sum()) < 1e-12
 
 
-def test_hierarchical_p3(golden):
-    g = golden('hier_thspline3_2d_l4')
+@pytest.mark.parametrize('name', ['hier_thspline3_2d_l4', 'hier_thspline3_2d_l10'])
+def test_hierarchical_p3(golden, name):
+    g = golden(name)
     v, rp, ci = oa.ragged_stiffness(g['t_dofs'], g['t_dof_offsets'], g['t_coeffs'], g['elem_origin'], g['elem_size'], g['gauss_coords'], g['gauss_weights'],
                                     int(g['t_ndofs']))
     assert numpy.array_equal(rp, g['tK_rowptr']) and numpy.array_equal(ci, g['tK_colidx'])
