@@ -120,3 +120,47 @@ def test_c2_full_size_through_the_api():
     ref = device.to_host(wl.values)
     assert numpy.abs(values - ref).max() <= 1e-13 * numpy.abs(ref).max()
     assert dt < 2., dt  # device assembly 0.25 ms; the rest is the copy of 1.4 GB of CSR arrays to the host
+
+
+def test_c4_full_size_consistency():
+    '''Cahn-Hilliard 512^2, p=2 splines, two fields (BASELINE.json configs[3]): at full size the residual must be the derivative of
+    the energy and the Jacobian the derivative of the residual (central differences along a random direction; the functional is
+    a polynomial of degree 4 in phi, so the truncation error is O(eps^2) and tiny), and the Jacobian must be symmetric.'''
+    from nutils_amd import mesh, function
+    from nutils_amd.solver import System
+    n = 512
+    size, eps_, M, stens, wn, wp, dt = 10., 1., 1., 50., 30., 20., .5
+    domain, geom = mesh.rectilinear([numpy.linspace(0, size, n + 1)] * 2)
+    phi = domain.field('φ', btype='spline', degree=2)
+    phi0 = domain.field('φ0', btype='spline', degree=2)
+    eta = domain.field('η', btype='spline', degree=2) * (stens / eps_)
+    p, p0 = function.value(phi), function.value(phi0)
+    dp = p - p0
+    psi = .25 * (p ** 2 - 1) ** 2
+    dpsi = .25 * dp ** 2 * (1 - p ** 2 + 2 * p * dp / 3 - dp ** 2 / 6)
+    dV = function.J(geom)
+    grad = lambda w: function.grad(w, geom)
+    nrg = domain.integral((psi + dpsi) * (stens / eps_) * dV, degree=8) \
+        + domain.integral(.5 * stens * eps_ * (grad(phi) * grad(phi)).sum(-1) * dV, degree=8) \
+        - domain.integral(eta * phi * dV, degree=8) + domain.integral(eta * phi0 * dV, degree=8) \
+        - domain.integral(.5 * dt * M * (grad(eta) * grad(eta)).sum(-1) * dV, degree=8) \
+        + domain.boundary.integral((wp + wn) / 2 * dV, degree=4) + domain.boundary.integral((wp - wn) / 2 * phi * dV, degree=4)
+    system = System(nrg, trial='φ,η')
+    nd = len(phi.arg.basis)
+    assert nd == (n + 2) ** 2
+    rng = numpy.random.default_rng(0)
+    x0 = {'φ': rng.normal(0, .5, nd), 'φ0': rng.normal(0, .5, nd), 'η': rng.normal(0, .1, nd)}
+    v = {'φ': rng.normal(0, 1, nd), 'η': rng.normal(0, 1, nd)}
+    shift = lambda s: {'φ': x0['φ'] + s * v['φ'], 'η': x0['η'] + s * v['η'], 'φ0': x0['φ0']}
+    vv = numpy.concatenate([v['φ'], v['η']])
+    res = system.assemble_residual(x0)
+    jac = system.assemble_jacobian(x0)
+    h = 1e-3
+    dE = (system.assemble_value(shift(h)) - system.assemble_value(shift(-h))) / (2 * h)
+    assert abs(dE - res @ vv) <= 1e-7 * (abs(dE) + numpy.abs(res).max() * numpy.abs(vv).max())
+    dR = (system.assemble_residual(shift(h)) - system.assemble_residual(shift(-h))) / (2 * h)
+    Jv = jac @ vv
+    assert numpy.abs(dR - Jv).max() <= 1e-6 * numpy.abs(Jv).max()
+    A = jac.core
+    assert abs(A - A.T).max() <= 1e-12 * abs(A).max()
+    assert A.nnz == 4 * (5 * (n + 2) - 6) ** 2  # four blocks of the 5-wide p=2 spline pattern: (5 N - 6)^2 per block, N = n + 2
