@@ -249,6 +249,11 @@ typedef struct {
 
 int nh_p1hex_pattern(const int *shape, int64_t row_begin, int64_t row_end, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream);
 int nh_p1hex_laplace(const nh_p1hex_args *args, void *stream);
+/* out (+)= K u for the same form, without the matrix: the element matrices are applied to the nodal values u_dev[ndofs] on the fly
+ * and reduced row-wise (residual / matrix-free product; replaces the Inflate + numpy.add.at scatter of a vector-valued LoopSum,
+ * evaluable.py:3405-3411).  Rows of the planes [plane_begin, plane_end) are written (accumulate = 0) or added to (1); needs
+ * verts_dev; values_dev and unit_matrix_dev are ignored. */
+int nh_p1hex_apply(const nh_p1hex_args *args, const double *u_dev, double *out_dev, int accumulate, void *stream);
 /* element matrix (64 doubles, row major) of the uniform cell scale[0] x scale[1] x scale[2] (verts_dev ignored) */
 int nh_p1hex_unit_matrix(const nh_p1hex_args *args, double *ke_dev, void *stream);
 

@@ -37,6 +37,9 @@ struct P1Args {
   double wk[2][2][2];      // kappa w_qa w_qb w_qc
   double *values;
   const double *qscale;    // NULL or [nelems][8] coefficient at the Gauss points
+  const double *u;         // vector variant: nodal values of the field the form is applied to
+  double *out;             // vector variant: out[dof] (+)= sum_n K[dof][n] u[n]
+  int accumulate;
   int nbj, nbk;            // boxes per axis (j, k)
   int nboxes;
   long long *tdbg;         // phase timers (ablation builds)
@@ -91,8 +94,8 @@ __device__ __forceinline__ double element_entry(const ElemTables &T, int a, int 
 // The circular plane buffer holds L + 2 planes: the previous plane (source of the dI = -1 entries), the L planes completed by this
 // step, and the partially summed plane carried to the next step.  Work is split over workgroups by (column, plane) units; every
 // contiguous run of planes inside a column costs one extra element layer at its start.
-template <int TJ, int TK, int L, int VPT>
-__device__ __forceinline__ void load_vertex_tile(const P1Args &p, bool valid, int J0, int K0, int L0, int tid, double (&V)[VPT][3]) {
+template <int TJ, int TK, int L, int VPT, int VW>
+__device__ __forceinline__ void load_vertex_tile(const P1Args &p, bool valid, int J0, int K0, int L0, int tid, double (&V)[VPT][VW]) {
   constexpr int NT = L * TJ * TK, VJ = TJ + 1, VK = TK + 1, NV = (L + 1) * VJ * VK;
   const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
 #pragma unroll
@@ -100,17 +103,22 @@ __device__ __forceinline__ void load_vertex_tile(const P1Args &p, bool valid, in
     const int v = tid + k * NT;
     const int c = v % VK, bb = (v / VK) % VJ, a = v / (VK * VJ);
     const int I = L0 + a, J = J0 - 1 + bb, K = K0 - 1 + c;
-    V[k][0] = V[k][1] = V[k][2] = 0.;
+#pragma unroll
+    for (int w = 0; w < VW; ++w) V[k][w] = 0.;
     if (valid && v < NV && I >= 0 && I < N0 && J >= 0 && J < N1 && K >= 0 && K < N2) {
-      const double *src = p.verts + (((i64)I * N1 + J) * N2 + K) * 3;
+      const i64 node = ((i64)I * N1 + J) * N2 + K;
+      const double *src = p.verts + node * 3;
       V[k][0] = src[0];
       V[k][1] = src[1];
       V[k][2] = src[2];
+      if (VW == 4) V[k][3] = p.u[node];
     }
   }
 }
 
-template <int TJ, int TK, int L>
+// VEC: instead of the matrix, out (+)= K u is assembled -- the same element matrices applied to the nodal values u on the fly and
+// reduced into ONE slot per row (residual of the same form: evaluable.py:3405-3411 Inflate + add.at in the reference).
+template <int TJ, int TK, int L, bool VEC>
 __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
 #ifdef NH_ABLATION
   long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
@@ -119,11 +127,12 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
 #define NH_TICK(i)
 #endif
   constexpr int NT = L * TJ * TK, NP = L + 2, OJ = TJ - 1, OK = TK - 1;
-  constexpr int NS = 15;  // 14 slots + 1 pad: an odd row stride (in doubles) spreads the 64 lanes of a ds_add_f64 over all LDS banks
+  constexpr int NS = VEC ? 1 : 15;  // 14 slots + 1 pad: an odd row stride (in doubles) spreads the 64 lanes of a ds_add_f64 over all LDS banks
+  constexpr int VW = VEC ? 4 : 3;   // doubles per staged vertex: coordinates (+ nodal value)
   constexpr int VJ = TJ + 1, VK = TK + 1, RP = VJ * VK, PS = (RP * NS + 1) & ~1, NV = (L + 1) * VJ * VK, VPT = (NV + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *acc = lds;             // [NP][RP][NS], plane stride PS
-  double *vbuf = lds + NP * PS;  // [L+1][VJ][VK][3]
+  double *vbuf = lds + NP * PS;  // [L+1][VJ][VK][VW]
   const int tid = threadIdx.x;
   const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
   const int NPL = p.pl1 - p.pl0;
@@ -134,17 +143,16 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
   auto slot_of = [](int P) { return (int)((unsigned)(P + 2 * NP) % NP) * PS; };  // P >= -2
   // current run: planes [A, B) of column (cj, ck); current step: element layers [L0, L0 + L)
   int col = (int)(u / NPL), A = p.pl0 + (int)(u % NPL), B = (int)min((i64)p.pl1, A + (u1 - u)), L0 = A - 1;
-  double V[VPT][3];
-  load_vertex_tile<TJ, TK, L, VPT>(p, true, (col / p.nbk) * OJ, (col % p.nbk) * OK, L0, tid, V);
+  double V[VPT][VW];
+  load_vertex_tile<TJ, TK, L, VPT, VW>(p, true, (col / p.nbk) * OJ, (col % p.nbk) * OK, L0, tid, V);
   for (int t = tid; t < NP * PS / 2; t += NT) reinterpret_cast<double2 *>(acc)[t] = make_double2(0., 0.);
   auto stage_vertex_tile = [&]() {
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
       const int v = tid + k * NT;
       if (v < NV) {
-        vbuf[v * 3 + 0] = V[k][0];
-        vbuf[v * 3 + 1] = V[k][1];
-        vbuf[v * 3 + 2] = V[k][2];
+#pragma unroll
+        for (int w = 0; w < VW; ++w) vbuf[v * VW + w] = V[k][w];
       }
     }
   };
@@ -166,23 +174,24 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
     NH_TICK(0)
     lds_barrier();  // vertex tile staged, plane slots zeroed
     NH_TICK(1)
-    load_vertex_tile<TJ, TK, L, VPT>(p, !last, (ncol / p.nbk) * OJ, (ncol % p.nbk) * OK, nL0, tid, V);
+    load_vertex_tile<TJ, TK, L, VPT, VW>(p, !last, (ncol / p.nbk) * OJ, (ncol % p.nbk) * OK, nL0, tid, V);
 
     {
       const int lay = tid / (TJ * TK), el = tid % (TJ * TK), ej = el / TK, ek = el % TK;
       const int gi = L0 + lay, gj = J0 - 1 + ej, gk = K0 - 1 + ek;
       if (gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2 && !(DEBUG(p) & 4)) {
-        double X[2][2][2][3];
+        double X[2][2][2][3], un[8];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-              const double *src = vbuf + (((lay + a) * VJ + (ej + bb)) * VK + (ek + c)) * 3;
+              const double *src = vbuf + (((lay + a) * VJ + (ej + bb)) * VK + (ek + c)) * VW;
               X[a][bb][c][0] = src[0];
               X[a][bb][c][1] = src[1];
               X[a][bb][c][2] = src[2];
+              un[a * 4 + bb * 2 + c] = VEC ? src[VW - 1] : 0.;
             }
         double qs[8];  // coefficient at the Gauss points (1 without a coefficient array)
 #pragma unroll
@@ -216,6 +225,18 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
         }
         // reduce: the accumulated rows of a plane are the vertices of the tile, so every local vertex has a row (no masking)
         double *const pl[2] = {acc + slot_of(gi) + (ej * VK + ek) * NS, acc + slot_of(gi + 1) + (ej * VK + ek) * NS};
+        if constexpr (VEC) {
+#pragma unroll
+          for (int a = 0; a < 8; ++a) {
+            double r = 0.;
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+              const int lo = a < bb ? a : bb, hi = a < bb ? bb : a;
+              r += Kt[lo * 8 - lo * (lo - 1) / 2 + (hi - lo)] * un[bb];
+            }
+            atomicAdd(pl[a >> 2] + ((a >> 1) & 1) * VK + (a & 1), r);
+          }
+        } else {
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
           const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
@@ -227,6 +248,7 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
             atomicAdd(&row[(b0 - a0) * 9 + (b1 - a1) * 3 + (b2 - a2)], Kt[a * 8 - a * (a - 1) / 2 + (bb - a)]);
           }
         }
+        }
       }
     }
     NH_TICK(2)
@@ -237,7 +259,18 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
     // ---- stream the completed planes to HBM ---------------------------------------------------------------------------------
     const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;
     const int Pb = max(L0, A), Pe = (DEBUG(p) & 2) ? Pb : min(L0 + L, B);
-    {
+    if constexpr (VEC) {
+      // one value per owned row: thread t -> (plane, oj, ok)
+      for (int t = tid; t < L * OJ * OK; t += NT) {
+        const int ok = t % OK, oj = (t / OK) % OJ, P = Pb + t / (OK * OJ);
+        const int J = J0 + oj, Kk = K0 + ok;
+        if (P < Pe && J < N1 && Kk < N2) {
+          double *dst = p.out + ((i64)P * N1 + J) * N2 + Kk;
+          const double r = acc[slot_of(P) + (oj + 1) * VK + (ok + 1)];
+          *dst = p.accumulate ? *dst + r : r;
+        }
+      }
+    } else {
       // 32 lanes per row (27 slots), one K line (or part of it) per pass.  (A variant with two entries per lane and 16-byte stores was
       // measured slower: 0.279 vs 0.252 ms.)
       constexpr int RPP = NT / 32, KP = (OK + RPP - 1) / RPP;  // rows per flush pass, passes per K line
@@ -474,6 +507,44 @@ __global__ void k_p1hex_pattern(int n0, int n1, int n2, i64 row0, i64 row1, i64 
 
 }  // namespace
 
+// launch of the marching kernel (matrix: VEC = false; K u: VEC = true)
+template <bool VEC>
+static int launch_march(const nh_p1hex_args *a, P1Args &p, void *stream) {
+#ifdef NH_ABLATION
+  p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
+#endif
+  constexpr int TJ = 16, TK = 16, L = 2, NTM = L * TJ * TK, NS = VEC ? 1 : 15, VW = VEC ? 4 : 3;
+  int dev = 0, cus = 256;
+  NH_CHECK_HIP(hipGetDevice(&dev));
+  NH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  p.nbj = (p.n1 + 1 + TJ - 2) / (TJ - 1);
+  p.nbk = (p.n2 + 1 + TK - 2) / (TK - 1);
+  const size_t ldsm = sizeof(double) * ((L + 2) * (((TJ + 1) * (TK + 1) * NS + 1) & ~1) + (L + 1) * (TJ + 1) * (TK + 1) * VW + 2);
+  const i64 units = (i64)p.nbj * p.nbk * (p.pl1 - p.pl0);
+  NH_REQUIRE(a->max_workgroups >= 0, "nh_p1hex: negative max_workgroups");
+  const unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
+  auto kern = k_p1hex_march<TJ, TK, L, VEC>;
+  NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+#ifdef NH_ABLATION
+  static long long *tdbg = nullptr;
+  if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, 16 * sizeof(long long)));
+  NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, 16 * sizeof(long long), nh_stream(stream)));
+  p.tdbg = getenv("NH_P1HEX_TIMERS") ? tdbg : nullptr;
+#endif
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTM), ldsm, nh_stream(stream), p);
+  NH_LAUNCH_CHECK();
+#ifdef NH_ABLATION
+  if (p.tdbg) {
+    long long h[16];
+    NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
+    const double nw = (double)grid * (NTM / 64);
+    fprintf(stderr, "p1hex_march cycles per wave: stage+next %.0f | B1 %.0f | load+math %.0f | B2 %.0f | stage+flush %.0f | B3 %.0f | zero %.0f\n", h[0] / nw, h[1] / nw,
+            h[2] / nw, h[3] / nw, h[4] / nw, h[5] / nw, h[6] / nw);
+  }
+#endif
+  return NH_OK;
+}
+
 extern "C" {
 
 int nh_p1hex_pattern(const int *shape, int64_t row_begin, int64_t row_end, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream) {
@@ -517,6 +588,9 @@ static int fill_p1args(const nh_p1hex_args *a, P1Args &p) {
       for (int qc = 0; qc < 2; ++qc) p.wk[qa][qb][qc] = a->kappa * a->gauss_w[qa] * a->gauss_w[qb] * a->gauss_w[qc];
   p.values = a->values_dev;
   p.qscale = a->qscale_dev;
+  p.u = nullptr;
+  p.out = nullptr;
+  p.accumulate = 0;
   p.nbj = p.nbk = p.nboxes = 0;
   p.debug = 0;
   p.tdbg = nullptr;
@@ -552,41 +626,20 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
     if (Ke) NH_CHECK_HIP(hipFreeAsync(Ke, nh_stream(stream)));
     return NH_OK;
   }
-#ifdef NH_ABLATION
-  p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
-#endif
-  {
-    constexpr int TJ = 16, TK = 16, L = 2, NTM = L * TJ * TK;
-    int dev = 0, cus = 256;
-    NH_CHECK_HIP(hipGetDevice(&dev));
-    NH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    p.nbj = (p.n1 + 1 + TJ - 2) / (TJ - 1);
-    p.nbk = (p.n2 + 1 + TK - 2) / (TK - 1);
-    const size_t ldsm = sizeof(double) * ((L + 2) * (((TJ + 1) * (TK + 1) * 15 + 1) & ~1) + (L + 1) * (TJ + 1) * (TK + 1) * 3 + 2);
-    const i64 units = (i64)p.nbj * p.nbk * (p.pl1 - p.pl0);
-    NH_REQUIRE(a->max_workgroups >= 0, "nh_p1hex_laplace: negative max_workgroups");
-    const unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
-    auto kern = k_p1hex_march<TJ, TK, L>;
-    NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
-#ifdef NH_ABLATION
-    static long long *tdbg = nullptr;
-    if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, 16 * sizeof(long long)));
-    NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, 16 * sizeof(long long), nh_stream(stream)));
-    p.tdbg = getenv("NH_P1HEX_TIMERS") ? tdbg : nullptr;
-#endif
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTM), ldsm, nh_stream(stream), p);
-    NH_LAUNCH_CHECK();
-#ifdef NH_ABLATION
-    if (p.tdbg) {
-      long long h[16];
-      NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
-      const double nw = (double)grid * (NTM / 64);
-      fprintf(stderr, "p1hex_march cycles per wave: stage+next %.0f | B1 %.0f | load+math %.0f | B2 %.0f | stage+flush %.0f | B3 %.0f | zero %.0f\n", h[0] / nw, h[1] / nw,
-              h[2] / nw, h[3] / nw, h[4] / nw, h[5] / nw, h[6] / nw);
-    }
-#endif
-    return NH_OK;
-  }
+  return launch_march<false>(a, p, stream);
+}
+
+int nh_p1hex_apply(const nh_p1hex_args *a, const double *u_dev, double *out_dev, int accumulate, void *stream) {
+  NH_REQUIRE(a && u_dev && out_dev, "nh_p1hex_apply: NULL argument");
+  NH_REQUIRE(a->verts_dev, "nh_p1hex_apply: explicit vertices required");
+  P1Args p;
+  int rc = fill_p1args(a, p);
+  if (rc) return rc;
+  if (a->plane_begin == a->plane_end) return NH_OK;
+  p.u = u_dev;
+  p.out = out_dev;
+  p.accumulate = accumulate != 0;
+  return launch_march<true>(a, p, stream);
 }
 
 }  // extern "C"

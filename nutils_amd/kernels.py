@@ -202,6 +202,15 @@ def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0.
     _lib.call('nh_p1hex_laplace', ctypes.byref(a), device.stream())
 
 
+def p1hex_apply(*, shape, u, out, gauss_x, gauss_w, verts, kappa=1., layers=None, planes=None, qscale=None, accumulate=True, max_workgroups=0):
+    '''out (+)= K u for the P1-hex Laplace form without forming K (nh_p1hex_apply).'''
+    n = (int(shape[0]) + 1) * (int(shape[1]) + 1) * (int(shape[2]) + 1)
+    if u.numel() != n or out.numel() != n:
+        raise ValueError('u and out must hold one value per vertex')
+    a = _p1hex_args(shape, None, gauss_x, gauss_w, verts, (0., 0., 0.), (1., 1., 1.), kappa, layers, planes, None, qscale, max_workgroups)
+    _lib.call('nh_p1hex_apply', ctypes.byref(a), device.ptr(u), device.ptr(out), int(bool(accumulate)), device.stream())
+
+
 def monomial_csr(rowptr, colidx, values, x, y, alpha=1.):
     '''y[r] += alpha * sum_k values[k] x[colidx[k]] (nh_monomial_csr).'''
     _lib.call('nh_monomial_csr', rowptr.numel() - 1, device.ptr(rowptr), device.ptr(colidx), device.ptr(values), device.ptr(x), float(alpha), device.ptr(y),

@@ -384,10 +384,61 @@ class _MatrixPlan:
         return values, rowptr, colidx, self.trial.basis.ndofs * ncr
 
 
+def _p1hex_setting(smp, basis, geom):
+    '''(vertices on the device, 1-D Gauss points and weights) if `basis` is the trilinear 'std' basis of the full 3-D structured
+    topology of `smp`, sampled with 2-point Gauss per axis, on a rectilinear or isoparametric-P1 geometry; else None.'''
+    from . import points as _points
+    if not (isinstance(basis, StructuredBasis) and basis.btype == 'std' and basis.degree == 1 and basis.ndims == 3
+            and basis.dofs_shape == tuple(n + 1 for n in basis.shape)):
+        return None
+    if smp.elist is not None or smp.bnd_axis >= 0 or smp.points.npoints != 8 or os.environ.get('NUTILS_AMD_NO_FAST_PATH'):
+        return None
+    ref = _points.gauss(2, 3)
+    if not (numpy.array_equal(smp.points.coords, ref.coords) and numpy.array_equal(smp.points.weights, ref.weights)):
+        return None
+    key = 'p1hex_verts', id(geom)
+    if key not in smp._tables:
+        if isinstance(geom, function.IsoGeometry):
+            g = geom.basis
+            if not (isinstance(g, StructuredBasis) and g.btype == 'std' and g.degree == 1 and g.shape == basis.shape and g.dofs_shape == basis.dofs_shape):
+                return None
+            smp._tables[key] = device.to_dev(geom.verts, 'float64')
+        elif isinstance(geom, function.RectilinearGeometry) and geom.topo.shape == basis.shape:
+            idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in basis.shape], indexing='ij'), -1).reshape(-1, 3)
+            smp._tables[key] = device.to_dev(geom.offset + geom.scale * idx, 'float64')
+        else:
+            return None
+    x1, w1 = _points.gauss1(2)
+    return smp._tables[key], list(x1), list(w1)
+
+
+def _p1hex_apply_term(smp, itg, fac, arguments, out):
+    '''Residual-type term `kappa grad(phi_m) . grad(u) J(geom)` of the headline setting: out += K u through nh_p1hex_apply (the
+    element matrices are applied on the fly, no matrix, no global atomics).  Returns False if the term is anything else.'''
+    if not (itg.B is not None and itg.rows and not itg.cols and itg.test.basis is itg.trial.basis and itg.test.ncomp == itg.trial.ncomp == 1):
+        return False
+    B = numpy.asarray(itg.B, dtype=float) * fac
+    if B.shape != (1, 4, 1, 4):
+        return False
+    B = B[0, :, 0, :]
+    if not numpy.array_equal(B, numpy.diag([0., B[1, 1], B[1, 1], B[1, 1]])):
+        return False
+    setting = _p1hex_setting(smp, itg.test.basis, itg.measure)
+    if setting is None:
+        return False
+    verts, x1, w1 = setting
+    u = device.to_dev(_argument(arguments, itg.trial), 'float64')
+    kernels.p1hex_apply(shape=itg.test.basis.shape, u=u, out=out, gauss_x=x1, gauss_w=w1, verts=verts, kappa=float(B[1, 1]),
+                        qscale=smp.scale(itg.scale, itg.fscale, arguments), accumulate=True)
+    return True
+
+
 def _vector_term(smp, itg, fac, arguments, out, scalar):
     nd, nq = smp.ndims, smp.points.npoints
     if itg.measure is None:
         raise NotImplementedError('integrand without J(geom)')
+    if out is not None and _p1hex_apply_term(smp, itg, fac, arguments, out):
+        return
     geom = smp.geometry(itg.measure)
     if itg.B is not None:
         tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)

@@ -309,3 +309,37 @@ def test_p1hex_fast_path_with_coefficients(iso, monkeypatch):
         close(vf, vg)
     assert numpy.abs(results['fast', 'a'][0] - results['fast', 'b'][0]).max() > 1e-3  # the field really enters
     assert calls == [True, True]  # the write-once kernel ran exactly for the two 'fast' evaluations, with a coefficient array
+
+
+@pytest.mark.parametrize('shape,iso', [((9, 20, 17), True), ((33, 16, 40), False), ((2, 1, 3), True), ((40, 33, 70), True)])
+def test_p1hex_residual_fast_path(shape, iso, monkeypatch):
+    '''Residual of the headline form, r_m = int kappa grad(phi_m) . grad(u): the front end applies the element matrices on the
+    fly through nh_p1hex_apply (no matrix, no global atomics); must equal the generic vector kernel and K u.'''
+    from nutils_amd import mesh, function, kernels
+    rng = numpy.random.default_rng(7)
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1. + .1 * i, n + 1) for i, n in enumerate(shape)])
+    basis = domain.basis('std', degree=1)
+    if iso:
+        verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3) * .1 + rng.uniform(-.02, .02, (len(basis), 3))
+        geom = basis @ verts
+    u = domain.field('u', btype='std', degree=1)
+    kappa = function.PointFunc(lambda x: 1.5 + x[:, 0] * x[:, 1] - x[:, 2], geom)
+    dV = function.J(geom)
+    gu = (function.grad(basis, geom) * function.grad(u, geom)).sum(-1)
+    res = domain.integral(kappa * gu * dV, degree=2) + domain.integral((1 + function.value(u) ** 2) * gu * dV, degree=2) + domain.integral(.5 * gu * dV, degree=2)
+    args = {'u': numpy.cos(numpy.arange(len(basis)) * .37)}
+    calls = []
+    orig = kernels.p1hex_apply
+    monkeypatch.setattr(kernels, 'p1hex_apply', lambda **kw: (calls.append(1), orig(**kw))[1])
+    monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')
+    rg = function.eval(res, arguments=args)
+    assert not calls
+    monkeypatch.delenv('NUTILS_AMD_NO_FAST_PATH')
+    rf = function.eval(res, arguments=args)
+    assert len(calls) == 3
+    close(rf, rg)
+    gg = function.outer(function.grad(basis, geom)).sum(-1)
+    K = domain.integral(kappa * gg * dV, degree=2) + domain.integral((1 + function.value(u) ** 2) * gg * dV, degree=2) + domain.integral(.5 * gg * dV, degree=2)
+    v, rp, ci = function.eval(function.as_csr(K), arguments=args)
+    import scipy.sparse
+    close(scipy.sparse.csr_matrix((v, ci, rp), (len(basis),) * 2) @ args['u'], rg)
