@@ -163,6 +163,10 @@ typedef struct {
   const double *scale_dev;   /* optional pointwise factor of the integrand [nelems][nq] (a coefficient function evaluated at
                                 the quadrature points), NULL = 1.  With elist_dev, scale and emap are indexed by LIST position. */
   int flags;                 /* NH_MATRIX_* bits */
+  const double *cq_dev;      /* optional coefficient tensor PER QUADRATURE POINT, [nelems][nq][nct][S][ncr][S] (indexed like scale_dev),
+                                replacing C_host (which then only provides the block mask): forms whose coefficients depend on a
+                                field and its gradient at the point -- the product-rule term kappa'(u) phi_n grad u . grad phi_m
+                                of a Newton Jacobian, advection with a computed velocity.  NULL = constant form. */
 } nh_matrix_args;
 
 #define NH_MATRIX_EXCLUSIVE 1        /* no two elements of this launch touch the same CSR entry (one colour of an element

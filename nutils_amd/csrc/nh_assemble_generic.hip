@@ -178,6 +178,7 @@ struct MatK {
   int qchunk;
   int maxnbt, maxnbr;
   int emap_by_elem;
+  const double *cq;  // per-point coefficient tensors [nelems][nq][nct][S][ncr][S], or NULL
   int use_w;      // pre-multiplied trial table W in LDS (pays when it does not cost occupancy)
   int exclusive;  // NH_MATRIX_EXCLUSIVE: no two elements of this launch share a matrix entry -> plain read-modify-write (deterministic)
 };
@@ -224,17 +225,21 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
           const int d = r % form.ncr; r /= form.ncr;
           const int n = r % nbr;
           const int ql = r / nbr;
-          const double *Cc = form.C + ((c * S) * form.ncr + d) * S;  // C[c][a][d][b] = Cc[a*ncr*S + b]
           const double *dr = Dr + (ql * nbr + n) * S;
           const double wq = Jw[(q0 + ql) * JW + ND * ND];
           double *w = W + (size_t)t * S;
+          const int coff = ((c * S) * form.ncr + d) * S;  // C[c][a][d][b] = Cc[a*ncr*S + b]
+          auto fill = [&](const double *Cc) {  // (two call sites: LDS-resident constant form / per-point tensors in global memory)
 #pragma unroll
-          for (int a = 0; a < S; ++a) {
-            double tt = 0;
+            for (int a = 0; a < S; ++a) {
+              double tt = 0;
 #pragma unroll
-            for (int b = 0; b < S; ++b) tt += Cc[a * form.ncr * S + b] * dr[b];
-            w[a] = wq * tt;
-          }
+              for (int b = 0; b < S; ++b) tt += Cc[a * form.ncr * S + b] * dr[b];
+              w[a] = wq * tt;
+            }
+          };
+          if (p.cq) fill(p.cq + ((p.emap_by_elem ? e : ie) * (i64)p.nq + (q0 + ql)) * (form.nct * S * form.ncr * S) + coff);
+          else fill(form.C + coff);
         }
         __syncthreads();
       }
@@ -254,8 +259,8 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
             for (int a = 0; a < S; ++a) acc += dt[a] * w[a];
           }
         } else {
-          const double *Cc = form.C + ((c * S) * form.ncr + d) * S;  // C[c][a][d][b] = Cc[a*ncr*S + b]
-          for (int q = q0; q < q1; ++q) {
+          const int coff = ((c * S) * form.ncr + d) * S;  // C[c][a][d][b] = Cc[a*ncr*S + b]
+          auto point = [&](const double *Cc, int q) {
             const double *dt = Dt + ((q - q0) * nbt + m) * S;
             const double *dr = Dr + ((q - q0) * nbr + n) * S;
             double sq = 0;
@@ -267,7 +272,11 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
               sq += dt[a] * t;
             }
             acc += Jw[q * JW + ND * ND] * sq;
-          }
+          };
+          if (p.cq)
+            for (int q = q0; q < q1; ++q) point(p.cq + ((p.emap_by_elem ? e : ie) * (i64)p.nq + q) * (form.nct * S * form.ncr * S) + coff, q);
+          else
+            for (int q = q0; q < q1; ++q) point(form.C + coff, q);
         }
         const i64 row = p.test.dofs[tdof0 + m];
         const i64 a0 = p.srowptr[row], len = p.srowptr[row + 1] - a0;
@@ -683,12 +692,13 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   p.scale = a->scale_dev;
   p.emap_by_elem = (a->flags & 2) != 0;
   p.exclusive = (a->flags & 1) != 0;
+  p.cq = a->cq_dev;
   NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "nh_assemble_matrix: elist with ragged bases is not supported");
   if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
   if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
   // MFMA path: uniform shared tables, >= 16 local rows and columns, tile counts we instantiate
   const int Nloc = a->trial.nb * a->ncr;
-  if (!(a->flags & 4) && p.same && a->test.nb >= 16 && Nloc >= 16 && !a->test.off_dev && a->ndims >= 2 && a->geom.kind != 0) {
+  if (!(a->flags & 4) && !a->cq_dev && p.same && a->test.nb >= 16 && Nloc >= 16 && !a->test.off_dev && a->ndims >= 2 && a->geom.kind != 0) {
     MfmaX x;
     x.nas = 0;
     for (int sa = 0; sa < S; ++sa) {

@@ -444,8 +444,11 @@ class Integrand:
 
     __array_ufunc__ = None
 
-    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False, scale=None, fscale=None):
+    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False, scale=None, fscale=None, bound=None):
         self.test, self.trial, self.B, self.L, self.f0 = test, trial, B, L, f0
+        # product-rule term of a Newton Jacobian: B acts on (test, VALUES of the field `bound` at the point) and the result multiplies the
+        # value of the trial function -- a bilinear form whose coefficients depend on the point (assembled with per-point tensors)
+        self.bound = bound
         self.scale = scale      # PointFunc multiplying the whole integrand, or None
         self.fscale = fscale    # FieldPoly multiplying the whole integrand, or None
         self.geom = geom        # geometry the gradients refer to
@@ -454,7 +457,7 @@ class Integrand:
 
     def _copy(self, **kw):
         d = dict(test=self.test, trial=self.trial, B=self.B, L=self.L, f0=self.f0, geom=self.geom, measure=self.measure, rows=self.rows, cols=self.cols,
-                 scale=self.scale, fscale=self.fscale)
+                 scale=self.scale, fscale=self.fscale, bound=self.bound)
         d.update(kw)
         return Integrand(**d)
 
@@ -633,6 +636,9 @@ def derivative(integral, name):
                     B = numpy.zeros(itg.L.shape + (1, S))
                     B[..., 0, 0] = itg.L
                     out.append((smp, itg._copy(trial=varg, B=B, L=None, cols=True, fscale=g), fac))
+                elif itg.B is not None and itg.rows and not itg.cols and itg.bound is None and itg.trial.ncomp == 1 and varg.ncomp == 1:
+                    # g(phi) * B(test, u)  ->  g'(phi) phi_n * B(test, u): bilinear (test x phi) with the coefficients B . U(u) of the point
+                    out.append((smp, itg._copy(trial=varg, cols=True, fscale=g, bound=itg.trial), fac))
                 else:
                     raise NotImplementedError('derivative of a field-dependent coefficient in this position (rank-3 tensor)')
         t_hit = itg.test is not None and itg.test.name == name and not itg.rows

@@ -107,15 +107,18 @@ def basis(T, dofs, nb=0, off=None, tab=None):
     return b
 
 
-def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0):
+def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0,
+                    cq=None):
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.'''
     C = numpy.ascontiguousarray(C, dtype=float)
     if C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
         raise ValueError(f'coefficient tensor has shape {C.shape}, expected {(nct, 1 + ndims, ncr, 1 + ndims)}')
     m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
+    if cq is not None and cq.numel() != nelems * nq * C.size:
+        raise ValueError('per-point coefficient tensor must have shape [nelems][nq] + C.shape')
     args = _lib.MatrixArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
                            device.host_ptr(m), pattern.srowptr_ptr, ctypes.c_void_p(pattern.emap_ptr.value + 4 * emap_offset), pattern.eoff_ptr,
-                           device.ptr(values), device.ptr(scale), int(flags))
+                           device.ptr(values), device.ptr(scale), int(flags), device.ptr(cq))
     _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
 
 

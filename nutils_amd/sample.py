@@ -288,7 +288,10 @@ class _MatrixPlan:
         self.test, self.trial = itg0.test, itg0.trial
         self.mask = numpy.zeros((self.test.ncomp, self.trial.ncomp), dtype=bool)
         for smp, itg, fac in terms:
-            self.mask |= _block_mask(itg.B)
+            if itg.bound is not None:  # blocks (c, 0): the trial side is the scalar field of the differentiated coefficient
+                self.mask |= (numpy.abs(itg.B).sum(axis=(1, 2, 3)) != 0)[:, None]
+            else:
+                self.mask |= _block_mask(itg.B)
         self.smp0 = smp0
 
     def _p1hex_laplace(self, arguments=None):
@@ -310,7 +313,7 @@ class _MatrixPlan:
         kappa, geom, qscale = 0., None, None
         for _, itg, fac in self.terms:
             B = numpy.asarray(itg.B, dtype=float) * fac
-            if B.shape != (1, 4, 1, 4):
+            if B.shape != (1, 4, 1, 4) or itg.bound is not None:
                 return None
             B = B[0, :, 0, :]
             k = B[1, 1]
@@ -374,6 +377,22 @@ class _MatrixPlan:
                           values=values)
             colors = None
             scale = smp.scale(itg.scale, itg.fscale, arguments)
+            if itg.bound is not None:
+                # per-point coefficient tensor C_q[c][a][0][0] = fac g'(..) sum_b B[c][a][0][b] U_q[b], U = (value, gradient) of the bound field
+                nq, S = smp.points.npoints, 1 + smp.ndims
+                U = device.empty(smp.nlist * nq * S, 'float64')
+                kernels.sample_eval(nelems=smp.nlist, ndims=smp.ndims, nq=nq, geom=smp.geometry(itg.geom if itg.geom is not None else itg.measure),
+                                    trial=smp.tables(itg.bound.basis).struct, ncr=1, points=smp._points_dev,
+                                    u=device.to_dev(_argument(arguments, itg.bound), 'float64'), U=U, elist=smp._elist_dev)
+                Bf = device.to_dev(numpy.ascontiguousarray(itg.B[:, :, 0, :]) * fac, 'float64')  # [nct][S][S]
+                T = (U.reshape(smp.nlist * nq, 1, 1, S) * Bf).sum(-1)                            # [e q][nct][S]
+                if scale is not None:
+                    T = T * scale.reshape(-1, 1, 1)
+                cq = device.zeros(smp.nlist * nq * nct * S * ncr * S, 'float64').reshape(smp.nlist * nq, nct, S, ncr, S)
+                cq[:, :, :, 0, 0] = T
+                common_q = dict(common, C=numpy.ones((nct, S, ncr, S)))
+                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, cq=cq.reshape(-1), **common_q)
+                continue
             if itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16:  # (small local matrices: 8 coloured launches measured slower than atomics, 4.7 vs 4.0 ms)
                 colors = _colors(smp, itg.test.basis)
             if colors:

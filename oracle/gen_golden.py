@@ -268,6 +268,36 @@ def cahnhilliard_case(name, nelems, degree=2, seed=3):
     save(name, **data)
 
 
+def quasilinear_case(name, ndims, btype, degree, n, seed=6):
+    '''Quasi-linear diffusion -div((1 + u^2) grad u) = 1 (the nonlinear example class of SURVEY 8f-1): residual and Jacobian of the
+    weak form at a random state -- the Jacobian contains the product-rule term 2 u phi_n grad u . grad phi_m (a rank-3 tensor in the
+    reference's `factor` language) -- and the Newton solution with u = 0 on the face x_0 = 0.'''
+    from nutils.solver import System
+    rng = numpy.random.default_rng(seed)
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1, n + 1)] * ndims)
+    ns = Namespace()
+    ns.x = geom
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    ns.u = domain.field('u', btype=btype, degree=degree)
+    ns.v = domain.field('v', btype=btype, degree=degree)
+    res = domain.integral('((1 + u^2) ∇_i(v) ∇_i(u) - v) dV' @ ns, degree=2 * degree + 2)
+    basis = domain.basis(btype, degree=degree)
+    nd = len(basis)
+    x0 = rng.normal(0, .5, nd)
+    rv = function.derivative(res, 'v')
+    data = dict(ndims=ndims, n=n, degree=degree, x0=x0)
+    data['res'] = function.eval(rv, dict(u=x0))
+    v, rp, ci = function.eval(function.as_csr(function.derivative(rv, 'u')), dict(u=x0))
+    data['jac_values'], data['jac_rowptr'], data['jac_colidx'] = v, rp, ci
+    m = n + degree if btype == 'spline' else n * degree + 1  # dofs per axis; dof index = first axis slowest
+    cons = numpy.full(nd, numpy.nan)
+    cons.reshape((m,) * ndims)[0] = 0.
+    data['cons'] = cons
+    sol = System(res, trial='u', test='v').solve(constrain=dict(u=cons), tol=1e-11)
+    data['sol'] = sol['u']
+    save(name, **data)
+
+
 def nurbs_case(name, nrefine=2, radius=.5, poisson=.3, seed=4):
     '''BASELINE.json configs[4] ingredient: the NURBS mode of examples/platewithhole.py:66-86 -- rational basis
     bspline_i w_i / W(xi) on a refined structured topology, NURBS geometry -- and the plane-strain elasticity stiffness
@@ -371,7 +401,9 @@ if __name__ == '__main__':
     cahnhilliard_case('cahnhilliard_p2_4', 4)
     nurbs_case('nurbs_plate_r2')
     hierarchical_p3_case('hier_thspline3_2d_l4')
-    hierarchical_p3_case('hier_thspline3_2d_l10', levels=10)  # BASELINE.json configs[4]: ten refinement levels
+    hierarchical_p3_case('hier_thspline3_2d_l10', levels=10)
+    quasilinear_case('quasilin3d_p1_4', 3, 'std', 1, 4)
+    quasilinear_case('quasilin2d_spline2_6', 2, 'spline', 2, 6)  # BASELINE.json configs[4]: ten refinement levels
     hierarchical_case('hier_spline2_1d', 1)
     hierarchical_case('hier_spline2_2d', 2)
     example_vectors()

@@ -8,6 +8,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def close(a, b, factor=1.):
+    '''max |a - b| <= factor * 1e-13 * max |b| (the fp64 tolerance of the parity tests).'''
+    a, b = numpy.asarray(a), numpy.asarray(b)
+    assert a.shape == b.shape
+    err = numpy.abs(a - b).max()
+    assert err <= factor * 1e-13 * numpy.abs(b).max(), err / numpy.abs(b).max()
+
+
 def laplace(nelems, btype, degree):
     from nutils_amd import mesh, function
     from nutils_amd.solver import System
@@ -174,3 +182,61 @@ def test_nonlinear_diffusion_picard_p1hex(monkeypatch):
         assert (calls['laplace'] > 0 and calls['apply'] > 0) == (mode == 'fast')
     assert numpy.abs(sol['fast']).max() > .1
     assert numpy.abs(sol['fast'] - sol['generic']).max() <= 1e-9 * numpy.abs(sol['generic']).max()
+
+
+@pytest.mark.parametrize('ndims,btype,degree', [(3, 'std', 1), (2, 'spline', 2)])
+def test_quasilinear_newton(ndims, btype, degree, monkeypatch):
+    '''Newton for -div((1 + u^2) grad u) = 1, u = 0 on x = 0, through System: the Jacobian contains the product-rule term
+    2 u phi_n grad u . grad phi_m, a bilinear form whose coefficients depend on the point (cq_dev); checked against central
+    differences of the residual, for symmetry breaking, and by quadratic convergence to the fixed-point solution.'''
+    from nutils_amd import mesh, function
+    from nutils_amd.solver import System
+    n = 6 if ndims == 3 else 10
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1, n + 1)] * ndims)
+    u = domain.field('u', btype=btype, degree=degree)
+    v = domain.field('v', btype=btype, degree=degree)
+    dV = function.J(geom)
+    res = domain.integral((1 + function.value(u) ** 2) * (function.grad(v, geom) * function.grad(u, geom)).sum(-1) * dV, degree=2 * degree + 2) \
+        - domain.integral(v * dV, degree=2 * degree)
+    system = System(res, trial='u', test='v')
+    assert not system.is_linear
+    nd = system.size
+    rng = numpy.random.default_rng(3)
+    x0, d = rng.normal(0, .5, nd), rng.normal(0, 1, nd)
+    jac = system.assemble_jacobian({'u': x0})
+    h = 1e-5
+    fd = (system.assemble_residual({'u': x0 + h * d}) - system.assemble_residual({'u': x0 - h * d})) / (2 * h)
+    Jd = jac @ d
+    assert numpy.abs(fd - Jd).max() <= 1e-8 * numpy.abs(Jd).max()
+    A = jac.core
+    assert abs(A - A.T).max() > 1e-3 * abs(A).max()  # the product-rule term makes the Jacobian non-symmetric
+    basis = u.arg.basis
+    cons = numpy.full(nd, numpy.nan)
+    shape = basis.dofs_shape
+    cons.reshape(shape)[0] = 0.
+    sol = system.solve(constrain={'u': cons}, tol=1e-11)['u']
+    r = system.assemble_residual({'u': sol})
+    assert numpy.linalg.norm(r[numpy.isnan(cons)]) < 1e-11 and numpy.abs(sol).max() > .1
+
+
+@pytest.mark.parametrize('name,btype', [('quasilin3d_p1_4', 'std'), ('quasilin2d_spline2_6', 'spline')])
+def test_quasilinear_reference(golden, name, btype):
+    '''Residual, Jacobian (CSR, index arrays bit-exact) and Newton solution of -div((1 + u^2) grad u) = 1 against the REAL reference
+    (oracle/gen_golden.py:quasilinear_case): the Jacobian's product-rule term goes through per-point coefficient tensors.'''
+    from nutils_amd import mesh, function
+    from nutils_amd.solver import System
+    g = golden(name)
+    ndims, n, degree = int(g['ndims']), int(g['n']), int(g['degree'])
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1, n + 1)] * ndims)
+    u = domain.field('u', btype=btype, degree=degree)
+    v = domain.field('v', btype=btype, degree=degree)
+    dV = function.J(geom)
+    res = domain.integral((1 + function.value(u) ** 2) * (function.grad(v, geom) * function.grad(u, geom)).sum(-1) * dV, degree=2 * degree + 2) \
+        - domain.integral(v * dV, degree=2 * degree + 2)
+    rv = function.derivative(res, 'v')
+    close(function.eval(rv, arguments={'u': g['x0']}), g['res'])
+    values, rowptr, colidx = function.eval(function.as_csr(function.derivative(rv, 'u')), arguments={'u': g['x0']})
+    assert numpy.array_equal(rowptr, g['jac_rowptr']) and numpy.array_equal(colidx, g['jac_colidx'])
+    close(values, g['jac_values'])
+    sol = System(res, trial='u', test='v').solve(constrain={'u': g['cons']}, tol=1e-11)['u']
+    close(sol, g['sol'], 1e4)
