@@ -246,6 +246,9 @@ typedef struct {
   const double *qscale_dev;      /* NULL, or [nelems][8]: coefficient at the Gauss points of every element (element index last
                                     axis fastest, points first coordinate slowest) multiplying kappa -- a scale_dev array of
                                     nh_assemble_matrix (variable or field-dependent diffusivity).  Needs verts_dev. */
+  double mass;                   /* constant coefficient of an additional mass term mass * phi_m phi_n (0: stiffness only) */
+  const double *qmass_dev;       /* NULL, or [nelems][8] like qscale_dev: mass coefficient at the Gauss points (multiplies `mass`,
+                                    which must then be nonzero, e.g. 1) */
   int max_workgroups;            /* 0: one persistent workgroup per CU.  > 0: upper bound -- a multi-GPU caller leaves a few CUs to
                                     the RCCL send/recv kernels that run concurrently (a workgroup here takes a whole CU's LDS,
                                     so nothing else can start on a CU it occupies) */

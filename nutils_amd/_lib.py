@@ -60,7 +60,7 @@ class P1HexArgs(ctypes.Structure):
     _fields_ = [('shape', ctypes.c_int * 3), ('layer_begin', ctypes.c_int), ('layer_end', ctypes.c_int), ('plane_begin', ctypes.c_int),
                 ('plane_end', ctypes.c_int), ('verts_dev', vp), ('origin', ctypes.c_double * 3), ('scale', ctypes.c_double * 3),
                 ('gauss_x', ctypes.c_double * 2), ('gauss_w', ctypes.c_double * 2), ('kappa', ctypes.c_double), ('values_dev', vp),
-                ('unit_matrix_dev', vp), ('qscale_dev', vp), ('max_workgroups', ctypes.c_int)]
+                ('unit_matrix_dev', vp), ('qscale_dev', vp), ('mass', ctypes.c_double), ('qmass_dev', vp), ('max_workgroups', ctypes.c_int)]
 
 
 GEOM_ISO = 1

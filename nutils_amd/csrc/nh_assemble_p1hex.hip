@@ -35,6 +35,9 @@ struct P1Args {
   double n[2][2];          // n[a][q] = N_a(g_q): 1-D shape functions at the 1-D Gauss points
   double c[3][2];          // c[x+y][q] = n[x][q] n[y][q]
   double wk[2][2][2];      // kappa w_qa w_qb w_qc
+  double wm[2][2][2];      // mass w_qa w_qb w_qc
+  int hasm;                // mass term requested (mass != 0 or a mass coefficient array)
+  const double *qmass;     // NULL or [nelems][8] mass coefficient at the Gauss points
   double *values;
   const double *qscale;    // NULL or [nelems][8] coefficient at the Gauss points
   const double *u;         // vector variant: nodal values of the field the form is applied to
@@ -67,6 +70,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct ElemTables {
   double R0[3][3], R1[3][3], R2[3][3];             // diagonal (j == k) terms, indexed by the pair classes p = a_d + b_d
   double W01[2][2][3], W02[2][2][3], W12[2][2][3];  // off-diagonal terms
+  double Mm[3][3][3];                               // mass term
 };
 
 // Everything per element except the final signed sums: Jacobian columns, metric tensors at the 8 Gauss points, axis-by-axis
@@ -81,7 +85,7 @@ __device__ __forceinline__ double element_entry(const ElemTables &T, int a, int 
   const double s02 = (a0 == b2) ? 1. : -1., s20 = (b0 == a2) ? 1. : -1.;
   const double s12 = (a1 == b2) ? 1. : -1., s21 = (b1 == a2) ? 1. : -1.;
   return s00 * T.R0[p1][p2] + s11 * T.R1[p0][p2] + s22 * T.R2[p0][p1] + s01 * T.W01[b0][a1][p2] + s10 * T.W01[a0][b1][p2] +
-         s02 * T.W02[b0][a2][p1] + s20 * T.W02[a0][b2][p1] + s12 * T.W12[b1][a2][p0] + s21 * T.W12[a1][b2][p0];
+         s02 * T.W02[b0][a2][p1] + s20 * T.W02[a0][b2][p1] + s12 * T.W12[b1][a2][p0] + s21 * T.W12[a1][b2][p0] + T.Mm[p0][p1][p2];
 }
 
 // ---- marching kernel: a workgroup owns a COLUMN tile of (TJ-1) x (TK-1) dofs and marches along axis 0, L element layers per
@@ -118,7 +122,7 @@ __device__ __forceinline__ void load_vertex_tile(const P1Args &p, bool valid, in
 
 // VEC: instead of the matrix, out (+)= K u is assembled -- the same element matrices applied to the nodal values u on the fly and
 // reduced into ONE slot per row (residual of the same form: evaluable.py:3405-3411 Inflate + add.at in the reference).
-template <int TJ, int TK, int L, bool VEC>
+template <int TJ, int TK, int L, bool VEC, bool MASS>
 __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
 #ifdef NH_ABLATION
   long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
@@ -201,10 +205,21 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) qs[q] = src[q];
         }
-        double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3];
+        constexpr bool hasm = MASS;  // separate instantiation: the mass tables would cost the stiffness-only kernel 70 VGPRs (spills)
+        double qm[8];  // mass coefficient at the Gauss points
+#pragma unroll
+        for (int q = 0; q < 8; ++q) qm[q] = 1.;
+        if (MASS && p.qmass) {
+          const double *src = p.qmass + (((i64)gi * p.n1 + gj) * p.n2 + gk) * 8;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) qm[q] = src[q];
+        }
+        double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3], Mm[3][3][3];
 #define NH_P1HEX_QS(q) qs[q]
+#define NH_P1HEX_QM(q) qm[q]
 #include "nh_p1hex_math.inc"
 #undef NH_P1HEX_QS
+#undef NH_P1HEX_QM
         double Kt[36];
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
@@ -222,6 +237,13 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
                                                    + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1]
                                                    + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
           }
+        }
+        if (hasm) {
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int bb = a; bb < 8; ++bb)
+              Kt[a * 8 - a * (a - 1) / 2 + (bb - a)] += Mm[(a >> 2) + (bb >> 2)][((a >> 1) & 1) + ((bb >> 1) & 1)][(a & 1) + (bb & 1)];
         }
         // reduce: the accumulated rows of a plane are the vertices of the tile, so every local vertex has a row (no masking)
         double *const pl[2] = {acc + slot_of(gi) + (ej * VK + ek) * NS, acc + slot_of(gi + 1) + (ej * VK + ek) * NS};
@@ -400,9 +422,14 @@ __global__ void k_p1hex_unit_matrix(P1Args p, double *Ke) {
   {
     double (&R0)[3][3] = T.R0, (&R1)[3][3] = T.R1, (&R2)[3][3] = T.R2;
     double (&W01)[2][2][3] = T.W01, (&W02)[2][2][3] = T.W02, (&W12)[2][2][3] = T.W12;
+    double (&Mm)[3][3][3] = T.Mm;
+    for (int i = 0; i < 27; ++i) (&Mm[0][0][0])[i] = 0.;
+    const bool hasm = p.hasm;
 #define NH_P1HEX_QS(q) 1.
+#define NH_P1HEX_QM(q) 1.
 #include "nh_p1hex_math.inc"
 #undef NH_P1HEX_QS
+#undef NH_P1HEX_QM
   }
 #pragma unroll
   for (int a = 0; a < 8; ++a)
@@ -508,8 +535,8 @@ __global__ void k_p1hex_pattern(int n0, int n1, int n2, i64 row0, i64 row1, i64 
 }  // namespace
 
 // launch of the marching kernel (matrix: VEC = false; K u: VEC = true)
-template <bool VEC>
-static int launch_march(const nh_p1hex_args *a, P1Args &p, void *stream) {
+template <bool VEC, bool MASS>
+static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
 #ifdef NH_ABLATION
   p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
 #endif
@@ -523,7 +550,7 @@ static int launch_march(const nh_p1hex_args *a, P1Args &p, void *stream) {
   const i64 units = (i64)p.nbj * p.nbk * (p.pl1 - p.pl0);
   NH_REQUIRE(a->max_workgroups >= 0, "nh_p1hex: negative max_workgroups");
   const unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
-  auto kern = k_p1hex_march<TJ, TK, L, VEC>;
+  auto kern = k_p1hex_march<TJ, TK, L, VEC, MASS>;
   NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
 #ifdef NH_ABLATION
   static long long *tdbg = nullptr;
@@ -543,6 +570,11 @@ static int launch_march(const nh_p1hex_args *a, P1Args &p, void *stream) {
   }
 #endif
   return NH_OK;
+}
+
+template <bool VEC>
+static int launch_march(const nh_p1hex_args *a, P1Args &p, void *stream) {
+  return p.hasm ? launch_march_inst<VEC, true>(a, p, stream) : launch_march_inst<VEC, false>(a, p, stream);
 }
 
 extern "C" {
@@ -585,7 +617,12 @@ static int fill_p1args(const nh_p1hex_args *a, P1Args &p) {
   }
   for (int qa = 0; qa < 2; ++qa)
     for (int qb = 0; qb < 2; ++qb)
-      for (int qc = 0; qc < 2; ++qc) p.wk[qa][qb][qc] = a->kappa * a->gauss_w[qa] * a->gauss_w[qb] * a->gauss_w[qc];
+      for (int qc = 0; qc < 2; ++qc) {
+        p.wk[qa][qb][qc] = a->kappa * a->gauss_w[qa] * a->gauss_w[qb] * a->gauss_w[qc];
+        p.wm[qa][qb][qc] = a->mass * a->gauss_w[qa] * a->gauss_w[qb] * a->gauss_w[qc];
+      }
+  p.hasm = a->mass != 0. || a->qmass_dev != nullptr;
+  p.qmass = a->qmass_dev;
   p.values = a->values_dev;
   p.qscale = a->qscale_dev;
   p.u = nullptr;
@@ -613,7 +650,7 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
   int rc = fill_p1args(a, p);
   if (rc) return rc;
   if (a->plane_begin == a->plane_end) return NH_OK;
-  NH_REQUIRE(!a->qscale_dev || a->verts_dev, "nh_p1hex_laplace: a coefficient array needs explicit vertices");
+  NH_REQUIRE(!(a->qscale_dev || a->qmass_dev) || a->verts_dev, "nh_p1hex_laplace: a coefficient array needs explicit vertices");
   if (!a->verts_dev) {  // uniform geometry: unit element matrix + streaming kernel
     double *Ke = nullptr;
     if (!a->unit_matrix_dev) {

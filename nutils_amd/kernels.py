@@ -167,7 +167,8 @@ def p1hex_pattern(shape, row_begin=0, row_end=None):
     return rowptr, colidx
 
 
-def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix=None, qscale=None, max_workgroups=0):
+def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix=None, qscale=None, max_workgroups=0, mass=0.,
+                qmass=None):
     n0 = int(shape[0])
     layers = (0, n0) if layers is None else layers
     planes = (0, n0 + 1) if planes is None else planes
@@ -187,30 +188,35 @@ def _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, la
         raise ValueError('qscale must hold 8 values per element')
     a.qscale_dev = device.ptr(qscale)
     a.max_workgroups = int(max_workgroups)
+    if qmass is not None and qmass.numel() != 8 * int(shape[0]) * int(shape[1]) * int(shape[2]):
+        raise ValueError('qmass must hold 8 values per element')
+    a.mass = float(mass) if qmass is None or mass else 1.
+    a.qmass_dev = device.ptr(qmass)
     return a
 
 
-def p1hex_unit_matrix(*, shape, gauss_x, gauss_w, origin=(0., 0., 0.), scale=(1., 1., 1.), kappa=1.):
+def p1hex_unit_matrix(*, shape, gauss_x, gauss_w, origin=(0., 0., 0.), scale=(1., 1., 1.), kappa=1., mass=0.):
     '''8x8 element matrix of the uniform cell (nh_p1hex_unit_matrix): computed once per mesh.'''
     ke = device.empty(64, 'float64')
-    a = _p1hex_args(shape, None, gauss_x, gauss_w, None, origin, scale, kappa, None, None)
+    a = _p1hex_args(shape, None, gauss_x, gauss_w, None, origin, scale, kappa, None, None, mass=mass)
     _lib.call('nh_p1hex_unit_matrix', ctypes.byref(a), device.ptr(ke), device.stream())
     return ke
 
 
 def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0., 0.), scale=(1., 1., 1.), kappa=1., layers=None, planes=None,
-                  unit_matrix=None, qscale=None, max_workgroups=0):
-    '''Write-once structured P1-hex Laplace assembly (nh_p1hex_laplace).'''
-    a = _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix, qscale, max_workgroups)
+                  unit_matrix=None, qscale=None, max_workgroups=0, mass=0., qmass=None):
+    '''Write-once structured P1-hex assembly of kappa grad.grad + mass phi phi (nh_p1hex_laplace).'''
+    a = _p1hex_args(shape, values, gauss_x, gauss_w, verts, origin, scale, kappa, layers, planes, unit_matrix, qscale, max_workgroups, mass, qmass)
     _lib.call('nh_p1hex_laplace', ctypes.byref(a), device.stream())
 
 
-def p1hex_apply(*, shape, u, out, gauss_x, gauss_w, verts, kappa=1., layers=None, planes=None, qscale=None, accumulate=True, max_workgroups=0):
+def p1hex_apply(*, shape, u, out, gauss_x, gauss_w, verts, kappa=1., layers=None, planes=None, qscale=None, accumulate=True, max_workgroups=0, mass=0.,
+                qmass=None):
     '''out (+)= K u for the P1-hex Laplace form without forming K (nh_p1hex_apply).'''
     n = (int(shape[0]) + 1) * (int(shape[1]) + 1) * (int(shape[2]) + 1)
     if u.numel() != n or out.numel() != n:
         raise ValueError('u and out must hold one value per vertex')
-    a = _p1hex_args(shape, None, gauss_x, gauss_w, verts, (0., 0., 0.), (1., 1., 1.), kappa, layers, planes, None, qscale, max_workgroups)
+    a = _p1hex_args(shape, None, gauss_x, gauss_w, verts, (0., 0., 0.), (1., 1., 1.), kappa, layers, planes, None, qscale, max_workgroups, mass, qmass)
     _lib.call('nh_p1hex_apply', ctypes.byref(a), device.ptr(u), device.ptr(out), int(bool(accumulate)), device.stream())
 
 

@@ -295,7 +295,7 @@ class _MatrixPlan:
         self.smp0 = smp0
 
     def _p1hex_laplace(self, arguments=None):
-        '''Recognise the headline form -- scalar Laplace stiffness `kappa grad(phi_m) . grad(phi_n) J(geom)` on the trilinear 'std'
+        '''Recognise the headline form -- scalar stiffness (+ mass) `(kappa grad(phi_m) . grad(phi_n) + mu phi_m phi_n) J(geom)` on the trilinear 'std'
         basis of a full 3-D structured topology, 2-point Gauss per axis, geometry either rectilinear or the isoparametric P1
         map -- and assemble it with the write-once structured kernel (nh_p1hex_pattern / nh_p1hex_laplace) instead of the
         generic one.  Anything else (other bases, coefficients, samples, extra terms) returns None.'''
@@ -310,27 +310,35 @@ class _MatrixPlan:
         ref = _points.gauss(2, 3) if hasattr(_points, 'gauss') else None
         if ref is None or not (numpy.array_equal(smp.points.coords, ref.coords) and numpy.array_equal(smp.points.weights, ref.weights)):
             return None
-        kappa, geom, qscale = 0., None, None
+        kappa, mass, geom, qscale, qmass = 0., 0., None, None, None
         for _, itg, fac in self.terms:
             B = numpy.asarray(itg.B, dtype=float) * fac
             if B.shape != (1, 4, 1, 4) or itg.bound is not None:
                 return None
             B = B[0, :, 0, :]
-            k = B[1, 1]
-            if not numpy.array_equal(B, numpy.diag([0., k, k, k])):
+            m, k = B[0, 0], B[1, 1]  # mass and diffusion coefficient of the term: B = diag(m, k, k, k)
+            if not numpy.array_equal(B, numpy.diag([m, k, k, k])):
                 return None
             if geom is not None and itg.measure is not geom:
                 return None
             geom = itg.measure
             if itg.scale is None and itg.fscale is None:
                 kappa += k
+                mass += m
             else:  # coefficient function (of position, or of a field): values at the Gauss points, summed over the terms
                 sc = smp.scale(itg.scale, itg.fscale, arguments)
-                qscale = sc * k if qscale is None else qscale.add_(sc, alpha=k)
+                if k:
+                    qscale = sc * k if qscale is None else qscale.add_(sc, alpha=k)
+                if m:
+                    qmass = sc * m if qmass is None else qmass.add_(sc, alpha=m)
         if qscale is not None:
             if kappa:
                 qscale = qscale + kappa
             kappa = 1.
+        if qmass is not None:
+            if mass:
+                qmass = qmass + mass
+            mass = 1.
         verts, origin, scale = None, (0., 0., 0.), (1., 1., 1.)
         if isinstance(geom, function.IsoGeometry):
             g = geom.basis
@@ -342,7 +350,7 @@ class _MatrixPlan:
             verts = smp._tables[key]
         elif isinstance(geom, function.RectilinearGeometry) and geom.topo.shape == basis.shape:
             origin, scale = tuple(geom.offset), tuple(geom.scale)
-            if qscale is not None:  # element matrices differ: explicit vertices for the isoparametric kernel
+            if qscale is not None or qmass is not None:  # element matrices differ: explicit vertices for the isoparametric kernel
                 key = 'p1hex_verts', id(geom)
                 if key not in smp._tables:
                     idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in basis.shape], indexing='ij'), -1).reshape(-1, 3)
@@ -356,7 +364,7 @@ class _MatrixPlan:
         rowptr, colidx = smp._tables[key]
         values = device.empty(colidx.numel(), 'float64')  # write-once kernel: no zero-fill
         kernels.p1hex_laplace(shape=basis.shape, values=values, gauss_x=list(x1), gauss_w=list(w1), verts=verts, origin=origin, scale=scale, kappa=kappa,
-                              qscale=qscale)
+                              qscale=qscale, mass=mass, qmass=qmass)
         return values, rowptr, colidx, basis.ndofs
 
     def run(self, arguments=None):
@@ -432,7 +440,7 @@ def _p1hex_setting(smp, basis, geom):
 
 
 def _p1hex_apply_term(smp, itg, fac, arguments, out):
-    '''Residual-type term `kappa grad(phi_m) . grad(u) J(geom)` of the headline setting: out += K u through nh_p1hex_apply (the
+    '''Residual-type term `(kappa grad(phi_m) . grad(u) + mu phi_m u) J(geom)` of the headline setting: out += K u through nh_p1hex_apply (the
     element matrices are applied on the fly, no matrix, no global atomics).  Returns False if the term is anything else.'''
     if not (itg.B is not None and itg.rows and not itg.cols and itg.test.basis is itg.trial.basis and itg.test.ncomp == itg.trial.ncomp == 1):
         return False
@@ -440,15 +448,17 @@ def _p1hex_apply_term(smp, itg, fac, arguments, out):
     if B.shape != (1, 4, 1, 4):
         return False
     B = B[0, :, 0, :]
-    if not numpy.array_equal(B, numpy.diag([0., B[1, 1], B[1, 1], B[1, 1]])):
+    m, k = float(B[0, 0]), float(B[1, 1])
+    if not numpy.array_equal(B, numpy.diag([m, k, k, k])):
         return False
     setting = _p1hex_setting(smp, itg.test.basis, itg.measure)
     if setting is None:
         return False
     verts, x1, w1 = setting
     u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-    kernels.p1hex_apply(shape=itg.test.basis.shape, u=u, out=out, gauss_x=x1, gauss_w=w1, verts=verts, kappa=float(B[1, 1]),
-                        qscale=smp.scale(itg.scale, itg.fscale, arguments), accumulate=True)
+    sc = smp.scale(itg.scale, itg.fscale, arguments)
+    kernels.p1hex_apply(shape=itg.test.basis.shape, u=u, out=out, gauss_x=x1, gauss_w=w1, verts=verts, kappa=k, mass=m,
+                        qscale=sc if k else None, qmass=sc if m else None, accumulate=True)
     return True
 
 

@@ -343,3 +343,46 @@ def test_p1hex_residual_fast_path(shape, iso, monkeypatch):
     v, rp, ci = function.eval(function.as_csr(K), arguments=args)
     import scipy.sparse
     close(scipy.sparse.csr_matrix((v, ci, rp), (len(basis),) * 2) @ args['u'], rg)
+
+
+@pytest.mark.parametrize('iso,coeff', [(True, True), (False, True), (False, False), (True, False)])
+def test_p1hex_fast_path_mass_and_stiffness(iso, coeff, monkeypatch):
+    '''Reaction-diffusion type forms on the trilinear basis, (kappa grad.grad + mu phi phi): matrix and residual through the front end
+    take the write-once kernels (mass instantiation; uniform meshes with constant coefficients: hoisted unit matrix incl. mass);
+    must equal the generic kernels.'''
+    from nutils_amd import mesh, function, kernels
+    shape = (9, 20, 17)
+    rng = numpy.random.default_rng(8)
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1.8, shape[0] + 1), numpy.linspace(0, 2., shape[1] + 1), numpy.linspace(-1, 0.7, shape[2] + 1)])
+    basis = domain.basis('std', degree=1)
+    if iso:
+        verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3) * .1 + rng.uniform(-.02, .02, (len(basis), 3))
+        geom = basis @ verts
+    u = domain.field('u', btype='std', degree=1)
+    dV = function.J(geom)
+    gg = function.outer(function.grad(basis, geom)).sum(-1)
+    gu = (function.grad(basis, geom) * function.grad(u, geom)).sum(-1)
+    K = domain.integral(.7 * gg * dV, degree=2) + domain.integral(2. * function.outer(basis) * dV, degree=2)
+    r = domain.integral(.7 * gu * dV, degree=2) + domain.integral(2. * basis * u * dV, degree=2)
+    if coeff:
+        rho = function.PointFunc(lambda x: 2. + numpy.cos(x[:, 0]) * x[:, 2], geom)
+        K = K + domain.integral(function.outer(basis) * rho * dV, degree=2) + domain.integral((1 + function.value(u) ** 2) * gg * dV, degree=2)
+        r = r + domain.integral(basis * u * rho * dV, degree=2) + domain.integral((1 + function.value(u) ** 2) * gu * dV, degree=2)
+    args = {'u': numpy.cos(numpy.arange(len(basis)) * .37)}
+    calls = {'laplace': 0, 'apply': 0}
+    for name in ('p1hex_laplace', 'p1hex_apply'):
+        orig = getattr(kernels, name)
+        monkeypatch.setattr(kernels, name, lambda _o=orig, _n=name.split('_')[1], **kw: (calls.__setitem__(_n, calls[_n] + 1), _o(**kw))[1])
+    monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')
+    vg, rpg, cig = function.eval(function.as_csr(K), arguments=args)
+    rg = function.eval(r, arguments=args)
+    assert calls == {'laplace': 0, 'apply': 0}
+    monkeypatch.delenv('NUTILS_AMD_NO_FAST_PATH')
+    vf, rpf, cif = function.eval(function.as_csr(K), arguments=args)
+    rf = function.eval(r, arguments=args)
+    assert calls == {'laplace': 1, 'apply': 4 if coeff else 2}
+    assert numpy.array_equal(rpg, rpf) and numpy.array_equal(cig, cif)
+    close(vf, vg)
+    close(rf, rg)
+    import scipy.sparse
+    close(scipy.sparse.csr_matrix((vf, cif, rpf), (len(basis),) * 2) @ args['u'], rg)
