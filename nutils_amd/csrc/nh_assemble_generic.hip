@@ -467,6 +467,7 @@ struct VecK {
   double *out_scalar;
   const double *scale;
   int qchunk, maxnbt, maxnbr;
+  int cs;  // component stride of the U / F tables = max(nct, ncr): the one-wave workgroups are latency bound, LDS decides occupancy
 };
 
 template <int ND>
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
   double *Dt = Jw + p.nq * JW;
   double *Dr = p.same ? Dt : Dt + p.qchunk * p.maxnbt * S;
   double *U = Dr + (p.same ? p.qchunk * p.maxnbt * S : p.qchunk * p.maxnbr * S);  // [qchunk][ncr][S]
-  double *F = U + p.qchunk * MAXC * S;                                              // [qchunk][nct][S]
+  double *F = U + p.qchunk * p.cs * S;                                              // [qchunk][nct][S]
   const int lane = threadIdx.x;
   double fsum = 0;
   for (i64 ie = blockIdx.x; ie < p.nelems; ie += gridDim.x) {
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
         double s = 0;
         if (p.u)
           for (int n = 0; n < nbr; ++n) s += Dr[(ql * nbr + n) * S + b] * p.u[(i64)p.trial.dofs[rdof0 + n] * form.ncr + d];
-        U[(ql * MAXC + d) * S + b] = s;
+        U[(ql * p.cs + d) * S + b] = s;
       }
       __syncthreads();
       // F[q][c][a] = f[c][a] + sum_db C[c][a][d][b] U[q][d][b]
@@ -515,8 +516,8 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
         double s = form.hasf ? form.f[c * S + a] : 0.;
         if (form.hasC)
           for (int d = 0; d < form.ncr; ++d)
-            for (int b = 0; b < S; ++b) s += form.C[((c * S + a) * form.ncr + d) * S + b] * U[(ql * MAXC + d) * S + b];
-        F[(ql * MAXC + c) * S + a] = s;
+            for (int b = 0; b < S; ++b) s += form.C[((c * S + a) * form.ncr + d) * S + b] * U[(ql * p.cs + d) * S + b];
+        F[(ql * p.cs + c) * S + a] = s;
       }
       __syncthreads();
       if (p.out) {
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
           for (int ql = 0; ql < nql; ++ql) {
             double s = 0;
 #pragma unroll
-            for (int a = 0; a < S; ++a) s += Dt[(ql * nbt + m) * S + a] * F[(ql * MAXC + c) * S + a];
+            for (int a = 0; a < S; ++a) s += Dt[(ql * nbt + m) * S + a] * F[(ql * p.cs + c) * S + a];
             acc += Jw[(q0 + ql) * JW + ND * ND] * s;
           }
           atomicAdd(p.out + (i64)p.test.dofs[tdof0 + m] * form.nct + c, acc);
@@ -540,12 +541,12 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
             double h = 0;
             for (int c = 0; c < form.nct; ++c)
               for (int a = 0; a < S; ++a)
-                h += U[(ql * MAXC + c) * S + a] * (F[(ql * MAXC + c) * S + a] - (form.hasf ? form.f[c * S + a] : 0.));
+                h += U[(ql * p.cs + c) * S + a] * (F[(ql * p.cs + c) * S + a] - (form.hasf ? form.f[c * S + a] : 0.));
             s += .5 * h;
           }
           if (form.hasf) {
             for (int c = 0; c < form.nct; ++c)
-              for (int a = 0; a < S; ++a) s += form.f[c * S + a] * U[(ql * MAXC + c) * S + a];
+              for (int a = 0; a < S; ++a) s += form.f[c * S + a] * U[(ql * p.cs + c) * S + a];
           }
           fsum += Jw[(q0 + ql) * JW + ND * ND] * s;
         }
@@ -801,7 +802,8 @@ int nh_assemble_vector(const nh_vector_args *a, void *stream) {
   p.scale = a->scale_dev;
   if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
   if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
-  const int per_q = ((p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S + 2 * MAXC * S) * (int)sizeof(double);
+  p.cs = std::max(a->nct, a->ncr);
+  const int per_q = ((p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S + 2 * p.cs * S) * (int)sizeof(double);
   p.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / per_q));
   const size_t lds = sizeof(double) * ((size_t)FORMD + (size_t)a->nq * JW) + (size_t)p.qchunk * per_q;
   NH_REQUIRE(lds <= 160 * 1024, "element too large for LDS (%zu bytes)", lds);
