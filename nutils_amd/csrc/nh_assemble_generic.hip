@@ -12,6 +12,7 @@
 #include "nh_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstddef>
 #include <vector>
 
 namespace {
@@ -22,19 +23,19 @@ constexpr int LDS_BUDGET = 60000;  // bytes of D tables per workgroup (q-chunked
 
 struct FormK {
   int nct, ncr;
-  double C[MAXC * MAXS * MAXC * MAXS];  // [c][a][d][b]
-  double f[MAXC * MAXS];                // [c][a]
+  int formd;                            // doubles of this struct that are staged in LDS: the header and the USED part of C (the
+                                        // one-wave workgroups are latency bound: every kB of LDS is occupancy)
+  int hasC, hasf;
   int cnt[MAXC], cum[MAXC], tot;
   unsigned char mask[MAXC][MAXC];
   signed char dpos[MAXC][MAXC];
-  int hasC, hasf;
-  int pad[2];
+  double f[MAXC * MAXS];                // [c][a]
+  double C[MAXC * MAXS * MAXC * MAXS];  // [c][a][d][b], nct * S * ncr * S entries used; LAST member
 };
-constexpr int FORMD = (int)((sizeof(FormK) + 15) / 16 * 2);  // doubles reserved at the start of dynamic LDS
 
 __device__ __forceinline__ const FormK &stage_form(double *lds, const FormK &arg, int lane) {
   const double *src = reinterpret_cast<const double *>(&arg);
-  for (int i = lane; i < (int)(sizeof(FormK) / 8); i += 64) lds[i] = src[i];
+  for (int i = lane; i < arg.formd; i += 64) lds[i] = src[i];
   __syncthreads();
   return *reinterpret_cast<const FormK *>(lds);
 }
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
   constexpr int S = 1 + ND, JW = ND * ND + 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FormK &form = stage_form(lds, formarg, threadIdx.x);
-  double *Jw = lds + FORMD;                           // [nq][JW]
+  double *Jw = lds + formarg.formd;                   // [nq][JW]
   double *Dt = Jw + p.nq * JW;                        // [qchunk][maxnbt][S]
   double *Dr = p.same ? Dt : Dt + p.qchunk * p.maxnbt * S;
   double *W = Dr + p.qchunk * p.maxnbr * S;            // [qchunk][maxnbr][ncr][nct][S]
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void k_matrix_mfma(MatK p, FormK formarg, Mfma
   const int nb = p.test.nb;  // test and trial share tables on this path (p.same)
   const int nqp = (p.nq + 3) & ~3;                 // q padded to the MFMA k-step: K index k = a * nqp + q (slot-major)
   const int nbp = MT * 16;                         // m padded to the M tiles
-  double *Jw = lds + FORMD;                        // [nq][JW]
+  double *Jw = lds + formarg.formd;                // [nq][JW]
   double *D = Jw + ((p.nq * JW + 3) & ~3);         // [nq][nb][S]   (32-byte aligned rows: B fragments are read as 4 doubles)
   double *At = D + (size_t)p.nq * nb * S;          // [nas][nqp][nbp] transposed copy of the active test slots, zero padded:
                                                    // the A fragment read A[m = li][k = lk] is conflict-free and branch-free
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
   constexpr int S = 1 + ND, JW = ND * ND + 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FormK &form = stage_form(lds, formarg, threadIdx.x);
-  double *Jw = lds + FORMD;
+  double *Jw = lds + formarg.formd;
   double *Dt = Jw + p.nq * JW;
   double *Dr = p.same ? Dt : Dt + p.qchunk * p.maxnbt * S;
   double *U = Dr + (p.same ? p.qchunk * p.maxnbt * S : p.qchunk * p.maxnbr * S);  // [qchunk][ncr][S]
@@ -615,6 +616,7 @@ int make_form(int nd, int nct, int ncr, const double *C, const double *f, const 
   fk->ncr = ncr;
   fk->hasC = C != nullptr;
   fk->hasf = f != nullptr;
+  fk->formd = (int)(((offsetof(FormK, C) / 8 + (size_t)nct * S * ncr * S) + 3) & ~(size_t)3);  // 32-byte granules: the tables behind it are read as 4 doubles
   if (C) memcpy(fk->C, C, sizeof(double) * nct * S * ncr * S);
   if (f) memcpy(fk->f, f, sizeof(double) * nct * S);
   for (int c = 0; c < nct; ++c) {
@@ -713,7 +715,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     x.nt = (Nloc + 15) / 16;
     x.kt = ((a->nq + 3) / 4) * x.nas;
     x.flags = a->flags | (getenv("NH_MFMA_DEBUG") ? atoi(getenv("NH_MFMA_DEBUG")) : 0);
-    const size_t ldsm = sizeof(double) * ((size_t)FORMD + (((size_t)a->nq * JW + 3) & ~(size_t)3) + (size_t)a->nq * a->test.nb * S +
+    const size_t ldsm = sizeof(double) * ((size_t)form.formd + (((size_t)a->nq * JW + 3) & ~(size_t)3) + (size_t)a->nq * a->test.nb * S +
                                           (size_t)x.nas * ((a->nq + 3) & ~3) * x.mt * 16);
     if (x.nas > 0 && ldsm <= 160 * 1024 && x.mt <= 4) {
       hipStream_t sm = nh_stream(stream);
@@ -746,7 +748,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   }
   const int per_q0 = (p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S * (int)sizeof(double);
   const int per_qw = per_q0 + p.maxnbr * a->nct * a->ncr * S * (int)sizeof(double);
-  const size_t fixed = sizeof(double) * ((size_t)FORMD + (size_t)a->nq * JW);
+  const size_t fixed = sizeof(double) * ((size_t)form.formd + (size_t)a->nq * JW);
   // the W table trades S*S for S multiply-adds per entry and point; these one-wave workgroups are latency bound, so it is only
   // used while the workgroup stays small enough for >= 16 of them per CU (measured: 3-D P1 4.8 -> 3.8 ms, 2-D p2 0.96 -> 1.1 ms)
   p.use_w = fixed + (size_t)a->nq * per_qw <= 10 * 1024;
@@ -805,7 +807,7 @@ int nh_assemble_vector(const nh_vector_args *a, void *stream) {
   p.cs = std::max(a->nct, a->ncr);
   const int per_q = ((p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S + 2 * p.cs * S) * (int)sizeof(double);
   p.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / per_q));
-  const size_t lds = sizeof(double) * ((size_t)FORMD + (size_t)a->nq * JW) + (size_t)p.qchunk * per_q;
+  const size_t lds = sizeof(double) * ((size_t)form.formd + (size_t)a->nq * JW) + (size_t)p.qchunk * per_q;
   NH_REQUIRE(lds <= 160 * 1024, "element too large for LDS (%zu bytes)", lds);
   hipStream_t s = nh_stream(stream);
   dim3 grid(grid_for(a->nelems)), block(64);
