@@ -444,11 +444,16 @@ class Integrand:
 
     __array_ufunc__ = None
 
-    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False, scale=None, fscale=None, bound=None):
+    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False, scale=None, fscale=None, qform=None, qscalar=None):
         self.test, self.trial, self.B, self.L, self.f0 = test, trial, B, L, f0
-        # product-rule term of a Newton Jacobian: B acts on (test, VALUES of the field `bound` at the point) and the result multiplies the
-        # value of the trial function -- a bilinear form whose coefficients depend on the point (assembled with per-point tensors)
-        self.bound = bound
+        # product-rule terms of Newton Jacobians / Hessians of energies: forms whose coefficients depend on the point through the VALUES
+        # (value and gradient) U of a field there.  With B the tensor of this integrand,
+        #   qform = ('trial', arg):    C_q[c][a][0][0] = sum_db B[c][a][d][b] U_arg[d][b]     (result on the value slot of the trial function)
+        #   qform = ('test', arg, L):  C_q[c][a][d][b] = L[c][a] sum_xy B[x][y][d][b] U_arg[x][y]
+        #   qscalar = (Bs, arg_t, arg_r): the whole integrand is multiplied by s_q = sum Bs[c][a][d][b] U_t[c][a] U_r[d][b]
+        # (scalar fields; assembled with per-point coefficient tensors / scale arrays built on the device)
+        self.qform = qform
+        self.qscalar = qscalar
         self.scale = scale      # PointFunc multiplying the whole integrand, or None
         self.fscale = fscale    # FieldPoly multiplying the whole integrand, or None
         self.geom = geom        # geometry the gradients refer to
@@ -457,7 +462,7 @@ class Integrand:
 
     def _copy(self, **kw):
         d = dict(test=self.test, trial=self.trial, B=self.B, L=self.L, f0=self.f0, geom=self.geom, measure=self.measure, rows=self.rows, cols=self.cols,
-                 scale=self.scale, fscale=self.fscale, bound=self.bound)
+                 scale=self.scale, fscale=self.fscale, qform=self.qform, qscalar=self.qscalar)
         d.update(kw)
         return Integrand(**d)
 
@@ -622,6 +627,7 @@ def derivative(integral, name):
     '''Derivative with respect to the named field argument (function.derivative):
     exposes that argument's dof axis.  Terms that do not depend on it vanish.'''
     out = []
+    T = lambda B: numpy.moveaxis(B, (-4, -3, -2, -1), (-2, -1, -4, -3))
     for smp, itg, fac in integral.terms:
         if itg.fscale is not None and itg.fscale.depends_on(name):
             g = itg.fscale.derivative(name)
@@ -636,31 +642,53 @@ def derivative(integral, name):
                     B = numpy.zeros(itg.L.shape + (1, S))
                     B[..., 0, 0] = itg.L
                     out.append((smp, itg._copy(trial=varg, B=B, L=None, cols=True, fscale=g), fac))
-                elif itg.B is not None and itg.rows and not itg.cols and itg.bound is None and itg.trial.ncomp == 1 and varg.ncomp == 1:
+                elif itg.B is not None and itg.rows and not itg.cols and itg.qform is None and itg.trial.ncomp == 1 and varg.ncomp == 1 and itg.B.ndim == 4:
                     # g(phi) * B(test, u)  ->  g'(phi) phi_n * B(test, u): bilinear (test x phi) with the coefficients B . U(u) of the point
-                    out.append((smp, itg._copy(trial=varg, cols=True, fscale=g, bound=itg.trial), fac))
+                    out.append((smp, itg._copy(trial=varg, cols=True, fscale=g, qform=('trial', itg.trial)), fac))
+                elif (itg.B is not None and not itg.rows and not itg.cols and itg.qform is None and itg.qscalar is None and itg.B.ndim == 4
+                      and itg.test.ncomp == itg.trial.ncomp == varg.ncomp == 1):
+                    # energy density g(phi) * B(u, w)  ->  g'(phi) phi_m * (U_u . B . U_w): linear form with a point factor
+                    L = numpy.zeros((1, S))
+                    L[0, 0] = 1.
+                    out.append((smp, itg._copy(test=varg, trial=None, B=None, L=L, rows=True, fscale=g, qscalar=(itg.B, itg.test, itg.trial)), fac))
                 else:
                     raise NotImplementedError('derivative of a field-dependent coefficient in this position (rank-3 tensor)')
+        if itg.qscalar is not None:
+            Bs, at, ar = itg.qscalar
+            hit_t, hit_r = at.name == name, ar.name == name
+            if hit_t or hit_r:
+                if not (itg.B is None and itg.L is not None and itg.rows and not itg.cols):
+                    raise NotImplementedError('derivative of a point factor in this position')
+                if hit_t and hit_r:
+                    if at.basis is not ar.basis:
+                        raise NotImplementedError
+                    Bv, bound, targ = Bs + T(Bs), at, at   # d(U.B.U) = phi_n . (B + B^T) . U
+                elif hit_r:
+                    Bv, bound, targ = Bs, at, ar           # U_t . B . phi_n: contract the test side with U_t
+                else:
+                    Bv, bound, targ = T(Bs), ar, at        # phi_n . B . U_r
+                out.append((smp, itg._copy(trial=targ, B=Bv, L=None, cols=True, qscalar=None, qform=('test', bound, itg.L)), fac))
         t_hit = itg.test is not None and itg.test.name == name and not itg.rows
         r_hit = itg.trial is not None and itg.trial.name == name and not itg.cols
+        if itg.qform is not None and (t_hit or r_hit or itg.qform[1].name == name):
+            raise NotImplementedError('third derivatives of field-dependent coefficients')
         if itg.B is not None and t_hit and r_hit:
             if itg.cols or itg.rows:
                 raise NotImplementedError
             # quadratic in the field: d/du B(u,u) = B(du,u) + B(u,du)
-            Bt = numpy.moveaxis(itg.B, (-4, -3, -2, -1), (-2, -1, -4, -3))
-            out.append((smp, itg._copy(B=itg.B + Bt, rows=True), fac))
+            out.append((smp, itg._copy(B=itg.B + T(itg.B), rows=True), fac))
         elif t_hit:
             if itg.rows or (itg.cols and itg.B is None):
                 raise NotImplementedError
             if itg.cols:  # keep the convention rows = first differentiated axis: transpose
-                out.append((smp, itg._copy(B=numpy.moveaxis(itg.B, (-4, -3, -2, -1), (-2, -1, -4, -3)), test=itg.trial, trial=itg.test, rows=True, cols=True), fac))
+                out.append((smp, itg._copy(B=T(itg.B), test=itg.trial, trial=itg.test, rows=True, cols=True), fac))
             else:
                 out.append((smp, itg._copy(rows=True), fac))
         elif r_hit:
             if itg.rows:
                 out.append((smp, itg._copy(cols=True), fac))
             else:  # derivative w.r.t. the trial-side field first: swap roles
-                out.append((smp, itg._copy(B=numpy.moveaxis(itg.B, (-4, -3, -2, -1), (-2, -1, -4, -3)), test=itg.trial, trial=itg.test, rows=True, cols=False), fac))
+                out.append((smp, itg._copy(B=T(itg.B), test=itg.trial, trial=itg.test, rows=True, cols=False), fac))
     return Integral(out)
 
 

@@ -267,6 +267,29 @@ def _colors(smp, basis):
     return smp._tables[key]
 
 
+def _field_values(smp, arg, geom, arguments):
+    '''U[e q][1 + nd]: value and gradient (w.r.t. `geom`) of a scalar field at the points of the sample, on the device.'''
+    nq, S = smp.points.npoints, 1 + smp.ndims
+    U = device.empty(smp.nlist * nq * S, 'float64')
+    kernels.sample_eval(nelems=smp.nlist, ndims=smp.ndims, nq=nq, geom=smp.geometry(geom), trial=smp.tables(arg.basis).struct, ncr=1,
+                        points=smp._points_dev, u=device.to_dev(_argument(arguments, arg), 'float64'), U=U, elist=smp._elist_dev)
+    return U.reshape(smp.nlist * nq, S)
+
+
+def _point_scale(smp, itg, arguments):
+    '''scale_dev array of a term: coefficient function of x, polynomial of field values, and (energies) the point factor U_t . B . U_r.'''
+    sc = smp.scale(itg.scale, itg.fscale, arguments)
+    if itg.qscalar is not None:
+        Bs, at, ar = itg.qscalar
+        geom = itg.geom if itg.geom is not None else itg.measure
+        Ut = _field_values(smp, at, geom, arguments)
+        Ur = Ut if ar is at else _field_values(smp, ar, geom, arguments)
+        Bd = device.to_dev(numpy.ascontiguousarray(Bs[0, :, 0, :]), 'float64')  # scalar fields: [S][S]
+        s = ((Ut @ Bd) * Ur).sum(-1)
+        sc = s if sc is None else sc.reshape(-1) * s
+    return sc
+
+
 def _block_mask(B):
     return (numpy.abs(B).sum(axis=(1, 3)) != 0)
 
@@ -288,8 +311,8 @@ class _MatrixPlan:
         self.test, self.trial = itg0.test, itg0.trial
         self.mask = numpy.zeros((self.test.ncomp, self.trial.ncomp), dtype=bool)
         for smp, itg, fac in terms:
-            if itg.bound is not None:  # blocks (c, 0): the trial side is the scalar field of the differentiated coefficient
-                self.mask |= (numpy.abs(itg.B).sum(axis=(1, 2, 3)) != 0)[:, None]
+            if itg.qform is not None:  # scalar fields: one block
+                self.mask |= True
             else:
                 self.mask |= _block_mask(itg.B)
         self.smp0 = smp0
@@ -313,7 +336,7 @@ class _MatrixPlan:
         kappa, mass, geom, qscale, qmass = 0., 0., None, None, None
         for _, itg, fac in self.terms:
             B = numpy.asarray(itg.B, dtype=float) * fac
-            if B.shape != (1, 4, 1, 4) or itg.bound is not None:
+            if B.shape != (1, 4, 1, 4) or itg.qform is not None:
                 return None
             B = B[0, :, 0, :]
             m, k = B[0, 0], B[1, 1]  # mass and diffusion coefficient of the term: B = diag(m, k, k, k)
@@ -322,11 +345,11 @@ class _MatrixPlan:
             if geom is not None and itg.measure is not geom:
                 return None
             geom = itg.measure
-            if itg.scale is None and itg.fscale is None:
+            if itg.scale is None and itg.fscale is None and itg.qscalar is None:
                 kappa += k
                 mass += m
             else:  # coefficient function (of position, or of a field): values at the Gauss points, summed over the terms
-                sc = smp.scale(itg.scale, itg.fscale, arguments)
+                sc = _point_scale(smp, itg, arguments)
                 if k:
                     qscale = sc * k if qscale is None else qscale.add_(sc, alpha=k)
                 if m:
@@ -384,20 +407,20 @@ class _MatrixPlan:
                           trial=tr.struct, nct=nct, ncr=ncr, C=itg.B * fac, mask=mask, pattern=smp.pattern(itg.test.basis, itg.trial.basis),
                           values=values)
             colors = None
-            scale = smp.scale(itg.scale, itg.fscale, arguments)
-            if itg.bound is not None:
-                # per-point coefficient tensor C_q[c][a][0][0] = fac g'(..) sum_b B[c][a][0][b] U_q[b], U = (value, gradient) of the bound field
+            scale = _point_scale(smp, itg, arguments)
+            if itg.qform is not None:
+                # per-point coefficient tensors built on the device from U = (value, gradient) of the bound field (scalar fields)
                 nq, S = smp.points.npoints, 1 + smp.ndims
-                U = device.empty(smp.nlist * nq * S, 'float64')
-                kernels.sample_eval(nelems=smp.nlist, ndims=smp.ndims, nq=nq, geom=smp.geometry(itg.geom if itg.geom is not None else itg.measure),
-                                    trial=smp.tables(itg.bound.basis).struct, ncr=1, points=smp._points_dev,
-                                    u=device.to_dev(_argument(arguments, itg.bound), 'float64'), U=U, elist=smp._elist_dev)
-                Bf = device.to_dev(numpy.ascontiguousarray(itg.B[:, :, 0, :]) * fac, 'float64')  # [nct][S][S]
-                T = (U.reshape(smp.nlist * nq, 1, 1, S) * Bf).sum(-1)                            # [e q][nct][S]
+                U = _field_values(smp, itg.qform[1], itg.geom if itg.geom is not None else itg.measure, arguments)
+                Bd = device.to_dev(numpy.ascontiguousarray(itg.B[0, :, 0, :]) * fac, 'float64')  # [S][S]
+                cq = device.zeros(smp.nlist * nq * S * S, 'float64').reshape(smp.nlist * nq, S, S)
+                if itg.qform[0] == 'trial':   # C_q[a][0] = sum_b B[a][b] U[b]
+                    cq[:, :, 0] = U @ Bd.T
+                else:                         # 'test': C_q[a][b] = L[a] sum_x B[x][b] U[x]
+                    Ld = device.to_dev(numpy.ascontiguousarray(itg.qform[2][0]), 'float64')
+                    cq[:, :, :] = Ld.reshape(1, S, 1) * (U @ Bd).reshape(-1, 1, S)
                 if scale is not None:
-                    T = T * scale.reshape(-1, 1, 1)
-                cq = device.zeros(smp.nlist * nq * nct * S * ncr * S, 'float64').reshape(smp.nlist * nq, nct, S, ncr, S)
-                cq[:, :, :, 0, 0] = T
+                    cq = cq * scale.reshape(-1, 1, 1)
                 common_q = dict(common, C=numpy.ones((nct, S, ncr, S)))
                 kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, cq=cq.reshape(-1), **common_q)
                 continue
@@ -456,7 +479,7 @@ def _p1hex_apply_term(smp, itg, fac, arguments, out):
         return False
     verts, x1, w1 = setting
     u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-    sc = smp.scale(itg.scale, itg.fscale, arguments)
+    sc = _point_scale(smp, itg, arguments)
     kernels.p1hex_apply(shape=itg.test.basis.shape, u=u, out=out, gauss_x=x1, gauss_w=w1, verts=verts, kappa=k, mass=m,
                         qscale=sc if k else None, qmass=sc if m else None, accumulate=True)
     return True
@@ -473,18 +496,18 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
         tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
         if itg.rows and not itg.cols:
             u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+            kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                     nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=out)
             return
         if not itg.rows and not itg.cols:
             if itg.test.same(itg.trial):
                 u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-                kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+                kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                         nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * (2 * fac), u=u, out_scalar=scalar[0])
             else:
                 tmp = device.zeros(itg.test.basis.ndofs * itg.test.ncomp, 'float64')
                 u = device.to_dev(_argument(arguments, itg.trial), 'float64')
-                kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
+                kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                         nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=tmp)
                 # v . r for two different bound fields: O(ndofs) post-processing on the host
                 scalar[1] += float(numpy.dot(device.to_host(tmp), _argument(arguments, itg.test).ravel()))
@@ -493,16 +516,16 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
     if itg.L is not None:
         tt = smp.tables(itg.test.basis)
         if itg.rows:
-            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
+            kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
                                     nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, out=out)
         else:
             u = device.to_dev(_argument(arguments, itg.test), 'float64')
-            kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
+            kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
                                     nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, u=u, out_scalar=scalar[0])
         return
     # constant integrand (volume-type functional): basis-free launch
     none = kernels.basis(None, None)
-    kernels.assemble_vector(elist=smp._elist_dev, scale=smp.scale(itg.scale, itg.fscale, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=none, trial=none, nct=1, ncr=1,
+    kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=none, trial=none, nct=1, ncr=1,
                             f0=float(itg.f0) * fac, out_scalar=scalar[0])
 
 

@@ -268,7 +268,7 @@ def cahnhilliard_case(name, nelems, degree=2, seed=3):
     save(name, **data)
 
 
-def quasilinear_case(name, ndims, btype, degree, n, seed=6):
+def quasilinear_case(name, ndims, btype, degree, n, seed=6, energy=False):
     '''Quasi-linear diffusion -div((1 + u^2) grad u) = 1 (the nonlinear example class of SURVEY 8f-1): residual and Jacobian of the
     weak form at a random state -- the Jacobian contains the product-rule term 2 u phi_n grad u . grad phi_m (a rank-3 tensor in the
     reference's `factor` language) -- and the Newton solution with u = 0 on the face x_0 = 0.'''
@@ -280,12 +280,18 @@ def quasilinear_case(name, ndims, btype, degree, n, seed=6):
     ns.define_for('x', gradient='∇', jacobians=('dV',))
     ns.u = domain.field('u', btype=btype, degree=degree)
     ns.v = domain.field('v', btype=btype, degree=degree)
-    res = domain.integral('((1 + u^2) ∇_i(v) ∇_i(u) - v) dV' @ ns, degree=2 * degree + 2)
     basis = domain.basis(btype, degree=degree)
     nd = len(basis)
     x0 = rng.normal(0, .5, nd)
-    rv = function.derivative(res, 'v')
+    if energy:  # the same problem class from its energy (System(nrg, trial='u') differentiates twice)
+        res = domain.integral('((1 + u^2) ∇_i(u) ∇_i(u) / 2 - u) dV' @ ns, degree=2 * degree + 2)
+        rv = function.derivative(res, 'u')
+    else:
+        res = domain.integral('((1 + u^2) ∇_i(v) ∇_i(u) - v) dV' @ ns, degree=2 * degree + 2)
+        rv = function.derivative(res, 'v')
     data = dict(ndims=ndims, n=n, degree=degree, x0=x0)
+    if energy:
+        data['energy'] = function.eval(res, dict(u=x0))
     data['res'] = function.eval(rv, dict(u=x0))
     v, rp, ci = function.eval(function.as_csr(function.derivative(rv, 'u')), dict(u=x0))
     data['jac_values'], data['jac_rowptr'], data['jac_colidx'] = v, rp, ci
@@ -293,7 +299,7 @@ def quasilinear_case(name, ndims, btype, degree, n, seed=6):
     cons = numpy.full(nd, numpy.nan)
     cons.reshape((m,) * ndims)[0] = 0.
     data['cons'] = cons
-    sol = System(res, trial='u', test='v').solve(constrain=dict(u=cons), tol=1e-11)
+    sol = (System(res, trial='u') if energy else System(res, trial='u', test='v')).solve(constrain=dict(u=cons), tol=1e-11)
     data['sol'] = sol['u']
     save(name, **data)
 
@@ -403,7 +409,9 @@ if __name__ == '__main__':
     hierarchical_p3_case('hier_thspline3_2d_l4')
     hierarchical_p3_case('hier_thspline3_2d_l10', levels=10)
     quasilinear_case('quasilin3d_p1_4', 3, 'std', 1, 4)
-    quasilinear_case('quasilin2d_spline2_6', 2, 'spline', 2, 6)  # BASELINE.json configs[4]: ten refinement levels
+    quasilinear_case('quasilin2d_spline2_6', 2, 'spline', 2, 6)
+    quasilinear_case('quasilin_energy3d_p1_4', 3, 'std', 1, 4, energy=True)
+    quasilinear_case('quasilin_energy2d_spline2_6', 2, 'spline', 2, 6, energy=True)  # BASELINE.json configs[4]: ten refinement levels
     hierarchical_case('hier_spline2_1d', 1)
     hierarchical_case('hier_spline2_2d', 2)
     example_vectors()

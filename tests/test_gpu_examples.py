@@ -240,3 +240,61 @@ def test_quasilinear_reference(golden, name, btype):
     close(values, g['jac_values'])
     sol = System(res, trial='u', test='v').solve(constrain={'u': g['cons']}, tol=1e-11)['u']
     close(sol, g['sol'], 1e4)
+
+
+@pytest.mark.parametrize('ndims,btype,degree', [(3, 'std', 1), (2, 'spline', 2)])
+def test_quasilinear_energy(ndims, btype, degree):
+    '''System built from an ENERGY, E(u) = int (1 + u^2) |grad u|^2 / 2 - u: residual and Hessian come from two derivatives of a
+    field-dependent coefficient times a form quadratic in the field (point factor U.B.U, per-point tensors on either side).
+    Residual = dE and Hessian = d residual by central differences; Hessian symmetric; the minimiser solves the quasi-linear PDE.'''
+    from nutils_amd import mesh, function
+    from nutils_amd.solver import System
+    n = 5 if ndims == 3 else 9
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1, n + 1)] * ndims)
+    u = domain.field('u', btype=btype, degree=degree)
+    dV = function.J(geom)
+    nrg = domain.integral((1 + function.value(u) ** 2) * (.5 * (function.grad(u, geom) * function.grad(u, geom)).sum(-1)) * dV, degree=2 * degree + 2) \
+        - domain.integral(u * dV, degree=2 * degree)
+    system = System(nrg, trial='u')
+    nd = system.size
+    rng = numpy.random.default_rng(4)
+    x0, d = rng.normal(0, .5, nd), rng.normal(0, 1, nd)
+    res = system.assemble_residual({'u': x0})
+    h = 1e-5
+    dE = (system.assemble_value({'u': x0 + h * d}) - system.assemble_value({'u': x0 - h * d})) / (2 * h)
+    assert abs(dE - res @ d) <= 1e-8 * numpy.abs(res).max() * numpy.abs(d).max() * nd ** .5
+    jac = system.assemble_jacobian({'u': x0})
+    fd = (system.assemble_residual({'u': x0 + h * d}) - system.assemble_residual({'u': x0 - h * d})) / (2 * h)
+    Jd = jac @ d
+    assert numpy.abs(fd - Jd).max() <= 1e-8 * numpy.abs(Jd).max()
+    A = jac.core
+    assert abs(A - A.T).max() <= 1e-12 * abs(A).max()
+    cons = numpy.full(nd, numpy.nan)
+    cons.reshape(u.arg.basis.dofs_shape)[0] = 0.
+    sol = system.solve(constrain={'u': cons}, tol=1e-11)['u']
+    r = system.assemble_residual({'u': sol})
+    assert numpy.linalg.norm(r[numpy.isnan(cons)]) < 1e-11 and numpy.abs(sol).max() > .1
+
+
+@pytest.mark.parametrize('name,btype', [('quasilin_energy3d_p1_4', 'std'), ('quasilin_energy2d_spline2_6', 'spline')])
+def test_quasilinear_energy_reference(golden, name, btype):
+    '''Energy, residual, Hessian (CSR, index arrays bit-exact) and minimiser of E(u) = int (1 + u^2) |grad u|^2 / 2 - u against the
+    REAL reference (oracle/gen_golden.py:quasilinear_case, energy=True).'''
+    from nutils_amd import mesh, function
+    from nutils_amd.solver import System
+    g = golden(name)
+    ndims, n, degree = int(g['ndims']), int(g['n']), int(g['degree'])
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1, n + 1)] * ndims)
+    u = domain.field('u', btype=btype, degree=degree)
+    dV = function.J(geom)
+    nrg = domain.integral((1 + function.value(u) ** 2) * (.5 * (function.grad(u, geom) * function.grad(u, geom)).sum(-1)) * dV, degree=2 * degree + 2) \
+        - domain.integral(u * dV, degree=2 * degree + 2)
+    args = {'u': g['x0']}
+    assert abs(function.eval(nrg, arguments=args) - float(g['energy'])) <= 1e-13 * abs(float(g['energy']))
+    ru = function.derivative(nrg, 'u')
+    close(function.eval(ru, arguments=args), g['res'])
+    values, rowptr, colidx = function.eval(function.as_csr(function.derivative(ru, 'u')), arguments=args)
+    assert numpy.array_equal(rowptr, g['jac_rowptr']) and numpy.array_equal(colidx, g['jac_colidx'])
+    close(values, g['jac_values'])
+    sol = System(nrg, trial='u').solve(constrain={'u': g['cons']}, tol=1e-11)['u']
+    close(sol, g['sol'], 1e4)
