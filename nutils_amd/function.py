@@ -345,6 +345,17 @@ class Operand:
     def __truediv__(self, other):
         return self._const(1. / numpy.asarray(other, dtype=float))
 
+    def __pow__(self, n):
+        if n == 1:
+            return self
+        if n == 2:
+            return self * self
+        raise NotImplementedError('powers of a field beyond 2: use function.value(field) ** n (pointwise coefficient)')
+
+    def __matmul__(self, other):
+        '''Contraction over the last axis (`g @ g` of examples/poisson.py:32).'''
+        return (self * other).sum(-1)
+
     def __neg__(self):
         return Operand(self.arg, -self.P, self.geom)
 
@@ -534,15 +545,54 @@ class Integrand:
             and self.measure is other.measure and (self.B is None) == (other.B is None) and (self.L is None) == (other.L is None) \
             and self.scale is other.scale and self.fscale is other.fscale
 
+    def __truediv__(self, other):
+        return self * (1. / numpy.asarray(other, dtype=float))
+
     def __add__(self, other):
+        if isinstance(other, IntegrandSum):
+            return IntegrandSum([self] + other.terms)
         other = _as_integrand(other)
-        if not self._compatible(other):
-            raise NotImplementedError('only integrands of the same kind can be added before integration; add the integrals instead')
+        if not self._compatible(other):  # e.g. (g @ g / 2 - u): a quadratic and a linear form -> kept apart, integrated term by term
+            return IntegrandSum([self, other])
         a, b, _ = _bcast(self._tensor, other._tensor, (self._keep, other._keep))
         return self._set(a + b)._copy(geom=self.geom or other.geom)
 
+    __radd__ = __add__
+
     def __sub__(self, other):
-        return self + (-_as_integrand(other))
+        return self + (-(other if isinstance(other, IntegrandSum) else _as_integrand(other)))
+
+    def __rsub__(self, other):
+        return (-self) + other
+
+
+class IntegrandSum:
+    '''Sum of integrands of different kinds (bilinear + linear + constant ...): distributes over multiplication with a measure or a
+    coefficient and over integration, so that `topo.integral((g @ g / 2 - u) * J, degree)` reads as in the reference.'''
+
+    __array_ufunc__ = None
+
+    def __init__(self, terms):
+        self.terms = list(terms)
+
+    def __mul__(self, other):
+        return IntegrandSum([t * other for t in self.terms])
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return IntegrandSum([t / other for t in self.terms])
+
+    def __neg__(self):
+        return IntegrandSum([-t for t in self.terms])
+
+    def __add__(self, other):
+        return IntegrandSum(self.terms + (other.terms if isinstance(other, IntegrandSum) else [_as_integrand(other)]))
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return self + (-(other if isinstance(other, IntegrandSum) else _as_integrand(other)))
 
 
 def _as_integrand(obj):

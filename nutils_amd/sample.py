@@ -177,6 +177,12 @@ class Sample:
 
     def integral(self, func):
         '''Postponed integration (sample.py:177-190).'''
+        if isinstance(func, function.IntegrandSum):
+            total = None
+            for t in func.terms:
+                part = self.integral(t)
+                total = part if total is None else total + part
+            return total
         itg = function._as_integrand(func)
         if itg._tensor.ndim - itg._keep:
             raise NotImplementedError(f'integrand has unreduced axes {itg.shape}; sum or contract them first')

@@ -380,6 +380,16 @@ def example_vectors():
     out['laplace_c1_lhs'] = lhs
     out['laplace_c1_err'] = err
     save('examples_laplace', **out)
+    import examples.poisson as poi
+    import matplotlib
+    matplotlib.use('Agg')
+    import tempfile
+    out, cwd = {}, os.getcwd()
+    os.chdir(tempfile.mkdtemp())  # the example writes u.png into the working directory
+    for nelems in (10, 32):
+        out[f'poisson_{nelems}_u'] = poi.main(nelems=nelems)['u']
+    os.chdir(cwd)
+    save('examples_poisson', **out)
 
 
 if __name__ == '__main__':

@@ -298,3 +298,22 @@ def test_quasilinear_energy_reference(golden, name, btype):
     close(values, g['jac_values'])
     sol = System(nrg, trial='u').solve(constrain={'u': g['cons']}, tol=1e-11)['u']
     close(sol, g['sol'], 1e4)
+
+
+@pytest.mark.parametrize('nelems', [10, 32])
+def test_poisson_example(golden, nelems):
+    '''/root/reference/examples/poisson.py:28-36 line by line ("direct function manipulation without namespace expressions"):
+    constraints from the boundary functional, minimisation of int |grad u|^2 / 2 - u; solution against the example's own return
+    value from the real reference (tests/golden/examples_poisson.npz).'''
+    from nutils_amd import mesh, function
+    from nutils_amd.solver import System
+    topo, x = mesh.unitsquare(nelems, etype='square')
+    u = topo.field('u', btype='std', degree=1)
+    g = u.grad(x)
+    J = function.J(x)
+    sqr = topo.boundary.integral(u**2 * J, degree=2)
+    cons = System(sqr, trial='u').solve_constraints(droptol=1e-12)
+    energy = topo.integral((g @ g / 2 - u) * J, degree=1)
+    args = System(energy, trial='u').solve(constrain=cons)
+    ref = golden('examples_poisson')[f'poisson_{nelems}_u']
+    assert numpy.abs(args['u'] - ref).max() <= 1e-12 * numpy.abs(ref).max()
