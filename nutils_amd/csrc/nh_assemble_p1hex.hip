@@ -43,8 +43,7 @@ struct P1Args {
   const double *u;         // vector variant: nodal values of the field the form is applied to
   double *out;             // vector variant: out[dof] (+)= sum_n K[dof][n] u[n]
   int accumulate;
-  int nbj, nbk;            // boxes per axis (j, k)
-  int nboxes;
+  int nbj, nbk;            // column tiles per axis (j, k)
   long long *tdbg;         // phase timers (ablation builds)
   int debug;               // ablation switches (NH_P1HEX_DEBUG env): 1 = no LDS reduction, 2 = no HBM stores, 4 = no element math
 };
@@ -628,7 +627,7 @@ static int fill_p1args(const nh_p1hex_args *a, P1Args &p) {
   p.u = nullptr;
   p.out = nullptr;
   p.accumulate = 0;
-  p.nbj = p.nbk = p.nboxes = 0;
+  p.nbj = p.nbk = 0;
   p.debug = 0;
   p.tdbg = nullptr;
   return NH_OK;
