@@ -136,6 +136,7 @@ def cpu_baseline(variant):
 
 def main():
     a = parse()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: required by RCCL / cross-process device memory on this driver
     import numpy
     import torch
     rank = int(os.environ.get('RANK', 0))
