@@ -377,7 +377,34 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
           }
         }
         };
-        if (!lowJ && !highJ) planes(std::integral_constant<int, 0>{});
+        if (L == 2 && !lowJ && !highJ && Pe - Pb == 2 && Pb > 0 && Pe < N0) {
+          // the common step: two planes, nothing on a boundary except possibly K -- one set of lane constants, ONE exec region, the 30
+          // LDS reads of both planes in flight before the first of the 30 stores
+          const int flag = 1 | 2 | loK << 2 | 8 | 16 | hiK << 5;
+          const unsigned voff8 = 8u * (unsigned)(9 * cumK + ((dI + 1) * 3 + (dJ + 1)) * lenK + (dK + loK));
+          const i64 stride8 = 8 * (i64)(9 * (int)T2);
+          if (kact && (flag & need) == need) {
+            const bool below = !upper && dI < 0;
+            const double *src0 = acc + (below ? slot_of(Pb - 1) : slot_of(Pb)) + srow, *src1 = acc + (below ? slot_of(Pb) : slot_of(Pb + 1)) + srow;
+            double v0[OJ], v1[OJ];
+#pragma unroll
+            for (int oj = 0; oj < OJ; ++oj) v0[oj] = src0[oj * (VK * NS)];
+#pragma unroll
+            for (int oj = 0; oj < OJ; ++oj) v1[oj] = src1[oj * (VK * NS)];
+            char *lp0 = reinterpret_cast<char *>(p.values + ((3 * (i64)Pb - 1) * T1 * T2 + 3 * (cumJ0 * T2)));
+            char *lp1 = lp0 + 8 * (3 * T1 * T2);
+#pragma unroll
+            for (int oj = 0; oj < OJ; ++oj) {
+              *reinterpret_cast<double *>(lp0 + voff8) = v0[oj];
+              lp0 += stride8;
+            }
+#pragma unroll
+            for (int oj = 0; oj < OJ; ++oj) {
+              *reinterpret_cast<double *>(lp1 + voff8) = v1[oj];
+              lp1 += stride8;
+            }
+          }
+        } else if (!lowJ && !highJ) planes(std::integral_constant<int, 0>{});
         else if (!(lowJ && highJ)) planes(std::integral_constant<int, 1>{});
         else planes(std::integral_constant<int, 2>{});
       }
