@@ -121,7 +121,7 @@ __device__ __forceinline__ void load_vertex_tile(const P1Args &p, bool valid, in
 
 // VEC: instead of the matrix, out (+)= K u is assembled -- the same element matrices applied to the nodal values u on the fly and
 // reduced into ONE slot per row (residual of the same form: evaluable.py:3405-3411 Inflate + add.at in the reference).
-template <int TJ, int TK, int L, bool VEC, bool MASS>
+template <int TJ, int TK, int L, bool VEC, bool MASS, bool COEF>
 __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
 #ifdef NH_ABLATION
   long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
@@ -199,7 +199,9 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
         double qs[8];  // coefficient at the Gauss points (1 without a coefficient array)
 #pragma unroll
         for (int q = 0; q < 8; ++q) qs[q] = 1.;
-        if (p.qscale) {
+        // (COEF is a separate instantiation: a conditional global load here makes the compiler wait for ALL outstanding vector memory
+        // operations -- the vertex prefetch just issued, the stores of the last flush -- at the first use, also when it is not taken)
+        if (COEF && p.qscale) {
           const double *src = p.qscale + (((i64)gi * p.n1 + gj) * p.n2 + gk) * 8;
 #pragma unroll
           for (int q = 0; q < 8; ++q) qs[q] = src[q];
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
         double qm[8];  // mass coefficient at the Gauss points
 #pragma unroll
         for (int q = 0; q < 8; ++q) qm[q] = 1.;
-        if (MASS && p.qmass) {
+        if (MASS && COEF && p.qmass) {
           const double *src = p.qmass + (((i64)gi * p.n1 + gj) * p.n2 + gk) * 8;
 #pragma unroll
           for (int q = 0; q < 8; ++q) qm[q] = src[q];
@@ -377,7 +379,54 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
           }
         }
         };
-        if (L == 2 && !lowJ && !highJ && Pe - Pb == 2 && Pb > 0 && Pe < N0) {
+        if (L == 2 && NT == 512 && KP == 1 && !lowJ && !highJ && Pe - Pb == 2 && Pb > 0 && Pe < N0 && K0 > 0 && K0 + OK < N2) {
+          // fully interior step (59 % of the steps at 128^3): all rows have 27 entries, a K line is 405 contiguous doubles.  Half a
+          // workgroup takes one line, TWO CONSECUTIVE ENTRIES PER LANE: the vector-memory issue path of a CU carries address + data of
+          // one 64-lane store per ~16 cycles whatever its width, so 16-byte stores halve the instruction count of this phase.
+          const int l = tid & 255, half = __builtin_amdgcn_readfirstlane(tid >> 8), e = 2 * l;
+          auto source = [&](int ee, bool &below) {  // LDS position of entry ee of the line, relative to (plane, first owned line)
+            const int ok_ = ee / 27, sl_ = ee - ok_ * 27;
+            const int dJ_ = (sl_ / 3) % 3 - 1, dK_ = sl_ % 3 - 1;
+            below = sl_ < 9;
+            return (VK + ok_ + 1) * NS + (sl_ >= 13 ? sl_ - 13 : (dJ_ * VK + dK_) * NS + 13 - sl_);
+          };
+          bool belowA, belowB;
+          const int offA = source(e < 405 ? e : 404, belowA) + half * (VK * NS), offB = source(e + 1 < 405 ? e + 1 : 404, belowB) + half * (VK * NS);
+          double a0[2][8], a1[2][8];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const double *sA = acc + (belowA ? slot_of(Pb + pl - 1) : slot_of(Pb + pl)) + offA;
+            const double *sB = acc + (belowB ? slot_of(Pb + pl - 1) : slot_of(Pb + pl)) + offB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {  // (line 15 of the odd half lies in the halo: read, not stored)
+              a0[pl][i] = sA[i * (2 * VK * NS)];
+              a1[pl][i] = sB[i * (2 * VK * NS)];
+            }
+          }
+          const i64 stride8 = 8 * (i64)(9 * (int)T2);
+          char *const base = reinterpret_cast<char *>(p.values + ((3 * (i64)Pb - 1) * T1 * T2 + 3 * (cumJ0 * T2) + 9 * (3 * (i64)K0 - 1))) + half * stride8;
+          const int nl = half ? 7 : 8;
+          if (l < 202) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+              char *lp = base + pl * (8 * (3 * T1 * T2)) + 16 * l;
+#pragma unroll
+              for (int i = 0; i < 8; ++i)
+                if (i < nl) {
+                  const double2 v = make_double2(a0[pl][i], a1[pl][i]);
+                  __builtin_memcpy(lp + i * (2 * stride8), &v, 16);  // 8-byte aligned 16-byte store
+                }
+            }
+          } else if (l == 202) {  // 405 is odd: the last entry of a line goes alone
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+              char *lp = base + pl * (8 * (3 * T1 * T2)) + 16 * l;
+#pragma unroll
+              for (int i = 0; i < 8; ++i)
+                if (i < nl) *reinterpret_cast<double *>(lp + i * (2 * stride8)) = a0[pl][i];
+            }
+          }
+        } else if (L == 2 && !lowJ && !highJ && Pe - Pb == 2 && Pb > 0 && Pe < N0) {
           // the common step: two planes, nothing on a boundary except possibly K -- one set of lane constants, ONE exec region, the 30
           // LDS reads of both planes in flight before the first of the 30 stores
           const int flag = 1 | 2 | loK << 2 | 8 | 16 | hiK << 5;
@@ -561,7 +610,7 @@ __global__ void k_p1hex_pattern(int n0, int n1, int n2, i64 row0, i64 row1, i64 
 }  // namespace
 
 // launch of the marching kernel (matrix: VEC = false; K u: VEC = true)
-template <bool VEC, bool MASS>
+template <bool VEC, bool MASS, bool COEF>
 static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
 #ifdef NH_ABLATION
   p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
@@ -576,7 +625,7 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
   const i64 units = (i64)p.nbj * p.nbk * (p.pl1 - p.pl0);
   NH_REQUIRE(a->max_workgroups >= 0, "nh_p1hex: negative max_workgroups");
   const unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
-  auto kern = k_p1hex_march<TJ, TK, L, VEC, MASS>;
+  auto kern = k_p1hex_march<TJ, TK, L, VEC, MASS, COEF>;
   NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
 #ifdef NH_ABLATION
   static long long *tdbg = nullptr;
@@ -600,7 +649,9 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
 
 template <bool VEC>
 static int launch_march(const nh_p1hex_args *a, P1Args &p, void *stream) {
-  return p.hasm ? launch_march_inst<VEC, true>(a, p, stream) : launch_march_inst<VEC, false>(a, p, stream);
+  const bool coef = p.qscale || p.qmass;
+  if (p.hasm) return coef ? launch_march_inst<VEC, true, true>(a, p, stream) : launch_march_inst<VEC, true, false>(a, p, stream);
+  return coef ? launch_march_inst<VEC, false, true>(a, p, stream) : launch_march_inst<VEC, false, false>(a, p, stream);
 }
 
 extern "C" {
