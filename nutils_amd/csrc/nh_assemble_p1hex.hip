@@ -114,7 +114,7 @@ __device__ __forceinline__ void load_vertex_tile(const P1Args &p, bool valid, in
       V[k][0] = src[0];
       V[k][1] = src[1];
       V[k][2] = src[2];
-      if (VW == 4) V[k][3] = p.u[node];
+      if constexpr (VW == 4) V[k][3] = p.u[node];
     }
   }
 }
