@@ -221,34 +221,28 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
 #include "nh_p1hex_math.inc"
 #undef NH_P1HEX_QS
 #undef NH_P1HEX_QM
-        double Kt[36];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
+        // the 36 entries a <= b of the local matrix: nine signed table values each (+ the mass term)
+        auto entry = [&](int a, int bb) {
           const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
-#pragma unroll
-          for (int bb = a; bb < 8; ++bb) {
-            const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
-            const int p0 = a0 + b0, p1 = a1 + b1, p2 = a2 + b2;
-            const double s00 = (a0 == b0) ? 1. : -1., s11 = (a1 == b1) ? 1. : -1., s22 = (a2 == b2) ? 1. : -1.;
-            const double s01 = (a0 == b1) ? 1. : -1., s10 = (b0 == a1) ? 1. : -1.;
-            const double s02 = (a0 == b2) ? 1. : -1., s20 = (b0 == a2) ? 1. : -1.;
-            const double s12 = (a1 == b2) ? 1. : -1., s21 = (b1 == a2) ? 1. : -1.;
-            Kt[a * 8 - a * (a - 1) / 2 + (bb - a)] = s00 * R0[p1][p2] + s11 * R1[p0][p2] + s22 * R2[p0][p1]
-                                                   + s01 * W01[b0][a1][p2] + s10 * W01[a0][b1][p2]
-                                                   + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1]
-                                                   + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
-          }
-        }
-        if (hasm) {
-#pragma unroll
-          for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int bb = a; bb < 8; ++bb)
-              Kt[a * 8 - a * (a - 1) / 2 + (bb - a)] += Mm[(a >> 2) + (bb >> 2)][((a >> 1) & 1) + ((bb >> 1) & 1)][(a & 1) + (bb & 1)];
-        }
+          const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
+          const int p0 = a0 + b0, p1 = a1 + b1, p2 = a2 + b2;
+          const double s00 = (a0 == b0) ? 1. : -1., s11 = (a1 == b1) ? 1. : -1., s22 = (a2 == b2) ? 1. : -1.;
+          const double s01 = (a0 == b1) ? 1. : -1., s10 = (b0 == a1) ? 1. : -1.;
+          const double s02 = (a0 == b2) ? 1. : -1., s20 = (b0 == a2) ? 1. : -1.;
+          const double s12 = (a1 == b2) ? 1. : -1., s21 = (b1 == a2) ? 1. : -1.;
+          double k = s00 * R0[p1][p2] + s11 * R1[p0][p2] + s22 * R2[p0][p1] + s01 * W01[b0][a1][p2] + s10 * W01[a0][b1][p2]
+                   + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1] + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
+          if (hasm) k += Mm[p0][p1][p2];
+          return k;
+        };
         // reduce: the accumulated rows of a plane are the vertices of the tile, so every local vertex has a row (no masking)
         double *const pl[2] = {acc + slot_of(gi) + (ej * VK + ek) * NS, acc + slot_of(gi + 1) + (ej * VK + ek) * NS};
         if constexpr (VEC) {
+          double Kt[36];
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int bb = a; bb < 8; ++bb) Kt[a * 8 - a * (a - 1) / 2 + (bb - a)] = entry(a, bb);
 #pragma unroll
           for (int a = 0; a < 8; ++a) {
             double r = 0.;
@@ -260,17 +254,20 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
             atomicAdd(pl[a >> 2] + ((a >> 1) & 1) * VK + (a & 1), r);
           }
         } else {
+          // every entry goes to LDS as soon as it is formed: the ds_add_f64 stream overlaps the remaining arithmetic of the same wave
+          // (issued in one burst at the end, the 36 atomics of all waves pile up in front of the barrier)
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
-          const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
-          double *row = pl[a0] + (a1 * VK + a2) * NS;
-          if (DEBUG(p) & 1) { if (Kt[a] == 1.2345e300) row[0] = 1.; continue; }
+          for (int a = 0; a < 8; ++a) {
+            const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
+            double *row = pl[a0] + (a1 * VK + a2) * NS;
 #pragma unroll
-          for (int bb = a; bb < 8; ++bb) {
-            const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
-            atomicAdd(&row[(b0 - a0) * 9 + (b1 - a1) * 3 + (b2 - a2)], Kt[a * 8 - a * (a - 1) / 2 + (bb - a)]);
+            for (int bb = a; bb < 8; ++bb) {
+              const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
+              const double k = entry(a, bb);
+              if (!(DEBUG(p) & 1)) atomicAdd(&row[(b0 - a0) * 9 + (b1 - a1) * 3 + (b2 - a2)], k);
+              else if (k == 1.2345e300) row[0] = 1.;
+            }
           }
-        }
         }
       }
     }
