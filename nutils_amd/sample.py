@@ -340,16 +340,18 @@ class _MatrixPlan:
         if ref is None or not (numpy.array_equal(smp.points.coords, ref.coords) and numpy.array_equal(smp.points.weights, ref.weights)):
             return None
         kappa, mass, geom, qscale, qmass = 0., 0., None, None, None
-        for _, itg, fac in self.terms:
+        rest = []  # terms of another shape (advection, product-rule tensors ...): added by the generic kernel afterwards
+        for term in self.terms:
+            _, itg, fac = term
             B = numpy.asarray(itg.B, dtype=float) * fac
-            if B.shape != (1, 4, 1, 4) or itg.qform is not None:
-                return None
-            B = B[0, :, 0, :]
-            m, k = B[0, 0], B[1, 1]  # mass and diffusion coefficient of the term: B = diag(m, k, k, k)
-            if not numpy.array_equal(B, numpy.diag([m, k, k, k])):
-                return None
-            if geom is not None and itg.measure is not geom:
-                return None
+            ok = B.shape == (1, 4, 1, 4) and itg.qform is None
+            if ok:
+                B = B[0, :, 0, :]
+                m, k = B[0, 0], B[1, 1]  # mass and diffusion coefficient of the term: B = diag(m, k, k, k)
+                ok = numpy.array_equal(B, numpy.diag([m, k, k, k])) and (geom is None or itg.measure is geom)
+            if not ok:
+                rest.append(term)
+                continue
             geom = itg.measure
             if itg.scale is None and itg.fscale is None and itg.qscalar is None:
                 kappa += k
@@ -360,6 +362,8 @@ class _MatrixPlan:
                     qscale = sc * k if qscale is None else qscale.add_(sc, alpha=k)
                 if m:
                     qmass = sc * m if qmass is None else qmass.add_(sc, alpha=m)
+        if geom is None:
+            return None
         if qscale is not None:
             if kappa:
                 qscale = qscale + kappa
@@ -394,18 +398,21 @@ class _MatrixPlan:
         values = device.empty(colidx.numel(), 'float64')  # write-once kernel: no zero-fill
         kernels.p1hex_laplace(shape=basis.shape, values=values, gauss_x=list(x1), gauss_w=list(w1), verts=verts, origin=origin, scale=scale, kappa=kappa,
                               qscale=qscale, mass=mass, qmass=qmass)
-        return values, rowptr, colidx, basis.ndofs
+        return values, rowptr, colidx, basis.ndofs, rest
 
     def run(self, arguments=None):
         fast = self._p1hex_laplace(arguments)
-        if fast is not None:
-            return fast
+        if fast is not None and not fast[4]:
+            return fast[:4]
         pat = self.smp0.pattern(self.test.basis, self.trial.basis)
         nct, ncr = self.test.ncomp, self.trial.ncomp
         mask = None if self.mask.all() else self.mask
         rowptr, colidx = pat.expand(nct, ncr, mask)
-        values = device.zeros(colidx.numel(), 'float64')
-        for smp, itg, fac in self.terms:
+        if fast is not None:  # same sorted-unique pattern: the generic kernel accumulates the remaining terms into the write-once result
+            values, terms = fast[0], fast[4]
+        else:
+            values, terms = device.zeros(colidx.numel(), 'float64'), self.terms
+        for smp, itg, fac in terms:
             if itg.measure is None:
                 raise NotImplementedError('integrand without J(geom): reference-space integrals are outside the accelerated path')
             tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)

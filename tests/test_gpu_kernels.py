@@ -386,3 +386,29 @@ def test_p1hex_fast_path_mass_and_stiffness(iso, coeff, monkeypatch):
     close(rf, rg)
     import scipy.sparse
     close(scipy.sparse.csr_matrix((vf, cif, rpf), (len(basis),) * 2) @ args['u'], rg)
+
+
+def test_p1hex_fast_path_mixed_terms(monkeypatch):
+    '''Diffusion + advection + reaction on the trilinear basis: the symmetric part takes the write-once kernel, the advection term (not
+    of that shape) is added by the generic kernel into the same array; result equal to the all-generic assembly.'''
+    from nutils_amd import mesh, function, kernels
+    shape = (7, 18, 20)
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1, n + 1) for n in shape])
+    basis = domain.basis('std', degree=1)
+    dV = function.J(geom)
+    gg = function.outer(function.grad(basis, geom)).sum(-1)
+    adv = function.outer(basis, (function.grad(basis, geom) * numpy.array([1., -2., .5])).sum(-1))
+    K = domain.integral(.3 * gg * dV, degree=2) + domain.integral(adv * dV, degree=2) + domain.integral(4. * function.outer(basis) * dV, degree=2)
+    calls = []
+    orig = kernels.p1hex_laplace
+    monkeypatch.setattr(kernels, 'p1hex_laplace', lambda **kw: (calls.append(1), orig(**kw))[1])
+    monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')
+    vg, rpg, cig = function.eval(function.as_csr(K))
+    monkeypatch.delenv('NUTILS_AMD_NO_FAST_PATH')
+    vf, rpf, cif = function.eval(function.as_csr(K))
+    assert calls == [1]
+    assert numpy.array_equal(rpg, rpf) and numpy.array_equal(cig, cif)
+    close(vf, vg)
+    import scipy.sparse
+    A = scipy.sparse.csr_matrix((vf, cif, rpf), (len(basis),) * 2)
+    assert abs(A - A.T).max() > 1e-3  # the advection term is there
