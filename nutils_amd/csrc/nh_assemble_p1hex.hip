@@ -140,8 +140,12 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
   const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
   const int NPL = p.pl1 - p.pl0;
   const i64 U = (i64)p.nbj * p.nbk * NPL;
-  i64 u = U * blockIdx.x / gridDim.x;
-  const i64 u1 = U * (blockIdx.x + 1) / gridDim.x;
+  // XCD-aware work order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b runs on XCD b % 8;
+  // give the workgroups of one XCD a CONTIGUOUS range of (column, plane) units -- neighbours in the mesh share vertex planes and the
+  // partially written cache lines at the tile edges in the same L2
+  const unsigned wg = gridDim.x % 8 == 0 ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+  i64 u = U * wg / gridDim.x;
+  const i64 u1 = U * (wg + 1) / gridDim.x;
   if (u >= u1) return;
   auto slot_of = [](int P) { return (int)((unsigned)(P + 2 * NP) % NP) * PS; };  // P >= -2
   // current run: planes [A, B) of column (cj, ck); current step: element layers [L0, L0 + L)
