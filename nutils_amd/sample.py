@@ -79,6 +79,7 @@ class Sample:
         self.npoints = self.nlist * points.npoints
         self._scales = {}
         self._tables = {}
+        self._p1verts = {}
         self._geoms = {}
         self._patterns = {}
         self.__dev = None
@@ -109,11 +110,7 @@ class Sample:
         values (FieldPoly, re-evaluated on the device for the current arguments); None if neither is present.'''
         out = None
         if pf is not None:
-            s = self._scales.get(id(pf))
-            if s is None:
-                x = self._eval_one(pf.geom, {})
-                s = self._scales[id(pf)] = (device.to_dev(pf(x), 'float64'), pf)
-            out = s[0]
+            out = _cached(self._scales, pf, lambda: device.to_dev(pf(self._eval_one(pf.geom, {})), 'float64'), limit=16)
         if fp is not None:
             nq, nd, ne = self.points.npoints, self.ndims, self.nlist
             xs = []
@@ -137,24 +134,21 @@ class Sample:
         return t
 
     def geometry(self, geom):
-        g = self._geoms.get(id(geom))
-        if g is None:
+        def make():
             if isinstance(geom, function.IsoGeometry):
                 t = self.tables(geom.basis)
-                g = kernels.geometry_iso(geom.basis.nb, t.T, t.dofs, device.to_dev(geom.verts, 'float64'), self.bnd_axis)
-            elif isinstance(geom, (function.RectilinearGeometry, function.BoxGeometry)):
+                return kernels.geometry_iso(geom.basis.nb, t.T, t.dofs, device.to_dev(geom.verts, 'float64'), self.bnd_axis)
+            if isinstance(geom, (function.RectilinearGeometry, function.BoxGeometry)):
                 origin, size = geom.element_boxes()
                 if len(origin) != self.nelems:
                     raise ValueError('geometry does not match the sample')
-                g = kernels.geometry_box(device.to_dev(origin, 'float64'), device.to_dev(size, 'float64'), self.bnd_axis)
-            elif isinstance(geom, function.TabulatedGeometry):
+                return kernels.geometry_box(device.to_dev(origin, 'float64'), device.to_dev(size, 'float64'), self.bnd_axis)
+            if isinstance(geom, function.TabulatedGeometry):
                 if geom.x.shape[:2] != (self.nelems, self.points.npoints):
                     raise ValueError('tabulated geometry does not match this sample')
-                g = kernels.geometry_tab(device.to_dev(geom.jac, 'float64'), device.to_dev(geom.x, 'float64'), self.bnd_axis)
-            else:
-                raise TypeError(f'unsupported geometry {type(geom).__name__}')
-            self._geoms[id(geom)] = g
-        return g
+                return kernels.geometry_tab(device.to_dev(geom.jac, 'float64'), device.to_dev(geom.x, 'float64'), self.bnd_axis)
+            raise TypeError(f'unsupported geometry {type(geom).__name__}')
+        return _cached(self._geoms, geom, make)
 
     def pattern(self, test_basis, trial_basis):
         key = id(test_basis), id(trial_basis)
@@ -273,6 +267,21 @@ def _colors(smp, basis):
     return smp._tables[key]
 
 
+def _cached(cache, obj, make, limit=4):
+    '''Device-side companion of a host object (geometry, coefficient function), cached by identity.  The entry keeps the object alive
+    -- so its id cannot be recycled for a different object while the entry exists -- and the cache is bounded: scripts that build a
+    new geometry object per time step do not accumulate vertex arrays on the device.'''
+    entry = cache.get(id(obj))
+    if entry is None or entry[0] is not obj:
+        value = make()
+        if value is None:
+            return None
+        while len(cache) >= limit:
+            cache.pop(next(iter(cache)))
+        entry = cache[id(obj)] = (obj, value)
+    return entry[1]
+
+
 def _field_values(smp, arg, geom, arguments):
     '''U[e q][1 + nd]: value and gradient (w.r.t. `geom`) of a scalar field at the points of the sample, on the device.'''
     nq, S = smp.points.npoints, 1 + smp.ndims
@@ -377,18 +386,11 @@ class _MatrixPlan:
             g = geom.basis
             if not (isinstance(g, StructuredBasis) and g.btype == 'std' and g.degree == 1 and g.shape == basis.shape and g.dofs_shape == basis.dofs_shape):
                 return None
-            key = 'p1hex_verts', id(geom)
-            if key not in smp._tables:
-                smp._tables[key] = device.to_dev(geom.verts, 'float64')
-            verts = smp._tables[key]
+            verts = _cached(smp._p1verts, geom, lambda: device.to_dev(geom.verts, 'float64'))
         elif isinstance(geom, function.RectilinearGeometry) and geom.topo.shape == basis.shape:
             origin, scale = tuple(geom.offset), tuple(geom.scale)
             if qscale is not None or qmass is not None:  # element matrices differ: explicit vertices for the isoparametric kernel
-                key = 'p1hex_verts', id(geom)
-                if key not in smp._tables:
-                    idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in basis.shape], indexing='ij'), -1).reshape(-1, 3)
-                    smp._tables[key] = device.to_dev(geom.offset + geom.scale * idx, 'float64')
-                verts = smp._tables[key]
+                verts = _cached(smp._p1verts, geom, lambda: _rectilinear_vertices(geom, basis.shape))
         else:
             return None
         key = 'p1hex_pattern', basis.shape
@@ -447,6 +449,11 @@ class _MatrixPlan:
         return values, rowptr, colidx, self.trial.basis.ndofs * ncr
 
 
+def _rectilinear_vertices(geom, shape):
+    idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3)
+    return device.to_dev(geom.offset + geom.scale * idx, 'float64')
+
+
 def _p1hex_setting(smp, basis, geom):
     '''(vertices on the device, 1-D Gauss points and weights) if `basis` is the trilinear 'std' basis of the full 3-D structured
     topology of `smp`, sampled with 2-point Gauss per axis, on a rectilinear or isoparametric-P1 geometry; else None.'''
@@ -459,20 +466,19 @@ def _p1hex_setting(smp, basis, geom):
     ref = _points.gauss(2, 3)
     if not (numpy.array_equal(smp.points.coords, ref.coords) and numpy.array_equal(smp.points.weights, ref.weights)):
         return None
-    key = 'p1hex_verts', id(geom)
-    if key not in smp._tables:
+    def make():
         if isinstance(geom, function.IsoGeometry):
             g = geom.basis
-            if not (isinstance(g, StructuredBasis) and g.btype == 'std' and g.degree == 1 and g.shape == basis.shape and g.dofs_shape == basis.dofs_shape):
-                return None
-            smp._tables[key] = device.to_dev(geom.verts, 'float64')
+            if isinstance(g, StructuredBasis) and g.btype == 'std' and g.degree == 1 and g.shape == basis.shape and g.dofs_shape == basis.dofs_shape:
+                return device.to_dev(geom.verts, 'float64')
         elif isinstance(geom, function.RectilinearGeometry) and geom.topo.shape == basis.shape:
-            idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in basis.shape], indexing='ij'), -1).reshape(-1, 3)
-            smp._tables[key] = device.to_dev(geom.offset + geom.scale * idx, 'float64')
-        else:
-            return None
+            return _rectilinear_vertices(geom, basis.shape)
+        return None
+    verts = _cached(smp._p1verts, geom, make)
+    if verts is None:
+        return None
     x1, w1 = _points.gauss1(2)
-    return smp._tables[key], list(x1), list(w1)
+    return verts, list(x1), list(w1)
 
 
 def _p1hex_apply_term(smp, itg, fac, arguments, out):
