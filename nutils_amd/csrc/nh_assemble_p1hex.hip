@@ -219,6 +219,17 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) qm[q] = src[q];
         }
+        double *const pl[2] = {acc + slot_of(gi) + (ej * VK + ek) * NS, acc + slot_of(gi + 1) + (ej * VK + ek) * NS};
+        if constexpr (VEC) {
+          double r[8];
+#define NH_P1HEX_QS(q) qs[q]
+#define NH_P1HEX_QM(q) qm[q]
+#include "nh_p1hex_apply.inc"
+#undef NH_P1HEX_QS
+#undef NH_P1HEX_QM
+#pragma unroll
+          for (int a = 0; a < 8; ++a) atomicAdd(pl[a >> 2] + ((a >> 1) & 1) * VK + (a & 1), r[a]);
+        } else {
         double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3], Mm[3][3][3];
 #define NH_P1HEX_QS(q) qs[q]
 #define NH_P1HEX_QM(q) qm[q]
@@ -239,25 +250,7 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
           if (hasm) k += Mm[p0][p1][p2];
           return k;
         };
-        // reduce: the accumulated rows of a plane are the vertices of the tile, so every local vertex has a row (no masking)
-        double *const pl[2] = {acc + slot_of(gi) + (ej * VK + ek) * NS, acc + slot_of(gi + 1) + (ej * VK + ek) * NS};
-        if constexpr (VEC) {
-          double Kt[36];
-#pragma unroll
-          for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int bb = a; bb < 8; ++bb) Kt[a * 8 - a * (a - 1) / 2 + (bb - a)] = entry(a, bb);
-#pragma unroll
-          for (int a = 0; a < 8; ++a) {
-            double r = 0.;
-#pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-              const int lo = a < bb ? a : bb, hi = a < bb ? bb : a;
-              r += Kt[lo * 8 - lo * (lo - 1) / 2 + (hi - lo)] * un[bb];
-            }
-            atomicAdd(pl[a >> 2] + ((a >> 1) & 1) * VK + (a & 1), r);
-          }
-        } else {
+        {  // reduce: the accumulated rows of a plane are the vertices of the tile, so every local vertex has a row (no masking)
           // every entry goes to LDS as soon as it is formed: the ds_add_f64 stream overlaps the remaining arithmetic of the same wave
           // (issued in one burst at the end, the 36 atomics of all waves pile up in front of the barrier)
 #pragma unroll
@@ -273,6 +266,7 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
             }
           }
         }
+        }  // !VEC
       }
     }
     NH_TICK(2)
