@@ -187,86 +187,9 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
       const int lay = tid / (TJ * TK), el = tid % (TJ * TK), ej = el / TK, ek = el % TK;
       const int gi = L0 + lay, gj = J0 - 1 + ej, gk = K0 - 1 + ek;
       if (gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2 && !(DEBUG(p) & 4)) {
-        double X[2][2][2][3], un[8];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              const double *src = vbuf + (((lay + a) * VJ + (ej + bb)) * VK + (ek + c)) * VW;
-              X[a][bb][c][0] = src[0];
-              X[a][bb][c][1] = src[1];
-              X[a][bb][c][2] = src[2];
-              un[a * 4 + bb * 2 + c] = VEC ? src[VW - 1] : 0.;
-            }
-        double qs[8];  // coefficient at the Gauss points (1 without a coefficient array)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) qs[q] = 1.;
-        // (COEF is a separate instantiation: a conditional global load here makes the compiler wait for ALL outstanding vector memory
-        // operations -- the vertex prefetch just issued, the stores of the last flush -- at the first use, also when it is not taken)
-        if (COEF && p.qscale) {
-          const double *src = p.qscale + (((i64)gi * p.n1 + gj) * p.n2 + gk) * 8;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) qs[q] = src[q];
-        }
-        constexpr bool hasm = MASS;  // separate instantiation: the mass tables would cost the stiffness-only kernel 70 VGPRs (spills)
-        double qm[8];  // mass coefficient at the Gauss points
-#pragma unroll
-        for (int q = 0; q < 8; ++q) qm[q] = 1.;
-        if (MASS && COEF && p.qmass) {
-          const double *src = p.qmass + (((i64)gi * p.n1 + gj) * p.n2 + gk) * 8;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) qm[q] = src[q];
-        }
-        double *const pl[2] = {acc + slot_of(gi) + (ej * VK + ek) * NS, acc + slot_of(gi + 1) + (ej * VK + ek) * NS};
-        if constexpr (VEC) {
-          double r[8];
-#define NH_P1HEX_QS(q) qs[q]
-#define NH_P1HEX_QM(q) qm[q]
-#include "nh_p1hex_apply.inc"
-#undef NH_P1HEX_QS
-#undef NH_P1HEX_QM
-#pragma unroll
-          for (int a = 0; a < 8; ++a) atomicAdd(pl[a >> 2] + ((a >> 1) & 1) * VK + (a & 1), r[a]);
-        } else {
-        double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3], Mm[3][3][3];
-#define NH_P1HEX_QS(q) qs[q]
-#define NH_P1HEX_QM(q) qm[q]
-#include "nh_p1hex_math.inc"
-#undef NH_P1HEX_QS
-#undef NH_P1HEX_QM
-        // the 36 entries a <= b of the local matrix: nine signed table values each (+ the mass term)
-        auto entry = [&](int a, int bb) {
-          const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
-          const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
-          const int p0 = a0 + b0, p1 = a1 + b1, p2 = a2 + b2;
-          const double s00 = (a0 == b0) ? 1. : -1., s11 = (a1 == b1) ? 1. : -1., s22 = (a2 == b2) ? 1. : -1.;
-          const double s01 = (a0 == b1) ? 1. : -1., s10 = (b0 == a1) ? 1. : -1.;
-          const double s02 = (a0 == b2) ? 1. : -1., s20 = (b0 == a2) ? 1. : -1.;
-          const double s12 = (a1 == b2) ? 1. : -1., s21 = (b1 == a2) ? 1. : -1.;
-          double k = s00 * R0[p1][p2] + s11 * R1[p0][p2] + s22 * R2[p0][p1] + s01 * W01[b0][a1][p2] + s10 * W01[a0][b1][p2]
-                   + s02 * W02[b0][a2][p1] + s20 * W02[a0][b2][p1] + s12 * W12[b1][a2][p0] + s21 * W12[a1][b2][p0];
-          if (hasm) k += Mm[p0][p1][p2];
-          return k;
-        };
-        {  // reduce: the accumulated rows of a plane are the vertices of the tile, so every local vertex has a row (no masking)
-          // every entry goes to LDS as soon as it is formed: the ds_add_f64 stream overlaps the remaining arithmetic of the same wave
-          // (issued in one burst at the end, the 36 atomics of all waves pile up in front of the barrier)
-#pragma unroll
-          for (int a = 0; a < 8; ++a) {
-            const int a0 = a >> 2, a1 = (a >> 1) & 1, a2 = a & 1;
-            double *row = pl[a0] + (a1 * VK + a2) * NS;
-#pragma unroll
-            for (int bb = a; bb < 8; ++bb) {
-              const int b0 = bb >> 2, b1 = (bb >> 1) & 1, b2 = bb & 1;
-              const double k = entry(a, bb);
-              if (!(DEBUG(p) & 1)) atomicAdd(&row[(b0 - a0) * 9 + (b1 - a1) * 3 + (b2 - a2)], k);
-              else if (k == 1.2345e300) row[0] = 1.;
-            }
-          }
-        }
-        }  // !VEC
+#define NH_P1HEX_VERT(a, bb, c) (vbuf + (((lay + (a)) * VJ + (ej + (bb))) * VK + (ek + (c))) * VW)
+#include "nh_p1hex_element.inc"
+#undef NH_P1HEX_VERT
       }
     }
     NH_TICK(2)
@@ -476,6 +399,229 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
 }
 #undef NH_TICK
 
+// ---- skewed marching kernel (matrix): the two halves of the workgroup alternate roles every slot ----------------------------------
+// In the kernel above all waves compute (f64 VALU saturated, memory idle) and then all waves flush (memory busy, VALU idle), and the
+// kernel time is the sum of the two phases.  Here a slot is ONE element layer: half A (4 waves, one per SIMD) computes layer s while
+// half B streams the plane completed one slot earlier to HBM, recycles a plane slot and stages the vertex plane of the next layer;
+// in the next slot the roles are swapped.  Plane P is complete after layers P-1 and P and is flushed in slot P+1 by the half that
+// computed layer P; the flush reads planes P-1 and P, the concurrent arithmetic writes planes P+1 and P+2: four plane slots, no
+// conflict.  One workgroup barrier per slot; the flushing half needs one barrier of its own (all its reads of plane P-2 before the
+// slot is zeroed): an LDS counter, since s_barrier cannot address half a workgroup.
+// The gain is modest (-3.3 % in steady-state A/B runs at 128^3): a lone wave per SIMD sustains only 65 % of the f64 rate of two, so the
+// arithmetic of a layer takes 7.9 k cycles instead of 5; the stores of a plane take ~7.6 k at the chip-wide write rate, plus ~2.7 k
+// until they are acknowledged (the wait for the vertex loads of the same waves is a wait for everything before it: one in-order
+// counter).  DESIGN.md section 5 lists the variants that were measured slower (fixed roles with LDS-counter hand-offs, a fourth wave
+// that only recycles and stages, vertex loads from the computing half, ...).
+__device__ __forceinline__ void half_arrive(unsigned *cnt) {  // this wave's LDS reads have returned
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) atomicAdd(cnt, 1u);
+}
+__device__ __forceinline__ void half_wait(unsigned *cnt, unsigned target) {
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
+template <int TJ, int TK, bool MASS, bool COEF>
+__global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
+  constexpr bool VEC = false;
+#ifdef NH_ABLATION
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#define NH_TICK(i) { const long long tnow = clock64(); tacc[i] += tnow - tprev; tprev = tnow; }
+#else
+#define NH_TICK(i)
+#endif
+  constexpr int G = TJ * TK, NT = 2 * G, NP = 4, OJ = TJ - 1, OK = TK - 1, NS = 15, VW = 3;
+  constexpr int VJ = TJ + 1, VK = TK + 1, RP = VJ * VK, PS = (RP * NS + 1) & ~1, VPG = (RP + G - 1) / G;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *acc = lds;                                               // [NP][RP][NS], plane stride PS
+  double *vbuf = lds + NP * PS;                                    // [3][VJ][VK][VW]
+  unsigned *hcnt = reinterpret_cast<unsigned *>(vbuf + 3 * RP * VW);  // arrivals at the half barrier
+  const int tid = threadIdx.x, lt = tid & (G - 1), grp = __builtin_amdgcn_readfirstlane(tid / G);
+  const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
+  const int NPL = p.pl1 - p.pl0;
+  const i64 U = (i64)p.nbj * p.nbk * NPL;
+  const unsigned wg = gridDim.x % 8 == 0 ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;  // XCD-aware, as above
+  i64 u = U * wg / gridDim.x;
+  const i64 u1 = U * (wg + 1) / gridDim.x;
+  if (u >= u1) return;
+  auto slot_of = [](int P) { return (int)((unsigned)(P + 2 * NP) % NP) * PS; };  // P >= -2 * NP
+  auto vslot_of = [](int P) { return (int)((unsigned)(P + 3) % 3) * (RP * VW); };  // P >= -3
+  auto load_vertex = [&](int I, int r, int J0, int K0, double (&x)[3]) {
+    const int bb = r / VK, c = r % VK, J = J0 - 1 + bb, K = K0 - 1 + c;
+    x[0] = x[1] = x[2] = 0.;
+    if (r < RP && I >= 0 && I < N0 && J >= 0 && J < N1 && K >= 0 && K < N2) {
+      const double *src = p.verts + (((i64)I * N1 + J) * N2 + K) * 3;
+      x[0] = src[0], x[1] = src[1], x[2] = src[2];
+    }
+  };
+  if (tid == 0) *hcnt = 0;
+  unsigned htarget = 0;
+  const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;
+
+  while (u < u1) {
+    // run: planes [A, B) of column col; element layers A-1 .. B-1 in slots A-1 .. B-1, plane P flushed in slot P+1
+    const int col = (int)(u / NPL), A = p.pl0 + (int)(u % NPL), B = (int)min((i64)p.pl1, A + (u1 - u));
+    const int J0 = (col / p.nbk) * OJ, K0 = (col % p.nbk) * OK;
+    for (int t = tid; t < NP * PS / 2; t += NT) reinterpret_cast<double2 *>(acc)[t] = make_double2(0., 0.);
+#pragma unroll
+    for (int k = 0; k < (2 * RP + NT - 1) / NT; ++k) {  // vertex planes A-1 and A
+      const int v = tid + k * NT, pl = v / RP, r = v % RP;
+      if (v < 2 * RP) {
+        double x[3];
+        load_vertex(A - 1 + pl, r, J0, K0, x);
+        double *dst = vbuf + vslot_of(A - 1 + pl) + r * VW;
+        dst[0] = x[0], dst[1] = x[1], dst[2] = x[2];
+      }
+    }
+    lds_barrier();
+
+    for (int s = A - 1; s <= B; ++s) {
+      htarget += G / 64;
+      NH_TICK(0)
+      const bool mathrole = ((s - (A - 1)) & 1) == grp;
+      if (mathrole) {
+        // ---- arithmetic role: element layer s -------------------------------------------------------------------------------
+        const int ej = lt / TK, ek = lt % TK;
+        const int gi = s, gj = J0 - 1 + ej, gk = K0 - 1 + ek;
+        if (s < B && gi >= p.lay0 && gi < p.lay1 && gj >= 0 && gj < p.n1 && gk >= 0 && gk < p.n2 && !(DEBUG(p) & 4)) {
+#define NH_P1HEX_VERT(a, bb, c) (vbuf + vslot_of(gi + (a)) + ((ej + (bb)) * VK + (ek + (c))) * VW)
+#include "nh_p1hex_element.inc"
+#undef NH_P1HEX_VERT
+        }
+        NH_TICK(3)
+      } else {
+        // ---- memory role: vertex plane s+2 (for layer s+1, next slot), flush of plane s-1, recycling of the slot of plane s-2 ------
+        const bool needv = s + 1 < B;  // vertex plane s+2 for layer s+1 (next slot): loaded in front of the stores, staged behind them
+        double Vn[VPG][3];
+#pragma unroll
+        for (int k = 0; k < VPG; ++k) load_vertex(needv ? s + 2 : -1, lt + k * G, J0, K0, Vn[k]);
+        const int P = s - 1;
+        bool arrived = false;
+        if (P >= A && !(DEBUG(p) & 2)) {
+          const bool lowJ = J0 == 0, highJ = J0 + OJ >= N1;
+          const int cumJ0 = J0 == 0 ? 0 : 3 * J0 - 1;
+          if (!lowJ && !highJ && P > 0 && P < N0 - 1 && K0 > 0 && K0 + OK < N2) {
+            // fully interior plane: every row has 27 entries, a K line is 405 contiguous doubles; two consecutive entries per lane
+            // (16-byte stores), one line per pass
+            const int e = 2 * lt;
+            auto source = [&](int ee, bool &below) {  // LDS position of entry ee of a line, relative to (plane, first owned line)
+              const int ok_ = ee / 27, sl_ = ee - ok_ * 27;
+              const int dJ_ = (sl_ / 3) % 3 - 1, dK_ = sl_ % 3 - 1;
+              below = sl_ < 9;
+              return (VK + ok_ + 1) * NS + (sl_ >= 13 ? sl_ - 13 : (dJ_ * VK + dK_) * NS + 13 - sl_);
+            };
+            bool belowA, belowB;
+            const int offA = source(e < 405 ? e : 404, belowA), offB = source(e + 1 < 405 ? e + 1 : 404, belowB);
+            const double *sA = acc + (belowA ? slot_of(P - 1) : slot_of(P)) + offA;
+            const double *sB = acc + (belowB ? slot_of(P - 1) : slot_of(P)) + offB;
+            double a0[OJ], a1[OJ];
+#pragma unroll
+            for (int i = 0; i < OJ; ++i) {
+              a0[i] = sA[i * (VK * NS)];
+              a1[i] = sB[i * (VK * NS)];
+            }
+            // 405 is odd: the last entries of the OJ lines go out in ONE more store of the last wave (lane 202 + i: line i)
+            const int li = lt - 202;
+            const bool lone = li >= 0 && li < OJ;
+            bool belowL;
+            const int offL = source(404, belowL);
+            const double aL = acc[(belowL ? slot_of(P - 1) : slot_of(P)) + offL + (lone ? li : 0) * (VK * NS)];
+            half_arrive(hcnt);
+            arrived = true;
+            const i64 stride8 = 8 * (i64)(9 * (int)T2);
+            char *l0 = reinterpret_cast<char *>(p.values + ((3 * (i64)P - 1) * T1 * T2 + 3 * (cumJ0 * T2) + 9 * (3 * (i64)K0 - 1)));
+            char *lp = l0 + 16 * lt;
+            if (lt < 202) {
+#pragma unroll
+              for (int i = 0; i < OJ; ++i) {
+                const double2 v = make_double2(a0[i], a1[i]);
+                __builtin_memcpy(lp + i * stride8, &v, 16);  // 8-byte aligned 16-byte store
+              }
+            }
+            if (lone) *reinterpret_cast<double *>(l0 + li * stride8 + 8 * 404) = aL;
+          } else {
+            // 32 lanes per row (27 slots), 8 rows per pass, two passes per K line
+            constexpr int RPP = G / 32, KP = (OK + RPP - 1) / RPP;
+            const int sl = lt & 31, rsub = lt >> 5;
+            const int dI = sl / 9 - 1, dJ = (sl / 3) % 3 - 1, dK = sl % 3 - 1;
+            const bool upper = sl >= 13;
+            const int need = (dI < 0 ? 1 : dI > 0 ? 8 : 0) | (dJ < 0 ? 2 : dJ > 0 ? 16 : 0) | (dK < 0 ? 4 : dK > 0 ? 32 : 0);
+            const int loI = P > 0, hiI = P < N0 - 1, lenI = loI + 1 + hiI;
+            double v[KP][OJ];  // ALL LDS reads of the plane first: the other half recycles the slot of plane s-2 as soon as they have returned
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) {
+              const int ok = kp * RPP + rsub;
+              const int srow = (VK + ok + 1) * NS + (upper ? sl - 13 : (dJ * VK + dK) * NS + 13 - sl);
+              const double *src = acc + ((!upper && dI < 0) ? slot_of(P - 1) : slot_of(P)) + (ok < OK ? srow : 0);
+#pragma unroll
+              for (int oj = 0; oj < OJ; ++oj) v[kp][oj] = src[oj * (VK * NS)];
+            }
+            half_arrive(hcnt);
+            arrived = true;
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) {
+              const int ok = kp * RPP + rsub, Kk = K0 + ok;
+              const bool kact = sl < 27 && ok < OK && Kk < N2;
+              const int loK = Kk > 0, hiK = Kk < N2 - 1, lenK = loK + 1 + hiK, cumK = Kk == 0 ? 0 : 3 * Kk - 1;
+              double *line = p.values + ((P == 0 ? 0 : 3 * (i64)P - 1) * T1 * T2 + lenI * (cumJ0 * T2));
+              if (!lowJ && !highJ) {
+                const int flag = loI | 2 | loK << 2 | hiI << 3 | 16 | hiK << 5;
+                const unsigned voff8 = 8u * (unsigned)(lenI * 3 * cumK + ((dI + loI) * 3 + (dJ + 1)) * lenK + (dK + loK));
+                const i64 stride8 = 8 * (i64)(lenI * 3 * (int)T2);
+                if (kact && (flag & need) == need) {
+                  char *lp = reinterpret_cast<char *>(line);
+#pragma unroll
+                  for (int oj = 0; oj < OJ; ++oj) {
+                    *reinterpret_cast<double *>(lp + voff8) = v[kp][oj];
+                    lp += stride8;
+                  }
+                }
+              } else {
+#pragma unroll
+                for (int oj = 0; oj < OJ; ++oj) {
+                  const int J = J0 + oj;
+                  const int loJ = J > 0, hiJ = J < N1 - 1, lenJ = loJ + 1 + hiJ;
+                  const int flag = loI | loJ << 1 | loK << 2 | hiI << 3 | hiJ << 4 | hiK << 5;
+                  const unsigned voff = (unsigned)(lenI * lenJ * cumK + ((dI + loI) * lenJ + (dJ + loJ)) * lenK + (dK + loK));
+                  if (kact && J < N1 && (flag & need) == need) line[voff] = v[kp][oj];
+                  line += lenI * lenJ * (int)T2;
+                }
+              }
+            }
+          }
+        }
+        NH_TICK(6)
+        if (!arrived) half_arrive(hcnt);
+        half_wait(hcnt, htarget);  // every wave of this half has read what it needs of plane s-2: recycle its slot
+        NH_TICK(7)
+        {
+          double2 *z = reinterpret_cast<double2 *>(acc + slot_of(s - 2));
+          for (int t = lt; t < PS / 2; t += G) z[t] = make_double2(0., 0.);
+        }
+        if (needv) {
+#pragma unroll
+          for (int k = 0; k < VPG; ++k) {
+            const int r = lt + k * G;
+            if (r < RP) {
+              double *dst = vbuf + vslot_of(s + 2) + r * VW;
+              dst[0] = Vn[k][0], dst[1] = Vn[k][1], dst[2] = Vn[k][2];
+            }
+          }
+        }
+      }
+      if (mathrole) { NH_TICK(1) } else { NH_TICK(4) }
+      lds_barrier();
+      if (mathrole) { NH_TICK(2) } else { NH_TICK(5) }
+    }
+    u += B - A;
+  }
+#ifdef NH_ABLATION
+  if (p.tdbg && (tid & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
+#endif
+}
+#undef NH_TICK
+
 // ---- uniform geometry: all element matrices are equal (the reference hoists them out of the loop too) -------------
 // One thread evaluates the element matrix of the unit cell; the assembly is then a pure streaming kernel: every CSR entry is the
 // sum of the <= 8 element-matrix entries of the elements that contain both its row and its column dof.
@@ -621,6 +767,10 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
   NH_REQUIRE(a->max_workgroups >= 0, "nh_p1hex: negative max_workgroups");
   const unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
   auto kern = k_p1hex_march<TJ, TK, L, VEC, MASS, COEF>;
+  if constexpr (!VEC && L == 2) {  // the matrix goes through the skewed kernel (same tile, same LDS, same launch) unless NH_P1HEX_MARCH=1
+    static const bool march = getenv("NH_P1HEX_MARCH") && atoi(getenv("NH_P1HEX_MARCH"));
+    if (!march) kern = k_p1hex_skew<TJ, TK, MASS, COEF>;
+  }
   NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
 #ifdef NH_ABLATION
   static long long *tdbg = nullptr;
@@ -635,6 +785,10 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
     long long h[16];
     NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
     const double nw = (double)grid * (NTM / 64);
+    if (kern != (void (*)(P1Args))k_p1hex_march<TJ, TK, L, VEC, MASS, COEF>)
+      fprintf(stderr, "p1hex_skew cycles per wave: prologue %.0f | math %.0f | - %.0f | math wait %.0f | flush %.0f | half wait %.0f | zero+stage %.0f | mem wait %.0f\n", h[0] / nw, h[3] / nw, h[1] / nw,
+              h[2] / nw, h[6] / nw, h[7] / nw, h[4] / nw, h[5] / nw);
+    else
     fprintf(stderr, "p1hex_march cycles per wave: stage+next %.0f | B1 %.0f | load+math %.0f | B2 %.0f | stage+flush %.0f | B3 %.0f | zero %.0f\n", h[0] / nw, h[1] / nw,
             h[2] / nw, h[3] / nw, h[4] / nw, h[5] / nw, h[6] / nw);
   }

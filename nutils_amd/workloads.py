@@ -59,7 +59,7 @@ class PoissonSlab:
             # closed-form structured pattern (K6 without sorting), write-once kernel
             self.pattern = None
             self.rowptr, self.colidx = kernels.p1hex_pattern((s.local_layers, self.n, self.n))
-            self.kernel_name = 'k_p1hex_march<16,16,2,false,false,false>' if self.variant == 'iso' else 'k_p1hex_uniform'
+            self.kernel_name = 'k_p1hex_skew<16,16,false,false>' if self.variant == 'iso' else 'k_p1hex_uniform'
         else:
             self.pattern = self.smp.pattern(self.basis, self.basis)
             self.rowptr, self.colidx = self.pattern.expand()

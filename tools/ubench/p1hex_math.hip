@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 typedef int64_t i64;
-struct P1Args { double n[2][2], c[3][2], wk[2][2][2]; };
+struct P1Args { double n[2][2], c[3][2], wk[2][2][2], wm[2][2][2]; };
 __device__ __forceinline__ double fast_rcp(double d) { double r = __builtin_amdgcn_rcp(d); r = fma(fma(-d, r, 1.), r, r); r = fma(fma(-d, r, 1.), r, r); return r; }
 __global__ __launch_bounds__(512) void k(P1Args p, const double *in, double *out, int iters) {
   double X[2][2][2][3];
@@ -12,7 +12,10 @@ __global__ __launch_bounds__(512) void k(P1Args p, const double *in, double *out
     X[a][b][c][d] = (d == 0 ? a : d == 1 ? b : c) + in[(threadIdx.x * 24 + ((a * 2 + b) * 2 + c) * 3 + d) % 4096];
   double acc = 0;
   for (int it = 0; it < iters; ++it) {
-    double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3];
+    double R0[3][3], R1[3][3], R2[3][3], W01[2][2][3], W02[2][2][3], W12[2][2][3], Mm[3][3][3];
+    constexpr bool hasm = false;
+#define NH_P1HEX_QS(q) 1.
+#define NH_P1HEX_QM(q) 1.
 #include "../../nutils_amd/csrc/nh_p1hex_math.inc"
     double s = 0;
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) s += R0[a][b] + 2 * R1[a][b] + 3 * R2[a][b];
@@ -31,6 +34,12 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   k<<<256, 512>>>(p, in, out, 2); hipDeviceSynchronize();
   const int iters = 200;
+  for (int nt : {256, 512, 256, 512}) {  // 1 and 2 waves per SIMD: can a lone wave keep the f64 pipe busy?
+    for (int w = 0; w < 3; ++w) k<<<256, nt>>>(p, in, out, iters);
+    hipEventRecord(e0); k<<<256, nt>>>(p, in, out, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms1; hipEventElapsedTime(&ms1, e0, e1);
+    printf("block %d: %.3f ms for %d iterations -> %.0f cycles @2.4GHz per element routine per SIMD-wave slot\n", nt, ms1, iters, ms1 * 1e-3 / iters * 2.4e9 / (nt / 256));
+  }
   hipEventRecord(e0); k<<<256, 512>>>(p, in, out, iters); hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("element routine: %.3f us per element-thread-iteration per wave; %d iters: %.3f ms -> %.1f ns per wave-element\n", 0., iters, ms, ms * 1e6 / iters);
