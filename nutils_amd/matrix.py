@@ -61,6 +61,8 @@ class ScipyMatrix:
             else:
                 free = numpy.isnan(constrain)
                 x[~free] = constrain[~free]
+        if free.all():
+            return x + scipy.sparse.linalg.spsolve(self.core.tocsc(), rhs - self.core @ x)
         b = (rhs - self.core @ x)[free]
         A = self.core[free, :][:, free].tocsc()
         x[free] += scipy.sparse.linalg.spsolve(A, b)

@@ -87,16 +87,22 @@ class System:
             grp['slot'] = device.to_dev(numpy.searchsorted(ukeys, key), 'int64')
         self._groups = groups
 
-    def assemble_jacobian(self, arguments):
+    def _merged_values(self, arguments):
+        '''Values of the merged block Jacobian on the device (pattern: _merged_rowptr, _merged_colidx).'''
         from . import device, kernels
-        if self._jac is not None and self.is_constant_matrix:
-            return self._jac
-        if not hasattr(self, '_groups'):
-            self._build_merge_plan(arguments)
         merged = device.zeros(len(self._merged_colidx), 'float64')
         for grp in self._groups:
             values = grp['values'] if grp['constant'] else grp['plan'].run(arguments)[0]
             kernels.monomial(values, [], [], merged, out_index=grp['slot'])
+        return merged
+
+    def assemble_jacobian(self, arguments):
+        from . import device
+        if self._jac is not None and self.is_constant_matrix:
+            return self._jac
+        if not hasattr(self, '_groups'):
+            self._build_merge_plan(arguments)
+        merged = self._merged_values(arguments)
         if getattr(self, '_pattern_validated', False):
             jac = _matrix.reassemble_csr(device.to_host(merged), self._merged_rowptr, self._merged_colidx, self.size)
         else:
@@ -104,6 +110,38 @@ class System:
             self._pattern_validated = True
         if self.is_constant_matrix:
             self._jac = jac
+        return jac
+
+    def assemble_jacobian_free(self, arguments, free):
+        '''jac.submatrix(free, free) of the reference (solver.py:332,386) WITHOUT the host-side slicing: the positions of the free-free
+        entries in the merged value array and the reduced (rowptr, colidx) are computed once per constraint set, a Newton step is
+        the device assembly + one device gather + the copy of the REDUCED values.'''
+        from . import device
+        if not hasattr(self, '_groups'):
+            self._build_merge_plan(arguments)
+        key = free.tobytes()
+        plan = getattr(self, '_free_plan', None)
+        if plan is None or plan['key'] != key:
+            rp, ci = self._merged_rowptr, self._merged_colidx
+            rows = numpy.repeat(numpy.arange(self.size, dtype=numpy.int64), numpy.diff(rp))
+            keep = numpy.flatnonzero(free[rows] & free[ci])
+            newcol = numpy.cumsum(free, dtype=numpy.int64) - 1
+            counts = numpy.bincount(rows[keep], minlength=self.size)[free]
+            frp = numpy.zeros(len(counts) + 1, dtype=numpy.int64)
+            numpy.cumsum(counts, out=frp[1:])
+            plan = self._free_plan = dict(key=key, keep=device.to_dev(keep, 'int64'), rowptr=frp, colidx=newcol[ci[keep]], n=int(free.sum()), validated=False,
+                                          matrix=None)
+        if plan['matrix'] is not None and self.is_constant_matrix:
+            return plan['matrix']
+        merged = self._merged_values(arguments)
+        values = device.to_host(merged.index_select(0, plan['keep']))
+        if plan['validated']:
+            jac = _matrix.reassemble_csr(values, plan['rowptr'], plan['colidx'], plan['n'])
+        else:
+            jac = _matrix.assemble_csr(values, plan['rowptr'], plan['colidx'], plan['n'])
+            plan['validated'] = True
+        if self.is_constant_matrix:
+            plan['matrix'] = jac
         return jac
 
     def assemble_residual(self, arguments):
@@ -168,8 +206,10 @@ class System:
                 break
             if it == maxiter:
                 raise SolverError(f'failed to converge in {maxiter} iterations (residual norm {resnorm:.1e})')
-            jac = self.assemble_jacobian(args)
-            x = x - jac.solve(res, constrain=~free)
+            if free.all():
+                x = x - self.assemble_jacobian(args).solve(res)
+            else:  # constraint elimination on the device: only the free-free block travels to the host solver
+                x[free] -= self.assemble_jacobian_free(args, free).solve(res[free])
             args = self._unpack(args, x)
         return args
 
