@@ -210,6 +210,24 @@ def p1hex_laplace(*, shape, values, gauss_x, gauss_w, verts=None, origin=(0., 0.
     _lib.call('nh_p1hex_laplace', ctypes.byref(a), device.stream())
 
 
+class P1HexLaplace:
+    '''nh_p1hex_laplace with the argument block filled ONCE: a re-assembly is one ctypes call (the per-step path of a Newton loop or of
+    bench.py; building the block costs more host time than the launch).  Call with the value array of the step.'''
+
+    def __init__(self, **kwargs):
+        self._keep = kwargs  # the tensors whose addresses the block holds
+        values = kwargs.pop('values', None)
+        self._args = _p1hex_args(kwargs['shape'], values, kwargs['gauss_x'], kwargs['gauss_w'], kwargs.get('verts'), kwargs.get('origin', (0., 0., 0.)),
+                                 kwargs.get('scale', (1., 1., 1.)), kwargs.get('kappa', 1.), kwargs.get('layers'), kwargs.get('planes'), kwargs.get('unit_matrix'),
+                                 kwargs.get('qscale'), kwargs.get('max_workgroups', 0), kwargs.get('mass', 0.), kwargs.get('qmass'))
+        self._ref = ctypes.byref(self._args)
+        self._fn = getattr(_lib.load(), 'nh_p1hex_laplace')
+
+    def __call__(self, values):
+        self._args.values_dev = values.data_ptr()
+        _lib.check(self._fn(self._ref, device.stream()))
+
+
 def p1hex_apply(*, shape, u, out, gauss_x, gauss_w, verts, kappa=1., layers=None, planes=None, qscale=None, accumulate=True, max_workgroups=0, mass=0.,
                 qmass=None):
     '''out (+)= K u for the P1-hex Laplace form without forming K (nh_p1hex_apply).'''

@@ -50,6 +50,7 @@ class HaloPlan:
     def __init__(self, slab, rowptr):
         import torch
         self.slab = slab
+        self._ops = {}
         p = slab.plane
         if slab.sends:
             r0 = slab.send_plane * p
@@ -76,11 +77,16 @@ class HaloPlan:
         if staged:
             send = send.cpu() if s.sends else None
             recv = recv.cpu() if s.recvs else None
-        ops = []
-        if s.sends:
-            ops.append(dist.P2POp(dist.isend, send, s.rank + 1))
-        if s.recvs:
-            ops.append(dist.P2POp(dist.irecv, recv, s.rank - 1))
+        key = (values.data_ptr(), staged)
+        ops = None if staged else self._ops.get(key)  # the descriptors of a value array are built once (two arrays when pipelined)
+        if ops is None:
+            ops = []
+            if s.sends:
+                ops.append(dist.P2POp(dist.isend, send, s.rank + 1))
+            if s.recvs:
+                ops.append(dist.P2POp(dist.irecv, recv, s.rank - 1))
+            if not staged:
+                self._ops[key] = ops
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()

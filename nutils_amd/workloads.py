@@ -90,6 +90,7 @@ class PoissonSlab:
         self._vals = [self.values, torch.zeros_like(self.values)]
         self._comm_stream = torch.cuda.Stream()
         self._comm_done = [None, None]
+        self._comm_ready, self._comm_fin = [None, None], [None, None]
         self._it = 0
 
     def _begin_step(self, exchange):
@@ -111,12 +112,13 @@ class PoissonSlab:
             self.halo.exchange(self.values)
             return
         import torch
-        ready = torch.cuda.Event()
+        if self._comm_ready[slot] is None:  # events are re-recorded every step (a wait refers to the record that precedes it)
+            self._comm_ready[slot], self._comm_fin[slot] = torch.cuda.Event(), torch.cuda.Event()
+        ready, done = self._comm_ready[slot], self._comm_fin[slot]
         ready.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._comm_stream):
             self._comm_stream.wait_event(ready)
             self.halo.exchange(self.values)
-            done = torch.cuda.Event()
             done.record(self._comm_stream)
         self._comm_done[slot] = done
 
@@ -145,12 +147,13 @@ class PoissonSlab:
         slot = self._begin_step(exchange)
         if self.fast:
             s = self.slab
-            gx, gw = self._gauss_x1(), self._gauss_w1()
+            if getattr(self, '_launch', None) is None:
+                self._launch = kernels.P1HexLaplace(shape=(s.local_layers, self.n, self.n), gauss_x=self._gauss_x1(), gauss_w=self._gauss_w1(), verts=self._verts_dev,
+                                                    origin=(float(s.first_global_plane), 0., 0.), layers=(s.ghost_layers, s.local_layers),
+                                                    planes=(s.ghost_layers, s.local_layers + 1), unit_matrix=self._ke, max_workgroups=self._max_wg)
             if kernel_events:
                 kernel_events[0].record()
-            kernels.p1hex_laplace(shape=(s.local_layers, self.n, self.n), values=self.values, gauss_x=gx, gauss_w=gw, verts=self._verts_dev,
-                                  origin=(float(s.first_global_plane), 0., 0.), layers=(s.ghost_layers, s.local_layers),
-                                  planes=(s.ghost_layers, s.local_layers + 1), unit_matrix=self._ke, max_workgroups=self._max_wg)
+            self._launch(self.values)
             if kernel_events:
                 kernel_events[1].record()
             self._end_step(slot, exchange)
