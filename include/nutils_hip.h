@@ -167,12 +167,19 @@ typedef struct {
                                 replacing C_host (which then only provides the block mask): forms whose coefficients depend on a
                                 field and its gradient at the point -- the product-rule term kappa'(u) phi_n grad u . grad phi_m
                                 of a Newton Jacobian, advection with a computed velocity.  NULL = constant form. */
+  int grid_shape[3];         /* NH_MATRIX_FIRST_TOUCH: elements per axis of the structured mesh (element id = last axis fastest) */
+  int nodes_per_axis;        /* NH_MATRIX_FIRST_TOUCH: p + 1 local nodes per axis of the C0 ('std') basis, local order first axis slowest */
 } nh_matrix_args;
 
 #define NH_MATRIX_EXCLUSIVE 1        /* no two elements of this launch touch the same CSR entry (one colour of an element
                                         colouring): entries are added with plain loads/stores -- deterministic -- not atomics */
 #define NH_MATRIX_EMAP_BY_ELEMENT 2  /* with elist_dev: emap (and the pattern) cover ALL elements, index it by element id */
 #define NH_MATRIX_NO_MFMA 4          /* force the generic one-wave-per-element VALU kernel */
+#define NH_MATRIX_FIRST_TOUCH 32     /* with EXCLUSIVE | EMAP_BY_ELEMENT, colours = element index parities launched in lexicographic order
+                                        (last axis fastest) on a FRESH value array of a structured C0 basis (grid_shape, nodes_per_axis):
+                                        an entry whose two nodes do not both lie on a face shared with an element of an earlier colour is
+                                        STORED, not added -- the caller does not zero-fill the values, and the ~70 % of the entries that
+                                        receive a single contribution are not read */
 
 int nh_assemble_matrix(const nh_matrix_args *args, void *stream);
 

@@ -163,7 +163,42 @@ __device__ __forceinline__ void fill_D(double *D, const BasisK &b, i64 e, int nb
   }
 }
 
+// NH_MATRIX_FIRST_TOUCH: which entries of an element of a parity colouring has no element of an EARLIER colour touched?  Colours are
+// launched in lexicographic order of the index parities, so of the elements that share a face, edge or corner the all-even one comes
+// first: the entry (m, n) was touched before iff nodes m and n both lie on a face of this element, along an axis on which its index is odd,
+// whose neighbour exists.
+struct FirstTouch {
+  int on, p1;
+  int shape[3];
+};
+template <int ND>
+__device__ __forceinline__ void ft_element(const FirstTouch &f, i64 e, int &lo, int &hi) {  // axes whose low / high face was touched earlier
+  lo = hi = 0;
+#pragma unroll
+  for (int d = ND - 1; d >= 0; --d) {
+    const int ed = (int)(e % f.shape[d]);
+    e /= f.shape[d];
+    if (ed & 1) {
+      lo |= 1 << d;
+      if (ed < f.shape[d] - 1) hi |= 1 << d;
+    }
+  }
+}
+template <int ND>
+__device__ __forceinline__ int ft_node(const FirstTouch &f, int m) {  // bit d: node on the low face of axis d, bit 3 + d: on the high face
+  int mask = 0;
+#pragma unroll
+  for (int d = ND - 1; d >= 0; --d) {
+    const int pd = m % f.p1;
+    m /= f.p1;
+    if (pd == 0) mask |= 1 << d;
+    if (pd == f.p1 - 1) mask |= 8 << d;
+  }
+  return mask;
+}
+
 struct MatK {
+  FirstTouch ft;
   i64 nelems;
   const int32_t *elist;
   int nq;
@@ -197,6 +232,8 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
   for (i64 ie = blockIdx.x; ie < p.nelems; ie += gridDim.x) {
     const i64 e = p.elist ? p.elist[ie] : ie;
     const int nbt = bnb(p.test, e), nbr = bnb(p.trial, e);
+    int ftlo = 0, fthi = 0;
+    if (p.ft.on) ft_element<ND>(p.ft, e, ftlo, fthi);
     for (int q = lane; q < p.nq; q += 64) {
       double Ji[ND][ND], det;
       geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
@@ -282,8 +319,12 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
         const i64 row = p.test.dofs[tdof0 + m];
         const i64 a0 = p.srowptr[row], len = p.srowptr[row + 1] - a0;
         const i64 slot = a0 * form.tot + len * form.cum[c] + (i64)p.emap[emap0 + m * nbr + n] * form.cnt[c] + form.dpos[c][d];
-        if (p.exclusive) p.values[slot] += acc;
-        else atomicAdd(p.values + slot, acc);
+        if (p.exclusive) {
+          const int both = ft_node<ND>(p.ft, m) & ft_node<ND>(p.ft, n);
+          const bool first = p.ft.on && q0 == 0 && !((both & ftlo) | ((both >> 3) & fthi));
+          p.values[slot] = first ? acc : p.values[slot] + acc;
+        } else
+          atomicAdd(p.values + slot, acc);
       }
       __syncthreads();
     }
@@ -374,9 +415,11 @@ __global__ __launch_bounds__(256) void k_matrix_mfma(MatK p, FormK formarg, Mfma
     __syncthreads();
     const i64 tdof0 = e * (i64)nb;
     const i64 emap0 = ((x.flags & 2) ? e : ie) * (i64)nb * p.trial.nb;
+    int ftlo = 0, fthi = 0;
+    if (p.ft.on) ft_element<ND>(p.ft, e, ftlo, fthi);
     // per-lane row bookkeeping: this lane owns rows (lk + 4 r) of every M tile
     i64 rbase[MT][4];
-    int rlen[MT][4];
+    int rlen[MT][4], rft[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -384,6 +427,7 @@ __global__ __launch_bounds__(256) void k_matrix_mfma(MatK p, FormK formarg, Mfma
         const int m = mt * 16 + lk + 4 * r;
         rbase[mt][r] = -1;
         rlen[mt][r] = 0;
+        rft[mt][r] = p.ft.on ? ft_node<ND>(p.ft, m) : 0;
         if (m < nb) {
           const i64 row = p.test.dofs[tdof0 + m];
           rbase[mt][r] = p.srowptr[row];
@@ -432,10 +476,15 @@ __global__ __launch_bounds__(256) void k_matrix_mfma(MatK p, FormK formarg, Mfma
           }
         if (x.flags & 1) {
           double old[MT][4];
+          const int cft = p.ft.on ? ft_node<ND>(p.ft, ncol) : 0;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) old[mt][r] = slot[mt][r] >= 0 ? p.values[slot[mt][r]] : 0.;
+            for (int r = 0; r < 4; ++r) {
+              const int both = rft[mt][r] & cft;
+              const bool first = p.ft.on && !((both & ftlo) | ((both >> 3) & fthi));
+              old[mt][r] = slot[mt][r] >= 0 && !first ? p.values[slot[mt][r]] : 0.;
+            }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -695,6 +744,21 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   p.scale = a->scale_dev;
   p.emap_by_elem = (a->flags & 2) != 0;
   p.exclusive = (a->flags & 1) != 0;
+  p.ft.on = (a->flags & 32) != 0;
+  p.ft.p1 = a->nodes_per_axis;
+  for (int d = 0; d < 3; ++d) p.ft.shape[d] = d < a->ndims ? a->grid_shape[d] : 1;
+  if (p.ft.on) {
+    NH_REQUIRE((a->flags & 3) == 3 && a->elist_dev, "NH_MATRIX_FIRST_TOUCH needs NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT and an element list");
+    NH_REQUIRE(!a->cq_dev && !a->test.off_dev, "NH_MATRIX_FIRST_TOUCH: constant forms on uniform bases only");
+    i64 ncell = 1, nloc = 1;
+    for (int d = 0; d < a->ndims; ++d) {
+      NH_REQUIRE(a->grid_shape[d] >= 1, "NH_MATRIX_FIRST_TOUCH: grid_shape");
+      ncell *= a->grid_shape[d];
+      nloc *= a->nodes_per_axis;
+    }
+    NH_REQUIRE(a->nodes_per_axis >= 2 && nloc == a->test.nb && nloc == a->trial.nb, "NH_MATRIX_FIRST_TOUCH: nodes_per_axis^ndims must equal the local basis size");
+    (void)ncell;
+  }
   p.cq = a->cq_dev;
   NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "nh_assemble_matrix: elist with ragged bases is not supported");
   if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;

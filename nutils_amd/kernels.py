@@ -108,8 +108,8 @@ def basis(T, dofs, nb=0, off=None, tab=None):
 
 
 def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0,
-                    cq=None):
-    '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.'''
+                    cq=None, first_touch=None):
+    '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.  `first_touch=(grid_shape, nodes_per_axis)`: NH_MATRIX_FIRST_TOUCH.'''
     C = numpy.ascontiguousarray(C, dtype=float)
     if C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
         raise ValueError(f'coefficient tensor has shape {C.shape}, expected {(nct, 1 + ndims, ncr, 1 + ndims)}')
@@ -118,7 +118,10 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
         raise ValueError('per-point coefficient tensor must have shape [nelems][nq] + C.shape')
     args = _lib.MatrixArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
                            device.host_ptr(m), pattern.srowptr_ptr, ctypes.c_void_p(pattern.emap_ptr.value + 4 * emap_offset), pattern.eoff_ptr,
-                           device.ptr(values), device.ptr(scale), int(flags), device.ptr(cq))
+                           device.ptr(values), device.ptr(scale), int(flags) | (32 if first_touch else 0), device.ptr(cq))
+    if first_touch:
+        args.grid_shape[:] = list(first_touch[0]) + [1] * (3 - len(first_touch[0]))
+        args.nodes_per_axis = int(first_touch[1])
     _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
 
 

@@ -402,6 +402,19 @@ class _MatrixPlan:
                               qscale=qscale, mass=mass, qmass=qmass)
         return values, rowptr, colidx, basis.ndofs, rest
 
+    def _first_touch(self, term):
+        '''(elements per axis, local nodes per axis) if the first term is assembled colour by colour on a non-periodic C0 ('std') basis
+        whose local order is the tensor order of its nodes: NH_MATRIX_FIRST_TOUCH applies.'''
+        smp, itg, fac = term
+        basis = itg.test.basis
+        if not (isinstance(basis, StructuredBasis) and basis.btype == 'std' and itg.trial.basis is basis and itg.qform is None and itg.measure is not None):
+            return None
+        if basis.dofs_shape != tuple(n * basis.degree + 1 for n in basis.shape) or os.environ.get('NUTILS_AMD_NO_FIRST_TOUCH'):
+            return None  # (periodic axes: the neighbour across the seam)
+        if not (smp.nlist >= COLOR_THRESHOLD and basis.nb >= 16 and _colors(smp, basis)):
+            return None
+        return basis.shape, basis.degree + 1
+
     def run(self, arguments=None):
         fast = self._p1hex_laplace(arguments)
         if fast is not None and not fast[4]:
@@ -410,11 +423,15 @@ class _MatrixPlan:
         nct, ncr = self.test.ncomp, self.trial.ncomp
         mask = None if self.mask.all() else self.mask
         rowptr, colidx = pat.expand(nct, ncr, mask)
+        first_touch = None
         if fast is not None:  # same sorted-unique pattern: the generic kernel accumulates the remaining terms into the write-once result
             values, terms = fast[0], fast[4]
         else:
-            values, terms = device.zeros(colidx.numel(), 'float64'), self.terms
-        for smp, itg, fac in terms:
+            # the first term of a coloured assembly on a C0 basis STORES the entries no earlier colour has touched (NH_MATRIX_FIRST_TOUCH):
+            # no zero-fill, no read of the entries that receive a single contribution
+            first_touch = self._first_touch(self.terms[0])
+            values, terms = (device.empty if first_touch else device.zeros)(colidx.numel(), 'float64'), self.terms
+        for iterm, (smp, itg, fac) in enumerate(terms):
             if itg.measure is None:
                 raise NotImplementedError('integrand without J(geom): reference-space integrals are outside the accelerated path')
             tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
@@ -442,8 +459,9 @@ class _MatrixPlan:
             if itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16:  # (small local matrices: 8 coloured launches measured slower than atomics, 4.7 vs 4.0 ms)
                 colors = _colors(smp, itg.test.basis)
             if colors:
+                ft = first_touch if iterm == 0 and terms is self.terms else None
                 for el in colors:
-                    kernels.assemble_matrix(nelems=el.numel(), elist=el, flags=1 | 2, scale=scale, **common)
+                    kernels.assemble_matrix(nelems=el.numel(), elist=el, flags=1 | 2, scale=scale, first_touch=ft, **common)
             else:
                 kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, scale=scale, **common)
         return values, rowptr, colidx, self.trial.basis.ndofs * ncr

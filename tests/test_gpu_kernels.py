@@ -412,3 +412,40 @@ def test_p1hex_fast_path_mixed_terms(monkeypatch):
     import scipy.sparse
     A = scipy.sparse.csr_matrix((vf, cif, rpf), (len(basis),) * 2)
     assert abs(A - A.T).max() > 1e-3  # the advection term is there
+
+
+@pytest.mark.parametrize('case', ['2d_p3', '3d_p2_vector', '2d_p3_odd'])
+def test_first_touch_coloured_assembly(case, monkeypatch):
+    '''NH_MATRIX_FIRST_TOUCH (no zero-fill, entries untouched by earlier colours are stored): bit-identical to the zero-filled coloured
+    assembly, and EVERY value is written -- the value array is handed over full of NaN.'''
+    from nutils_amd import mesh, function, device, sample
+    if case == '3d_p2_vector':
+        shape = [16, 16, 17]
+        domain, geom = mesh.rectilinear(shape)
+        gb = domain.basis('std', degree=1)
+        rng = numpy.random.default_rng(1)
+        verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, (len(gb), 3))
+        geom = gb @ verts
+        u = domain.field('u', btype='std', degree=2, shape=[3])
+        v = domain.field('v', btype='std', degree=2, shape=[3])
+        eps = lambda w: function.symgrad(w, geom)
+        sigma = function.div(u, geom) * function.eye(3) + 1.3 * eps(u)
+        res = domain.integral(function.inner(eps(v), sigma) * function.J(geom), degree=4)
+    else:
+        shape = [64, 64] if case == '2d_p3' else [65, 67]
+        domain, geom = mesh.rectilinear([numpy.linspace(0, 1, shape[0] + 1), numpy.linspace(0, 2, shape[1] + 1)])
+        u = domain.field('u', btype='std', degree=3)
+        v = domain.field('v', btype='std', degree=3)
+        res = domain.integral(((function.grad(v, geom) * function.grad(u, geom)).sum(-1) + v * u) * function.J(geom), degree=6)
+    jac = function.derivative(function.derivative(res, 'v'), 'u')
+    plan = sample._MatrixPlan(jac.terms)
+    assert plan._first_touch(plan.terms[0]) == (tuple(shape), 3 if case == '3d_p2_vector' else 4)
+    monkeypatch.setenv('NUTILS_AMD_NO_FIRST_TOUCH', '1')
+    ref = [device.to_host(t) for t in sample._MatrixPlan(jac.terms).run()[:3]]
+    monkeypatch.delenv('NUTILS_AMD_NO_FIRST_TOUCH')
+    real_empty = device.empty
+    monkeypatch.setattr(device, 'empty', lambda n, dtype: real_empty(n, dtype).fill_(float('nan')) if dtype == 'float64' else real_empty(n, dtype))
+    got = [device.to_host(t) for t in plan.run()[:3]]
+    assert numpy.array_equal(got[1], ref[1]) and numpy.array_equal(got[2], ref[2])
+    assert not numpy.isnan(got[0]).any()
+    assert numpy.array_equal(got[0], ref[0])
