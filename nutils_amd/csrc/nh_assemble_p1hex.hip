@@ -212,8 +212,7 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
         }
       }
     } else {
-      // 32 lanes per row (27 slots), one K line (or part of it) per pass.  (A variant with two entries per lane and 16-byte stores was
-      // measured slower: 0.279 vs 0.252 ms.)
+      // 32 lanes per row (27 slots), one K line (or part of it) per pass; fully interior steps take the 16-byte path further down
       constexpr int RPP = NT / 32, KP = (OK + RPP - 1) / RPP;  // rows per flush pass, passes per K line
       const int sl = tid & 31, rsub = tid >> 5;
       const int dI = sl / 9 - 1, dJ = (sl / 3) % 3 - 1, dK = sl % 3 - 1;
@@ -410,7 +409,7 @@ __global__ __launch_bounds__(L * TJ * TK) void k_p1hex_march(P1Args p) {
 // The gain is modest (-3.3 % in steady-state A/B runs at 128^3): a lone wave per SIMD sustains only 65 % of the f64 rate of two, so the
 // arithmetic of a layer takes 7.9 k cycles instead of 5; the stores of a plane take ~7.6 k at the chip-wide write rate, plus ~2.7 k
 // until they are acknowledged (the wait for the vertex loads of the same waves is a wait for everything before it: one in-order
-// counter).  DESIGN.md section 5 lists the variants that were measured slower (fixed roles with LDS-counter hand-offs, a fourth wave
+// counter).  profiles/r01_e_skewed_marching_kernel.md lists the variants that were measured slower (fixed roles with LDS-counter hand-offs, a fourth wave
 // that only recycles and stages, vertex loads from the computing half, ...).
 __device__ __forceinline__ void half_arrive(unsigned *cnt) {  // this wave's LDS reads have returned
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
