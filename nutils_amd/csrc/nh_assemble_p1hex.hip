@@ -767,7 +767,8 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
   const unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
   auto kern = k_p1hex_march<TJ, TK, L, VEC, MASS, COEF>;
   if constexpr (!VEC && L == 2) {  // the matrix goes through the skewed kernel (same tile, same LDS, same launch) unless NH_P1HEX_MARCH=1
-    static const bool march = getenv("NH_P1HEX_MARCH") && atoi(getenv("NH_P1HEX_MARCH"));
+    const char *env = getenv("NH_P1HEX_MARCH");  // (read per launch: the tests compare the two kernels within one process)
+    const bool march = env && atoi(env);
     if (!march) kern = k_p1hex_skew<TJ, TK, MASS, COEF>;
   }
   NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));

@@ -449,3 +449,32 @@ def test_first_touch_coloured_assembly(case, monkeypatch):
     assert numpy.array_equal(got[1], ref[1]) and numpy.array_equal(got[2], ref[2])
     assert not numpy.isnan(got[0]).any()
     assert numpy.array_equal(got[0], ref[0])
+
+
+def test_p1hex_skewed_vs_marching_kernel(monkeypatch):
+    '''The role-skewed matrix kernel (default) against the marching kernel (NH_P1HEX_MARCH=1) on random shapes, layer / plane ranges and
+    workgroup limits: the same set of entries is written (the value array is handed over full of NaN), values agree to rounding.'''
+    from nutils_amd import kernels, device, points
+    x1, w1 = points.gauss1(2)
+    rng = numpy.random.default_rng(11)
+    for it in range(16):
+        shape = tuple(int(x) for x in rng.integers(2, 45, 3))
+        n0 = shape[0]
+        l0 = int(rng.integers(0, n0)); l1 = int(rng.integers(l0 + 1, n0 + 1))
+        p0 = int(rng.integers(0, n0 + 1)); p1 = int(rng.integers(p0 + 1, n0 + 2))
+        if it % 4 == 0:
+            l0, l1, p0, p1 = 0, n0, 0, n0 + 1
+        nv = (shape[0] + 1) * (shape[1] + 1) * (shape[2] + 1)
+        g = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3) + numpy.random.default_rng(it).uniform(-.2, .2, (nv, 3))
+        verts = device.to_dev(g, 'float64')
+        rowptr, colidx = kernels.p1hex_pattern(shape)
+        got = []
+        for march in ('0', '1'):
+            monkeypatch.setenv('NH_P1HEX_MARCH', march)
+            values = device.empty(colidx.numel(), 'float64')
+            values.fill_(float('nan'))
+            kernels.p1hex_laplace(shape=shape, values=values, gauss_x=x1, gauss_w=w1, verts=verts, layers=(l0, l1), planes=(p0, p1), max_workgroups=(it % 3) * 100)
+            got.append(device.to_host(values))
+        written = ~numpy.isnan(got[1])
+        assert numpy.array_equal(~numpy.isnan(got[0]), written) and written.any()
+        assert numpy.abs(got[0][written] - got[1][written]).max() <= 1e-14 * numpy.abs(got[1][written]).max()
