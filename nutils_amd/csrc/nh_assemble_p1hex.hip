@@ -461,15 +461,28 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
     // run: planes [A, B) of column col; element layers A-1 .. B-1 in slots A-1 .. B-1, plane P flushed in slot P+1
     const int col = (int)(u / NPL), A = p.pl0 + (int)(u % NPL), B = (int)min((i64)p.pl1, A + (u1 - u));
     const int J0 = (col / p.nbk) * OJ, K0 = (col % p.nbk) * OK;
-    for (int t = tid; t < NP * PS / 2; t += NT) reinterpret_cast<double2 *>(acc)[t] = make_double2(0., 0.);
+    {
+      // vertex planes A-1 and A: unconditional loads from clamped addresses (predicated ones cost one memory round trip EACH: the compiler
+      // waits at every join), issued in front of the zeroing of the plane slots
+      constexpr int NVL = (2 * RP + NT - 1) / NT;
+      double x[NVL][3];
+      bool valid[NVL];
 #pragma unroll
-    for (int k = 0; k < (2 * RP + NT - 1) / NT; ++k) {  // vertex planes A-1 and A
-      const int v = tid + k * NT, pl = v / RP, r = v % RP;
-      if (v < 2 * RP) {
-        double x[3];
-        load_vertex(A - 1 + pl, r, J0, K0, x);
-        double *dst = vbuf + vslot_of(A - 1 + pl) + r * VW;
-        dst[0] = x[0], dst[1] = x[1], dst[2] = x[2];
+      for (int k = 0; k < NVL; ++k) {
+        const int v = min(tid + k * NT, 2 * RP - 1), pl = v / RP, r = v % RP, I = A - 1 + pl;
+        const int J = J0 - 1 + r / VK, K = K0 - 1 + r % VK;
+        valid[k] = I >= 0 && I < N0 && J >= 0 && J < N1 && K >= 0 && K < N2;
+        const double *src = p.verts + (((i64)min(max(I, 0), N0 - 1) * N1 + min(max(J, 0), N1 - 1)) * N2 + min(max(K, 0), N2 - 1)) * 3;
+        x[k][0] = src[0], x[k][1] = src[1], x[k][2] = src[2];
+      }
+      for (int t = tid; t < NP * PS / 2; t += NT) reinterpret_cast<double2 *>(acc)[t] = make_double2(0., 0.);
+#pragma unroll
+      for (int k = 0; k < NVL; ++k) {
+        const int v = tid + k * NT, pl = v / RP, r = v % RP;
+        if (v < 2 * RP) {
+          double *dst = vbuf + vslot_of(A - 1 + pl) + r * VW;
+          dst[0] = valid[k] ? x[k][0] : 0., dst[1] = valid[k] ? x[k][1] : 0., dst[2] = valid[k] ? x[k][2] : 0.;
+        }
       }
     }
     lds_barrier();
