@@ -438,10 +438,17 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
   const int tid = threadIdx.x, lt = tid & (G - 1), grp = __builtin_amdgcn_readfirstlane(tid / G);
   const int N0 = p.n0 + 1, N1 = p.n1 + 1, N2 = p.n2 + 1;
   const int NPL = p.pl1 - p.pl0;
-  const i64 U = (i64)p.nbj * p.nbk * NPL;
   const unsigned wg = gridDim.x % 8 == 0 ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;  // XCD-aware, as above
-  i64 u = U * wg / gridDim.x;
-  const i64 u1 = U * (wg + 1) / gridDim.x;
+  // Work split in SLOTS, not planes: a run of n planes costs n + 2 slots (the first has nothing to flush, the last nothing to compute), so a
+  // workgroup whose share crosses a column boundary gets two planes less -- every column is given NPL + 2 cost units, one in front of
+  // its first plane and one behind its last, and the workgroups share the cost axis evenly
+  const i64 CP = NPL + 2, ctot = (i64)p.nbj * p.nbk * CP;
+  auto unit_at = [&](i64 c) {
+    const i64 col = c / CP;
+    return col * NPL + min(max(c - col * CP - 1, (i64)0), (i64)NPL);
+  };
+  i64 u = unit_at(ctot * wg / gridDim.x);
+  const i64 u1 = unit_at(ctot * (wg + 1) / gridDim.x);
   if (u >= u1) return;
   auto slot_of = [](int P) { return (int)((unsigned)(P + 2 * NP) % NP) * PS; };  // P >= -2 * NP
   auto vslot_of = [](int P) { return (int)((unsigned)(P + 3) % 3) * (RP * VW); };  // P >= -3
