@@ -187,8 +187,14 @@ def main():
     if world > 1:
         dist.all_reduce(check, op=dist.ReduceOp.MAX)
     row_sum_rel = float(check.item())
-    if not row_sum_rel < 1e-10:
-        print(f'WARNING: owned rows do not sum to zero (relative {row_sum_rel:.2e}): the assembled matrix is wrong', file=sys.stderr)
+    if not row_sum_rel < 1e-10:  # a broken kernel or halo reduce must not be recorded as a (possibly faster) valid result
+        print(f'ERROR: owned rows do not sum to zero (relative {row_sum_rel:.2e}): the assembled matrix is wrong', file=sys.stderr)
+        if rank == 0:
+            print(json.dumps({'metric': 'elements assembled/sec (global stiffness K)', 'value': None, 'unit': 'elements/s', 'n_gpus': world,
+                              'error': f'correctness gate failed: owned row sums relative {row_sum_rel:.3e}'}))
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(1)
 
     if rank == 0:
         nelems_total = wl.nelems * world

@@ -448,7 +448,12 @@ __global__ __launch_bounds__(256) void k_matrix_mfma(MatK p, FormK formarg, Mfma
 #pragma unroll
         for (int bb = 0; bb < S; ++bb) Cc[bb] = ncol >= 0 ? Cp[bb] : 0.;
         const double *Aa = At + (size_t)a * nqp * nbp;
-        for (int ks = 0; ks < ((x.flags & 16) ? 1 : kq); ++ks) {
+        #ifdef NH_ABLATION
+        const int kend = (x.flags & 16) ? 1 : kq;
+#else
+        const int kend = kq;
+#endif
+        for (int ks = 0; ks < kend; ++ks) {
           const int q = ks * 4 + lk;
           const int qq = q < p.nq ? q : p.nq - 1;
           const double wq = q < p.nq ? Jw[qq * JW + ND * ND] : 0.;
@@ -462,7 +467,12 @@ __global__ __launch_bounds__(256) void k_matrix_mfma(MatK p, FormK formarg, Mfma
         }
       }
       // scatter this 16-column slab: all loads of the old values first (one memory latency), then add + store
-      if (ncol >= 0 && form.mask[c][dcol] && !((x.flags & 8) && acc[0][0] != 1.2345e300)) {
+      #ifdef NH_ABLATION
+      const bool skip_scatter = (x.flags & 8) && acc[0][0] != 1.2345e300;
+#else
+      constexpr bool skip_scatter = false;
+#endif
+      if (ncol >= 0 && form.mask[c][dcol] && !skip_scatter) {
         i64 slot[MT][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -718,6 +728,8 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   NH_REQUIRE(a, "nh_assemble_matrix: NULL args");
   NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
   NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
+  NH_REQUIRE((a->flags & ~(NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_NO_MFMA | NH_MATRIX_FIRST_TOUCH)) == 0,
+             "nh_assemble_matrix: unknown flag bits 0x%x", a->flags & ~(NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_NO_MFMA | NH_MATRIX_FIRST_TOUCH));
   NH_REQUIRE(a->C_host && a->srowptr_dev && a->emap_dev && a->values_dev, "nh_assemble_matrix: NULL coefficient / pattern / values");
   NH_REQUIRE(a->test.T_dev && a->test.dofs_dev && a->trial.T_dev && a->trial.dofs_dev, "basis tables missing");
   int rc = check_geom(a->geom);
@@ -778,7 +790,10 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     x.mt = (a->test.nb + 15) / 16;
     x.nt = (Nloc + 15) / 16;
     x.kt = ((a->nq + 3) / 4) * x.nas;
-    x.flags = a->flags | (getenv("NH_MFMA_DEBUG") ? atoi(getenv("NH_MFMA_DEBUG")) : 0);
+    x.flags = a->flags;
+#ifdef NH_ABLATION  // ablation hooks (skip the scatter: 8, one k-step: 16) exist only in -DNH_ABLATION builds
+    if (getenv("NH_MFMA_DEBUG")) x.flags |= atoi(getenv("NH_MFMA_DEBUG")) & (8 | 16);
+#endif
     const size_t ldsm = sizeof(double) * ((size_t)form.formd + (((size_t)a->nq * JW + 3) & ~(size_t)3) + (size_t)a->nq * a->test.nb * S +
                                           (size_t)x.nas * ((a->nq + 3) & ~3) * x.mt * 16);
     if (x.nas > 0 && ldsm <= 160 * 1024 && x.mt <= 4) {

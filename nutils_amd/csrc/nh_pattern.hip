@@ -248,9 +248,11 @@ int nh_pattern_build(const nh_pattern_args *a, nh_pattern **out, void *stream) {
   hipStream_t s = nh_stream(stream);
   const i64 ne = a->nelems, nrows = a->nrows;
   // totals of the ragged lists
-  i64 ntot_t, ntot_r;
-  if (a->toff_dev) NH_CHECK_HIP(hipMemcpy(&ntot_t, a->toff_dev + ne, sizeof(i64), hipMemcpyDeviceToHost)); else ntot_t = ne * a->nbt;
-  if (a->roff_dev) NH_CHECK_HIP(hipMemcpy(&ntot_r, a->roff_dev + ne, sizeof(i64), hipMemcpyDeviceToHost)); else ntot_r = ne * a->nbr;
+  // (copies are issued on `stream`, so that offsets a caller produced asynchronously on that stream are complete when read)
+  i64 ntot_t = ne * a->nbt, ntot_r = ne * a->nbr;
+  if (a->toff_dev) NH_CHECK_HIP(hipMemcpyAsync(&ntot_t, a->toff_dev + ne, sizeof(i64), hipMemcpyDeviceToHost, s));
+  if (a->roff_dev) NH_CHECK_HIP(hipMemcpyAsync(&ntot_r, a->roff_dev + ne, sizeof(i64), hipMemcpyDeviceToHost, s));
+  NH_CHECK_HIP(hipStreamSynchronize(s));
   (void)ntot_r;
 
   nh_pattern *p = new nh_pattern();
@@ -332,15 +334,16 @@ int nh_pattern_build(const nh_pattern_args *a, nh_pattern **out, void *stream) {
     if (a->toff_dev || a->roff_dev) {
       // ragged: eoff[e] = prefix of nbt_e * nbr_e (computed on the host side of this call)
       std::vector<i64> ht(ne + 1), hr(ne + 1), he(ne + 1);
-      if (a->toff_dev) PB_CHECK(hipMemcpy(ht.data(), a->toff_dev, sizeof(i64) * (ne + 1), hipMemcpyDeviceToHost));
+      if (a->toff_dev) PB_CHECK(hipMemcpyAsync(ht.data(), a->toff_dev, sizeof(i64) * (ne + 1), hipMemcpyDeviceToHost, s));
       else for (i64 e = 0; e <= ne; ++e) ht[e] = e * a->nbt;
-      if (a->roff_dev) PB_CHECK(hipMemcpy(hr.data(), a->roff_dev, sizeof(i64) * (ne + 1), hipMemcpyDeviceToHost));
+      if (a->roff_dev) PB_CHECK(hipMemcpyAsync(hr.data(), a->roff_dev, sizeof(i64) * (ne + 1), hipMemcpyDeviceToHost, s));
       else for (i64 e = 0; e <= ne; ++e) hr[e] = e * a->nbr;
+      PB_CHECK(hipStreamSynchronize(s));
       he[0] = 0;
       for (i64 e = 0; e < ne; ++e) he[e + 1] = he[e] + (ht[e + 1] - ht[e]) * (hr[e + 1] - hr[e]);
       p->emap_len = he[ne];
       PB_CHECK(hipMalloc((void **)&p->eoff, sizeof(i64) * (ne + 1)));
-      PB_CHECK(hipMemcpy(p->eoff, he.data(), sizeof(i64) * (ne + 1), hipMemcpyHostToDevice));
+      PB_CHECK(hipMemcpyAsync(p->eoff, he.data(), sizeof(i64) * (ne + 1), hipMemcpyHostToDevice, s)); PB_CHECK(hipStreamSynchronize(s));
     } else {
       p->emap_len = ne * (i64)a->nbt * a->nbr;
     }

@@ -122,24 +122,31 @@ static int scan_rec(const Tin *in, i64 *out, i64 n, hipStream_t stream) {
   i64 *tot = nullptr, *off = nullptr;
   NH_CHECK_HIP(hipMalloc((void **)&tot, sizeof(i64) * (nblocks + 1) * 2));
   off = tot + nblocks + 1;
-  hipLaunchKernelGGL(k_scan_block<Tin>, dim3((unsigned)nblocks), dim3(SCAN_T), 0, stream, in, out, tot, n);
-  NH_LAUNCH_CHECK();
   int rc = NH_OK;
-  if (nblocks == 1) {
-    NH_CHECK_HIP(hipMemsetAsync(off, 0, sizeof(i64), stream));
-    NH_CHECK_HIP(hipMemcpyAsync(off + 1, tot, sizeof(i64), hipMemcpyDeviceToDevice, stream));
-  } else {
-    rc = scan_rec<i64>(tot, off, nblocks, stream);
+  hipError_t e = hipSuccess;
+#define SCAN_CHECK(expr)                                                                     \
+  do {                                                                                       \
+    if (rc == NH_OK && (e = (expr)) != hipSuccess) {                                         \
+      nh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e), __FILE__, __LINE__); \
+      rc = NH_EHIP;                                                                          \
+    }                                                                                        \
+  } while (0)
+  hipLaunchKernelGGL(k_scan_block<Tin>, dim3((unsigned)nblocks), dim3(SCAN_T), 0, stream, in, out, tot, n);
+  SCAN_CHECK(hipGetLastError());
+  if (rc == NH_OK) {
+    if (nblocks == 1) {
+      SCAN_CHECK(hipMemsetAsync(off, 0, sizeof(i64), stream));
+      SCAN_CHECK(hipMemcpyAsync(off + 1, tot, sizeof(i64), hipMemcpyDeviceToDevice, stream));
+    } else {
+      rc = scan_rec<i64>(tot, off, nblocks, stream);
+    }
   }
   if (rc == NH_OK) {
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, off, n, out + n);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-      nh_set_error("scan add launch failed: %s", hipGetErrorString(e));
-      rc = NH_EHIP;
-    }
+    SCAN_CHECK(hipGetLastError());
   }
-  hipStreamSynchronize(stream);
+#undef SCAN_CHECK
+  hipStreamSynchronize(stream);  // the scratch is freed below: every path (also the error paths) leaves through here
   hipFree(tot);
   return rc;
 }

@@ -88,6 +88,13 @@ def dot_basis(basis, values):
     raise NotImplementedError('basis @ array is supported for geometry construction only; use fields with arguments otherwise')
 
 
+def _same_geom(a, b):
+    '''Geometry of a sum of gradient operands: mixing gradients with respect to different geometries in one operand is not representable.'''
+    if a is not None and b is not None and a is not b:
+        raise NotImplementedError('sum of gradients with respect to different geometries')
+    return a if a is not None else b
+
+
 class Measure:
     '''J(geom): the volume measure |det dx/dxi| (function.py:1266-1295).'''
 
@@ -99,6 +106,8 @@ class Measure:
         self.geom = geom
 
     def __mul__(self, other):
+        if isinstance(other, IntegrandSum):  # J(geom) * (a - b): distributes like (a - b) * J(geom)
+            return other * self
         return _as_integrand(other).with_measure(self.geom)
 
     __rmul__ = __mul__
@@ -137,6 +146,8 @@ class PointFunc:
         if isinstance(other, (int, float)):
             f = self.func
             return PointFunc(lambda x: numpy.asarray(f(x)) * other, self.geom)
+        if isinstance(other, IntegrandSum):
+            return other * self
         return _as_integrand(other).with_scale(self)
 
     __rmul__ = __mul__
@@ -211,6 +222,8 @@ class FieldPoly:
         if o is None:
             if isinstance(other, PointFunc):
                 return NotImplemented
+            if isinstance(other, IntegrandSum):
+                return other * self
             return _as_integrand(other).with_fscale(self)
         args, a, b = FieldPoly._merge(self, o)
         out = {}
@@ -363,7 +376,7 @@ class Operand:
         if not isinstance(other, Operand) or not other.arg.same(self.arg):
             raise NotImplementedError('operands can only be added to operands of the same argument')
         a, b, _ = _bcast(self.P, other.P, (2, 2))
-        return Operand(self.arg, a + b, self.geom or other.geom)
+        return Operand(self.arg, a + b, _same_geom(self.geom, other.geom))
 
     def __sub__(self, other):
         return self + (-other)
@@ -543,7 +556,8 @@ class Integrand:
             return (a is None and b is None) or (a is not None and b is not None and a.same(b))
         return same(self.test, other.test) and same(self.trial, other.trial) and self.rows == other.rows and self.cols == other.cols \
             and self.measure is other.measure and (self.B is None) == (other.B is None) and (self.L is None) == (other.L is None) \
-            and self.scale is other.scale and self.fscale is other.fscale
+            and self.scale is other.scale and self.fscale is other.fscale \
+            and (self.geom is None or other.geom is None or self.geom is other.geom)  # gradients w.r.t. different geometries stay separate terms
 
     def __truediv__(self, other):
         return self * (1. / numpy.asarray(other, dtype=float))

@@ -588,6 +588,8 @@ def evaluate(f, arguments):
         return f.integral.as_csr()
     if not isinstance(f, function.Integral):
         raise TypeError(f'cannot evaluate {type(f).__name__}')
+    if not f.terms:  # every term vanished (derivative with respect to an argument the integral does not depend on): the dof shape is unknown
+        raise ValueError('empty integral: all terms vanished, the result shape is not defined (did you differentiate with respect to an absent argument?)')
     kinds = {(itg.rows, itg.cols) for _, itg, _ in f.terms}
     if kinds == {(True, True)}:
         values, rowptr, colidx, ncols = _MatrixPlan(f.terms).run(arguments)
