@@ -271,6 +271,38 @@ int nh_p1hex_apply(const nh_p1hex_args *args, const double *u_dev, double *out_d
 /* element matrix (64 doubles, row major) of the uniform cell scale[0] x scale[1] x scale[2] (verts_dev ignored) */
 int nh_p1hex_unit_matrix(const nh_p1hex_args *args, double *ke_dev, void *stream);
 
+/* ---- fast path: structured C0 quadratic hexahedra, constant-coefficient forms, scalar or vector valued ------------------
+ * Same result as nh_pattern_* + nh_assemble_matrix for the 3-D 'std' degree-2 basis (27 nodes per element, local order first axis
+ * slowest: StructuredBasis function.py:3080-3100, mesh.py:34-60) of a full structured mesh, test = trial basis with ncomp
+ * components, constant tensor C (BASELINE.json configs[2]: examples/elasticity.py stiffness scaled to 3-D), but WRITE-ONCE: a
+ * workgroup owns K-lines of nodes, recomputes for every touching element only the rows it owns -- as (4 nodes x slots) x
+ * (16 nodes) x (quadrature points) products on v_mfma_f64_16x16x4_f64, the form tensor applied to the 3x3 / 4x4 slot blocks
+ * afterwards --, reduces in LDS row buffers laid out like the CSR rows and streams finished node planes to HBM.  No global
+ * atomics, no zero-fill, no element map; the sorted-unique pattern of this basis is closed form (nh_p2hex_rowptr: scalar row
+ * pointer of a node; per axis node X couples to [X-2, X+2] (X even) or [X-1, X+1] (X odd), clipped).  values_dev is laid out as
+ * by nh_pattern_expand with all ncomp x ncomp blocks present.
+ * owner_begin..owner_end (inclusive): lines of owner cells along axis 0 whose rows are written (owner io holds the node planes
+ * 2 io and 2 io + 1; io = shape[0] holds the last plane); layer_begin..layer_end: element layers along axis 0 that contribute
+ * (multi-GPU slabs, nutils_amd/partition.py).  Returns NH_ELIMIT when the tables do not fit the LDS (nq too large): use
+ * nh_assemble_matrix. */
+typedef struct {
+  int shape[3];
+  int nq;
+  const double *weights_dev; /* [nq] */
+  nh_geometry geom;
+  const double *T_dev;       /* tabulated basis [27][nq][4] (one table: all elements of a 'std' basis share it) */
+  int ncomp;                 /* components of the test = trial field, 1..3 */
+  const double *C_host;      /* [ncomp][4][ncomp][4] (host memory) */
+  double *values_dev;
+  const double *scale_dev;   /* optional pointwise factor [nelems][nq], NULL = 1 */
+  int layer_begin, layer_end;
+  int owner_begin, owner_end;
+  int max_workgroups;        /* 0: one persistent workgroup per CU */
+} nh_p2hex_args;
+
+int nh_p2hex_matrix(const nh_p2hex_args *args, void *stream);
+int nh_p2hex_rowptr(const int *shape, int64_t node, int64_t *rowptr_out);
+
 /* ---- Monomial: evaluation of factored (pre-integrated) polynomial functionals -------------
  * replaces evaluable.Monomial (evaluable.py:5693-5751; `out = values.copy(); out *= arg[index]`
  * + Inflate/add.at), the per-Newton-step work after evaluable.factor (evaluable.py:5785-5874)

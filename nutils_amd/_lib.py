@@ -64,6 +64,12 @@ class P1HexArgs(ctypes.Structure):
                 ('unit_matrix_dev', vp), ('qscale_dev', vp), ('mass', ctypes.c_double), ('qmass_dev', vp), ('max_workgroups', ctypes.c_int)]
 
 
+class P2HexArgs(ctypes.Structure):
+    _fields_ = [('shape', ctypes.c_int * 3), ('nq', ctypes.c_int), ('weights_dev', vp), ('geom', Geometry), ('T_dev', vp), ('ncomp', ctypes.c_int),
+                ('C_host', vp), ('values_dev', vp), ('scale_dev', vp), ('layer_begin', ctypes.c_int), ('layer_end', ctypes.c_int),
+                ('owner_begin', ctypes.c_int), ('owner_end', ctypes.c_int), ('max_workgroups', ctypes.c_int)]
+
+
 GEOM_ISO = 1
 GEOM_BOX = 2
 GEOM_TAB = 3
@@ -100,6 +106,8 @@ SIGNATURES = {
     'nh_p1hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64, vp, vp, vp]),
     'nh_p1hex_laplace': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp]),
     'nh_p1hex_apply': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp, vp, ctypes.c_int, vp]),
+    'nh_p2hex_matrix': (ctypes.c_int, [ctypes.POINTER(P2HexArgs), vp]),
+    'nh_p2hex_rowptr': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64p]),
     'nh_p1hex_unit_matrix': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp, vp]),
 }
 

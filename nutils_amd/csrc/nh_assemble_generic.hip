@@ -40,102 +40,7 @@ __device__ __forceinline__ const FormK &stage_form(double *lds, const FormK &arg
   return *reinterpret_cast<const FormK *>(lds);
 }
 
-template <int ND>
-__device__ __forceinline__ void invert(const double (&J)[ND][ND], double (&Ji)[ND][ND], double &det) {
-  if constexpr (ND == 1) {
-    det = J[0][0];
-    Ji[0][0] = 1. / det;
-  } else if constexpr (ND == 2) {
-    det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-    const double r = 1. / det;
-    Ji[0][0] = J[1][1] * r;
-    Ji[0][1] = -J[0][1] * r;
-    Ji[1][0] = -J[1][0] * r;
-    Ji[1][1] = J[0][0] * r;
-  } else {
-    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-    det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-    const double r = 1. / det;
-    Ji[0][0] = c00 * r;
-    Ji[1][0] = c01 * r;
-    Ji[2][0] = c02 * r;
-    Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-    Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-    Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-    Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-    Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-    Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
-  }
-}
-
-// geometry at point q of element e: Jinv (row-major [j][i]), det, optionally x
-template <int ND>
-__device__ __forceinline__ void geometry_at(const GeomK &g, i64 e, int q, int nq, const double *points, double (&Ji)[ND][ND], double &det,
-                                            double *x) {
-  constexpr int S = 1 + ND;
-  double J[ND][ND];
-#pragma unroll
-  for (int i = 0; i < ND; ++i)
-#pragma unroll
-    for (int j = 0; j < ND; ++j) J[i][j] = 0;
-  if (g.kind == NH_GEOM_ISO) {
-    if (x)
-      for (int i = 0; i < ND; ++i) x[i] = 0;
-    auto accumulate = [&](int a, const double *X) {
-      const double *t = g.gT + ((i64)a * nq + q) * S;
-#pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        const double xi = X[i];
-        if (x) x[i] += xi * t[0];
-#pragma unroll
-        for (int j = 0; j < ND; ++j) J[i][j] += xi * t[1 + j];
-      }
-    };
-    if (g.ngb == (1 << ND)) {
-      // multilinear geometry: fully unrolled so that all index loads, then all vertex loads, are in flight together
-      // (two memory latencies per point instead of 2 * ngb)
-      constexpr int NG = 1 << ND;
-      int idx[NG];
-#pragma unroll
-      for (int a = 0; a < NG; ++a) idx[a] = g.gdofs[e * NG + a];
-      double X[NG][ND];
-#pragma unroll
-      for (int a = 0; a < NG; ++a)
-#pragma unroll
-        for (int i = 0; i < ND; ++i) X[a][i] = g.verts[(i64)idx[a] * ND + i];
-#pragma unroll
-      for (int a = 0; a < NG; ++a) accumulate(a, X[a]);
-    } else {
-      for (int a = 0; a < g.ngb; ++a) accumulate(a, g.verts + (i64)g.gdofs[e * g.ngb + a] * ND);
-    }
-  } else if (g.kind == NH_GEOM_TAB) {
-    const double *Jt = g.jac + ((i64)e * nq + q) * ND * ND;
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-#pragma unroll
-      for (int j = 0; j < ND; ++j) J[i][j] = Jt[i * ND + j];
-      if (x) x[i] = g.x ? g.x[((i64)e * nq + q) * ND + i] : 0.;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      J[i][i] = g.size[e * ND + i];
-      if (x) x[i] = g.origin[e * ND + i] + J[i][i] * points[q * ND + i];
-    }
-  }
-  invert<ND>(J, Ji, det);
-  if (g.bnd_axis >= 0) {  // surface measure of the face xi_axis = const: |det J| |J^-T e_axis|
-    double s2 = 0;
-#pragma unroll
-    for (int j = 0; j < ND; ++j)
-#pragma unroll
-      for (int i = 0; i < ND; ++i)
-        if (j == g.bnd_axis) s2 += Ji[j][i] * Ji[j][i];
-    det *= sqrt(s2);
-  }
-}
+#include "nh_geom.inc"
 
 __device__ __forceinline__ i64 boff(const BasisK &b, i64 e) { return b.off ? b.off[e] : e * (i64)b.nb; }
 __device__ __forceinline__ int bnb(const BasisK &b, i64 e) { return b.off ? (int)(b.off[e + 1] - b.off[e]) : b.nb; }

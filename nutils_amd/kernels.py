@@ -241,6 +241,48 @@ def p1hex_apply(*, shape, u, out, gauss_x, gauss_w, verts, kappa=1., layers=None
     _lib.call('nh_p1hex_apply', ctypes.byref(a), device.ptr(u), device.ptr(out), int(bool(accumulate)), device.stream())
 
 
+def p2hex_rowptr(shape, node):
+    '''Scalar row pointer of a node of the structured C0 quadratic basis (closed form, nh_p2hex_rowptr).'''
+    out = ctypes.c_int64()
+    _lib.call('nh_p2hex_rowptr', (ctypes.c_int * 3)(*[int(n) for n in shape]), int(node), ctypes.byref(out))
+    return out.value
+
+
+class P2HexMatrix:
+    '''Write-once assembly of a constant-coefficient form on the structured C0 quadratic hex basis (nh_p2hex_matrix), argument block
+    filled once: a re-assembly is one ctypes call.  Call with the value array of the step.'''
+
+    def __init__(self, *, shape, nq, weights, geom, T, ncomp, C, scale=None, layers=None, owners=None, max_workgroups=0):
+        C = numpy.ascontiguousarray(C, dtype=float)
+        if C.shape != (ncomp, 4, ncomp, 4):
+            raise ValueError(f'coefficient tensor has shape {C.shape}, expected {(ncomp, 4, ncomp, 4)}')
+        n0 = int(shape[0])
+        a = _lib.P2HexArgs()
+        a.shape[:] = [int(n) for n in shape]
+        a.nq = int(nq)
+        a.weights_dev = device.ptr(weights)
+        a.geom = geom
+        a.T_dev = device.ptr(T)
+        a.ncomp = int(ncomp)
+        a.C_host = device.host_ptr(C)
+        a.scale_dev = device.ptr(scale)
+        a.layer_begin, a.layer_end = (0, n0) if layers is None else layers
+        a.owner_begin, a.owner_end = (0, n0) if owners is None else owners
+        a.max_workgroups = int(max_workgroups)
+        self._keep = (weights, geom, T, C, scale)
+        self._args = a
+        self._ref = ctypes.byref(a)
+        self._fn = getattr(_lib.load(), 'nh_p2hex_matrix')
+
+    def __call__(self, values):
+        self._args.values_dev = values.data_ptr()
+        _lib.check(self._fn(self._ref, device.stream()))
+
+
+def p2hex_matrix(*, values, **kwargs):
+    P2HexMatrix(**kwargs)(values)
+
+
 def monomial_csr(rowptr, colidx, values, x, y, alpha=1.):
     '''y[r] += alpha * sum_k values[k] x[colidx[k]] (nh_monomial_csr).'''
     _lib.call('nh_monomial_csr', rowptr.numel() - 1, device.ptr(rowptr), device.ptr(colidx), device.ptr(values), device.ptr(x), float(alpha), device.ptr(y),

@@ -309,6 +309,11 @@ def _block_mask(B):
     return (numpy.abs(B).sum(axis=(1, 3)) != 0)
 
 
+def _lib_error():
+    from ._lib import NutilsHipError
+    return NutilsHipError
+
+
 class _MatrixPlan:
     '''All matrix-type terms of one integral share test/trial basis; accumulate into one values buffer.'''
 
@@ -402,6 +407,47 @@ class _MatrixPlan:
                               qscale=qscale, mass=mass, qmass=qmass)
         return values, rowptr, colidx, basis.ndofs, rest
 
+    def _p2hex(self, rowptr, colidx):
+        '''Constant-coefficient forms (summed over the terms) on the quadratic 'std' basis of a full 3-D structured topology, scalar or
+        vector valued with all component blocks coupled -- BASELINE.json configs[2], the 3-D elasticity stiffness matrix -- go to the
+        write-once kernel nh_p2hex_matrix: every CSR value is formed in LDS from the (up to 8) elements that touch it and stored once; no
+        zero-fill, no colours, no element map.  Returns the value array, or None when the integral is of another kind (then the
+        generic path assembles it).'''
+        basis, smp = self.test.basis, self.smp0
+        nc = self.test.ncomp
+        if not (basis is self.trial.basis and isinstance(basis, StructuredBasis) and basis.btype == 'std' and basis.degree == 2 and basis.ndims == 3
+                and basis.dofs_shape == tuple(2 * n + 1 for n in basis.shape) and nc == self.trial.ncomp and nc <= 3 and self.mask.all()):
+            return None
+        if smp.elist is not None or smp.bnd_axis >= 0 or os.environ.get('NUTILS_AMD_NO_FAST_PATH'):
+            return None
+        C, geom = 0., None
+        for _, itg, fac in self.terms:
+            if not (itg.qform is None and itg.qscalar is None and itg.scale is None and itg.fscale is None and itg.measure is not None
+                    and numpy.shape(itg.B) == (nc, 4, nc, 4) and (geom is None or itg.measure is geom)):
+                return None
+            geom = itg.measure
+            C = C + numpy.asarray(itg.B, dtype=float) * fac
+        key = 'p2hex', id(geom), C.tobytes()
+        fn = smp._tables.get(key)
+        if fn is None:
+            try:
+                fn = kernels.P2HexMatrix(shape=basis.shape, nq=smp.points.npoints, weights=smp._weights_dev, geom=smp.geometry(geom), T=smp.tables(basis).T,
+                                         ncomp=nc, C=C)
+                probe = device.empty(colidx.numel(), 'float64')
+                fn(probe)  # NH_ELIMIT (tables do not fit the LDS for this quadrature) surfaces here
+            except _lib_error() as e:
+                if 'LDS' not in str(e):
+                    raise
+                smp._tables[key] = fn = False
+            else:
+                smp._tables[key] = fn
+                return probe
+        if fn is False:
+            return None
+        values = device.empty(colidx.numel(), 'float64')
+        fn(values)
+        return values
+
     def _first_touch(self, term):
         '''(elements per axis, local nodes per axis) if the first term is assembled colour by colour on a non-periodic C0 ('std') basis
         whose local order is the tensor order of its nodes: NH_MATRIX_FIRST_TOUCH applies.'''
@@ -424,6 +470,10 @@ class _MatrixPlan:
         mask = None if self.mask.all() else self.mask
         rowptr, colidx = pat.expand(nct, ncr, mask)
         first_touch = None
+        if fast is None:
+            values = self._p2hex(rowptr, colidx)
+            if values is not None:
+                return values, rowptr, colidx, self.trial.basis.ndofs * ncr
         if fast is not None:  # same sorted-unique pattern: the generic kernel accumulates the remaining terms into the write-once result
             values, terms = fast[0], fast[4]
         else:
