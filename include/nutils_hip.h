@@ -302,6 +302,9 @@ typedef struct {
 
 int nh_p2hex_matrix(const nh_p2hex_args *args, void *stream);
 int nh_p2hex_rowptr(const int *shape, int64_t node, int64_t *rowptr_out);
+/* closed-form CSR index arrays of the component-expanded pattern (all ncomp x ncomp blocks): rowptr_dev int64[nnodes*ncomp+1],
+ * colidx_dev int64[nh_p2hex_rowptr(shape, nnodes) * ncomp^2]; equal to nh_pattern_build + nh_pattern_expand for this basis */
+int nh_p2hex_pattern(const int *shape, int ncomp, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream);
 
 /* ---- Monomial: evaluation of factored (pre-integrated) polynomial functionals -------------
  * replaces evaluable.Monomial (evaluable.py:5693-5751; `out = values.copy(); out *= arg[index]`

@@ -11,7 +11,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(_HERE, 'libnutils_hip.so')
+LIBPATH = os.environ.get('NUTILS_AMD_LIB') or os.path.join(_HERE, 'libnutils_hip.so')  # (override: A/B runs of two builds)
 
 c_i64 = ctypes.c_int64
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -107,6 +107,7 @@ SIGNATURES = {
     'nh_p1hex_laplace': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp]),
     'nh_p1hex_apply': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp, vp, ctypes.c_int, vp]),
     'nh_p2hex_matrix': (ctypes.c_int, [ctypes.POINTER(P2HexArgs), vp]),
+    'nh_p2hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, vp, vp, vp]),
     'nh_p2hex_rowptr': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64p]),
     'nh_p1hex_unit_matrix': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp, vp]),
 }

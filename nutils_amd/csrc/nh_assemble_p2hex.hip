@@ -7,8 +7,8 @@
 //
 // Formulation.  A[(m,c),(n,d)] = sum_{a,b} C[c,a,d,b] G_mn[a,b] with the generalised Gram matrices
 //     G_mn[a,b] = sum_q w_q |J_q| D_m[q,a] D_n[q,b]            (D[.,.,0] = value, D[.,.,1+i] = d/dx_i)
-// so the quadrature sum is ONE symmetric rank-nq update per element, independent of the form and of the number of components:
-// (4 nodes x NS slots) x (16 nodes) tiles on v_mfma_f64_16x16x4_f64 with K = quadrature points, the 9 (or 16) slot pairs of a node
+// so the quadrature sum is ONE rank-nq update per element, independent of the form and of the number of components:
+// (4 nodes x NS slots) x (16 nodes) tiles on v_mfma_f64_16x16x4_f64 with K = quadrature points; the 9 (or 16) slot pairs of a node
 // pair end up in the SAME lane (row = 4 a + node, register index = a; one tile per trial slot b), where the constant tensor C
 // is applied on the VALU.  For elasticity this is 3.0x fewer MFMAs than contracting (m) x (n,d) per test component.
 //
@@ -16,15 +16,21 @@
 // a in {0,1}; a persistent workgroup takes whole K-lines of owner cells and marches along K.  In step k it visits the (up to) four
 // elements (io-di, jo-dj, k) and computes of each only the rows of nodes the line owns, in units of 4 nodes; contributions are
 // reduced in LDS (ds_add_f64) into row buffers laid out exactly like the CSR rows -- one buffer per node plane K, a ring of 3 even +
-// 2 odd planes -- and a finished plane (all of its rows complete, each node's 3 rows contiguous in the value array) is streamed to HBM
+// 2 odd planes -- and a finished plane (all of its rows complete, each node's rows contiguous in the value array) is streamed to HBM
 // with 16-byte stores.  Every element is visited by 4 lines (halo recomputation of the cheap part: geometry + D table); the MFMA
 // work is 8 units of 4 rows per element instead of 6.75.
+//
+// Two kernels: k_p2hex_pipe (default) splits the workgroup into 4 MFMA waves and 4 service waves that run one element ahead -- the
+// service waves evaluate the geometry of the next slice, build the next D table and stream the planes finished in the previous
+// step while the matrix pipe works -- one barrier per element; k_p2hex (all waves in lockstep through the same phases, less LDS)
+// takes the configurations whose tables do not fit twice.
 //
 // The closed-form pattern of this basis: along an axis with n elements node X couples to [X-2, X+2] (X even, clipped) or
 // [X-1, X+1] (X odd); rows are tensor products of these ranges, so row pointers and column positions are arithmetic.
 #include "nh_common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 #include "nh_geom.inc"
@@ -32,8 +38,9 @@ namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-constexpr int NB = 27;  // local nodes, order first axis slowest
-constexpr int NT = 512;
+constexpr int NB = 27;   // local nodes, order first axis slowest
+constexpr int NT = 512;  // lockstep kernel
+constexpr int NQMAX = 28;  // quadrature points per element (7 k-steps): beyond that the tables exceed the LDS anyway
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -56,7 +63,7 @@ struct P2K {
   int io0, io1;      // owner lines io in [io0, io1] along axis 0
   int l0, l1;        // element layers [l0, l1) along axis 0 contribute
   int esz, osz, dsz; // doubles per even / odd plane buffer, per D table
-  int ndb;           // D tables in LDS (2: the table of the next element is built while the MFMA tasks of this one run)
+  int ndb;           // lockstep kernel: D tables in LDS (2: the table of the next element is built while the tasks of this one run)
   const double *weights;
   GeomK geom;
   const double *T;   // [27][nq][4]
@@ -64,250 +71,681 @@ struct P2K {
   const double *scale;
   double lam, mu, mu2;
   double C[144];     // dense: [c][a][d][b] over the active slots
+#ifdef NH_ABLATION
+  long long *tdbg;   // phase timers (cycles summed over waves): see nh_p2hex_matrix
+  int debug;         // 1: no global stores, 2: no LDS atomics, 4: no MFMA loop, 8: no D build, 16: no geometry
+#endif
 };
 
+#ifdef NH_ABLATION
+#define TICK(i) do { const long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
+#define DBG(p, bit) ((p).debug & (bit))
+#else
+#define TICK(i) do {} while (0)
+#define DBG(p, bit) 0
+#endif
+
 struct Line {  // constants of an owner line (io, jo)
-  int io, jo;
+  int io, jo, vmask;  // vmask bit v: element (io - (v >> 1), jo - (v & 1)) exists and contributes
   int loI[2], cntI[2], cumI[2];
   int loJ[2], cntJ[2], cumJ[2];
   int SJ, SK;
 };
 
+struct Lds {
+  double *E, *O, *Dt, *Jv;
+  int *meta;   // [8 planes][4 nodes][2]: offset of the node's rows in the plane buffer, scalar row length (0: node absent)
+  i64 *gmeta;  // [8][4]: offset of the node's first row in the value array
+  int esz, osz;
+  __device__ __forceinline__ double *pbuf(int K) const { return (K & 1) ? O + ((K >> 1) & 1) * osz : E + ((K >> 1) % 3) * esz; }
+};
+
+__device__ __forceinline__ Line make_line(const P2K &p, int line) {
+  Line L;
+  L.io = p.io0 + line / (p.n1 + 1);
+  L.jo = line % (p.n1 + 1);
+  L.SJ = 8 * p.n1 + 1;
+  L.SK = 8 * p.n2 + 1;
+  L.vmask = 0;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int ei = L.io - (v >> 1), ej = L.jo - (v & 1);
+    if (ei >= p.l0 && ei < p.l1 && ej >= 0 && ej < p.n1) L.vmask |= 1 << v;
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int I = 2 * L.io + a, J = 2 * L.jo + a;
+    L.loI[a] = ax_lo(I); L.cntI[a] = ax_cnt(I, p.n0); L.cumI[a] = ax_cum(I, p.n0);
+    L.loJ[a] = ax_lo(J); L.cntJ[a] = ax_cnt(J, p.n1); L.cumJ[a] = ax_cum(J, p.n1);
+  }
+  return L;
+}
+
+// one thread: where the rows of the 4 nodes (ai, aj) of node plane K live -- in the plane buffer and in the value array
+template <int NC>
+__device__ __forceinline__ void plane_meta(const P2K &p, const Line &L, const Lds &S, int K) {
+  const int cK = ax_cnt(K, p.n2), cumK = ax_cum(K, p.n2);
+  int cur = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ai = j >> 1, aj = j & 1;
+    bool ex = false;  // the node has contributions iff an element that contains it is visited
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (((L.vmask >> v) & 1) && (!(v >> 1) || ai == 0) && (!(v & 1) || aj == 0)) ex = true;
+    const int len = ex ? L.cntI[ai] * L.cntJ[aj] * cK : 0;
+    const i64 row0 = (i64)L.cumI[ai] * L.SJ * L.SK + (i64)L.cntI[ai] * ((i64)L.cumJ[aj] * L.SK + (i64)L.cntJ[aj] * cumK);
+    const i64 goff = row0 * (NC * NC);
+    cur = ((cur + 1) & ~1) + (int)(goff & 1);  // blocks never share a 16-byte pair: the flush copies and zeroes whole pairs
+    S.meta[((K & 7) * 4 + j) * 2] = cur;
+    S.meta[((K & 7) * 4 + j) * 2 + 1] = len;
+    S.gmeta[(K & 7) * 4 + j] = goff;
+    cur += len * NC * NC;
+  }
+}
+
+// 16-byte pairs the rows of node j of plane K occupy in the value array
+template <int NC>
+__device__ __forceinline__ int node_pairs(const Lds &S, int K, int j) {
+  const int len = S.meta[((K & 7) * 4 + j) * 2 + 1];
+  if (!len) return 0;
+  const int par = (int)(S.gmeta[(K & 7) * 4 + j] & 1);
+  return (par + len * NC * NC + 1) >> 1;
+}
+// stream pairs [pair0, pair1) of the finished rows of node j of plane K to the value array and zero them in the buffer (thread t of nt)
+template <int NC>
+__device__ __forceinline__ void flush_node(const P2K &p, const Lds &S, int K, int j, int pair0, int pair1, int t, int nt) {
+  const int off = S.meta[((K & 7) * 4 + j) * 2], len = S.meta[((K & 7) * 4 + j) * 2 + 1];
+  if (!len) return;
+  const i64 goff = S.gmeta[(K & 7) * 4 + j];
+  const int par = (int)(goff & 1), nd = len * NC * NC;
+  double *lb = S.pbuf(K) + off - par;
+  double *gb = p.values + (goff - par);
+  for (int pi = pair0 + t; pi < pair1; pi += nt) {
+    const v2d v = *reinterpret_cast<const v2d *>(lb + 2 * pi);
+    *reinterpret_cast<v2d *>(lb + 2 * pi) = v2d{0., 0.};
+    const int e0 = 2 * pi;
+    const bool v0 = e0 >= par, v1 = e0 + 1 < par + nd;
+    if (DBG(p, 1)) continue;
+    if (v0 && v1) *reinterpret_cast<v2d *>(gb + e0) = v;
+    else if (v0) gb[e0] = v[0];
+    else if (v1) gb[e0 + 1] = v[1];
+  }
+}
+template <int NC>
+__device__ __forceinline__ void flush_plane(const P2K &p, const Lds &S, int K, int t, int nt) {
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) flush_node<NC>(p, S, K, j, 0, node_pairs<NC>(S, K, j), t, nt);
+}
+
+// geometry of point q of element (visit v, slice k): Jinv (row major [j][i]) and w |det J| scale
+__device__ __forceinline__ void geometry_point(const P2K &p, const Line &L, int v, int k, int q, double *o) {
+  const i64 e = ((i64)(L.io - (v >> 1)) * p.n1 + (L.jo - (v & 1))) * p.n2 + k;
+  double Ji[3][3], det;
+  geometry_at<3>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[j * 3 + i] = Ji[j][i];
+  o[9] = p.weights[q] * fabs(det) * (p.scale ? p.scale[e * p.nq + q] : 1.);
+}
+
+// D table entry (q, n): physical derivatives in MFMA operand order [slot][kstep][ntile][lk][li], q = 4 kstep + lk, n = 16 ntile + li
+template <int NS>
+__device__ __forceinline__ void d_entry(const P2K &p, const double (&T4)[4], const double *Ji, double *D, int q, int n) {
+  double d[4];
+  d[0] = T4[0];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d[1 + i] = T4[1] * Ji[i] + T4[2] * Ji[3 + i] + T4[3] * Ji[6 + i];
+  double *o = D + (((q >> 2) * 2 + (n >> 4)) * 64 + (q & 3) * 16 + (n & 15));
+#pragma unroll
+  for (int a = 0; a < NS; ++a) {
+    const int sl = p.slot[a];
+    o[a * p.ks * 128] = sl == 0 ? d[0] : sl == 1 ? d[1] : sl == 2 ? d[2] : d[3];
+  }
+}
+
+// MFMA tasks of one element (visit v of slice k): (unit of 4 row nodes, tile of 16 column nodes, half of the k-steps), dealt to
+// the nw waves; results go to the plane buffers with ds_add_f64
+template <int NC, int NS, int MODE>
+__device__ __forceinline__ void mfma_tasks(const P2K &p, const Line &L, const Lds &S, const double *D, const double *Jvs, int v, int k, int wave,
+                                           int nw, int lane) {
+  const int lk = lane >> 4, li = lane & 15, KS = p.ks;
+  const int di = v >> 1, dj = v & 1;
+  const int nunits = v == 0 ? 3 : v == 3 ? 1 : 2;
+  const int ei = L.io - di, ej = L.jo - dj;
+#pragma unroll 1
+  for (int t = wave; t < nunits * 4; t += nw) {
+    const int u = t >> 2, nt = (t >> 1) & 1, h = t & 1;
+    // local node (ai, aj, ak) of row slot mu of this unit, or invalid
+    auto unit_node = [&](int mu, int &ai, int &aj, int &ak) -> bool {
+      if (v == 0) { ai = mu >> 1; aj = mu & 1; ak = u; return true; }
+      if (v == 1) { aj = 2; if (u == 0) { ai = mu >> 1; ak = mu & 1; return true; } ai = mu & 1; ak = 2; return mu < 2; }
+      if (v == 2) { ai = 2; if (u == 0) { aj = mu >> 1; ak = mu & 1; return true; } aj = mu & 1; ak = 2; return mu < 2; }
+      ai = 2; aj = 2; ak = mu < 3 ? mu : 0; return mu < 3;
+    };
+    int Aoff;
+    {
+      int ai, aj, ak;
+      const int aslot = li >> 2;
+      const bool ok = unit_node(li & 3, ai, aj, ak) && aslot < NS;
+      const int node = ok ? (ai * 3 + aj) * 3 + ak : 31;  // node 31: a pad column of the table, always zero
+      Aoff = (ok ? aslot : 0) * KS * 128 + (node >> 4) * 64 + lk * 16 + (node & 15);
+    }
+    const int Boff = nt * 64 + lane;
+    const int kh = (KS + 1) >> 1;
+    const int ks0 = h ? kh : 0, ks1 = h ? KS : kh;
+    v4d acc[NS];
+#pragma unroll
+    for (int b = 0; b < NS; ++b) acc[b] = v4d{0., 0., 0., 0.};
+#pragma unroll 1
+    for (int ks = ks0; ks < (DBG(p, 4) ? ks0 : ks1); ++ks) {
+      const double a = D[Aoff + ks * 128];
+      const double wq = Jvs[(v * p.nq + min(4 * ks + lk, p.nq - 1)) * 10 + 9];  // (pad points: the table entries are zero)
+      double bv[NS];
+#pragma unroll
+      for (int b = 0; b < NS; ++b) bv[b] = wq * D[Boff + (b * KS + ks) * 128];
+#pragma unroll
+      for (int b = 0; b < NS; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[b], acc[b], 0, 0, 0);
+    }
+    // this lane: row node mu = lk, column node n = 16 nt + li, G[a][b] = acc[b][a]
+    int ai, aj, ak;
+    const bool okr = unit_node(lk, ai, aj, ak);
+    const int n = nt * 16 + li;
+    if (okr && n < NB && !DBG(p, 2)) {
+      double Kcd[NC][NC];
+      if constexpr (MODE == 1) {  // C[c,a,d,b] = lam d_ca d_db + mu d_cd d_ab + mu2 d_cb d_ad over the three gradient slots
+        const double tr = p.mu * (acc[0][0] + acc[1][1] + acc[2][2]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int d = 0; d < NC; ++d) Kcd[c][d] = p.lam * acc[d][c] + p.mu2 * acc[c][d] + (c == d ? tr : 0.);
+      } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int d = 0; d < NC; ++d) {
+            double s = 0;
+#pragma unroll
+            for (int a = 0; a < NS; ++a)
+#pragma unroll
+              for (int b = 0; b < NS; ++b) s += p.C[((c * NS + a) * NC + d) * NS + b] * acc[b][a];
+            Kcd[c][d] = s;
+          }
+      }
+      const int alI = di ? 0 : ai, alJ = dj ? 0 : aj;
+      const int K = 2 * k + ak;
+      const int j = alI * 2 + alJ;
+      const int off = S.meta[((K & 7) * 4 + j) * 2], len = S.meta[((K & 7) * 4 + j) * 2 + 1];
+      const int cK = ax_cnt(K, p.n2), lK = ax_lo(K);
+      const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
+      const int loI = alI ? L.loI[1] : L.loI[0], loJ = alJ ? L.loJ[1] : L.loJ[0], cJ = alJ ? L.cntJ[1] : L.cntJ[0];
+      const int pos = ((2 * ei + ni - loI) * cJ + (2 * ej + nj - loJ)) * cK + (2 * k + nk - lK);
+      double *row = S.pbuf(K) + off + pos * NC;
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int d = 0; d < NC; ++d) atomicAdd(row + c * len * NC + d, Kcd[c][d]);
+    }
+  }
+}
+
+__device__ __forceinline__ int nth_visit(int vmask, int i) {  // index of the i-th set bit
+  int v = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if ((vmask >> b) & 1) {
+      if (i == 0) v = b;
+      --i;
+    }
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lockstep kernel: every wave walks through geometry -> D table -> MFMA tasks -> flush
 template <int NC, int NS, int MODE>
 __global__ __launch_bounds__(NT) void k_p2hex(P2K p) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lk = lane >> 4, li = lane & 15;
-  constexpr int NC2 = NC * NC;
-  double *E = lds;                     // 3 even-plane buffers
-  double *O = E + 3 * p.esz;           // 2 odd-plane buffers
-  double *Dt = O + 2 * p.osz;          // 2 D tables, layout [slot][kstep][ntile][lk][li] = D_n[q = 4 kstep + lk][slot], n = 16 ntile + li
-  double *Jv = Dt + p.ndb * p.dsz;         // [4 visits][nq][10]: Jinv (row major [j][i]), w |det J| scale
-  int *meta = reinterpret_cast<int *>(Jv + 4 * p.nq * 10);  // [8 planes][4 nodes][2]: offset in the plane buffer, scalar row length
-  i64 *gmeta = reinterpret_cast<i64 *>(meta + 64);           // [8][4]: offset of the node's first row in the value array
-
+  Lds S;
+  S.esz = p.esz; S.osz = p.osz;
+  S.E = lds;                      // 3 even-plane buffers
+  S.O = S.E + 3 * p.esz;          // 2 odd-plane buffers
+  S.Dt = S.O + 2 * p.osz;         // ndb D tables
+  S.Jv = S.Dt + p.ndb * p.dsz;    // [4 visits][nq][10]
+  S.meta = reinterpret_cast<int *>(S.Jv + 4 * p.nq * 10);
+  S.gmeta = reinterpret_cast<i64 *>(S.meta + 64);
   // zero everything once: row buffers are re-zeroed by the flush, the pad entries of the D tables (q >= nq, n >= 27) stay zero
-  {
-    const int tot = 3 * p.esz + 2 * p.osz + p.ndb * p.dsz;
-    for (int i = tid; i < tot; i += NT) lds[i] = 0.;
-  }
-  const int KS = p.ks;
+  for (int i = tid; i < 3 * p.esz + 2 * p.osz + p.ndb * p.dsz; i += NT) lds[i] = 0.;
   const int nlines = (p.io1 - p.io0 + 1) * (p.n1 + 1);
-  auto pbuf = [&](int K) -> double * { return (K & 1) ? O + ((K >> 1) & 1) * p.osz : E + ((K >> 1) % 3) * p.esz; };
-
   for (int line = blockIdx.x; line < nlines; line += gridDim.x) {
-    Line L;
-    L.io = p.io0 + line / (p.n1 + 1);
-    L.jo = line % (p.n1 + 1);
-    L.SJ = 8 * p.n1 + 1;
-    L.SK = 8 * p.n2 + 1;
-    int vmask = 0;  // valid visits (bit v: element (io - (v >> 1), jo - (v & 1)) exists and contributes)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int ei = L.io - (v >> 1), ej = L.jo - (v & 1);
-      if (ei >= p.l0 && ei < p.l1 && ej >= 0 && ej < p.n1) vmask |= 1 << v;
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int I = 2 * L.io + a, J = 2 * L.jo + a;
-      L.loI[a] = ax_lo(I); L.cntI[a] = ax_cnt(I, p.n0); L.cumI[a] = ax_cum(I, p.n0);
-      L.loJ[a] = ax_lo(J); L.cntJ[a] = ax_cnt(J, p.n1); L.cumJ[a] = ax_cum(J, p.n1);
-    }
-    if (!vmask) continue;
-    // node (ai, aj) of this line has contributions iff an element containing it is visited
-    auto node_exists = [&](int ai, int aj) -> bool {
-      bool ex = false;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int di = v >> 1, dj = v & 1;
-        // element (io - di, jo - dj) contains node (2io + ai, 2jo + aj) iff (di ? ai == 0 : true) and (dj ? aj == 0 : true)
-        if (((vmask >> v) & 1) && (!di || ai == 0) && (!dj || aj == 0)) ex = true;
-      }
-      return ex;
-    };
-    auto plane_meta = [&](int K) {  // one thread: offsets of the 4 nodes of plane K inside its buffer, global offsets
-      const int cK = ax_cnt(K, p.n2), cumK = ax_cum(K, p.n2);
-      int cur = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ai = j >> 1, aj = j & 1;
-        const bool ex = node_exists(ai, aj);
-        const int len = ex ? L.cntI[ai] * L.cntJ[aj] * cK : 0;
-        const i64 row0 = (i64)L.cumI[ai] * L.SJ * L.SK + (i64)L.cntI[ai] * ((i64)L.cumJ[aj] * L.SK + (i64)L.cntJ[aj] * cumK);
-        const i64 goff = row0 * NC2;
-        cur = ((cur + 1) & ~1) + (int)(goff & 1);  // blocks never share a 16-byte pair: the flush copies and zeroes whole pairs
-        meta[((K & 7) * 4 + j) * 2] = cur;
-        meta[((K & 7) * 4 + j) * 2 + 1] = len;
-        gmeta[(K & 7) * 4 + j] = goff;
-        cur += len * NC2;
-      }
-    };
-    auto flush_plane = [&](int K) {
-      double *buf = pbuf(K);
-#pragma unroll 1
-      for (int j = 0; j < 4; ++j) {
-        const int off = meta[((K & 7) * 4 + j) * 2], len = meta[((K & 7) * 4 + j) * 2 + 1];
-        if (!len) continue;
-        const i64 goff = gmeta[(K & 7) * 4 + j];
-        const int par = (int)(goff & 1), nd = len * NC2;
-        double *lb = buf + off - par;
-        double *gb = p.values + (goff - par);
-        const int npairs = (par + nd + 1) >> 1;
-        for (int pi = tid; pi < npairs; pi += NT) {
-          const v2d v = *reinterpret_cast<const v2d *>(lb + 2 * pi);
-          *reinterpret_cast<v2d *>(lb + 2 * pi) = v2d{0., 0.};
-          const int e0 = 2 * pi;
-          const bool v0 = e0 >= par, v1 = e0 + 1 < par + nd;
-          if (v0 && v1) *reinterpret_cast<v2d *>(gb + e0) = v;
-          else if (v0) gb[e0] = v[0];
-          else if (v1) gb[e0 + 1] = v[1];
-        }
-      }
-    };
-
+    const Line L = make_line(p, line);
+    if (!L.vmask) continue;
     lds_barrier();  // previous line done (meta, buffers)
-    if (tid == 0) plane_meta(0);
+    if (tid == 0) plane_meta<NC>(p, L, S, 0);
     for (int k = 0; k < p.n2; ++k) {
-      // ---- phase G: meta of the planes entering the ring, geometry of the 4 elements of this slice
-      if (tid == 64) plane_meta(2 * k + 1);
-      if (tid == 128) plane_meta(2 * k + 2);
+      // ---- meta of the planes entering the ring, geometry of the 4 elements of this slice
+      if (tid == 64) plane_meta<NC>(p, L, S, 2 * k + 1);
+      if (tid == 128) plane_meta<NC>(p, L, S, 2 * k + 2);
       if (tid < 4 * p.nq) {
         const int v = tid / p.nq, q = tid - v * p.nq;
-        if ((vmask >> v) & 1) {
-          const i64 e = ((i64)(L.io - (v >> 1)) * p.n1 + (L.jo - (v & 1))) * p.n2 + k;
-          double Ji[3][3], det;
-          geometry_at<3>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
-          double *o = Jv + (v * p.nq + q) * 10;
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) o[j * 3 + i] = Ji[j][i];
-          o[9] = p.weights[q] * fabs(det) * (p.scale ? p.scale[e * p.nq + q] : 1.);
-        }
+        if ((L.vmask >> v) & 1) geometry_point(p, L, v, k, q, S.Jv + (v * p.nq + q) * 10);
       }
       lds_barrier();
       int nbuilt = 0;
 #pragma unroll 1
       for (int v = 0; v < 4; ++v) {
-        if (!((vmask >> v) & 1)) continue;
-        double *D = Dt + (p.ndb == 2 ? (nbuilt & 1) * p.dsz : 0);
+        if (!((L.vmask >> v) & 1)) continue;
+        double *D = S.Dt + (p.ndb == 2 ? (nbuilt & 1) * p.dsz : 0);
         if (p.ndb == 1 && nbuilt) lds_barrier();  // single table: the tasks of the previous element have read it
         ++nbuilt;
-        // ---- D table of element v: physical derivatives in MFMA operand order (the weight w |J| multiplies the B operand when it is read)
         for (int idx = tid; idx < p.nq * NB; idx += NT) {
           const int q = idx / NB, n = idx - q * NB;
-          const double *T4 = p.T + ((i64)n * p.nq + q) * 4;
-          const double *Ji = Jv + (v * p.nq + q) * 10;
-          double d[4];
-          d[0] = T4[0];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) d[1 + i] = T4[1] * Ji[i] + T4[2] * Ji[3 + i] + T4[3] * Ji[6 + i];
-          double *o = D + (((q >> 2) * 2 + (n >> 4)) * 64 + (q & 3) * 16 + (n & 15));
-#pragma unroll
-          for (int a = 0; a < NS; ++a) {
-            const int sl = p.slot[a];
-            o[a * KS * 128] = sl == 0 ? d[0] : sl == 1 ? d[1] : sl == 2 ? d[2] : d[3];
-          }
+          const double *Tp = p.T + ((i64)n * p.nq + q) * 4;
+          const double T4[4] = {Tp[0], Tp[1], Tp[2], Tp[3]};
+          d_entry<NS>(p, T4, S.Jv + (v * p.nq + q) * 10, D, q, n);
         }
         lds_barrier();
-        // ---- MFMA tasks: (unit of 4 row nodes, tile of 16 column nodes, half of the k-steps)
-        const int di = v >> 1, dj = v & 1;
-        const int nunits = v == 0 ? 3 : v == 3 ? 1 : 2;
-        const int ei = L.io - di, ej = L.jo - dj;
-#pragma unroll 1
-        for (int t = wave; t < nunits * 4; t += NT / 64) {
-          const int u = t >> 2, nt = (t >> 1) & 1, h = t & 1;
-          // local node of row slot mu of this unit: (ai, aj, ak), or invalid
-          auto unit_node = [&](int mu, int &ai, int &aj, int &ak) -> bool {
-            if (v == 0) { ai = mu >> 1; aj = mu & 1; ak = u; return true; }
-            if (v == 1) { aj = 2; if (u == 0) { ai = mu >> 1; ak = mu & 1; return true; } ai = mu & 1; ak = 2; return mu < 2; }
-            if (v == 2) { ai = 2; if (u == 0) { aj = mu >> 1; ak = mu & 1; return true; } aj = mu & 1; ak = 2; return mu < 2; }
-            ai = 2; aj = 2; ak = mu < 3 ? mu : 0; return mu < 3;
-          };
-          int Aoff;
-          {
-            int ai, aj, ak;
-            const int aslot = li >> 2;
-            const bool ok = unit_node(li & 3, ai, aj, ak) && aslot < NS;
-            const int node = ok ? (ai * 3 + aj) * 3 + ak : 31;  // node 31: a pad column of the table, always zero
-            Aoff = (ok ? aslot : 0) * KS * 128 + (node >> 4) * 64 + lk * 16 + (node & 15);
-          }
-          const int Boff = nt * 64 + lane;
-          const int kh = (KS + 1) >> 1;
-          const int ks0 = h ? kh : 0, ks1 = h ? KS : kh;
-          v4d acc[NS];
-#pragma unroll
-          for (int b = 0; b < NS; ++b) acc[b] = v4d{0., 0., 0., 0.};
-#pragma unroll 1
-          for (int ks = ks0; ks < ks1; ++ks) {
-            const double a = D[Aoff + ks * 128];
-            const double wq = Jv[(v * p.nq + min(4 * ks + lk, p.nq - 1)) * 10 + 9];  // (pad points: the table entries are zero)
-            double bv[NS];
-#pragma unroll
-            for (int b = 0; b < NS; ++b) bv[b] = wq * D[Boff + (b * KS + ks) * 128];
-#pragma unroll
-            for (int b = 0; b < NS; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[b], acc[b], 0, 0, 0);
-          }
-          // ---- this lane: row node mu = lk, column node n = 16 nt + li, G[a][b] = acc[b][a]
-          int ai, aj, ak;
-          const bool okr = unit_node(lk, ai, aj, ak);
-          const int n = nt * 16 + li;
-          if (okr && n < NB) {
-            double Kcd[NC][NC];
-            if constexpr (MODE == 1) {  // C[c,a,d,b] = lam d_ca d_db + mu d_cd d_ab + mu2 d_cb d_ad over the three gradient slots
-              const double tr = p.mu * (acc[0][0] + acc[1][1] + acc[2][2]);
-#pragma unroll
-              for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int d = 0; d < NC; ++d) Kcd[c][d] = p.lam * acc[d][c] + p.mu2 * acc[c][d] + (c == d ? tr : 0.);
-            } else {
-#pragma unroll
-              for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int d = 0; d < NC; ++d) {
-                  double s = 0;
-#pragma unroll
-                  for (int a = 0; a < NS; ++a)
-#pragma unroll
-                    for (int b = 0; b < NS; ++b) s += p.C[((c * NS + a) * NC + d) * NS + b] * acc[b][a];
-                  Kcd[c][d] = s;
-                }
-            }
-            const int alI = di ? 0 : ai, alJ = dj ? 0 : aj;
-            const int K = 2 * k + ak;
-            const int j = alI * 2 + alJ;
-            const int off = meta[((K & 7) * 4 + j) * 2], len = meta[((K & 7) * 4 + j) * 2 + 1];
-            const int cK = ax_cnt(K, p.n2), lK = ax_lo(K);
-            const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
-            const int loI = alI ? L.loI[1] : L.loI[0], loJ = alJ ? L.loJ[1] : L.loJ[0], cJ = alJ ? L.cntJ[1] : L.cntJ[0];
-            const int pos = ((2 * ei + ni - loI) * cJ + (2 * ej + nj - loJ)) * cK + (2 * k + nk - lK);
-            double *row = pbuf(K) + off + pos * NC;
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-              for (int d = 0; d < NC; ++d) atomicAdd(row + c * len * NC + d, Kcd[c][d]);
-          }
-        }
+        mfma_tasks<NC, NS, MODE>(p, L, S, D, S.Jv, v, k, wave, NT / 64, lane);
       }
       lds_barrier();  // all contributions of slice k are in LDS
-      flush_plane(2 * k);
-      flush_plane(2 * k + 1);
+      flush_plane<NC>(p, S, 2 * k, tid, NT);
+      flush_plane<NC>(p, S, 2 * k + 1, tid, NT);
     }
     lds_barrier();
-    flush_plane(2 * p.n2);
+    flush_plane<NC>(p, S, 2 * p.n2, tid, NT);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pipelined kernel (NS = 3 slots, 25..28 quadrature points = 7 k-steps): waves 0..3 -- one per SIMD -- run the MFMA tasks of
+// element r while waves 4..7 build the D table of element r + 1, evaluate the geometry of the next slice and stream the planes
+// finished in the previous slice; one barrier per element.  On gfx950 an f64 MFMA occupies its SIMD for all 64 cycles: VALU work of a
+// co-resident wave does NOT overlap it (tools/ubench/mfma_valu_overlap.hip), so every VALU instruction of either role adds to the
+// matrix time of its SIMD; the roles exist to overlap LATENCIES (LDS, vertex loads, store issue), and both are written for the lowest
+// instruction count: k-steps fully unrolled with immediate offsets, all per-lane task constants computed once per line, the flush in
+// node blocks with wave-uniform bases.
+constexpr int PKS = 7, PNQ = 4 * PKS;                      // k-steps, padded quadrature points
+constexpr int NMW4 = 4, NTP4 = 512, NST4 = 256, NFW = 3;  // MFMA waves, threads, service threads, flushing service waves
+
+// local node (ai, aj, ak) of row slot mu of unit u of visit V, or invalid
+template <int V>
+__device__ __forceinline__ bool unit_node(int u, int mu, int &ai, int &aj, int &ak) {
+  if constexpr (V == 0) { ai = mu >> 1; aj = mu & 1; ak = u; return true; }
+  if constexpr (V == 1) { aj = 2; if (u == 0) { ai = mu >> 1; ak = mu & 1; return true; } ai = mu & 1; ak = 2; return mu < 2; }
+  if constexpr (V == 2) { ai = 2; if (u == 0) { aj = mu >> 1; ak = mu & 1; return true; } aj = mu & 1; ak = 2; return mu < 2; }
+  ai = 2; aj = 2; ak = mu < 3 ? mu : 0; return mu < 3;
+}
+
+// what a lane needs to know about one of its wave's tasks (constant along a line)
+struct TaskD {
+  int Aoff;   // A operand: offset (doubles) of this lane's entry in the D table at k-step 0
+  int Boff;   // B operand
+  int posIJ;  // column position of this lane's (row node, column node) pair in the row, without the K part
+  int info;   // bit 0: valid pair; bits 1-2: ak (0, 1: planes 2k, 2k+1 of this slice, 2: plane 2k+2); bits 3-4: node index in the plane; bits 5-6: nk
+};
+
+template <int V>
+__device__ __forceinline__ TaskD make_task(const Line &L, int u, int nt, int lane) {
+  const int lk = lane >> 4, li = lane & 15;
+  constexpr int di = V >> 1, dj = V & 1;
+  TaskD d;
+  {
+    int ai, aj, ak;
+    const int aslot = li >> 2;
+    const bool ok = unit_node<V>(u, li & 3, ai, aj, ak) && aslot < 3;
+    const int node = ok ? (ai * 3 + aj) * 3 + ak : 31;  // node 31: a pad column of the table, always zero
+    d.Aoff = (ok ? aslot : 0) * PKS * 128 + (node >> 4) * 64 + lk * 16 + (node & 15);
+  }
+  d.Boff = nt * 64 + lane;
+  int ai, aj, ak;
+  const bool okr = unit_node<V>(u, lk, ai, aj, ak);
+  const int n = nt * 16 + li;
+  const int alI = di ? 0 : ai, alJ = dj ? 0 : aj;
+  const int ni = n / 9, nj = (n / 3) % 3, nk = n % 3;
+  const int loI = alI ? L.loI[1] : L.loI[0], loJ = alJ ? L.loJ[1] : L.loJ[0], cJ = alJ ? L.cntJ[1] : L.cntJ[0];
+  d.posIJ = (2 * (L.io - di) + ni - loI) * cJ + (2 * (L.jo - dj) + nj - loJ);
+  d.info = (okr && n < NB ? 1 : 0) | ak << 1 | (alI * 2 + alJ) << 3 | nk << 5;
+  return d;
+}
+
+struct StepU {    // constants of a slice k (uniform)
+  int pb0, pb1, pb2;  // buffers of the planes 2k, 2k+1, 2k+2 (offsets from S.E in doubles)
+  int cK0, cK2;       // columns along K of a row of plane 2k / 2k+2 (3 in a boundary plane, else 5; plane 2k+1: 3)
+  int dK0;            // 2k - first column of a row of plane 2k
+  int m0;             // meta slot of plane 2k
+};
+
+// k-steps [K0, K1) of one (unit, column tile) product + the form tensor + the LDS reduction
+template <int NC, int MODE, int K0, int K1>
+__device__ __forceinline__ void run_task(const P2K &p, const Lds &S, const StepU &U, const TaskD &d, const double *D, const double *Jw, int lane) {
+  const int lk = lane >> 4;
+  const int ak = (d.info >> 1) & 3, j = (d.info >> 3) & 3;
+  // where the row lives: read ahead of the MFMA chain
+  const int2 m = *reinterpret_cast<const int2 *>(S.meta + ((((U.m0 + ak) & 7) * 4 + j) * 2));
+  const double *pa = D + d.Aoff, *pb = D + d.Boff, *pw = Jw + lk * 10;
+  v4d acc[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) acc[b] = v4d{0., 0., 0., 0.};
+  if (!DBG(p, 4)) {
+    double an = pa[K0 * 128], wn = pw[K0 * 40], bn[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) bn[b] = pb[(b * PKS + K0) * 128];
+#pragma unroll
+    for (int ks = K0; ks < K1; ++ks) {
+      const double a = an * wn;  // the weight w |J| enters through the A operand
+      double bv[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) bv[b] = bn[b];
+      if (ks + 1 < K1) {  // operands of the next k-step are in flight while the matrix pipe works
+        an = pa[(ks + 1) * 128];
+        wn = pw[(ks + 1) * 40];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) bn[b] = pb[(b * PKS + ks + 1) * 128];
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[b], acc[b], 0, 0, 0);
+    }
+  }
+  // this lane: G[a][b] = acc[b][a] of its (row node, column node) pair
+  if ((d.info & 1) && !DBG(p, 2)) {
+    double Kcd[NC][NC];
+    if constexpr (MODE == 1) {  // C[c,a,d,b] = lam d_ca d_db + mu d_cd d_ab + mu2 d_cb d_ad over the three gradient slots
+      const double tr = p.mu * (acc[0][0] + acc[1][1] + acc[2][2]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int dd = 0; dd < NC; ++dd) Kcd[c][dd] = p.lam * acc[dd][c] + p.mu2 * acc[c][dd] + (c == dd ? tr : 0.);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int dd = 0; dd < NC; ++dd) {
+          double sum = 0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) sum += p.C[((c * 3 + a) * NC + dd) * 3 + b] * acc[b][a];
+          Kcd[c][dd] = sum;
+        }
+    }
+    // per-lane choice among the three planes by masks (a select chain on ak is turned into a table in scratch by the compiler)
+    const int m1 = -(ak & 1), m2 = -(ak >> 1), m0 = ~(m1 | m2);
+    const int cK = U.cK0 + (m1 & (3 - U.cK0)) + (m2 & (U.cK2 - U.cK0));
+    const int pos = d.posIJ * cK + ((d.info >> 5) & 3) + (m0 & U.dK0);
+    double *row = S.E + (U.pb0 + (m1 & (U.pb1 - U.pb0)) + (m2 & (U.pb2 - U.pb0)) + m.x + pos * NC);
+    const int rs = m.y * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int dd = 0; dd < NC; ++dd) atomicAdd(row + c * rs + dd, Kcd[c][dd]);
+  }
+}
+
+// stream the finished rows of node j of plane K to the value array and zero them in the buffer: 16-byte pairs with wave-uniform
+// bases (the block is contiguous in both memories and starts with the same parity), the odd head / tail element by one lane
+template <int NC>
+__device__ __forceinline__ void flush_block(const P2K &p, const Lds &S, int K, int j, int t, int nt) {
+  const int2 m = *reinterpret_cast<const int2 *>(S.meta + (((K & 7) * 4 + j) * 2));
+  const int off = __builtin_amdgcn_readfirstlane(m.x), nd = __builtin_amdgcn_readfirstlane(m.y) * NC * NC;
+  if (!nd) return;
+  const i64 g0 = S.gmeta[(K & 7) * 4 + j];
+  const i64 goff = ((i64)__builtin_amdgcn_readfirstlane((int)(g0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g0);
+  double *lb = S.pbuf(K) + off;
+  double *gb = p.values + goff;
+  const int head = off & 1, npairs = (nd - head) >> 1, tail = (nd - head) & 1;
+  v2d *lp = reinterpret_cast<v2d *>(lb + head);
+  v2d *gp = reinterpret_cast<v2d *>(gb + head);
+  for (int pi = t; pi < npairs; pi += nt) {
+    const v2d v = lp[pi];
+    lp[pi] = v2d{0., 0.};
+    if (!DBG(p, 1)) gp[pi] = v;
+  }
+  if (t == 0 && head) {
+    const double v = lb[0];
+    lb[0] = 0.;
+    if (!DBG(p, 1)) gb[0] = v;
+  }
+  if (t == 1 && tail) {
+    const double v = lb[nd - 1];
+    lb[nd - 1] = 0.;
+    if (!DBG(p, 1)) gb[nd - 1] = v;
+  }
+}
+
+template <int NC, int MODE>
+__device__ __forceinline__ void mfma_role(const P2K &p, const Lds &S, int wave, int lane) {
+  constexpr int jsz = 4 * PNQ * 10;
+#ifdef NH_ABLATION
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+  const int nlines = (p.io1 - p.io0 + 1) * (p.n1 + 1);
+  for (int line = blockIdx.x; line < nlines; line += gridDim.x) {
+    const Line L = make_line(p, line);
+    if (!L.vmask) continue;
+    const int nv = __builtin_popcount(L.vmask), nph = nv < 2 ? 2 : nv;
+    // the tasks of this wave, one matrix pipe each: element 0 (6 products): a whole one + half the k-steps of another;
+    // elements 1, 2 (4 products): one each; element 3 (2 products): half of one
+    const TaskD d0 = make_task<0>(L, wave >> 1, wave & 1, lane), d0h = make_task<0>(L, 2, wave >> 1, lane);
+    const TaskD d1 = make_task<1>(L, wave >> 1, wave & 1, lane), d2 = make_task<2>(L, wave >> 1, wave & 1, lane), d3h = make_task<3>(L, 0, wave >> 1, lane);
+    lds_barrier();
+    lds_barrier();
+    lds_barrier();
+    int r = 0;
+#pragma unroll 1
+    for (int k = 0; k < p.n2; ++k) {
+      StepU U;
+      U.pb0 = (int)(S.pbuf(2 * k) - S.E); U.pb1 = (int)(S.pbuf(2 * k + 1) - S.E); U.pb2 = (int)(S.pbuf(2 * k + 2) - S.E);
+      U.cK0 = ax_cnt(2 * k, p.n2); U.cK2 = ax_cnt(2 * k + 2, p.n2);
+      U.dK0 = k > 0 ? 2 : 0;
+      U.m0 = (2 * k) & 7;
+      const double *Jvs = S.Jv + (k & 1) * jsz + 9;
+#pragma unroll 1
+      for (int i = 0; i < nph; ++i) {
+        TICK(7);
+        if (i < nv) {
+          const int v = nth_visit(L.vmask, i);
+          const double *D = S.Dt + (r & 1) * p.dsz, *Jw = Jvs + v * PNQ * 10;
+          if (v == 0) {
+            run_task<NC, MODE, 0, PKS>(p, S, U, d0, D, Jw, lane);
+            if (wave & 1) run_task<NC, MODE, 4, PKS>(p, S, U, d0h, D, Jw, lane);
+            else run_task<NC, MODE, 0, 4>(p, S, U, d0h, D, Jw, lane);
+          } else if (v == 1) {
+            run_task<NC, MODE, 0, PKS>(p, S, U, d1, D, Jw, lane);
+          } else if (v == 2) {
+            run_task<NC, MODE, 0, PKS>(p, S, U, d2, D, Jw, lane);
+          } else {
+            if (wave & 1) run_task<NC, MODE, 4, PKS>(p, S, U, d3h, D, Jw, lane);
+            else run_task<NC, MODE, 0, 4>(p, S, U, d3h, D, Jw, lane);
+          }
+          ++r;
+        }
+        TICK(0);
+        lds_barrier();
+        TICK(1);
+      }
+    }
+    lds_barrier();  // the service waves stream the planes of the last slice
+  }
+#ifdef NH_ABLATION
+  if (p.tdbg && lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
+#endif
+}
+
+template <int NC, int S0>
+__device__ __forceinline__ void service_role(const P2K &p, const Lds &S, int swave, int lane, int st) {
+  constexpr int jsz = 4 * PNQ * 10;
+  // this thread's share of every D table: point q = st / 9, nodes 3 g .. 3 g + 2 (g = st % 9); its slice of the basis table stays in registers
+  const bool tok = st < p.nq * 9;
+  const int tq = tok ? st / 9 : 0, tg = tok ? st % 9 : 0;
+  double T4[3][4];
+  int to[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int n = 3 * tg + r;
+    to[r] = ((tq >> 2) * 2 + (n >> 4)) * 64 + (tq & 3) * 16 + (n & 15);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) T4[r][s] = p.T[((i64)n * p.nq + tq) * 4 + s];
+  }
+  // pin the table values HERE: without a use the loads stay "pending" for the compiler's wait-count bookkeeping, and it puts
+  // s_waitcnt vmcnt(0) in front of their first use -- inside the D-table build of every element, where that waits for all the
+  // stores of the flush issued before it (microseconds under load)
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(T4[r][s]));
+#ifdef NH_ABLATION
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+  const int nlines = (p.io1 - p.io0 + 1) * (p.n1 + 1);
+  for (int line = blockIdx.x; line < nlines; line += gridDim.x) {
+    const Line L = make_line(p, line);
+    if (!L.vmask) continue;
+    const int nv = __builtin_popcount(L.vmask), nph = nv < 2 ? 2 : nv;
+    auto build_D = [&](int k, int v, double *D) {  // D table of element (v, k): physical derivatives in MFMA operand order
+      if (DBG(p, 8) || !tok) return;
+      const double *Ji = S.Jv + (k & 1) * jsz + (v * PNQ + tq) * 10;
+      double J9[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) J9[i] = Ji[i];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        double d[4];
+        d[0] = T4[r][0];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d[1 + i] = T4[r][1] * J9[i] + T4[r][2] * J9[3 + i] + T4[r][3] * J9[6 + i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) D[to[r] + a * PKS * 128] = d[S0 + a];  // active slots S0 .. S0 + 2
+      }
+    };
+    auto geometry_slice = [&](int k, int t, int nt) {  // all valid (v, q) of slice k by threads t of nt
+      double *Jvs = S.Jv + (k & 1) * jsz;
+      for (int i = t; i < 4 * p.nq; i += nt) {
+        const int v = i / p.nq, q = i - v * p.nq;
+        if (((L.vmask >> v) & 1) && !DBG(p, 16)) geometry_point(p, L, v, k, q, Jvs + (v * PNQ + q) * 10);
+      }
+    };
+    // ---- prologue
+    lds_barrier();  // previous line done
+    if (st < 3) plane_meta<NC>(p, L, S, st);
+    geometry_slice(0, st, NST4);
+    lds_barrier();
+    build_D(0, nth_visit(L.vmask, 0), S.Dt);
+    lds_barrier();
+    // ---- main loop
+    int r = 0;  // elements done
+#pragma unroll 1
+    for (int k = 0; k < p.n2; ++k) {
+#pragma unroll 1
+      for (int i = 0; i < nph; ++i) {
+        TICK(7);
+        // D table of the next element: within the slice right away, across slices in the last phase (its geometry is due in the first)
+        if (i + 1 < nv) build_D(k, nth_visit(L.vmask, i + 1), S.Dt + ((r + 1) & 1) * p.dsz);
+        else if (i == nph - 1 && k + 1 < p.n2) build_D(k + 1, nth_visit(L.vmask, 0), S.Dt + (((k + 1) * nv) & 1) * p.dsz);
+        TICK(2);
+        if (swave == NFW) {
+          if (i == 0 && k + 1 < p.n2) {  // geometry of the next slice, row bookkeeping of the planes that enter the ring with it
+            if (lane == 0) plane_meta<NC>(p, L, S, 2 * k + 3);
+            if (lane == 1) plane_meta<NC>(p, L, S, 2 * k + 4);
+            geometry_slice(k + 1, lane, 64);
+          }
+          TICK(3);
+        } else if (k > 0) {
+          // the planes 2k-2, 2k-1 finished in the previous slice: 8 node blocks, nph phases
+          const int c0 = 8 * i / nph, c1 = 8 * (i + 1) / nph;
+#pragma unroll 1
+          for (int c = c0; c < c1; ++c) flush_block<NC>(p, S, 2 * k - 2 + (c >> 2), c & 3, st, NFW * 64);
+          TICK(4);
+        }
+        if (i < nv) ++r;
+        lds_barrier();
+        TICK(swave == NFW ? 6 : 5);
+      }
+    }
+    // ---- epilogue: the planes of the last slice (all service waves)
+#pragma unroll 1
+    for (int c = 0; c < 12; ++c) flush_block<NC>(p, S, 2 * p.n2 - 2 + (c >> 2), c & 3, st, NST4);
+    lds_barrier();
+  }
+#ifdef NH_ABLATION
+  if (p.tdbg && lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
+#endif
+}
+
+template <int NC, int S0, int MODE>
+__global__ __launch_bounds__(NTP4) void k_p2hex_pipe(P2K p) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Lds S;
+  S.esz = p.esz; S.osz = p.osz;
+  S.E = lds;
+  S.O = S.E + 3 * p.esz;
+  S.Dt = S.O + 2 * p.osz;              // 2 D tables (element parity)
+  S.Jv = S.Dt + 2 * p.dsz;             // 2 x [4 visits][28][10] (slice parity): Jinv, w |det J| scale; the pad points keep weight 0
+  S.meta = reinterpret_cast<int *>(S.Jv + 8 * PNQ * 10);
+  S.gmeta = reinterpret_cast<i64 *>(S.meta + 64);
+  for (int i = tid; i < 3 * p.esz + 2 * p.osz + 2 * p.dsz + 8 * PNQ * 10; i += NTP4) lds[i] = 0.;
+  if (wave < NMW4) mfma_role<NC, MODE>(p, S, wave, lane);
+  else service_role<NC, S0>(p, S, wave - NMW4, lane, tid - NMW4 * 64);
+}
+
+// closed-form CSR index arrays: one wave per node, rows (node, c) of length len * NC, columns (colnode, d) lexicographic
+__global__ __launch_bounds__(256) void k_p2hex_pattern(int n0, int n1, int n2, int nc, i64 *rowptr, i64 *colidx) {
+  const i64 N1 = 2 * n1 + 1, N2 = 2 * n2 + 1, nnodes = (2 * (i64)n0 + 1) * N1 * N2;
+  const i64 SJ = 8 * n1 + 1, SK = 8 * n2 + 1;
+  const int lane = threadIdx.x & 63;
+  for (i64 node = (i64)blockIdx.x * 4 + (threadIdx.x >> 6); node < nnodes; node += (i64)gridDim.x * 4) {
+    const int K = (int)(node % N2), J = (int)((node / N2) % N1), I = (int)(node / (N2 * N1));
+    const int cI = ax_cnt(I, n0), cJ = ax_cnt(J, n1), cK = ax_cnt(K, n2), lI = ax_lo(I), lJ = ax_lo(J), lK = ax_lo(K);
+    const int len = cI * cJ * cK;
+    const i64 row0 = (i64)ax_cum(I, n0) * SJ * SK + (i64)cI * ((i64)ax_cum(J, n1) * SK + (i64)cJ * ax_cum(K, n2));
+    const i64 base = row0 * nc * nc;
+    if (lane < nc) rowptr[node * nc + lane] = base + (i64)lane * len * nc;
+    if (node == nnodes - 1 && lane == 0) rowptr[nnodes * nc] = base + (i64)len * nc * nc;
+    for (int t = lane; t < len * nc; t += 64) {
+      const int cn = t / nc, d = t - cn * nc;
+      const int pk = cn % cK, pj = (cn / cK) % cJ, pi = cn / (cK * cJ);
+      const i64 col = (((i64)(lI + pi) * N1 + (lJ + pj)) * N2 + (lK + pk)) * nc + d;
+      for (int c = 0; c < nc; ++c) colidx[base + (i64)c * len * nc + t] = col;
+    }
+  }
+}
+
+template <int NC, int S0, int MODE>
+hipError_t launch_pipe(unsigned grid, size_t ldsb, hipStream_t s, const P2K &p) {
+  hipError_t e = hipFuncSetAttribute((const void *)k_p2hex_pipe<NC, S0, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_p2hex_pipe<NC, S0, MODE>), dim3(grid), dim3(NTP4), ldsb, s, p);
+  return hipSuccess;
 }
 
 }  // namespace
 
 extern "C" {
 
+int nh_p2hex_pattern(const int *shape, int ncomp, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream) {
+  NH_REQUIRE(shape && rowptr_dev && colidx_dev, "nh_p2hex_pattern: NULL argument");
+  NH_REQUIRE(shape[0] >= 1 && shape[1] >= 1 && shape[2] >= 1 && ncomp >= 1 && ncomp <= 3, "nh_p2hex_pattern: shape / ncomp");
+  const i64 nnodes = (2 * (i64)shape[0] + 1) * (2 * shape[1] + 1) * (2 * shape[2] + 1);
+  const unsigned grid = (unsigned)std::min<i64>((nnodes + 3) / 4, 256 * 64);
+  hipLaunchKernelGGL(k_p2hex_pattern, dim3(grid), dim3(256), 0, nh_stream(stream), shape[0], shape[1], shape[2], ncomp, (i64 *)rowptr_dev, (i64 *)colidx_dev);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
 int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   NH_REQUIRE(a, "nh_p2hex_matrix: NULL args");
   NH_REQUIRE(a->shape[0] >= 1 && a->shape[1] >= 1 && a->shape[2] >= 1, "nh_p2hex_matrix: shape");
-  NH_REQUIRE(a->nq >= 1 && a->nq <= 128 && a->weights_dev && a->T_dev && a->values_dev && a->C_host, "nh_p2hex_matrix: NULL table / weights / values / C");
+  NH_REQUIRE(a->nq >= 1 && a->weights_dev && a->T_dev && a->values_dev && a->C_host, "nh_p2hex_matrix: NULL table / weights / values / C");
   NH_REQUIRE(a->ncomp >= 1 && a->ncomp <= 3, "nh_p2hex_matrix: ncomp must be 1..3");
   NH_REQUIRE((i64)(8 * a->shape[0] + 1) * (8 * a->shape[1] + 1) * (8 * a->shape[2] + 1) * a->ncomp * a->ncomp < ((i64)1 << 62), "nh_p2hex_matrix: size");
+  if (a->nq > NQMAX) {
+    nh_set_error("nh_p2hex_matrix: %d quadrature points per element: the tables exceed the LDS (at most %d)", a->nq, NQMAX);
+    return NH_ELIMIT;
+  }
   const nh_geometry &g = a->geom;
   if (g.kind == NH_GEOM_ISO) NH_REQUIRE(g.ngb > 0 && g.gT_dev && g.gdofs_dev && g.verts_dev, "isoparametric geometry needs ngb, gT, gdofs, verts");
   else if (g.kind == NH_GEOM_TAB) NH_REQUIRE(g.jac_dev, "tabulated geometry needs jac_dev");
@@ -324,7 +762,8 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   p.io0 = a->owner_begin; p.io1 = a->owner_end;
   NH_REQUIRE(0 <= p.l0 && p.l0 <= p.l1 && p.l1 <= p.n0, "nh_p2hex_matrix: element layers [%d, %d) outside the mesh", p.l0, p.l1);
   NH_REQUIRE(0 <= p.io0 && p.io0 <= p.io1 && p.io1 <= p.n0, "nh_p2hex_matrix: owner lines [%d, %d] outside the mesh", p.io0, p.io1);
-  // active slots: those with a nonzero coefficient on either side
+  // active operator slots (those with a nonzero coefficient on either side) -> a contiguous window S0 .. S0 + NS - 1
+  bool act[4];
   int ns = 0;
   for (int s = 0; s < S; ++s) {
     bool any = false;
@@ -332,25 +771,20 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
       for (int d = 0; d < nc && !any; ++d)
         for (int b = 0; b < S && !any; ++b)
           any = a->C_host[((c * S + s) * nc + d) * S + b] != 0. || a->C_host[((c * S + b) * nc + d) * S + s] != 0.;
-    if (any) p.slot[ns++] = s;
+    act[s] = any;
+    ns += any;
   }
   NH_REQUIRE(ns > 0, "nh_p2hex_matrix: zero coefficient tensor");
-  const int NS = ns <= 3 ? 3 : 4;  // instantiated slot counts (unused slots carry zero coefficients)
-  if (ns < NS) {  // pad the slot list with unused slot ids
-    for (int s = 0; s < S && ns < NS; ++s) {
-      bool used = false;
-      for (int i = 0; i < ns; ++i) used |= p.slot[i] == s;
-      if (!used) p.slot[ns++] = s;
-    }
-    std::sort(p.slot, p.slot + NS);
-  }
+  const int NS = (!act[0] || !act[3]) ? 3 : 4;  // instantiated windows: {1,2,3} (gradient forms), {0,1,2}, {0,1,2,3}
+  const int S0 = NS == 3 && !act[0] ? 1 : 0;
+  for (int i = 0; i < NS; ++i) p.slot[i] = S0 + i;
   for (int c = 0; c < nc; ++c)
     for (int sa = 0; sa < NS; ++sa)
       for (int d = 0; d < nc; ++d)
         for (int sb = 0; sb < NS; ++sb) p.C[((c * NS + sa) * nc + d) * NS + sb] = a->C_host[((c * S + p.slot[sa]) * nc + d) * S + p.slot[sb]];
   // isotropic three-parameter family over the gradient slots?
   int mode = 0;
-  if (nc == 3 && NS == 3 && p.slot[0] == 1) {
+  if (nc == 3 && NS == 3 && S0 == 1) {
     const double lam = p.C[((0 * 3 + 0) * 3 + 1) * 3 + 1], mu2 = p.C[((0 * 3 + 1) * 3 + 1) * 3 + 0], mu = p.C[((0 * 3 + 1) * 3 + 0) * 3 + 1];
     bool iso = true;
     for (int c = 0; c < 3 && iso; ++c)
@@ -373,9 +807,13 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   p.T = a->T_dev;
   p.values = a->values_dev;
   p.scale = a->scale_dev;
-  auto lds_bytes = [&](int ndb) { return sizeof(double) * ((size_t)3 * p.esz + 2 * p.osz + ndb * p.dsz + 4 * p.nq * 10) + 64 * sizeof(int) + 32 * sizeof(i64); };
-  p.ndb = lds_bytes(2) <= 160 * 1024 ? 2 : 1;
-  const size_t ldsb = lds_bytes(p.ndb);
+  const size_t fixed = sizeof(double) * ((size_t)3 * p.esz + 2 * p.osz) + 64 * sizeof(int) + 32 * sizeof(i64);
+  const size_t lds_pipe = fixed + sizeof(double) * ((size_t)2 * p.dsz + 8 * PNQ * 10);
+  auto lds_lock = [&](int ndb) { return fixed + sizeof(double) * ((size_t)ndb * p.dsz + 4 * p.nq * 10); };
+  const char *env = getenv("NH_P2HEX_LOCKSTEP");  // tuning switch between the two (equivalent) kernels
+  const bool pipe = NS == 3 && p.ks == PKS && lds_pipe <= 160 * 1024 && !(env && atoi(env));
+  p.ndb = lds_lock(2) <= 160 * 1024 ? 2 : 1;
+  const size_t ldsb = pipe ? lds_pipe : lds_lock(p.ndb);
   if (ldsb > 160 * 1024) {
     nh_set_error("nh_p2hex_matrix: %zu bytes of LDS needed (nq = %d)", ldsb, a->nq);
     return NH_ELIMIT;
@@ -387,10 +825,24 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   NH_REQUIRE(a->max_workgroups >= 0, "nh_p2hex_matrix: negative max_workgroups");
   const unsigned grid = (unsigned)std::min(nlines, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
   hipStream_t s = nh_stream(stream);
-#define LAUNCH(NC, NS_, MODE)                                                                                                  \
-  do {                                                                                                                         \
-    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_p2hex<NC, NS_, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
-    hipLaunchKernelGGL((k_p2hex<NC, NS_, MODE>), dim3(grid), dim3(NT), ldsb, s, p);                                            \
+#ifdef NH_ABLATION
+  static long long *tdbg = nullptr;
+  if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, 8 * sizeof(long long)));
+  NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, 8 * sizeof(long long), s));
+  p.tdbg = getenv("NH_P2HEX_TIMERS") ? tdbg : nullptr;
+  p.debug = getenv("NH_P2HEX_DEBUG") ? atoi(getenv("NH_P2HEX_DEBUG")) : 0;
+#endif
+#define LAUNCH(NC, NS_, MODE)                                                                                                         \
+  do {                                                                                                                                \
+    if (pipe) {                                                                                                                       \
+      if (S0)                                                                                                                         \
+        NH_CHECK_HIP((launch_pipe<NC, 1, MODE>(grid, ldsb, s, p)));                                                                   \
+      else                                                                                                                            \
+        NH_CHECK_HIP((launch_pipe<NC, 0, 0>(grid, ldsb, s, p)));                                                                      \
+    } else {                                                                                                                          \
+      NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_p2hex<NC, NS_, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));  \
+      hipLaunchKernelGGL((k_p2hex<NC, NS_, MODE>), dim3(grid), dim3(NT), ldsb, s, p);                                                 \
+    }                                                                                                                                 \
   } while (0)
   const int key = nc * 100 + NS * 10 + mode;
   switch (key) {
@@ -405,6 +857,15 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   }
 #undef LAUNCH
   NH_LAUNCH_CHECK();
+#ifdef NH_ABLATION
+  if (p.tdbg && pipe) {
+    long long h[8];
+    NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
+    const double g = grid;
+    fprintf(stderr, "p2hex_pipe cycles per wave: MFMA waves: tasks %.0f + barrier %.0f | service: D %.0f, flush %.0f + barrier %.0f | geometry wave: D %.0f.. geometry %.0f + barrier %.0f | loop head %.0f\n",
+            h[0] / (g * NMW4), h[1] / (g * NMW4), h[2] / (g * 4), h[4] / (g * NFW), h[5] / (g * NFW), 0., h[3] / g, h[6] / g, h[7] / (g * 8));
+  }
+#endif
   return NH_OK;
 }
 

@@ -248,6 +248,17 @@ def p2hex_rowptr(shape, node):
     return out.value
 
 
+def p2hex_pattern(shape, ncomp):
+    '''Closed-form CSR index arrays of the structured C0 quadratic hex basis with ncomp fully coupled components (nh_p2hex_pattern).'''
+    n0, n1, n2 = (int(n) for n in shape)
+    nnodes = (2 * n0 + 1) * (2 * n1 + 1) * (2 * n2 + 1)
+    nnz = p2hex_rowptr(shape, nnodes) * ncomp * ncomp
+    rowptr = device.empty(nnodes * ncomp + 1, 'int64')
+    colidx = device.empty(nnz, 'int64')
+    _lib.call('nh_p2hex_pattern', (ctypes.c_int * 3)(n0, n1, n2), int(ncomp), device.ptr(rowptr), device.ptr(colidx), device.stream())
+    return rowptr, colidx
+
+
 class P2HexMatrix:
     '''Write-once assembly of a constant-coefficient form on the structured C0 quadratic hex basis (nh_p2hex_matrix), argument block
     filled once: a re-assembly is one ctypes call.  Call with the value array of the step.'''

@@ -189,3 +189,67 @@ class PoissonSlab:
         '''(values, rowptr, colidx) of the rows this rank owns, global numbering, on the host.'''
         self.finish()
         return partition.owned_rows(self.slab, device.to_host(self.values), device.to_host(self.rowptr), device.to_host(self.colidx))
+
+
+class ElasticityP2:
+    '''configs[2]: 3-D linear elasticity (examples/elasticity.py scaled to 3-D: lambda = 1, mu = .5/nu - 1, nu = .3),
+    quadratic C0 vector basis (27 nodes x 3 components per element), 3x3x3 Gauss, n^3 elements, isoparametric P1 geometry with the
+    vertices perturbed by default_rng(seed).uniform(-.2, .2).  Stiffness-matrix (re)assembly through nh_p2hex_matrix; the pattern is the
+    closed-form one of nh_p2hex_pattern (bit-equal to the generic row-wise build: tests/test_gpu_p2hex.py).'''
+
+    ncomp = 3
+
+    def __init__(self, n=64, variant='iso', seed=0, lam=1., mu=.5 / .3 - 1):
+        self.n, self.variant, self.seed, self.lam, self.mu = int(n), variant, seed, float(lam), float(mu)
+        self.kernel_name = 'k_p2hex_pipe<3,3,1>'
+
+    def setup(self):
+        n = self.n
+        self.domain, _ = mesh.rectilinear([n] * 3)
+        self.basis = self.domain.basis('std', degree=2)
+        gb = self.domain.basis('std', degree=1)
+        verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.)] * 3, indexing='ij'), -1).reshape(-1, 3)
+        if self.variant == 'iso':
+            verts = verts + numpy.random.default_rng(self.seed).uniform(-.2, .2, verts.shape)
+        self.verts = verts
+        self.geom = gb @ verts
+        self.smp = self.domain.sample('gauss', 4)
+        self.tables = self.smp.tables(self.basis)
+        self.kgeom = self.smp.geometry(self.geom)
+        self.nelems = n ** 3
+        C = numpy.zeros((3, 4, 3, 4))
+        for c in range(3):
+            for i in range(3):
+                for d in range(3):
+                    for j in range(3):
+                        C[c, 1 + i, d, 1 + j] = self.lam * (c == i) * (d == j) + self.mu * ((c == d) * (i == j) + (c == j) * (d == i))
+        self.C = C
+
+    def build_pattern(self):
+        shape = (self.n,) * 3
+        self.rowptr, self.colidx = kernels.p2hex_pattern(shape, 3)
+        self.nnz = int(self.colidx.numel())
+        self.values = device.empty(self.nnz, 'float64')  # write-once kernel: no zero-fill
+        self._launch = kernels.P2HexMatrix(shape=shape, nq=self.smp.points.npoints, weights=self.smp._weights_dev, geom=self.kgeom, T=self.tables.T, ncomp=3,
+                                           C=self.C)
+
+    def step(self, kernel_events=None, exchange=True):
+        if kernel_events:
+            kernel_events[0].record()
+        self._launch(self.values)
+        if kernel_events:
+            kernel_events[1].record()
+
+    def finish(self):
+        pass
+
+    def algorithmic_bytes_per_element(self):
+        '''unique vertex coordinates + CSR values written once (structured connectivity is generated in-kernel).'''
+        n = self.n
+        return (n + 1) ** 3 / n ** 3 * 24 + self.nnz / n ** 3 * 8
+
+    def algorithmic_flops_per_element(self):
+        '''Gram-matrix formulation: G = D^T W D over (27 nodes x 3 gradient slots)^2 x 27 points, multiply-add = 2 flops; the form
+        tensor costs 21 flops per node pair on top.  (SURVEY 8d's 2.3 Mflop counts the B^T C B product per point, which this
+        formulation does not execute.)'''
+        return 2. * 81 * 81 * 27 + 21. * 27 * 27
