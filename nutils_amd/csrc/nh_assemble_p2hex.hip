@@ -63,6 +63,7 @@ struct P2K {
   int io0, io1;      // owner lines io in [io0, io1] along axis 0
   int l0, l1;        // element layers [l0, l1) along axis 0 contribute
   int esz, osz, dsz; // doubles per even / odd plane buffer, per D table
+  int prio;          // pipelined kernel: raise the priority of the table / geometry waves
   int ndb;           // lockstep kernel: D tables in LDS (2: the table of the next element is built while the tasks of this one run)
   const double *weights;
   GeomK geom;
@@ -360,14 +361,23 @@ __global__ __launch_bounds__(NT) void k_p2hex(P2K p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // pipelined kernel (NS = 3 slots, 25..28 quadrature points = 7 k-steps): waves 0..3 -- one per SIMD -- run the MFMA tasks of
-// element r while waves 4..7 build the D table of element r + 1, evaluate the geometry of the next slice and stream the planes
-// finished in the previous slice; one barrier per element.  On gfx950 an f64 MFMA occupies its SIMD for all 64 cycles: VALU work of a
-// co-resident wave does NOT overlap it (tools/ubench/mfma_valu_overlap.hip), so every VALU instruction of either role adds to the
-// matrix time of its SIMD; the roles exist to overlap LATENCIES (LDS, vertex loads, store issue), and both are written for the lowest
-// instruction count: k-steps fully unrolled with immediate offsets, all per-lane task constants computed once per line, the flush in
-// node blocks with wave-uniform bases.
-constexpr int PKS = 7, PNQ = 4 * PKS;                      // k-steps, padded quadrature points
-constexpr int NMW4 = 4, NTP4 = 512, NST4 = 256, NFW = 3;  // MFMA waves, threads, service threads, flushing service waves
+// element r while waves 4..6 build the D table of element r + 1 and stream the planes finished in the previous slice and wave 7
+// evaluates the geometry of the next slice; one barrier per element.  On gfx950 an f64 MFMA occupies its SIMD for all 64 cycles: VALU
+// work of a co-resident wave does NOT overlap it (tools/ubench/mfma_valu_overlap.hip), so every VALU instruction of any role adds to
+// the matrix time of its SIMD; the roles exist to overlap LATENCIES (LDS, vertex loads, store issue), and all are written for the
+// lowest instruction count: compile-time LDS layout, k-steps fully unrolled with immediate offsets, per-lane task constants computed
+// once per line, the flush in node blocks with wave-uniform bases from records prepared by the geometry wave.
+constexpr int PKS = 7, PNQ = 4 * PKS;  // k-steps, padded quadrature points
+constexpr int NTP4 = 512, NTW = 3;     // threads; table / flush waves (waves 4 .. 4 + NTW - 1), wave 7: geometry
+
+template <int NC>
+struct PL {  // LDS layout in doubles from the start of the dynamic LDS
+  static constexpr int ESZ = 320 * NC * NC + 8, OSZ = 192 * NC * NC + 8, DSZ = 3 * PKS * 128, JSZ = 4 * PNQ * 10;
+  static constexpr int O = 3 * ESZ, DT = O + 2 * OSZ, JV = DT + 2 * DSZ, META = JV + 2 * JSZ, END = META + 32 * 3;
+  // meta, per (plane slot K & 7, node j): int2 row {offset of the node's rows, scalar row length}, int2 fl {first whole 16-byte pair,
+  // pairs | head << 30 | tail << 31}, i64 element offset of the first row in the value array
+  __device__ static __forceinline__ int plane(int K) { return (K & 1) ? O + ((K >> 1) & 1) * OSZ : ((K >> 1) % 3) * ESZ; }
+};
 
 // local node (ai, aj, ak) of row slot mu of unit u of visit V, or invalid
 template <int V>
@@ -410,20 +420,15 @@ __device__ __forceinline__ TaskD make_task(const Line &L, int u, int nt, int lan
   return d;
 }
 
-struct StepU {    // constants of a slice k (uniform)
-  int pb0, pb1, pb2;  // buffers of the planes 2k, 2k+1, 2k+2 (offsets from S.E in doubles)
-  int cK0, cK2;       // columns along K of a row of plane 2k / 2k+2 (3 in a boundary plane, else 5; plane 2k+1: 3)
-  int dK0;            // 2k - first column of a row of plane 2k
-  int m0;             // meta slot of plane 2k
-};
-
-// k-steps [K0, K1) of one (unit, column tile) product + the form tensor + the LDS reduction
+// k-steps [K0, K1) of one (unit, column tile) product + the form tensor + the LDS reduction.
+// cK0 / cK2: columns along K of a row of plane 2k / 2k+2 (3 in a boundary plane, else 5; plane 2k+1: 3); dK0 = 2k - first column of
+// a row of plane 2k; m0 = meta slot of plane 2k
 template <int NC, int MODE, int K0, int K1>
-__device__ __forceinline__ void run_task(const P2K &p, const Lds &S, const StepU &U, const TaskD &d, const double *D, const double *Jw, int lane) {
+__device__ __forceinline__ void run_task(const P2K &p, double *lds, int cK0, int cK2, int dK0, int m0s, const TaskD &d, const double *D, const double *Jw, int lane) {
   const int lk = lane >> 4;
   const int ak = (d.info >> 1) & 3, j = (d.info >> 3) & 3;
   // where the row lives: read ahead of the MFMA chain
-  const int2 m = *reinterpret_cast<const int2 *>(S.meta + ((((U.m0 + ak) & 7) * 4 + j) * 2));
+  const int2 m = *reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(lds + PL<NC>::META) + ((((m0s + ak) & 7) * 4 + j) * 2));
   const double *pa = D + d.Aoff, *pb = D + d.Boff, *pw = Jw + lk * 10;
   v4d acc[3];
 #pragma unroll
@@ -470,11 +475,11 @@ __device__ __forceinline__ void run_task(const P2K &p, const Lds &S, const StepU
           Kcd[c][dd] = sum;
         }
     }
-    // per-lane choice among the three planes by masks (a select chain on ak is turned into a table in scratch by the compiler)
+    // per-lane constants of the plane by masks (a select chain on ak is turned into a table in scratch by the compiler)
     const int m1 = -(ak & 1), m2 = -(ak >> 1), m0 = ~(m1 | m2);
-    const int cK = U.cK0 + (m1 & (3 - U.cK0)) + (m2 & (U.cK2 - U.cK0));
-    const int pos = d.posIJ * cK + ((d.info >> 5) & 3) + (m0 & U.dK0);
-    double *row = S.E + (U.pb0 + (m1 & (U.pb1 - U.pb0)) + (m2 & (U.pb2 - U.pb0)) + m.x + pos * NC);
+    const int cK = cK0 + (m1 & (3 - cK0)) + (m2 & (cK2 - cK0));
+    const int pos = d.posIJ * cK + ((d.info >> 5) & 3) + (m0 & dK0);
+    double *row = lds + (m.x + pos * NC);
     const int rs = m.y * NC;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -483,40 +488,94 @@ __device__ __forceinline__ void run_task(const P2K &p, const Lds &S, const StepU
   }
 }
 
-// stream the finished rows of node j of plane K to the value array and zero them in the buffer: 16-byte pairs with wave-uniform
-// bases (the block is contiguous in both memories and starts with the same parity), the odd head / tail element by one lane
+// one thread: the records of the 4 nodes (ai, aj) of node plane K
 template <int NC>
-__device__ __forceinline__ void flush_block(const P2K &p, const Lds &S, int K, int j, int t, int nt) {
-  const int2 m = *reinterpret_cast<const int2 *>(S.meta + (((K & 7) * 4 + j) * 2));
-  const int off = __builtin_amdgcn_readfirstlane(m.x), nd = __builtin_amdgcn_readfirstlane(m.y) * NC * NC;
-  if (!nd) return;
-  const i64 g0 = S.gmeta[(K & 7) * 4 + j];
-  const i64 goff = ((i64)__builtin_amdgcn_readfirstlane((int)(g0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g0);
-  double *lb = S.pbuf(K) + off;
-  double *gb = p.values + goff;
-  const int head = off & 1, npairs = (nd - head) >> 1, tail = (nd - head) & 1;
-  v2d *lp = reinterpret_cast<v2d *>(lb + head);
-  v2d *gp = reinterpret_cast<v2d *>(gb + head);
-  for (int pi = t; pi < npairs; pi += nt) {
-    const v2d v = lp[pi];
-    lp[pi] = v2d{0., 0.};
-    if (!DBG(p, 1)) gp[pi] = v;
+__device__ __forceinline__ void pipe_meta(const P2K &p, const Line &L, double *lds, int K) {
+  int *meta = reinterpret_cast<int *>(lds + PL<NC>::META);
+  i64 *gm = reinterpret_cast<i64 *>(lds + PL<NC>::META + 64);
+  const int cK = ax_cnt(K, p.n2), cumK = ax_cum(K, p.n2);
+  int cur = PL<NC>::plane(K);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ai = j >> 1, aj = j & 1;
+    bool ex = false;  // the node has contributions iff an element that contains it is visited
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (((L.vmask >> v) & 1) && (!(v >> 1) || ai == 0) && (!(v & 1) || aj == 0)) ex = true;
+    const int len = ex ? L.cntI[ai] * L.cntJ[aj] * cK : 0, nd = len * NC * NC;
+    const i64 row0 = (i64)L.cumI[ai] * L.SJ * L.SK + (i64)L.cntI[ai] * ((i64)L.cumJ[aj] * L.SK + (i64)L.cntJ[aj] * cumK);
+    const i64 goff = row0 * (NC * NC);
+    const int head = nd ? (int)(goff & 1) : 0;
+    cur = ((cur + 1) & ~1) + head;  // blocks never share a 16-byte pair: the flush copies and zeroes whole pairs
+    const int s = (K & 7) * 4 + j;
+    meta[s * 2] = cur;
+    meta[s * 2 + 1] = len;
+    meta[64 + s * 2] = cur + head;
+    meta[64 + s * 2 + 1] = ((nd - head) >> 1) | head << 30 | ((nd - head) & 1) << 31;
+    gm[s] = goff;
+    cur += nd;
   }
-  if (t == 0 && head) {
-    const double v = lb[0];
-    lb[0] = 0.;
-    if (!DBG(p, 1)) gb[0] = v;
+}
+
+// stream the finished rows of NBLK node blocks (block c = plane K0 + (c >> 2), node c & 3) to the value array and zero them in the
+// buffers: 16-byte pairs with wave-uniform bases (a block is contiguous in both memories and starts with the same parity), the odd head
+// / tail element by one lane.  All records are read together, then all data, then the stores: the flushing waves have nothing else
+// to hide an LDS round trip behind.
+template <int NC, int NBLK>
+__device__ __forceinline__ void flush_blocks(const P2K &p, double *lds, int K0, int c0, int t, int nt) {
+  constexpr int UB = 3;  // pairs per thread and block: 125 * 9 / 2 = 563 <= 3 * 192
+  const int *meta = reinterpret_cast<const int *>(lds + PL<NC>::META);
+  const i64 *gm = reinterpret_cast<const i64 *>(lds + PL<NC>::META + 64);
+  int2 f[NBLK];
+  i64 g[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int s = ((K0 + ((c0 + b) >> 2)) & 7) * 4 + ((c0 + b) & 3);
+    f[b] = *reinterpret_cast<const int2 *>(meta + 64 + s * 2);
+    g[b] = gm[s];
   }
-  if (t == 1 && tail) {
-    const double v = lb[nd - 1];
-    lb[nd - 1] = 0.;
-    if (!DBG(p, 1)) gb[nd - 1] = v;
+  v2d v[NBLK][UB];
+  double hv[NBLK], tv[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int first = __builtin_amdgcn_readfirstlane(f[b].x), w = __builtin_amdgcn_readfirstlane(f[b].y);
+    const int np = w & 0x3fffffff;
+    const v2d *lp = reinterpret_cast<const v2d *>(lds + first);
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (t + u * nt < np) v[b][u] = lp[t + u * nt];
+    if (t == 0 && (w & (1 << 30))) hv[b] = lds[first - 1];
+    if (t == 1 && (w < 0)) tv[b] = lds[first + 2 * np];
+  }
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int first = __builtin_amdgcn_readfirstlane(f[b].x), w = __builtin_amdgcn_readfirstlane(f[b].y);
+    const int np = w & 0x3fffffff;
+    v2d *lp = reinterpret_cast<v2d *>(lds + first);
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (t + u * nt < np) lp[t + u * nt] = v2d{0., 0.};
+    if (t == 0 && (w & (1 << 30))) lds[first - 1] = 0.;
+    if (t == 1 && (w < 0)) lds[first + 2 * np] = 0.;
+  }
+  if (DBG(p, 1)) return;
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int w = __builtin_amdgcn_readfirstlane(f[b].y);
+    const int np = w & 0x3fffffff, head = (w >> 30) & 1;
+    const i64 goff = ((i64)__builtin_amdgcn_readfirstlane((int)(g[b] >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g[b]);
+    double *gb = p.values + goff + head;
+    v2d *gp = reinterpret_cast<v2d *>(gb);
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (t + u * nt < np) gp[t + u * nt] = v[b][u];
+    if (t == 0 && head) gb[-1] = hv[b];
+    if (t == 1 && (w < 0)) gb[2 * np] = tv[b];
   }
 }
 
 template <int NC, int MODE>
-__device__ __forceinline__ void mfma_role(const P2K &p, const Lds &S, int wave, int lane) {
-  constexpr int jsz = 4 * PNQ * 10;
+__device__ __forceinline__ void mfma_role(const P2K &p, double *lds, int wave, int lane) {
 #ifdef NH_ABLATION
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
@@ -535,29 +594,25 @@ __device__ __forceinline__ void mfma_role(const P2K &p, const Lds &S, int wave, 
     int r = 0;
 #pragma unroll 1
     for (int k = 0; k < p.n2; ++k) {
-      StepU U;
-      U.pb0 = (int)(S.pbuf(2 * k) - S.E); U.pb1 = (int)(S.pbuf(2 * k + 1) - S.E); U.pb2 = (int)(S.pbuf(2 * k + 2) - S.E);
-      U.cK0 = ax_cnt(2 * k, p.n2); U.cK2 = ax_cnt(2 * k + 2, p.n2);
-      U.dK0 = k > 0 ? 2 : 0;
-      U.m0 = (2 * k) & 7;
-      const double *Jvs = S.Jv + (k & 1) * jsz + 9;
+      const int cK0 = ax_cnt(2 * k, p.n2), cK2 = ax_cnt(2 * k + 2, p.n2), dK0 = k > 0 ? 2 : 0, m0s = (2 * k) & 7;
+      const double *Jvs = lds + PL<NC>::JV + (k & 1) * PL<NC>::JSZ + 9;
 #pragma unroll 1
       for (int i = 0; i < nph; ++i) {
         TICK(7);
         if (i < nv) {
           const int v = nth_visit(L.vmask, i);
-          const double *D = S.Dt + (r & 1) * p.dsz, *Jw = Jvs + v * PNQ * 10;
+          const double *D = lds + PL<NC>::DT + (r & 1) * PL<NC>::DSZ, *Jw = Jvs + v * PNQ * 10;
           if (v == 0) {
-            run_task<NC, MODE, 0, PKS>(p, S, U, d0, D, Jw, lane);
-            if (wave & 1) run_task<NC, MODE, 4, PKS>(p, S, U, d0h, D, Jw, lane);
-            else run_task<NC, MODE, 0, 4>(p, S, U, d0h, D, Jw, lane);
+            run_task<NC, MODE, 0, PKS>(p, lds, cK0, cK2, dK0, m0s, d0, D, Jw, lane);
+            if (wave & 1) run_task<NC, MODE, 4, PKS>(p, lds, cK0, cK2, dK0, m0s, d0h, D, Jw, lane);
+            else run_task<NC, MODE, 0, 4>(p, lds, cK0, cK2, dK0, m0s, d0h, D, Jw, lane);
           } else if (v == 1) {
-            run_task<NC, MODE, 0, PKS>(p, S, U, d1, D, Jw, lane);
+            run_task<NC, MODE, 0, PKS>(p, lds, cK0, cK2, dK0, m0s, d1, D, Jw, lane);
           } else if (v == 2) {
-            run_task<NC, MODE, 0, PKS>(p, S, U, d2, D, Jw, lane);
+            run_task<NC, MODE, 0, PKS>(p, lds, cK0, cK2, dK0, m0s, d2, D, Jw, lane);
           } else {
-            if (wave & 1) run_task<NC, MODE, 4, PKS>(p, S, U, d3h, D, Jw, lane);
-            else run_task<NC, MODE, 0, 4>(p, S, U, d3h, D, Jw, lane);
+            if (wave & 1) run_task<NC, MODE, 4, PKS>(p, lds, cK0, cK2, dK0, m0s, d3h, D, Jw, lane);
+            else run_task<NC, MODE, 0, 4>(p, lds, cK0, cK2, dK0, m0s, d3h, D, Jw, lane);
           }
           ++r;
         }
@@ -566,7 +621,7 @@ __device__ __forceinline__ void mfma_role(const P2K &p, const Lds &S, int wave, 
         TICK(1);
       }
     }
-    lds_barrier();  // the service waves stream the planes of the last slice
+    lds_barrier();  // the table waves stream the planes of the last slice
   }
 #ifdef NH_ABLATION
   if (p.tdbg && lane == 0)
@@ -574,17 +629,17 @@ __device__ __forceinline__ void mfma_role(const P2K &p, const Lds &S, int wave, 
 #endif
 }
 
+// waves 4 .. 6: D tables one element ahead, flush of the previous slice
 template <int NC, int S0>
-__device__ __forceinline__ void service_role(const P2K &p, const Lds &S, int swave, int lane, int st) {
-  constexpr int jsz = 4 * PNQ * 10;
-  // this thread's share of every D table: point q = st / 9, nodes 3 g .. 3 g + 2 (g = st % 9); its slice of the basis table stays in registers
-  const bool tok = st < p.nq * 9;
-  const int tq = tok ? st / 9 : 0, tg = tok ? st % 9 : 0;
-  double T4[3][4];
-  int to[3];
+__device__ __forceinline__ void table_role(const P2K &p, double *lds, int lane, int st) {
+  // this thread's share of every D table: point q = st / 7, nodes 4 g .. 4 g + 3 (g = st % 7); its slice of the basis table stays in registers
+  const bool tok = st < p.nq * 7;
+  const int tq = tok ? st / 7 : 0, tg = tok ? st % 7 : 0;
+  double T4[4][4];
+  int to[4];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int n = 3 * tg + r;
+  for (int r = 0; r < 4; ++r) {
+    const int n = min(4 * tg + r, NB - 1);
     to[r] = ((tq >> 2) * 2 + (n >> 4)) * 64 + (tq & 3) * 16 + (n & 15);
 #pragma unroll
     for (int s = 0; s < 4; ++s) T4[r][s] = p.T[((i64)n * p.nq + tq) * 4 + s];
@@ -593,9 +648,77 @@ __device__ __forceinline__ void service_role(const P2K &p, const Lds &S, int swa
   // s_waitcnt vmcnt(0) in front of their first use -- inside the D-table build of every element, where that waits for all the
   // stores of the flush issued before it (microseconds under load)
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(T4[r][s]));
+#ifdef NH_ABLATION
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+  const int nlines = (p.io1 - p.io0 + 1) * (p.n1 + 1);
+  for (int line = blockIdx.x; line < nlines; line += gridDim.x) {
+    const int io = p.io0 + line / (p.n1 + 1), jo = line % (p.n1 + 1);
+    int vmask = 0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int ei = io - (v >> 1), ej = jo - (v & 1);
+      if (ei >= p.l0 && ei < p.l1 && ej >= 0 && ej < p.n1) vmask |= 1 << v;
+    }
+    if (!vmask) continue;
+    const int nv = __builtin_popcount(vmask), nph = nv < 2 ? 2 : nv;
+    auto build_D = [&](int k, int v, double *D) {  // D table of element (v, k): physical derivatives in MFMA operand order
+      if (DBG(p, 8) || !tok) return;
+      const double *Ji = lds + PL<NC>::JV + (k & 1) * PL<NC>::JSZ + (v * PNQ + tq) * 10;
+      double J9[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) J9[i] = Ji[i];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double d[4];
+        d[0] = T4[r][0];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d[1 + i] = T4[r][1] * J9[i] + T4[r][2] * J9[3 + i] + T4[r][3] * J9[6 + i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) D[to[r] + a * PKS * 128] = d[S0 + a];  // active slots S0 .. S0 + 2 (group 6 writes node 26 twice)
+      }
+    };
+    lds_barrier();  // previous line done
+    lds_barrier();  // geometry of slice 0
+    build_D(0, nth_visit(vmask, 0), lds + PL<NC>::DT);
+    lds_barrier();
+    int r = 0;  // elements done
+#pragma unroll 1
+    for (int k = 0; k < p.n2; ++k) {
+#pragma unroll 1
+      for (int i = 0; i < nph; ++i) {
+        TICK(7);
+        // D table of the next element: within the slice right away, across slices in the last phase (its geometry is due in the first)
+        if (i + 1 < nv) build_D(k, nth_visit(vmask, i + 1), lds + PL<NC>::DT + ((r + 1) & 1) * PL<NC>::DSZ);
+        else if (i == nph - 1 && k + 1 < p.n2) build_D(k + 1, nth_visit(vmask, 0), lds + PL<NC>::DT + (((k + 1) * nv) & 1) * PL<NC>::DSZ);
+        TICK(2);
+        if (k > 0) {  // the planes 2k-2, 2k-1 finished in the previous slice: 8 node blocks, nph phases
+          if (nph == 4) flush_blocks<NC, 2>(p, lds, 2 * k - 2, 2 * i, st, NTW * 64);
+          else flush_blocks<NC, 4>(p, lds, 2 * k - 2, 4 * i, st, NTW * 64);
+        }
+        TICK(4);
+        if (i < nv) ++r;
+        lds_barrier();
+        TICK(5);
+      }
+    }
+    // the planes of the last slice
+#pragma unroll 1
+    for (int c = 0; c < 12; c += 2) flush_blocks<NC, 2>(p, lds, 2 * p.n2 - 2, c, st, NTW * 64);
+    lds_barrier();
+  }
+#ifdef NH_ABLATION
+  if (p.tdbg && lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
+#endif
+}
+
+// wave 7: geometry of the next slice, row records of the planes that enter the ring with it
+template <int NC>
+__device__ __forceinline__ void geometry_role(const P2K &p, double *lds, int lane) {
 #ifdef NH_ABLATION
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
@@ -604,69 +727,33 @@ __device__ __forceinline__ void service_role(const P2K &p, const Lds &S, int swa
     const Line L = make_line(p, line);
     if (!L.vmask) continue;
     const int nv = __builtin_popcount(L.vmask), nph = nv < 2 ? 2 : nv;
-    auto build_D = [&](int k, int v, double *D) {  // D table of element (v, k): physical derivatives in MFMA operand order
-      if (DBG(p, 8) || !tok) return;
-      const double *Ji = S.Jv + (k & 1) * jsz + (v * PNQ + tq) * 10;
-      double J9[9];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) J9[i] = Ji[i];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        double d[4];
-        d[0] = T4[r][0];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) d[1 + i] = T4[r][1] * J9[i] + T4[r][2] * J9[3 + i] + T4[r][3] * J9[6 + i];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) D[to[r] + a * PKS * 128] = d[S0 + a];  // active slots S0 .. S0 + 2
-      }
-    };
-    auto geometry_slice = [&](int k, int t, int nt) {  // all valid (v, q) of slice k by threads t of nt
-      double *Jvs = S.Jv + (k & 1) * jsz;
-      for (int i = t; i < 4 * p.nq; i += nt) {
+    auto geometry_slice = [&](int k) {  // all valid (v, q) of slice k
+      double *Jvs = lds + PL<NC>::JV + (k & 1) * PL<NC>::JSZ;
+      for (int i = lane; i < 4 * p.nq; i += 64) {
         const int v = i / p.nq, q = i - v * p.nq;
         if (((L.vmask >> v) & 1) && !DBG(p, 16)) geometry_point(p, L, v, k, q, Jvs + (v * PNQ + q) * 10);
       }
     };
-    // ---- prologue
     lds_barrier();  // previous line done
-    if (st < 3) plane_meta<NC>(p, L, S, st);
-    geometry_slice(0, st, NST4);
+    if (lane < 3) pipe_meta<NC>(p, L, lds, lane);
+    geometry_slice(0);
     lds_barrier();
-    build_D(0, nth_visit(L.vmask, 0), S.Dt);
     lds_barrier();
-    // ---- main loop
-    int r = 0;  // elements done
 #pragma unroll 1
     for (int k = 0; k < p.n2; ++k) {
 #pragma unroll 1
       for (int i = 0; i < nph; ++i) {
         TICK(7);
-        // D table of the next element: within the slice right away, across slices in the last phase (its geometry is due in the first)
-        if (i + 1 < nv) build_D(k, nth_visit(L.vmask, i + 1), S.Dt + ((r + 1) & 1) * p.dsz);
-        else if (i == nph - 1 && k + 1 < p.n2) build_D(k + 1, nth_visit(L.vmask, 0), S.Dt + (((k + 1) * nv) & 1) * p.dsz);
-        TICK(2);
-        if (swave == NFW) {
-          if (i == 0 && k + 1 < p.n2) {  // geometry of the next slice, row bookkeeping of the planes that enter the ring with it
-            if (lane == 0) plane_meta<NC>(p, L, S, 2 * k + 3);
-            if (lane == 1) plane_meta<NC>(p, L, S, 2 * k + 4);
-            geometry_slice(k + 1, lane, 64);
-          }
-          TICK(3);
-        } else if (k > 0) {
-          // the planes 2k-2, 2k-1 finished in the previous slice: 8 node blocks, nph phases
-          const int c0 = 8 * i / nph, c1 = 8 * (i + 1) / nph;
-#pragma unroll 1
-          for (int c = c0; c < c1; ++c) flush_block<NC>(p, S, 2 * k - 2 + (c >> 2), c & 3, st, NFW * 64);
-          TICK(4);
+        if (i == 0 && k + 1 < p.n2) {
+          if (lane == 0) pipe_meta<NC>(p, L, lds, 2 * k + 3);
+          if (lane == 1) pipe_meta<NC>(p, L, lds, 2 * k + 4);
+          geometry_slice(k + 1);
         }
-        if (i < nv) ++r;
+        TICK(3);
         lds_barrier();
-        TICK(swave == NFW ? 6 : 5);
+        TICK(6);
       }
     }
-    // ---- epilogue: the planes of the last slice (all service waves)
-#pragma unroll 1
-    for (int c = 0; c < 12; ++c) flush_block<NC>(p, S, 2 * p.n2 - 2 + (c >> 2), c & 3, st, NST4);
     lds_barrier();
   }
 #ifdef NH_ABLATION
@@ -679,17 +766,17 @@ template <int NC, int S0, int MODE>
 __global__ __launch_bounds__(NTP4) void k_p2hex_pipe(P2K p) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  Lds S;
-  S.esz = p.esz; S.osz = p.osz;
-  S.E = lds;
-  S.O = S.E + 3 * p.esz;
-  S.Dt = S.O + 2 * p.osz;              // 2 D tables (element parity)
-  S.Jv = S.Dt + 2 * p.dsz;             // 2 x [4 visits][28][10] (slice parity): Jinv, w |det J| scale; the pad points keep weight 0
-  S.meta = reinterpret_cast<int *>(S.Jv + 8 * PNQ * 10);
-  S.gmeta = reinterpret_cast<i64 *>(S.meta + 64);
-  for (int i = tid; i < 3 * p.esz + 2 * p.osz + 2 * p.dsz + 8 * PNQ * 10; i += NTP4) lds[i] = 0.;
-  if (wave < NMW4) mfma_role<NC, MODE>(p, S, wave, lane);
-  else service_role<NC, S0>(p, S, wave - NMW4, lane, tid - NMW4 * 64);
+  // row buffers are re-zeroed by the flush; the pad entries of the D tables (q >= nq, n >= 27) and the weights of the pad points stay zero
+  for (int i = tid; i < PL<NC>::META; i += NTP4) lds[i] = 0.;
+  if (wave < 4) {
+    mfma_role<NC, MODE>(p, lds, wave, lane);
+    return;
+  }
+  // an f64 MFMA holds its SIMD for 64 cycles and the MFMA waves issue them back to back: without priority the co-resident wave gets
+  // about one issue slot per MFMA, and the element-ahead work of these roles falls behind the matrix pipe
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
+  if (wave < 4 + NTW) table_role<NC, S0>(p, lds, lane, tid - 256);
+  else geometry_role<NC>(p, lds, lane);
 }
 
 // closed-form CSR index arrays: one wave per node, rows (node, c) of length len * NC, columns (colnode, d) lexicographic
@@ -808,10 +895,14 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   p.values = a->values_dev;
   p.scale = a->scale_dev;
   const size_t fixed = sizeof(double) * ((size_t)3 * p.esz + 2 * p.osz) + 64 * sizeof(int) + 32 * sizeof(i64);
-  const size_t lds_pipe = fixed + sizeof(double) * ((size_t)2 * p.dsz + 8 * PNQ * 10);
+  const size_t lds_pipe = sizeof(double) * (nc == 1 ? PL<1>::END : nc == 2 ? PL<2>::END : PL<3>::END);
   auto lds_lock = [&](int ndb) { return fixed + sizeof(double) * ((size_t)ndb * p.dsz + 4 * p.nq * 10); };
-  const char *env = getenv("NH_P2HEX_LOCKSTEP");  // tuning switch between the two (equivalent) kernels
-  const bool pipe = NS == 3 && p.ks == PKS && lds_pipe <= 160 * 1024 && !(env && atoi(env));
+  bool pipe = NS == 3 && p.ks == PKS && lds_pipe <= 160 * 1024;
+  p.prio = 1;
+#ifdef NH_ABLATION  // A/B switches of the ablation build only
+  if (getenv("NH_P2HEX_LOCKSTEP") && atoi(getenv("NH_P2HEX_LOCKSTEP"))) pipe = false;
+  if (getenv("NH_P2HEX_PRIO")) p.prio = atoi(getenv("NH_P2HEX_PRIO"));
+#endif
   p.ndb = lds_lock(2) <= 160 * 1024 ? 2 : 1;
   const size_t ldsb = pipe ? lds_pipe : lds_lock(p.ndb);
   if (ldsb > 160 * 1024) {
@@ -862,8 +953,8 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
     long long h[8];
     NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
     const double g = grid;
-    fprintf(stderr, "p2hex_pipe cycles per wave: MFMA waves: tasks %.0f + barrier %.0f | service: D %.0f, flush %.0f + barrier %.0f | geometry wave: D %.0f.. geometry %.0f + barrier %.0f | loop head %.0f\n",
-            h[0] / (g * NMW4), h[1] / (g * NMW4), h[2] / (g * 4), h[4] / (g * NFW), h[5] / (g * NFW), 0., h[3] / g, h[6] / g, h[7] / (g * 8));
+    fprintf(stderr, "p2hex_pipe cycles per wave: MFMA waves: tasks %.0f + barrier %.0f | table waves: D %.0f, flush %.0f + barrier %.0f | geometry wave: geometry %.0f + barrier %.0f | loop head %.0f\n",
+            h[0] / (g * 4), h[1] / (g * 4), h[2] / (g * NTW), h[4] / (g * NTW), h[5] / (g * NTW), h[3] / g, h[6] / g, h[7] / (g * 8));
   }
 #endif
   return NH_OK;
