@@ -420,6 +420,7 @@ def test_first_touch_coloured_assembly(case, monkeypatch):
     assembly, and EVERY value is written -- the value array is handed over full of NaN.'''
     from nutils_amd import mesh, function, device, sample
     if case == '3d_p2_vector':
+        monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')  # this test is about the coloured generic path (the write-once kernel nh_p2hex_matrix would take the form)
         shape = [16, 16, 17]
         domain, geom = mesh.rectilinear(shape)
         gb = domain.basis('std', degree=1)
