@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 '''bench.py -- elements assembled/sec for the global stiffness matrix K.
 
-Workload (BASELINE.json configs[1]): 3-D Poisson on a 128^3 structured hex mesh,
-p=1, 2x2x2 Gauss, stiffness-matrix assembly on one MI355X.  Geometry variant:
-isoparametric (vertices perturbed by default_rng(0).uniform(-.2,.2))
-so that Jacobians, inverses and the local contraction are really computed per
-element; `--variant uniform` times the exact-uniform mesh instead.
+Default workload (BASELINE.json configs[1], `--config c2`): 3-D Poisson on a 128^3 structured hex mesh, p=1,
+2x2x2 Gauss, stiffness-matrix assembly on one MI355X.  Geometry variant: isoparametric (vertices perturbed by
+default_rng(0).uniform(-.2,.2)) so that Jacobians, inverses and the local contraction are really
+computed per element; `--variant uniform` times the exact-uniform mesh instead.
+`--config c3` (BASELINE.json configs[2]): 3-D linear elasticity, P2 vector basis, 64^3 elements, 3x3x3 Gauss.
 
-A "step" is one full (re)assembly of the CSR values with all inputs resident in HBM
-(connectivity, vertex coordinates, tabulated bases, sparsity pattern): zero-fill (if
-the kernel accumulates) + element kernel.  The one-time pattern build is reported
-separately (`pattern_ms`).  With --gpus N every rank assembles its own 128^3-element
-slab of a (128 N) x 128 x 128 mesh (weak scaling) and the shared dof plane between
-neighbouring slabs is reduced over RCCL.
+A "step" is one full (re)assembly of the CSR values with all inputs resident in HBM (vertex coordinates, tabulated
+bases, sparsity pattern): zero-fill (if the kernel accumulates) + element kernel; `value` is measured on that.  The
+regions of BASELINE.md 3 are reported next to it: `first_assembly_ms` (pattern + values, device resident),
+`host_ready_ms` (pattern + values + the copy of (values, rowptr, colidx) to host memory, i.e. "CSR ready for scipy")
+and `reassembly_host_ready_ms` (values only); the CPU leg times pattern + values on the host, so
+`speedup_vs_cpu_port.first_assembly_host_ready` is the like-for-like ratio.
+
+With --gpus N: `--scaling weak` (default) every rank assembles its own n^3-element slab of an (n N) x n x n mesh;
+`--scaling strong` the ONE n^3 mesh is split into N slabs of n/N element layers.  The shared dof plane
+between neighbouring slabs is reduced over RCCL (point to point, interface rows only).
 
 Prints ONE JSON line on rank 0.
 '''
@@ -25,28 +29,39 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+F64_MFMA_PEAK_TF = 78.6  # dense f64 MFMA (= f64 vector) peak, 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz
+TRAFFIC_FILE = 'profiles/r02_traffic.json'
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--settle', type=int, default=300, help='untimed steps before the warm-up: the first ~50 launches after idle run ~10 %% slower (clock ramp)')
-    ap.add_argument('--n', '--elements-per-axis', dest='n', type=int, default=128,
-                    help='elements per axis per GPU (use the long form behind torch.distributed.run, whose parser claims --n)')
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--config', choices=['c2', 'c3'], default='c2', help='c2: 128^3 P1 Poisson (headline); c3: 64^3 P2 vector elasticity')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--settle', type=int, default=None, help='untimed steps before the warm-up: the first ~50 launches after idle run ~10 %% slower (clock ramp)')
+    ap.add_argument('--n', '--elements-per-axis', dest='n', type=int, default=None,
+                    help='elements per axis (per GPU with weak scaling; use the long form behind torch.distributed.run, whose parser claims --n)')
     ap.add_argument('--variant', choices=['iso', 'uniform'], default='iso')
     ap.add_argument('--kernel', choices=['auto', 'generic', 'fast'], default='auto')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-graph', dest='graph', action='store_false', help='launch every step eagerly instead of replaying a captured HIP graph')
-    return ap.parse_args()
+    a = ap.parse_args()
+    c3 = a.config == 'c3'
+    a.n = a.n or (64 if c3 else 128)
+    a.steps = a.steps if a.steps is not None else (30 if c3 else 200)
+    a.warmup = a.warmup if a.warmup is not None else (3 if c3 else 20)
+    a.settle = a.settle if a.settle is not None else (10 if c3 else 300)
+    return a
 
 
 def measured_traffic(kernel_name, n):
-    '''HBM bytes per launch measured with rocprofv3 PMC counters for this kernel (profiles/r01_traffic.json), or None.'''
+    '''HBM bytes per launch measured with rocprofv3 PMC counters for this kernel (TRAFFIC_FILE: separate --pmc passes of this
+    command, FETCH_SIZE + WRITE_SIZE), or None.  Static: a profile of the same kernel at the same size, not measured in this run.'''
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'))).get(kernel_name)
+        d = json.load(open(os.path.join(ROOT, TRAFFIC_FILE))).get(kernel_name)
         return d['fetch_bytes'] + d['write_bytes'] if d and d['n'] == n else None
     except Exception:
         return None
@@ -73,6 +88,7 @@ def timed_steps(wl, steps, world, dist, use_graph):
         except Exception:
             graph = None
             torch.cuda.synchronize()
+
     def run(replay):
         if world > 1:
             dist.barrier()
@@ -102,7 +118,40 @@ def timed_steps(wl, steps, world, dist, use_graph):
     return elapsed, kernel_ms, launch
 
 
-def cpu_baseline(variant):
+def host_regions(make_workload, copy=True):
+    '''BASELINE.md 3 regions on a fresh workload object: first assembly (pattern + values) device resident, the same with the CSR
+    copied to host memory, and a re-assembly (values only) copied to host.  The copies go through page-locked memory
+    (device.to_host); one untimed round first, so that the pinned blocks exist.'''
+    import torch
+    from nutils_amd import device
+    out = {}
+    for timed in (False, True):
+        wl = make_workload()
+        wl.setup()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wl.build_pattern()
+        wl.step(exchange=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if not copy:  # (configs[2]: 19.5 GB of CSR -- the copy is not timed, the size is reported)
+            if timed:
+                out = {'first_assembly_ms': (t1 - t0) * 1e3, 'host_bytes': int(8 * (2 * wl.values.numel() + wl.rowptr.numel()))}
+            del wl
+            continue
+        host = [device.to_host(wl.values), device.to_host(wl.rowptr), device.to_host(wl.colidx)]
+        t2 = time.perf_counter()
+        wl.step(exchange=False)
+        v = device.to_host(wl.values)
+        t3 = time.perf_counter()
+        if timed:
+            out = {'first_assembly_ms': (t1 - t0) * 1e3, 'host_ready_ms': (t2 - t0) * 1e3, 'reassembly_host_ready_ms': (t3 - t2) * 1e3,
+                   'host_bytes': int(sum(h.nbytes for h in host))}
+        del wl, host, v
+    return out
+
+
+def cpu_baseline_c2(variant):
     '''Oracle port (oracle/c, kind "port") on the host cores: bounded sample of the same workload.'''
     import numpy
     from oracle import assemble as oa, port
@@ -130,14 +179,68 @@ def cpu_baseline(variant):
             n = cand
     t, tl, td = (t32, 0, 0) if n == 32 else run(n)
     return {'value': n ** 3 / t, 'unit': 'elements/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n}^3-element {variant} P1 hex Laplace, full COO->sort->CSR assembly, {t:.2f} s '
+            'sample': f'{n}^3-element {variant} P1 hex Laplace, full COO->sort->CSR assembly (pattern + values, on the host), {t:.2f} s '
                       f'(element loop {tl:.2f} s on {cores} OpenMP threads, serial radix-sort dedup {td:.2f} s)'}
+
+
+def cpu_baseline_c3(wl):
+    '''Oracle port of the vector form (port_form3d): element loop on all cores, serial stable-sort dedup as in the reference.'''
+    import numpy
+    from oracle import assemble as oa, port
+    if not port.available():
+        return None
+    cores = len(os.sched_getaffinity(0))
+    pts, w = oa.gauss(4, 3)
+    _, coeffs, _ = oa.structured_basis((1, 1, 1), 'std', 2)
+    _, gcoeffs, _ = oa.structured_basis((1, 1, 1), 'std', 1)
+    N, dN = oa.tabulate(coeffs[0], pts)
+    gN, gdN = oa.tabulate(gcoeffs[0], pts)
+    T = numpy.concatenate([N.T[:, :, None], dN.transpose(1, 0, 2)], axis=2)
+    gT = numpy.concatenate([gN.T[:, :, None], gdN.transpose(1, 0, 2)], axis=2)
+
+    def run(n):
+        rng = numpy.random.default_rng(0)
+        verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.)] * 3, indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, ((n + 1) ** 3, 3))
+        t0 = time.perf_counter()
+        v, rp, ci, (tl, td) = port.form3d((n, n, n), 2, wl.C, T, gT, w, verts, threads=cores)
+        return time.perf_counter() - t0, tl, td
+
+    t8, _, _ = run(8)
+    n = 8
+    for cand in (12, 16, 20, 24):
+        if t8 * (cand / 8) ** 3 <= 25.:
+            n = cand
+    t, tl, td = (t8, 0, 0) if n == 8 else run(n)
+    return {'value': n ** 3 / t, 'unit': 'elements/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n}^3-element iso P2 vector elasticity, full COO->sort->CSR assembly (pattern + values, on the host), {t:.2f} s '
+                      f'(element loop {tl:.2f} s on {cores} OpenMP threads, serial radix-sort dedup {td:.2f} s)'}
+
+
+def row_sum_check(values, rowptr, a_row, b_row, world, dist, stride=1):
+    '''max |sum of row| / max |K| over rows [a_row, b_row) (constants lie in the kernel of the Laplace stiffness matrix)'''
+    import torch
+    lo = int(rowptr[a_row])
+    owned = values[lo:int(rowptr[b_row])]
+    csum = torch.cat([torch.zeros(1, dtype=torch.float64, device=owned.device), torch.cumsum(owned, 0)])  # stays O(|K|): every row sums to ~0
+    rowsum = csum[rowptr[a_row + 1:b_row + 1] - lo] - csum[rowptr[a_row:b_row] - lo]
+    check = torch.stack([rowsum.abs().max() / owned.abs().max()])
+    if world > 1:
+        dist.all_reduce(check, op=dist.ReduceOp.MAX)
+    return float(check.item())
+
+
+def fail(msg, rank, world, dist, metric):
+    print('ERROR: ' + msg, file=sys.stderr)
+    if rank == 0:  # a broken kernel or halo reduce must not be recorded as a (possibly faster) valid result
+        print(json.dumps({'metric': metric, 'value': None, 'unit': 'elements/s', 'n_gpus': world, 'error': 'correctness gate failed: ' + msg}))
+    if world > 1:
+        dist.destroy_process_group()
+    sys.exit(1)
 
 
 def main():
     a = parse()
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: required by RCCL / cross-process device memory on this driver
-    import numpy
     import torch
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -150,15 +253,24 @@ def main():
     if one_gpu:
         local = 0
     torch.cuda.set_device(local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if one_gpu:
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-
+    metric = 'elements assembled/sec (global stiffness K)'
     from nutils_amd import workloads
-    wl = workloads.PoissonSlab(n=a.n, rank=rank, world=world, variant=a.variant, kernel=a.kernel)
+    strong = a.scaling == 'strong' and world > 1
+    if strong and a.n % world:
+        raise SystemExit(f'--scaling strong: {a.n} element layers do not split into {world} slabs')
+    layers = a.n // world if strong else a.n
+    if a.config == 'c3':
+        make = lambda r=rank, w=world: workloads.ElasticityP2(n=a.n, layers=layers, rank=r, world=w, variant=a.variant)
+    else:
+        make = lambda r=rank, w=world: workloads.PoissonSlab(n=a.n, layers=layers, rank=r, world=w, variant=a.variant, kernel=a.kernel)
+    wl = make()
     t0 = time.perf_counter()
     wl.setup()
     torch.cuda.synchronize()
@@ -168,52 +280,56 @@ def main():
     torch.cuda.synchronize()
     pattern_ms = (time.perf_counter() - t0) * 1e3
 
-    for _ in range(a.settle + a.warmup):  # settle: bring the GPU out of its idle power state (0.236 ms per step over the first 20
-        wl.step()                          # launches, 0.215 ms in steady state); then the W warm-up steps of the contract
+    for _ in range(a.settle + a.warmup):  # settle: bring the GPU out of its idle power state; then the W warm-up steps of the contract
+        wl.step()
     torch.cuda.synchronize()
-    elapsed, kernel_ms, launch = timed_steps(wl, a.steps, world, dist if world > 1 else None, a.graph)
+    elapsed, kernel_ms, launch = timed_steps(wl, a.steps, world, dist, a.graph)
 
-    # size-independent check of the assembled matrix on every rank (rows it owns are complete after the interface reduce):
-    # K 1 = 0, i.e. every owned row sums to zero; catches a lost or doubled halo contribution without moving the matrix
+    # size-independent check of the assembled matrix on every rank (rows it owns are complete after the interface reduce)
     wl.finish()
-    s = wl.slab
-    a_row, b_row = s.own_plane_begin * s.plane, s.own_plane_end * s.plane
-    lo = int(wl.rowptr[a_row])
-    owned = wl.values[lo:int(wl.rowptr[b_row])]
-    csum = torch.cat([torch.zeros(1, dtype=torch.float64, device=owned.device), torch.cumsum(owned, 0)])  # stays O(|K|): every row sums to ~0
-    rowsum = csum[wl.rowptr[a_row + 1:b_row + 1] - lo] - csum[wl.rowptr[a_row:b_row] - lo]
-    check = torch.stack([rowsum.abs().max() / owned.abs().max()])
-    del csum, rowsum
-    if world > 1:
-        dist.all_reduce(check, op=dist.ReduceOp.MAX)
-    row_sum_rel = float(check.item())
-    if not row_sum_rel < 1e-10:  # a broken kernel or halo reduce must not be recorded as a (possibly faster) valid result
-        print(f'ERROR: owned rows do not sum to zero (relative {row_sum_rel:.2e}): the assembled matrix is wrong', file=sys.stderr)
-        if rank == 0:
-            print(json.dumps({'metric': 'elements assembled/sec (global stiffness K)', 'value': None, 'unit': 'elements/s', 'n_gpus': world,
-                              'error': f'correctness gate failed: owned row sums relative {row_sum_rel:.3e}'}))
-        if world > 1:
-            dist.destroy_process_group()
-        sys.exit(1)
+    checks = wl.check(world, dist)
+    bad = [k for k, v in checks.items() if not v < 1e-10]
+    if bad:
+        fail(', '.join(f'{k} = {checks[k]:.3e}' for k in bad) + ': the assembled matrix is wrong', rank, world, dist, metric)
 
     if rank == 0:
         nelems_total = wl.nelems * world
         value = nelems_total * a.steps / elapsed
         bytes_per_elem = wl.algorithmic_bytes_per_element()
-        achieved = bytes_per_elem * wl.nelems / (kernel_ms * 1e-3) / 1e9
+        gbs = bytes_per_elem * wl.nelems / (kernel_ms * 1e-3) / 1e9
+        traffic = measured_traffic(wl.kernel_name, a.n) if world == 1 else None
+        if a.config == 'c3':
+            flops = wl.algorithmic_flops_per_element() * wl.nelems
+            tf = flops / (kernel_ms * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'achieved': tf, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / F64_MFMA_PEAK_TF, 'traffic': traffic,
+                        'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_flops_per_element': wl.algorithmic_flops_per_element(),
+                        'mfma_instructions_per_element': wl.mfma_per_element(),
+                        'matrix_pipe_busy': wl.mfma_per_element() * wl.nelems * 64 / 1024 / (kernel_ms * 1e-3 * 2.4e9),
+                        'hbm': {'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes_per_element': bytes_per_elem},
+                        'note': 'Gram-matrix formulation: the quadrature sum needs 336 v_mfma_f64_16x16x4 per element (756 in round 1); matrix_pipe_busy = their 64 cycles '
+                                'each over the kernel time at 2.4 GHz; neither the matrix pipe nor HBM bounds this kernel yet (DESIGN.md 5b)'}
+            workload = f'3D linear elasticity stiffness, {a.n}^3 structured hex, p=2 vector basis (81 local dofs), 3x3x3 Gauss, {a.variant} geometry (BASELINE.json configs[2])'
+        else:
+            roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': traffic,
+                        'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bytes_per_elem}
+            per = f'{layers} x {a.n} x {a.n} per GPU' if world > 1 else f'{a.n}^3'
+            workload = f'3D Poisson stiffness, {per} structured hex, p=1, 2x2x2 Gauss, {a.variant} geometry (BASELINE.json configs[1])'
+        if traffic is not None:
+            roofline['traffic_source'] = TRAFFIC_FILE + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, separate passes; not measured in this run)'
         out = {
-            'metric': 'elements assembled/sec (global stiffness K)', 'value': value, 'unit': 'elements/s', 'n_gpus': world,
-            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'metric': metric, 'value': value, 'unit': 'elements/s', 'n_gpus': world,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'3D Poisson stiffness, {a.n}^3 structured hex per GPU, p=1, 2x2x2 Gauss, {a.variant} geometry '
-                                   f'(BASELINE.json configs[1])', 'nelems_per_gpu': wl.nelems, 'nnz_per_gpu': wl.nnz, 'kernel': wl.kernel_name,
+            'config': {'workload': workload, 'nelems_per_gpu': wl.nelems, 'nnz_per_gpu': wl.nnz, 'kernel': wl.kernel_name,
                        'parallelism': f'element slabs x{world}, halo-plane reduce' if world > 1 else 'single GPU', 'launch': launch,
-                       'settle_steps': a.settle},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': measured_traffic(wl.kernel_name, a.n) if world == 1 else None, 'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bytes_per_elem},
-            'pattern_ms': pattern_ms, 'setup_s': setup_s, 'checks': {'owned_row_sums_rel': row_sum_rel},
+                       'settle_steps': a.settle, 'timed_region': 'device-resident re-assembly of the CSR values (pattern, tables, vertices in HBM)'},
+            'roofline': roofline, 'pattern_ms': pattern_ms, 'setup_s': setup_s, 'checks': checks,
         }
-        if world == 1 and a.variant == 'iso':
+        if world == 1:
+            del wl
+            torch.cuda.empty_cache()
+            out.update(host_regions(lambda: make(0, 1), copy=a.config == 'c2'))
+        if world == 1 and a.variant == 'iso' and a.config == 'c2':
             # secondary variant of the same config: exact-uniform mesh (what mesh.rectilinear gives the reference; there the
             # element matrix is hoisted out of the loop and the work is index generation + dedup).  Not the headline value.
             w2 = workloads.PoissonSlab(n=a.n, rank=0, world=1, variant='uniform', kernel=a.kernel)
@@ -231,10 +347,15 @@ def main():
                                                         'kernel_ms': kms, 'algorithmic_bytes_per_element': b2}}}
             del w2
         if not a.no_cpu and world == 1:
-            cb = cpu_baseline(a.variant)
+            cb = cpu_baseline_c3(make(0, 1)) if a.config == 'c3' else cpu_baseline_c2(a.variant)
             if cb:
                 out['cpu_baseline'] = cb
-                out['speedup_vs_cpu_port'] = value / cb['value']
+                nel = a.n ** 3
+                out['speedup_vs_cpu_port'] = {'device_resident_reassembly': value / cb['value'],
+                                              'first_assembly_device_resident': nel / (out['first_assembly_ms'] * 1e-3) / cb['value'],
+                                              'note': 'the CPU leg times pattern + values on the host (BASELINE.md 3)'}
+                if 'host_ready_ms' in out:  # the like-for-like ratio: pattern + values + CSR in host memory on both sides
+                    out['speedup_vs_cpu_port']['first_assembly_host_ready'] = nel / (out['host_ready_ms'] * 1e-3) / cb['value']
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

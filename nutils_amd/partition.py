@@ -23,24 +23,29 @@ import numpy
 
 
 class Slab:
-    '''Index bookkeeping of one rank's slab (P1 dofs: one dof plane per element-layer boundary).'''
+    '''Index bookkeeping of one rank's slab of n element layers for a C0 ('std') basis of the given degree with ncomp components:
+    `degree` dof planes per element layer, the plane on a slab boundary is shared; a row of that plane couples 2 degree + 1 planes,
+    degree + 1 of them through the elements below.'''
 
-    def __init__(self, n, rank, world, shape_jk):
+    def __init__(self, n, rank, world, shape_jk, degree=1, ncomp=1):
         self.n, self.rank, self.world = int(n), int(rank), int(world)
         self.nj, self.nk = (int(x) for x in shape_jk)
+        self.degree, self.ncomp = int(degree), int(ncomp)
+        p = self.degree
         if not 0 <= rank < world:
             raise ValueError('rank out of range')
         self.ghost_layers = 1 if rank > 0 else 0
         self.own_layers = self.n
         self.local_layers = self.n + self.ghost_layers
-        self.first_global_plane = rank * self.n - self.ghost_layers  # global index of local dof plane 0 (= element layer 0)
-        self.plane = (self.nj + 1) * (self.nk + 1)                   # dofs per plane
-        self.own_plane_begin = self.ghost_layers
-        self.own_plane_end = self.ghost_layers + self.n + (1 if rank == world - 1 else 0)
-        self.sends = rank < world - 1   # top plane (local index ghost+n) -> rank+1
-        self.recvs = rank > 0           # into local plane `ghost_layers` (= 1) <- rank-1
-        self.send_plane = self.ghost_layers + self.n
-        self.recv_plane = self.ghost_layers
+        self.first_global_plane = p * (rank * self.n - self.ghost_layers)  # global index of local dof plane 0
+        self.plane = (p * self.nj + 1) * (p * self.nk + 1) * self.ncomp    # rows (= flat dofs) per plane
+        self.own_plane_begin = p * self.ghost_layers
+        self.own_plane_end = p * (self.ghost_layers + self.n) + (1 if rank == world - 1 else 0)
+        self.sends = rank < world - 1   # top plane -> rank+1
+        self.recvs = rank > 0           # into the first owned plane <- rank-1
+        self.send_plane = p * (self.ghost_layers + self.n)
+        self.recv_plane = p * self.ghost_layers
+        self.lower_planes, self.coupled_planes = p + 1, 2 * p + 1
 
 
 class HaloPlan:
@@ -59,9 +64,9 @@ class HaloPlan:
             r0 = slab.recv_plane * p
             rp = rowptr[r0:r0 + p + 1]
             lens = rp[1:] - rp[:-1]
-            if int((lens % 3).abs().sum()) != 0:
-                raise ValueError('interface rows are expected to couple three dof planes')
-            slen = lens * 2 // 3
+            if int((lens % slab.coupled_planes).abs().sum()) != 0:
+                raise ValueError(f'interface rows are expected to couple {slab.coupled_planes} dof planes')
+            slen = lens * slab.lower_planes // slab.coupled_planes
             starts = torch.cumsum(slen, 0) - slen
             total = int(slen.sum())
             within = torch.arange(total, device=rowptr.device, dtype=rowptr.dtype) - torch.repeat_interleave(starts, slen)

@@ -16,11 +16,12 @@ from . import device, function, kernels, mesh, partition
 
 class PoissonSlab:
 
-    def __init__(self, n=128, rank=0, world=1, variant='iso', kernel='auto', seed=0):
+    def __init__(self, n=128, rank=0, world=1, variant='iso', kernel='auto', seed=0, layers=None):
         self.n, self.rank, self.world, self.variant = int(n), int(rank), int(world), variant
+        self.layers = int(layers) if layers else self.n  # element layers per rank (strong scaling: n / world)
         self.kernel = kernel
         self.seed = seed
-        self.slab = partition.Slab(self.n, self.rank, self.world, shape_jk=(self.n, self.n))
+        self.slab = partition.Slab(self.layers, self.rank, self.world, shape_jk=(self.n, self.n))
 
     def setup(self):
         s = self.slab
@@ -31,7 +32,7 @@ class PoissonSlab:
             # global vertex field: (I, J, K) + U(-.2, .2)^3 with default_rng(seed) over the GLOBAL mesh;
             # every rank draws the same stream and keeps its planes
             rng = numpy.random.default_rng(self.seed)
-            nI = n * self.world + 1
+            nI = self.layers * self.world + 1
             pert = rng.uniform(-.2, .2, (nI, n + 1, n + 1, 3))
             I0 = s.first_global_plane
             idx = numpy.stack(numpy.meshgrid(numpy.arange(I0, I0 + s.local_layers + 1, dtype=float), numpy.arange(n + 1.), numpy.arange(n + 1.), indexing='ij'), -1)
@@ -168,6 +169,20 @@ class PoissonSlab:
             kernel_events[1].record()
         self._end_step(slot, exchange)
 
+    def check(self, world=1, dist=None):
+        '''Size-independent check on the rows this rank owns (complete after the interface reduce): K 1 = 0.'''
+        import torch
+        s = self.slab
+        a_row, b_row = s.own_plane_begin * s.plane, s.own_plane_end * s.plane
+        lo = int(self.rowptr[a_row])
+        owned = self.values[lo:int(self.rowptr[b_row])]
+        csum = torch.cat([torch.zeros(1, dtype=torch.float64, device=owned.device), torch.cumsum(owned, 0)])  # stays O(|K|): every row sums to ~0
+        rowsum = csum[self.rowptr[a_row + 1:b_row + 1] - lo] - csum[self.rowptr[a_row:b_row] - lo]
+        check = torch.stack([rowsum.abs().max() / owned.abs().max()])
+        if world > 1:
+            dist.all_reduce(check, op=dist.ReduceOp.MAX)
+        return {'owned_row_sums_rel': float(check.item())}
+
     def _gauss_w1(self):
         from . import points
         return list(points.gauss1(2)[1])
@@ -193,45 +208,59 @@ class PoissonSlab:
 
 class ElasticityP2:
     '''configs[2]: 3-D linear elasticity (examples/elasticity.py scaled to 3-D: lambda = 1, mu = .5/nu - 1, nu = .3),
-    quadratic C0 vector basis (27 nodes x 3 components per element), 3x3x3 Gauss, n^3 elements, isoparametric P1 geometry with the
-    vertices perturbed by default_rng(seed).uniform(-.2, .2).  Stiffness-matrix (re)assembly through nh_p2hex_matrix; the pattern is the
-    closed-form one of nh_p2hex_pattern (bit-equal to the generic row-wise build: tests/test_gpu_p2hex.py).'''
+    quadratic C0 vector basis (27 nodes x 3 components per element), 3x3x3 Gauss, isoparametric P1 geometry with the vertices
+    perturbed by default_rng(seed).uniform(-.2, .2).  Stiffness-matrix (re)assembly through nh_p2hex_matrix; the pattern is the
+    closed-form one of nh_p2hex_pattern (bit-equal to the generic row-wise build: tests/test_gpu_p2hex.py).  With world > 1 rank r
+    owns `layers` element layers of a (layers * world) x n x n mesh plus one ghost layer below (pattern of the interface plane only);
+    the rows of its top node plane go to rank r + 1 (partition.HaloPlan).'''
 
     ncomp = 3
 
-    def __init__(self, n=64, variant='iso', seed=0, lam=1., mu=.5 / .3 - 1):
-        self.n, self.variant, self.seed, self.lam, self.mu = int(n), variant, seed, float(lam), float(mu)
-        self.kernel_name = 'k_p2hex_pipe<3,3,1>'
+    def __init__(self, n=64, rank=0, world=1, variant='iso', seed=0, lam=1., mu=.5 / .3 - 1, layers=None):
+        self.n, self.rank, self.world, self.variant, self.seed = int(n), int(rank), int(world), variant, seed
+        self.layers = int(layers) if layers else self.n
+        self.C = self.form_tensor(lam, mu)
+        self.kernel_name = 'k_p2hex_pipe<3,1,1>'
+        self.slab = partition.Slab(self.layers, self.rank, self.world, shape_jk=(self.n, self.n), degree=2, ncomp=3)
 
-    def setup(self):
-        n = self.n
-        self.domain, _ = mesh.rectilinear([n] * 3)
-        self.basis = self.domain.basis('std', degree=2)
-        gb = self.domain.basis('std', degree=1)
-        verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.)] * 3, indexing='ij'), -1).reshape(-1, 3)
-        if self.variant == 'iso':
-            verts = verts + numpy.random.default_rng(self.seed).uniform(-.2, .2, verts.shape)
-        self.verts = verts
-        self.geom = gb @ verts
-        self.smp = self.domain.sample('gauss', 4)
-        self.tables = self.smp.tables(self.basis)
-        self.kgeom = self.smp.geometry(self.geom)
-        self.nelems = n ** 3
+    @staticmethod
+    def form_tensor(lam, mu):
         C = numpy.zeros((3, 4, 3, 4))
         for c in range(3):
             for i in range(3):
                 for d in range(3):
                     for j in range(3):
-                        C[c, 1 + i, d, 1 + j] = self.lam * (c == i) * (d == j) + self.mu * ((c == d) * (i == j) + (c == j) * (d == i))
-        self.C = C
+                        C[c, 1 + i, d, 1 + j] = lam * (c == i) * (d == j) + mu * ((c == d) * (i == j) + (c == j) * (d == i))
+        return C
+
+    def setup(self):
+        n, s = self.n, self.slab
+        self.shape = (s.local_layers, n, n)
+        self.domain, _ = mesh.rectilinear(list(self.shape))
+        self.basis = self.domain.basis('std', degree=2)
+        gb = self.domain.basis('std', degree=1)
+        # global vertex field over the (layers * world) x n x n mesh: every rank draws the same stream and keeps its planes
+        nI = self.layers * self.world + 1
+        I0 = s.first_global_plane // 2
+        idx = numpy.stack(numpy.meshgrid(numpy.arange(I0, I0 + s.local_layers + 1, dtype=float), numpy.arange(n + 1.), numpy.arange(n + 1.), indexing='ij'), -1)
+        if self.variant == 'iso':
+            pert = numpy.random.default_rng(self.seed).uniform(-.2, .2, (nI, n + 1, n + 1, 3))
+            idx = idx + pert[I0:I0 + s.local_layers + 1]
+        self.verts = idx.reshape(-1, 3)
+        self.geom = gb @ self.verts
+        self.smp = self.domain.sample('gauss', 4)
+        self.tables = self.smp.tables(self.basis)
+        self.kgeom = self.smp.geometry(self.geom)
+        self.nelems = s.own_layers * n * n
 
     def build_pattern(self):
-        shape = (self.n,) * 3
-        self.rowptr, self.colidx = kernels.p2hex_pattern(shape, 3)
+        s = self.slab
+        self.rowptr, self.colidx = kernels.p2hex_pattern(self.shape, 3)
         self.nnz = int(self.colidx.numel())
-        self.values = device.empty(self.nnz, 'float64')  # write-once kernel: no zero-fill
-        self._launch = kernels.P2HexMatrix(shape=shape, nq=self.smp.points.npoints, weights=self.smp._weights_dev, geom=self.kgeom, T=self.tables.T, ncomp=3,
-                                           C=self.C)
+        self.values = device.zeros(self.nnz, 'float64')  # write-once kernel: no zero-fill per step (rows of a ghost plane are never written)
+        self._launch = kernels.P2HexMatrix(shape=self.shape, nq=self.smp.points.npoints, weights=self.smp._weights_dev, geom=self.kgeom, T=self.tables.T, ncomp=3,
+                                           C=self.C, layers=(s.ghost_layers, s.local_layers), owners=(s.ghost_layers, s.local_layers))
+        self.halo = partition.HaloPlan(s, self.rowptr) if self.world > 1 else None
 
     def step(self, kernel_events=None, exchange=True):
         if kernel_events:
@@ -239,17 +268,30 @@ class ElasticityP2:
         self._launch(self.values)
         if kernel_events:
             kernel_events[1].record()
+        if self.halo is not None and exchange:
+            self.halo.exchange(self.values)
 
     def finish(self):
         pass
 
+    check = PoissonSlab.check  # rigid translations lie in the kernel of K: the owned rows sum to zero
+
     def algorithmic_bytes_per_element(self):
         '''unique vertex coordinates + CSR values written once (structured connectivity is generated in-kernel).'''
         n = self.n
-        return (n + 1) ** 3 / n ** 3 * 24 + self.nnz / n ** 3 * 8
+        return (n + 1) ** 3 / n ** 3 * 24 + (8 * n + 1) ** 3 * 9 / n ** 3 * 8
 
     def algorithmic_flops_per_element(self):
         '''Gram-matrix formulation: G = D^T W D over (27 nodes x 3 gradient slots)^2 x 27 points, multiply-add = 2 flops; the form
         tensor costs 21 flops per node pair on top.  (SURVEY 8d's 2.3 Mflop counts the B^T C B product per point, which this
         formulation does not execute.)'''
         return 2. * 81 * 81 * 27 + 21. * 27 * 27
+
+    @staticmethod
+    def mfma_per_element():
+        '''v_mfma_f64_16x16x4_f64 per element: 8 units of 4 row nodes x 2 column tiles x 3 trial slots x 7 k-steps'''
+        return 8 * 2 * 3 * 7
+
+    def owned_csr(self):
+        '''(values, rowptr, colidx) of the rows this rank owns, global numbering, on the host.'''
+        return partition.owned_rows(self.slab, device.to_host(self.values), device.to_host(self.rowptr), device.to_host(self.colidx))

@@ -42,6 +42,42 @@ def test_two_slabs_equal_single_mesh(kernel, variant, monkeypatch):
     assert numpy.abs(v - vo).max() <= 1e-13 * numpy.abs(vo).max()
 
 
+@pytest.mark.parametrize('world,layers', [(2, 3), (3, 2)])
+def test_p2_elasticity_slabs_equal_single_mesh(world, layers):
+    '''configs[2] partitioned: every "rank" assembles its slab of the quadratic vector elasticity matrix with the HIP kernel
+    (nh_p2hex_matrix with layer / owner ranges), the rows of the interface plane travel as HaloPlan prescribes, and the concatenated
+    owned row blocks equal the single-mesh assembly ENTRY BY ENTRY (index arrays bit-exact).'''
+    from nutils_amd import workloads, partition
+    n = 4
+    blocks, prev_tail = [], None
+    for rank in range(world):
+        wl = workloads.ElasticityP2(n=n, layers=layers, rank=rank, world=world)
+        wl.setup()
+        wl.build_pattern()
+        wl.step(exchange=False)
+        if wl.slab.recvs:  # what irecv + index_add_ do in HaloPlan.exchange
+            assert prev_tail.numel() == wl.halo.recv_buf.numel()
+            wl.values.index_add_(0, wl.halo.recv_idx, prev_tail)
+        if wl.slab.sends:
+            prev_tail = wl.values[wl.halo.send_a:wl.halo.send_b].clone()
+        blocks.append(wl.owned_csr())
+        assert wl.check()['owned_row_sums_rel'] < 1e-12
+    v, rp, ci = partition.concatenate(blocks)
+    from nutils_amd import device
+    single = workloads.ElasticityP2(n=n, layers=layers * world, rank=0, world=1)
+    single.setup()
+    single.build_pattern()
+    single.step()
+    vo, rpo, cio = device.to_host(single.values), device.to_host(single.rowptr), device.to_host(single.colidx)
+    assert numpy.array_equal(rp, rpo) and numpy.array_equal(ci, cio)
+    assert numpy.abs(v - vo).max() <= 1e-13 * numpy.abs(vo).max()
+    # a misplaced interface row would also show here: the six rigid body modes lie in the kernel of the global matrix
+    import scipy.sparse
+    K = scipy.sparse.csr_matrix((v, ci, rp), shape=(len(rp) - 1,) * 2)
+    X = numpy.stack(numpy.meshgrid(numpy.arange(2 * layers * world + 1.), numpy.arange(2 * n + 1.), numpy.arange(2 * n + 1.), indexing='ij'), -1).reshape(-1, 3)
+    assert abs(K @ numpy.ones(K.shape[0])).max() < 1e-12 * abs(v).max() * 100
+
+
 def test_pipelined_exchange_matches_serial():
     '''The double-buffered, side-stream exchange of PoissonSlab (world > 1) orchestrated on ONE GPU: the network hop is replaced
     by a local stand-in with the same stream semantics (reads the send range, adds into the receive rows on the current
@@ -106,3 +142,21 @@ def test_bench_multiprocess_on_one_gpu(world):
     assert rec['config']['nelems_per_gpu'] == 32 ** 3 and rec['value'] > 0
     assert rec['checks']['owned_row_sums_rel'] < 1e-12
     assert 'WARNING' not in out.stderr
+
+
+@pytest.mark.parametrize('args,nel', [(['--scaling', 'strong', '--elements-per-axis', '32'], 32 ** 3 // 2),
+                                      (['--config', 'c3', '--elements-per-axis', '8'], 8 ** 3),
+                                      (['--config', 'c3', '--scaling', 'strong', '--elements-per-axis', '8'], 8 ** 3 // 2)])
+def test_bench_modes_multiprocess_on_one_gpu(args, nel):
+    '''strong scaling (one mesh split into slabs) and the configs[2] workload, two ranks on the one GPU of this box'''
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NUTILS_AMD_BENCH_ONE_GPU='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port', '29511',
+           'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--settle', '2', '--no-cpu'] + args
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert rec['n_gpus'] == 2 and rec['scaling'] == ('strong' if '--scaling' in args else 'weak')
+    assert rec['config']['nelems_per_gpu'] == nel and rec['value'] > 0
+    assert rec['checks']['owned_row_sums_rel'] < 1e-12

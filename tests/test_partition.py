@@ -12,25 +12,37 @@ import pytest
 from oracle import assemble as oa
 
 
-def local_assembly(n, nj, nk, rank, world, verts_global):
+def form(degree):
+    '''degree 1: scalar Laplace (configs[1]); degree 2: 3-component elasticity (configs[2])'''
+    return (oa.laplace_coefficient(3), 1) if degree == 1 else (oa.elasticity_coefficient(3, 1., .5 / .3 - 1), 3)
+
+
+def assemble(shape, degree, verts, zero_layers=0):
+    C, nc = form(degree)
+    dofs, coeffs, ndofs = oa.structured_basis(shape, 'std', degree)
+    gdofs, gcoeffs, _ = oa.structured_basis(shape, 'std', 1)
+    pts, w = oa.gauss(2 * degree, 3)
+    N, dN = oa.tabulate(coeffs, pts)
+    gN, gdN = oa.tabulate(gcoeffs, pts)
+    x, J = oa.geometry_iso(verts, gdofs, gN, gdN)
+    D, det = oa.physical_tables(N, dN, J)
+    A = oa.local_matrices(D, D, det * w, C)
+    A[:zero_layers * shape[1] * shape[2]] = 0.
+    return oa.assemble_csr(A, dofs, dofs, ndofs, ndofs)
+
+
+def local_assembly(n, nj, nk, rank, world, verts_global, degree=1):
     '''Oracle stand-in for one rank's device assembly: local mesh = own layers + ghost layer below,
     values from the own layers only (ghost elements contribute structural zeros = pattern only).'''
     from nutils_amd import partition
-    slab = partition.Slab(n, rank, world, (nj, nk))
+    slab = partition.Slab(n, rank, world, (nj, nk), degree=degree, ncomp=form(degree)[1])
     shape = (slab.local_layers, nj, nk)
-    dofs, coeffs, ndofs = oa.structured_basis(shape, 'std', 1)
-    pts, w = oa.gauss(2, 3)
-    N, dN = oa.tabulate(coeffs, pts)
-    p0 = slab.first_global_plane
-    verts = verts_global[p0:p0 + slab.local_layers + 1].reshape(-1, 3)
-    x, J = oa.geometry_iso(verts, dofs, N, dN)
-    D, det = oa.physical_tables(N, dN, J)
-    A = oa.local_matrices(D, D, det * w, oa.laplace_coefficient(3))
-    A[:slab.ghost_layers * nj * nk] = 0.
-    return slab, oa.assemble_csr(A, dofs, dofs, ndofs, ndofs)
+    l0 = slab.first_global_plane // degree
+    verts = verts_global[l0:l0 + slab.local_layers + 1].reshape(-1, 3)
+    return slab, assemble(shape, degree, verts, zero_layers=slab.ghost_layers)
 
 
-def worker(rank, world, port, n, nj, nk, tmp):
+def worker(rank, world, port, n, nj, nk, tmp, degree=1):
     import torch
     import torch.distributed as dist
     from nutils_amd import partition
@@ -40,7 +52,7 @@ def worker(rank, world, port, n, nj, nk, tmp):
     NI = n * world + 1
     verts_global = numpy.stack(numpy.meshgrid(numpy.arange(NI, dtype=float), numpy.arange(nj + 1.), numpy.arange(nk + 1.), indexing='ij'), -1) \
         + rng.uniform(-.2, .2, (NI, nj + 1, nk + 1, 3))
-    slab, (values, rowptr, colidx) = local_assembly(n, nj, nk, rank, world, verts_global)
+    slab, (values, rowptr, colidx) = local_assembly(n, nj, nk, rank, world, verts_global, degree)
     tv, trp = torch.from_numpy(values.copy()), torch.from_numpy(rowptr.copy())
     plan = partition.HaloPlan(slab, trp)
     plan.exchange(tv)
@@ -50,15 +62,17 @@ def worker(rank, world, port, n, nj, nk, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_slab_partition_gloo(tmp_path, world):
+@pytest.mark.parametrize('world,degree', [(2, 1), (3, 1), (2, 2), (3, 2)])
+def test_slab_partition_gloo(tmp_path, world, degree):
+    '''degree 1: the Poisson slabs of configs[1]; degree 2: the 3-component elasticity slabs of configs[2] (two dof planes per layer,
+    interface rows couple five planes, three of them through the rank below).'''
     import torch.multiprocessing as mp
     from nutils_amd import partition
-    n, nj, nk = 3, 4, 2
+    n, nj, nk = (3, 4, 2) if degree == 1 else (2, 2, 1)
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    mp.spawn(worker, args=(world, port, n, nj, nk, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, port, n, nj, nk, str(tmp_path), degree), nprocs=world, join=True)
     blocks = []
     for r in range(world):
         d = numpy.load(tmp_path / f'block{r}.npz')
@@ -69,13 +83,7 @@ def test_slab_partition_gloo(tmp_path, world):
     NI = n * world + 1
     verts = (numpy.stack(numpy.meshgrid(numpy.arange(NI, dtype=float), numpy.arange(nj + 1.), numpy.arange(nk + 1.), indexing='ij'), -1)
              + rng.uniform(-.2, .2, (NI, nj + 1, nk + 1, 3))).reshape(-1, 3)
-    shape = (n * world, nj, nk)
-    dofs, coeffs, ndofs = oa.structured_basis(shape, 'std', 1)
-    pts, w = oa.gauss(2, 3)
-    N, dN = oa.tabulate(coeffs, pts)
-    x, J = oa.geometry_iso(verts, dofs, N, dN)
-    D, det = oa.physical_tables(N, dN, J)
-    vo, rpo, cio = oa.assemble_csr(oa.local_matrices(D, D, det * w, oa.laplace_coefficient(3)), dofs, dofs, ndofs, ndofs)
+    vo, rpo, cio = assemble((n * world, nj, nk), degree, verts)
     assert numpy.array_equal(rp, rpo) and numpy.array_equal(ci, cio)
     assert numpy.abs(v - vo).max() <= 1e-13 * numpy.abs(vo).max()
 
@@ -91,3 +99,9 @@ def test_slab_bookkeeping():
     assert s0.sends and not s0.recvs and s1.sends and s1.recvs and s2.recvs and not s2.sends
     with pytest.raises(ValueError):
         partition.Slab(4, 3, 3, (1, 1))
+    # quadratic vector basis: two planes per layer, 3 components
+    q0, q1, q2 = (partition.Slab(4, r, 3, (5, 6), degree=2, ncomp=3) for r in range(3))
+    assert q1.plane == 11 * 13 * 3 and (q0.first_global_plane, q1.first_global_plane, q2.first_global_plane) == (0, 6, 14)
+    owned = [range(s.first_global_plane + s.own_plane_begin, s.first_global_plane + s.own_plane_end) for s in (q0, q1, q2)]
+    assert [(o[0], o[-1]) for o in owned] == [(0, 7), (8, 15), (16, 24)]
+    assert (q1.send_plane, q1.recv_plane, q1.lower_planes, q1.coupled_planes) == (10, 2, 3, 5)
