@@ -9,6 +9,8 @@ results are committed as small ``.npz`` files under tests/golden/.  Nothing here
 travels to the GPU box except those data files.
 
 Usage:  python oracle/gen_golden.py            (regenerates tests/golden/*.npz)
+        python oracle/gen_golden.py --check    (regenerates into a scratch directory and compares with the committed
+                                                files: integer arrays identical, floats to 1e-12; exit status 1 on a difference)
 '''
 
 import os
@@ -392,7 +394,7 @@ def example_vectors():
     save('examples_poisson', **out)
 
 
-if __name__ == '__main__':
+def generate_all():
     os.makedirs(OUT, exist_ok=True)
     scalar_case('lap1d_p1_5', (5,), 'std', 1, iso=False)
     scalar_case('lap2d_p1_4x4', (4, 4), 'std', 1, iso=False)
@@ -425,3 +427,46 @@ if __name__ == '__main__':
     hierarchical_case('hier_spline2_1d', 1)
     hierarchical_case('hier_spline2_2d', 2)
     example_vectors()
+
+
+def check():
+    '''Regenerate every fixture in a scratch directory and compare it with the committed file.'''
+    import tempfile
+    global OUT
+    committed = OUT
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT = tmp
+        generate_all()
+        OUT = committed
+        names = sorted(f for f in os.listdir(tmp) if f.endswith('.npz'))
+        missing = sorted(set(f for f in os.listdir(committed) if f.endswith('.npz')) ^ set(names))
+        bad += [f'{f}: present on one side only' for f in missing]
+        for f in names:
+            if f in missing:
+                continue
+            new, old = numpy.load(os.path.join(tmp, f), allow_pickle=False), numpy.load(os.path.join(committed, f), allow_pickle=False)
+            if sorted(new.files) != sorted(old.files):
+                bad.append(f'{f}: different keys')
+                continue
+            for k in new.files:
+                a, b = new[k], old[k]
+                if a.shape != b.shape or a.dtype != b.dtype:
+                    bad.append(f'{f}[{k}]: shape / dtype')
+                elif a.dtype.kind in 'iub' or a.dtype.kind in 'US':
+                    if not numpy.array_equal(a, b):
+                        bad.append(f'{f}[{k}]: integer data differs')
+                elif a.size and not numpy.array_equal(numpy.isnan(a), numpy.isnan(b)):  # (constraint vectors: NaN = free dof)
+                    bad.append(f'{f}[{k}]: NaN pattern differs')
+                elif a.size and not numpy.nanmax(numpy.abs(a - b), initial=0.) <= 1e-12 * max(1., numpy.nanmax(numpy.abs(b), initial=0.)):
+                    bad.append(f'{f}[{k}]: float data differs by {numpy.nanmax(numpy.abs(a - b)):.2e}')
+    print(f'{len(names)} fixtures regenerated, {len(bad)} differences')
+    for line in bad:
+        print('  ' + line)
+    return not bad
+
+
+if __name__ == '__main__':
+    if '--check' in sys.argv[1:]:
+        raise SystemExit(0 if check() else 1)
+    generate_all()
