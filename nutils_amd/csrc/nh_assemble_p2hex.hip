@@ -521,9 +521,8 @@ __device__ __forceinline__ void pipe_meta(const P2K &p, const Line &L, double *l
 // buffers: 16-byte pairs with wave-uniform bases (a block is contiguous in both memories and starts with the same parity), the odd head
 // / tail element by one lane.  All records are read together, then all data, then the stores: the flushing waves have nothing else
 // to hide an LDS round trip behind.
-template <int NC, int NBLK>
+template <int NC, int NBLK, int UB = 3>  // UB pairs per thread and block: 125 * 9 / 2 = 563 <= UB * nt
 __device__ __forceinline__ void flush_blocks(const P2K &p, double *lds, int K0, int c0, int t, int nt) {
-  constexpr int UB = 3;  // pairs per thread and block: 125 * 9 / 2 = 563 <= 3 * 192
   const int *meta = reinterpret_cast<const int *>(lds + PL<NC>::META);
   const i64 *gm = reinterpret_cast<const i64 *>(lds + PL<NC>::META + 64);
   int2 f[NBLK];
@@ -803,9 +802,10 @@ __global__ __launch_bounds__(256) void k_p2hex_pattern(int n0, int n1, int n2, i
 
 template <int NC, int S0, int MODE>
 hipError_t launch_pipe(unsigned grid, size_t ldsb, hipStream_t s, const P2K &p) {
-  hipError_t e = hipFuncSetAttribute((const void *)k_p2hex_pipe<NC, S0, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  auto kern = k_p2hex_pipe<NC, S0, MODE>;
+  hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_p2hex_pipe<NC, S0, MODE>), dim3(grid), dim3(NTP4), ldsb, s, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTP4), ldsb, s, p);
   return hipSuccess;
 }
 
@@ -954,7 +954,7 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
     NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
     const double g = grid;
     fprintf(stderr, "p2hex_pipe cycles per wave: MFMA waves: tasks %.0f + barrier %.0f | table waves: D %.0f, flush %.0f + barrier %.0f | geometry wave: geometry %.0f + barrier %.0f | loop head %.0f\n",
-            h[0] / (g * 4), h[1] / (g * 4), h[2] / (g * NTW), h[4] / (g * NTW), h[5] / (g * NTW), h[3] / g, h[6] / g, h[7] / (g * 8));
+              h[0] / (g * 4), h[1] / (g * 4), h[2] / (g * NTW), h[4] / (g * NTW), h[5] / (g * NTW), h[3] / g, h[6] / g, h[7] / (g * 8));
   }
 #endif
   return NH_OK;
