@@ -29,3 +29,23 @@ def test_reference_examples_and_poly_tests_pass_through_the_shim():
 def test_golden_fixtures_reproduce():
     out = run('oracle/gen_golden.py', '--check')
     assert ' 0 differences' in out
+
+
+def test_plans_of_the_unmodified_examples_reproduce(tmp_path):
+    '''tools/hip_plan.py walks the function-level graph of the integrals that examples/laplace.py and examples/elasticity.py hand to
+    solver.System (the examples are run unmodified) and must give the committed plans again'''
+    import numpy
+    out = subprocess.run([sys.executable, 'tools/hip_plan.py'], cwd=ROOT, capture_output=True, text=True, timeout=1500,
+                         env=dict(os.environ, NUTILS_AMD_PLAN_OUT=str(tmp_path)))
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    committed = os.path.join(ROOT, 'tests', 'golden', 'plans')
+    names = sorted(f for f in os.listdir(committed) if f.endswith('.npz'))
+    assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith('.npz')) and len(names) >= 6
+    for f in names:
+        a, b = numpy.load(os.path.join(committed, f)), numpy.load(tmp_path / f)
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            if a[k].dtype.kind in 'iubUS':
+                assert numpy.array_equal(a[k], b[k]), (f, k)
+            else:
+                assert numpy.allclose(a[k], b[k], rtol=1e-12, atol=1e-14), (f, k)
