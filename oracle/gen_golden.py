@@ -365,6 +365,116 @@ def nurbs_case(name, nrefine=2, radius=.5, poisson=.3, seed=4):
     save(name, **data)
 
 
+def iga_plate_case(name, levels=10, degree=3, radius=.5, poisson=.3, seed=5):
+    '''BASELINE.json configs[4] as ONE workload: the NURBS plate-with-hole geometry of examples/platewithhole.py:66-86 (quadratic
+    NURBS map, coarse weight function W), `levels` hierarchical refinements towards the hole (topology.refined_by as in
+    examples/adaptivity.py:58-70), a p = `degree` truncated hierarchical spline basis made rational with projected weights
+    (N_i = w_i B_i / W, platewithhole.py:80-85) -- ragged functions per element, rational, hierarchical, p = 3 together -- and the
+    plane-strain elasticity stiffness matrix / residual of platewithhole.py:126-153 on it.'''
+    from nutils.solver import System
+    rng = numpy.random.default_rng(seed)
+    topo, geom0 = mesh.rectilinear([1, 2])
+    b2 = topo.basis('spline', degree=2)
+    cw = numpy.ones(12)
+    cw[1:3] = .5 + .25 * numpy.sqrt(2)
+    weightfunc = b2 @ cw
+    A = 0, 0, 0
+    B = (2**.5 - 1) * radius, .3 * (radius + 1) / 2, 1
+    C = radius, (radius + 1) / 2, 1
+    controlpoints = numpy.array([[A, B, C, C], [C, C, B, A]]).T.reshape(-1, 2)
+    geom = (b2 * cw / weightfunc) @ controlpoints
+    topo = topo.refine(1)
+    for lvl in range(levels):  # towards the point (0, 1) of the parameter domain: the middle of the hole boundary
+        n = len(topo)
+        c = topo.sample('gauss', 1).eval(geom0).reshape(n, 2)
+        sel = [i for i, x in enumerate(c) if max(abs(x[0]), abs(x[1] - 1.)) < .5 ** lvl]
+        topo = topo.refined_by(sel)
+    hb = topo.basis('th-spline', degree=degree)
+    sqr = topo.integral((function.field('w', hb) - weightfunc)**2, degree=2 * degree + 3)
+    w = System(sqr, trial='w').solve()['w']
+    nurbs = hb * w / weightfunc
+    nelems = len(topo)
+    smp = topo.sample('gauss', 8)
+    pts = smp.points[0]
+    nq = len(pts.weights)
+    data = dict(levels=levels, degree=degree, weights=w, lam=2 * poisson, mu=1 - poisson, gauss_coords=numpy.asarray(pts.coords, dtype=float),
+                gauss_weights=numpy.asarray(pts.weights, dtype=float))
+    tb = basis_tables(hb, nelems)
+    data['dofs'], data['dof_offsets'], data['coeffs'], data['ndofs'] = tb['dofs'], tb['dof_offsets'], tb['coeffs'], len(hb)
+    corners = topo.sample('bezier', 2).eval(geom0).reshape(nelems, 4, 2)
+    data['elem_origin'] = corners.min(axis=1)
+    data['elem_size'] = corners.max(axis=1) - corners.min(axis=1)
+    data['W'] = smp.eval(weightfunc).reshape(nelems, nq)
+    data['dW_dparam'] = smp.eval(function.grad(weightfunc, geom0)).reshape(nelems, nq, 2)
+    data['x'] = smp.eval(geom).reshape(nelems, nq, 2)
+    data['dx_dparam'] = smp.eval(function.grad(geom, geom0)).reshape(nelems, nq, 2, 2)
+    ns = Namespace()
+    ns.δ = function.eye(2)
+    ns.x = geom
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    ns.λ = 2 * poisson
+    ns.μ = 1 - poisson
+    ns.u = function.field('u', nurbs, shape=[2])
+    ns.v = function.field('v', nurbs, shape=[2])
+    ns.ε_ij = '(∇_j(u_i) + ∇_i(u_j)) / 2'
+    ns.σ_ij = 'λ ε_kk δ_ij + 2 μ ε_ij'
+    res = smp.integral('∇_j(v_i) σ_ij dV' @ ns)
+    n = len(hb)
+    u = rng.normal(size=(n, 2))
+    data['u'] = u
+    jac = function.derivative(function.derivative(res, 'v'), 'u')
+    jac2 = function.Array.cast(numpy.reshape(function.Array.cast(jac), (n * 2, n * 2)))
+    data.update(csr('K', jac2, dict(u=u * 0, v=u * 0)))
+    data['res'] = numpy.asarray(function.eval(function.derivative(res, 'v'), dict(u=u, v=u * 0)))
+    data['area'] = smp.integrate('dV' @ ns)
+    nb = numpy.diff(tb['dof_offsets'])
+    print(f'  {nelems} elements, {n} dofs, functions per element {nb.min()}..{nb.max()}, element sizes {data["elem_size"].min():.2e}..{data["elem_size"].max():.2e}')
+    save(name, **data)
+
+
+def factor_rank3_case(name, n=4, degree=2, seed=8):
+    '''SURVEY 8a row a14 with its own object: function.factor (function.py:2630-2642 -> evaluable.factor, evaluable.py:5785-5874) of a
+    CUBIC functional E(u) = int (u^3 / 3 + |grad u|^2 / 2 - u) dV.  The sparse Taylor coefficient tensors of the reference's Monomials
+    (evaluable.py:5693-5751: values + one index array per argument axis, powers) are the INPUT of the per-step work; stored with the
+    reference's value and gradient at a random argument.'''
+    from nutils import evaluable
+    rng = numpy.random.default_rng(seed)
+    domain, geom = mesh.rectilinear([numpy.linspace(0, 1, n + 1)] * 2)
+    ns = Namespace()
+    ns.x = geom
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    ns.u = domain.field('u', btype='spline', degree=degree)
+    E = domain.integral('(u^3 / 3 + ∇_i(u) ∇_i(u) / 2 - u) dV' @ ns, degree=3 * degree)
+    F = function.factor(E)
+    poly = F._array  # evaluable: sum of Sum(Monomial(...))
+    monomials = []
+
+    def walk(node, seen=set()):
+        if id(node) in seen:
+            return
+        seen.add(id(node))
+        if isinstance(node, evaluable.Monomial):
+            monomials.append(node)
+            return
+        for dep in node.dependencies:
+            walk(dep)
+    walk(poly)
+    ndofs = len(domain.basis('spline', degree=degree))
+    u = rng.normal(size=ndofs)
+    data = dict(nmonomials=len(monomials), ndofs=ndofs, u=u, value=numpy.asarray(function.eval(F, dict(u=u))),
+                gradient=numpy.asarray(function.eval(function.derivative(F, 'u'), dict(u=u))),
+                value_unfactored=numpy.asarray(function.eval(E, dict(u=u))))
+    for i, m in enumerate(sorted(monomials, key=lambda m: len(m.args))):
+        data[f'm{i}_values'] = numpy.asarray(evaluable.eval_once(m.values))
+        data[f'm{i}_nargs'] = len(m.args)
+        data[f'm{i}_powers'] = numpy.asarray(m.powers, dtype=numpy.int64)
+        for k, indices in enumerate(m.indices):
+            assert len(indices) == 1 and m.args[k].name == 'u'
+            data[f'm{i}_idx{k}'] = numpy.asarray(evaluable.eval_once(indices[0]), dtype=numpy.int64)
+    assert max(len(m.args) for m in monomials) == 3
+    save(name, **data)
+
+
 def example_vectors():
     '''Decoded assertAlmostEqual64 payloads of the reference examples
     (examples/laplace.py:111-152, examples/elasticity.py:89-146): the embedded
@@ -424,6 +534,8 @@ def generate_all():
     quasilinear_case('quasilin2d_spline2_6', 2, 'spline', 2, 6)
     quasilinear_case('quasilin_energy3d_p1_4', 3, 'std', 1, 4, energy=True)
     quasilinear_case('quasilin_energy2d_spline2_6', 2, 'spline', 2, 6, energy=True)  # BASELINE.json configs[4]: ten refinement levels
+    factor_rank3_case('factor_cubic2d_spline2_4')
+    iga_plate_case('iga_plate_p3_l10')
     hierarchical_case('hier_spline2_1d', 1)
     hierarchical_case('hier_spline2_2d', 2)
     example_vectors()

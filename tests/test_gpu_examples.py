@@ -139,6 +139,36 @@ def test_nurbs_plate_with_hole(golden):
     assert numpy.abs(val - 1).max() < 1e-14 and numpy.abs(grad).max() < 1e-12
 
 
+def test_iga_plate_p3_ten_levels_one_workload(golden):
+    '''BASELINE.json configs[4] as ONE workload (tests/golden/iga_plate_p3_l10.npz from the real reference): NURBS plate-with-hole
+    geometry (examples/platewithhole.py:66-86), 10 hierarchical refinement levels towards the hole (refined_by, examples/adaptivity.py:
+    58-70), p = 3 truncated hierarchical splines made rational with projected weights -- 16..24 functions per element, element sizes
+    over a factor 2^9, rational, tabulated geometry, vector-valued -- plane-strain elasticity stiffness matrix, residual, area.'''
+    from nutils_amd import function, topology, basis as _basis
+    g = golden('iga_plate_p3_l10')
+    topo = topology.ElementList(g['elem_origin'], g['elem_size'])
+    smp = topo.sample('gauss', 8)
+    assert numpy.abs(smp.points.coords - g['gauss_coords']).max() < 1e-15
+    off = g['dof_offsets']
+    nb = numpy.diff(off)
+    assert nb.min() == 16 and nb.max() > 16 and int(g['levels']) == 10 and int(g['degree']) == 3
+    hb = topo.plain_basis([g['coeffs'][a:b] for a, b in zip(off, off[1:])], [g['dofs'][a:b] for a, b in zip(off, off[1:])], int(g['ndofs']))
+    size = g['elem_size']  # element coordinates xi in [0,1]^2: param = origin + size * xi
+    nurbs = _basis.RationalBasis(hb, g['weights'], W=g['W'], dW=g['dW_dparam'] * size[:, None, :])
+    geom = function.TabulatedGeometry(g['x'], g['dx_dparam'] * size[:, None, None, :])
+    u = function.field('u', nurbs, shape=[2])
+    v = function.field('v', nurbs, shape=[2])
+    lam, mu = float(g['lam']), float(g['mu'])
+    sigma = lam * function.div(u, geom) * function.eye(2) + 2 * mu * function.symgrad(u, geom)
+    res = smp.integral(function.inner(function.grad(v, geom), sigma) * function.J(geom))
+    values, rowptr, colidx = function.eval(function.as_csr(function.derivative(function.derivative(res, 'v'), 'u')))
+    assert numpy.array_equal(rowptr, g['K_rowptr']) and numpy.array_equal(colidx, g['K_colidx'])
+    assert numpy.abs(values - g['K_values']).max() < 1e-11 * numpy.abs(g['K_values']).max()
+    r = function.eval(function.derivative(res, 'v'), u=g['u'])
+    assert numpy.abs(r - g['res']).max() < 1e-11 * numpy.abs(g['res']).max()
+    assert abs(smp.integrate(function.J(geom)) - float(g['area'])) < 1e-13
+
+
 def test_nonlinear_diffusion_picard_p1hex(monkeypatch):
     '''Quasi-linear diffusion -div((1 + u^2) grad u) = 1 on a perturbed P1 hex mesh, u = 0 on x = 0, by fixed-point iteration
     K(u_k) u_{k+1} = f.  Every step re-assembles the stiffness matrix with the field-dependent coefficient and evaluates the residual
