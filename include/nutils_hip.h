@@ -169,6 +169,10 @@ typedef struct {
                                 of a Newton Jacobian, advection with a computed velocity.  NULL = constant form. */
   int grid_shape[3];         /* NH_MATRIX_FIRST_TOUCH: elements per axis of the structured mesh (element id = last axis fastest) */
   int nodes_per_axis;        /* NH_MATRIX_FIRST_TOUCH: p + 1 local nodes per axis of the C0 ('std') basis, local order first axis slowest */
+  const nh_pattern *pattern; /* optional: the handle the pattern pointers above come from.  With ragged bases (hierarchical / imported:
+                                PlainBasis function.py:2881-2913) and no elist_dev the elements are launched per SIZE CLASS of the pattern
+                                (functions per element <= 8, 16, 24, 32, 48, 64 ...), each class with the LDS footprint of its own largest
+                                element; scale_dev / cq_dev stay indexed by element.  NULL: one launch sized by the largest element. */
 } nh_matrix_args;
 
 #define NH_MATRIX_EXCLUSIVE 1        /* no two elements of this launch touch the same CSR entry (one colour of an element

@@ -43,7 +43,7 @@ class MatrixArgs(ctypes.Structure):
     _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp),
                 ('geom', Geometry), ('test', Basis), ('trial', Basis), ('nct', ctypes.c_int), ('ncr', ctypes.c_int),
                 ('C_host', vp), ('mask_host', vp), ('srowptr_dev', vp), ('emap_dev', vp), ('eoff_dev', vp), ('values_dev', vp), ('scale_dev', vp), ('flags', ctypes.c_int), ('cq_dev', vp),
-                ('grid_shape', ctypes.c_int * 3), ('nodes_per_axis', ctypes.c_int)]
+                ('grid_shape', ctypes.c_int * 3), ('nodes_per_axis', ctypes.c_int), ('pattern', vp)]
 
 
 class VectorArgs(ctypes.Structure):

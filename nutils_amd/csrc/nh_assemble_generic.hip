@@ -678,8 +678,17 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   }
   p.cq = a->cq_dev;
   NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "nh_assemble_matrix: elist with ragged bases is not supported");
-  if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
-  if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
+  const bool bucketed = (a->test.off_dev || a->trial.off_dev) && a->pattern && a->pattern->nbuckets && !a->elist_dev && a->pattern->nelems == a->nelems;
+  if (bucketed) {  // (the size classes of the pattern carry their own maxima: no scan of the offsets per call)
+    p.maxnbt = p.maxnbr = 0;
+    for (int b = 0; b < a->pattern->nbuckets; ++b) {
+      p.maxnbt = std::max(p.maxnbt, a->pattern->bucket_nbt[b]);
+      p.maxnbr = std::max(p.maxnbr, a->pattern->bucket_nbr[b]);
+    }
+  } else {
+    if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
+    if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
+  }
   // MFMA path: uniform shared tables, >= 16 local rows and columns, tile counts we instantiate
   const int Nloc = a->trial.nb * a->ncr;
   if (!(a->flags & 4) && !a->cq_dev && p.same && a->test.nb >= 16 && Nloc >= 16 && !a->test.off_dev && a->ndims >= 2 && a->geom.kind != 0) {
@@ -730,29 +739,47 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
       }
     }
   }
-  const int per_q0 = (p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S * (int)sizeof(double);
-  const int per_qw = per_q0 + p.maxnbr * a->nct * a->ncr * S * (int)sizeof(double);
-  const size_t fixed = sizeof(double) * ((size_t)form.formd + (size_t)a->nq * JW);
-  // the W table trades S*S for S multiply-adds per entry and point; these one-wave workgroups are latency bound, so it is only
-  // used while the workgroup stays small enough for >= 16 of them per CU (measured: 3-D P1 4.8 -> 3.8 ms, 2-D p2 0.96 -> 1.1 ms)
-  p.use_w = fixed + (size_t)a->nq * per_qw <= 10 * 1024;
-  const int per_q = p.use_w ? per_qw : per_q0;
-  p.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / std::max(per_q, 1)));
-  const size_t lds = fixed + (size_t)p.qchunk * per_q;
-  NH_REQUIRE(lds <= 160 * 1024, "element too large for LDS (%zu bytes)", lds);
   hipStream_t s = nh_stream(stream);
-  dim3 grid(grid_for(a->nelems)), block(64);
+  auto launch_generic = [&](MatK q) -> int {  // q.nelems / elist / maxnb* select the elements, LDS sized for them
+    const int per_q0 = (q.same ? q.maxnbt : q.maxnbt + q.maxnbr) * S * (int)sizeof(double);
+    const int per_qw = per_q0 + q.maxnbr * a->nct * a->ncr * S * (int)sizeof(double);
+    const size_t fixed = sizeof(double) * ((size_t)form.formd + (size_t)a->nq * JW);
+    // the W table trades S*S for S multiply-adds per entry and point; these one-wave workgroups are latency bound, so it is only
+    // used while the workgroup stays small enough for >= 16 of them per CU (measured: 3-D P1 4.8 -> 3.8 ms, 2-D p2 0.96 -> 1.1 ms)
+    q.use_w = fixed + (size_t)a->nq * per_qw <= 10 * 1024;
+    const int per_q = q.use_w ? per_qw : per_q0;
+    q.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / std::max(per_q, 1)));
+    const size_t lds = fixed + (size_t)q.qchunk * per_q;
+    NH_REQUIRE(lds <= 160 * 1024, "element too large for LDS (%zu bytes)", lds);
+    dim3 grid(grid_for(q.nelems)), block(64);
 #define LAUNCH(ND)                                                                                                          \
   do {                                                                                                                      \
     NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_matrix_generic<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k_matrix_generic<ND>, grid, block, lds, s, p, form);                                                 \
+    hipLaunchKernelGGL(k_matrix_generic<ND>, grid, block, lds, s, q, form);                                                 \
   } while (0)
-  if (a->ndims == 1) LAUNCH(1);
-  if (a->ndims == 2) LAUNCH(2);
-  if (a->ndims == 3) LAUNCH(3);
+    if (a->ndims == 1) LAUNCH(1);
+    if (a->ndims == 2) LAUNCH(2);
+    if (a->ndims == 3) LAUNCH(3);
 #undef LAUNCH
-  NH_LAUNCH_CHECK();
-  return NH_OK;
+    NH_LAUNCH_CHECK();
+    return NH_OK;
+  };
+  const bool ragged = a->test.off_dev || a->trial.off_dev;
+  if (ragged && a->pattern && a->pattern->nbuckets && !a->elist_dev && a->pattern->nelems == a->nelems) {
+    // one launch per size class (LDS-bucketed): element lists of the pattern, everything indexed by element id
+    for (int b = 0; b < a->pattern->nbuckets; ++b) {
+      if (!a->pattern->bucket_n[b]) continue;
+      MatK q = p;
+      q.nelems = a->pattern->bucket_n[b];
+      q.elist = a->pattern->bucket_elist[b];
+      q.emap_by_elem = 1;
+      q.maxnbt = a->pattern->bucket_nbt[b];
+      q.maxnbr = a->pattern->bucket_nbr[b];
+      if ((rc = launch_generic(q)) != NH_OK) return rc;
+    }
+    return NH_OK;
+  }
+  return launch_generic(p);
 }
 
 int nh_assemble_vector(const nh_vector_args *a, void *stream) {

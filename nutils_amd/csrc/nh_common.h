@@ -59,3 +59,21 @@ struct BasisK {
 
 static inline GeomK to_k(const nh_geometry &g) { return GeomK{g.kind, g.ngb, g.gT_dev, g.gdofs_dev, g.verts_dev, g.origin_dev, g.size_dev, g.jac_dev, g.x_dev, g.bnd_axis}; }
 static inline BasisK to_k(const nh_basis &b) { return BasisK{b.nb, b.T_dev, b.dofs_dev, b.off_dev, b.tab_dev}; }
+
+// sparsity pattern handle (nh_pattern.hip owns it; the element kernels read the size classes of ragged bases from it)
+constexpr int NH_MAX_BUCKETS = 9;
+struct nh_pattern {
+  i64 nelems, nrows, ncols, nnz;
+  int nbt, nbr;
+  i64 *srowptr;     // [nrows+1]
+  int32_t *scol;    // [nnz]
+  int32_t *emap;    // [sum_e nbt_e*nbr_e]
+  i64 *eoff;        // ragged only: [nelems+1] prefix sums of nbt_e*nbr_e
+  i64 emap_len;
+  // ragged only: elements grouped by functions per element
+  int nbuckets;
+  i64 bucket_n[NH_MAX_BUCKETS];
+  int32_t *bucket_elist[NH_MAX_BUCKETS];  // views into bucket_store
+  int bucket_nbt[NH_MAX_BUCKETS], bucket_nbr[NH_MAX_BUCKETS];
+  int32_t *bucket_store;
+};

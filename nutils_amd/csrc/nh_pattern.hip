@@ -11,16 +11,6 @@
 #include "nh_common.h"
 #include <vector>
 
-struct nh_pattern {
-  i64 nelems, nrows, ncols, nnz;
-  int nbt, nbr;
-  i64 *srowptr;     // [nrows+1]
-  int32_t *scol;    // [nnz]
-  int32_t *emap;    // [sum_e nbt_e*nbr_e]
-  i64 *eoff;        // ragged only: [nelems+1] prefix sums of nbt_e*nbr_e
-  i64 emap_len;
-};
-
 __device__ __forceinline__ i64 elem_off(const i64 *off, int nb, i64 e) { return off ? off[e] : e * (i64)nb; }
 __device__ __forceinline__ int elem_nb(const i64 *off, int nb, i64 e) { return off ? (int)(off[e + 1] - off[e]) : nb; }
 
@@ -341,6 +331,32 @@ int nh_pattern_build(const nh_pattern_args *a, nh_pattern **out, void *stream) {
       PB_CHECK(hipStreamSynchronize(s));
       he[0] = 0;
       for (i64 e = 0; e < ne; ++e) he[e + 1] = he[e] + (ht[e + 1] - ht[e]) * (hr[e + 1] - hr[e]);
+      // size classes of the ragged elements (functions per element, test or trial side: <= 8, 16, 24, 32, 48, 64, 96, 128, more): the
+      // element kernels are launched per class with the LDS footprint of that class instead of the largest element of the mesh
+      {
+        static const int caps[NH_MAX_BUCKETS] = {8, 16, 24, 32, 48, 64, 96, 128, 1 << 30};
+        std::vector<std::vector<int32_t>> lists(NH_MAX_BUCKETS);
+        for (i64 e = 0; e < ne; ++e) {
+          const int nb = (int)std::max(ht[e + 1] - ht[e], hr[e + 1] - hr[e]);
+          int b = 0;
+          while (nb > caps[b]) ++b;
+          lists[b].push_back((int32_t)e);
+          p->bucket_nbt[b] = std::max(p->bucket_nbt[b], (int)(ht[e + 1] - ht[e]));
+          p->bucket_nbr[b] = std::max(p->bucket_nbr[b], (int)(hr[e + 1] - hr[e]));
+        }
+        i64 tot = 0;
+        for (int b = 0; b < NH_MAX_BUCKETS; ++b) tot += (i64)lists[b].size();
+        PB_CHECK(hipMalloc((void **)&p->bucket_store, sizeof(int32_t) * (tot + 1)));
+        i64 at = 0;
+        for (int b = 0; b < NH_MAX_BUCKETS; ++b) {
+          p->bucket_n[b] = (i64)lists[b].size();
+          p->bucket_elist[b] = p->bucket_store + at;
+          if (!lists[b].empty()) PB_CHECK(hipMemcpyAsync(p->bucket_store + at, lists[b].data(), sizeof(int32_t) * lists[b].size(), hipMemcpyHostToDevice, s));
+          at += (i64)lists[b].size();
+        }
+        PB_CHECK(hipStreamSynchronize(s));
+        p->nbuckets = NH_MAX_BUCKETS;
+      }
       p->emap_len = he[ne];
       PB_CHECK(hipMalloc((void **)&p->eoff, sizeof(i64) * (ne + 1)));
       PB_CHECK(hipMemcpyAsync(p->eoff, he.data(), sizeof(i64) * (ne + 1), hipMemcpyHostToDevice, s)); PB_CHECK(hipStreamSynchronize(s));
@@ -376,6 +392,7 @@ int nh_pattern_free(nh_pattern *p) {
   hipFree(p->scol);
   hipFree(p->emap);
   hipFree(p->eoff);
+  hipFree(p->bucket_store);
   delete p;
   return NH_OK;
 }

@@ -2,6 +2,7 @@
 Arguments are device tensors (see device.py); nothing here computes.'''
 
 import ctypes
+import os
 import numpy
 
 from . import _lib, device
@@ -122,6 +123,8 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     if first_touch:
         args.grid_shape[:] = list(first_touch[0]) + [1] * (3 - len(first_touch[0]))
         args.nodes_per_axis = int(first_touch[1])
+    if elist is None and emap_offset == 0 and not os.environ.get('NUTILS_AMD_NO_BUCKETS'):
+        args.pattern = pattern._handle  # ragged bases: launches per size class of the pattern
     _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
 
 
