@@ -45,6 +45,9 @@ struct P1Args {
   int accumulate;
   int nbj, nbk;            // column tiles per axis (j, k)
   long long *tdbg;         // phase timers (ablation builds)
+  int wbnd;                // cost weight (x16) of a plane of a J-boundary column in the work split of the skewed kernel
+  int stagphases;          // number of phases of the start delay
+  int stagger;             // skewed kernel: start delay in cycles of every second workgroup (de-phases the store bursts of the CUs)
   int debug;               // ablation switches (NH_P1HEX_DEBUG env): 1 = no LDS reduction, 2 = no HBM stores, 4 = no element math
 };
 
@@ -424,8 +427,14 @@ template <int TJ, int TK, bool MASS, bool COEF>
 __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
   constexpr bool VEC = false;
 #ifdef NH_ABLATION
-  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+  long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+  const long long tstart = tprev;
+  int nslow = 0, nfast = 0;
+#ifdef NH_NOTICKS
+#define NH_TICK(i)
+#else
 #define NH_TICK(i) { const long long tnow = clock64(); tacc[i] += tnow - tprev; tprev = tnow; }
+#endif
 #else
 #define NH_TICK(i)
 #endif
@@ -442,10 +451,18 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
   // Work split in SLOTS, not planes: a run of n planes costs n + 2 slots (the first has nothing to flush, the last nothing to compute), so a
   // workgroup whose share crosses a column boundary gets two planes less -- every column is given NPL + 2 cost units, one in front of
   // its first plane and one behind its last, and the workgroups share the cost axis evenly
-  const i64 CP = NPL + 2, ctot = (i64)p.nbj * p.nbk * CP;
+  // Columns on the J boundary (first and last tile row) flush through the general path (rows of different lengths, 8-byte stores) and take
+  // ~1.3x as long per plane: their cost units are weighted p.wbnd / 16 so that all workgroups finish together
+  const i64 CP = NPL + 2, WI = 16, WB = p.nbj > 1 ? p.wbnd : 16;
+  const i64 rowB = p.nbk * CP * WB, rowI = p.nbk * CP * WI, nmid = max(p.nbj - 2, 0);
+  const i64 ctot = (p.nbj > 1 ? 2 : 1) * rowB + nmid * rowI;
   auto unit_at = [&](i64 c) {
-    const i64 col = c / CP;
-    return col * NPL + min(max(c - col * CP - 1, (i64)0), (i64)NPL);
+    i64 jt, rem, w;
+    if (c < rowB) jt = 0, rem = c, w = WB;
+    else if (c < rowB + nmid * rowI) jt = 1 + (c - rowB) / rowI, rem = (c - rowB) % rowI, w = WI;
+    else jt = p.nbj > 1 ? p.nbj - 1 : 1, rem = c - rowB - nmid * rowI, w = WB;  // (c == ctot: one past the last column)
+    const i64 kt = rem / (CP * w), pos = (rem - kt * CP * w) / w;
+    return (jt * p.nbk + kt) * NPL + min(max(pos - 1, (i64)0), (i64)NPL);
   };
   i64 u = unit_at(ctot * wg / gridDim.x);
   const i64 u1 = unit_at(ctot * (wg + 1) / gridDim.x);
@@ -463,6 +480,11 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
   if (tid == 0) *hcnt = 0;
   unsigned htarget = 0;
   const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;
+  if (p.stagger > 0) {
+    const int phase = (blockIdx.x / 8) % p.stagphases;
+    const long long t0 = clock64(), dl = (long long)p.stagger * phase;
+    while (clock64() - t0 < dl) __builtin_amdgcn_s_sleep(8);
+  }
 
   while (u < u1) {
     // run: planes [A, B) of column col; element layers A-1 .. B-1 in slots A-1 .. B-1, plane P flushed in slot P+1
@@ -519,6 +541,9 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
         if (P >= A && !(DEBUG(p) & 2)) {
           const bool lowJ = J0 == 0, highJ = J0 + OJ >= N1;
           const int cumJ0 = J0 == 0 ? 0 : 3 * J0 - 1;
+#ifdef NH_ABLATION
+          if (!lowJ && !highJ && P > 0 && P < N0 - 1 && K0 > 0 && K0 + OK < N2) ++nfast; else ++nslow;
+#endif
           if (!lowJ && !highJ && P > 0 && P < N0 - 1 && K0 > 0 && K0 + OK < N2) {
             // fully interior plane: every row has 27 entries, a K line is 405 contiguous doubles; two consecutive entries per lane
             // (16-byte stores), one line per pass
@@ -547,6 +572,7 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
             const double aL = acc[(belowL ? slot_of(P - 1) : slot_of(P)) + offL + (lone ? li : 0) * (VK * NS)];
             half_arrive(hcnt);
             arrived = true;
+            NH_TICK(8)
             const i64 stride8 = 8 * (i64)(9 * (int)T2);
             char *l0 = reinterpret_cast<char *>(p.values + ((3 * (i64)P - 1) * T1 * T2 + 3 * (cumJ0 * T2) + 9 * (3 * (i64)K0 - 1)));
             char *lp = l0 + 16 * lt;
@@ -617,6 +643,7 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
           double2 *z = reinterpret_cast<double2 *>(acc + slot_of(s - 2));
           for (int t = lt; t < PS / 2; t += G) z[t] = make_double2(0., 0.);
         }
+        NH_TICK(9)
         if (needv) {
 #pragma unroll
           for (int k = 0; k < VPG; ++k) {
@@ -635,8 +662,13 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
     u += B - A;
   }
 #ifdef NH_ABLATION
+  if (p.tdbg && tid == 0) {
+    p.tdbg[16 + 4 * blockIdx.x] = clock64() - tstart;
+    p.tdbg[16 + 4 * blockIdx.x + 1] = nfast;
+    p.tdbg[16 + 4 * blockIdx.x + 2] = nslow;
+  }
   if (p.tdbg && (tid & 63) == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
+    for (int i = 0; i < 10; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
 #endif
 }
 #undef NH_TICK
@@ -775,6 +807,9 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
 #ifdef NH_ABLATION
   p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
 #endif
+  p.wbnd = getenv("NH_P1HEX_WBND") ? atoi(getenv("NH_P1HEX_WBND")) : 16;
+  p.stagger = getenv("NH_P1HEX_STAGGER") ? atoi(getenv("NH_P1HEX_STAGGER")) : 0;
+  p.stagphases = getenv("NH_P1HEX_STAGPHASES") ? atoi(getenv("NH_P1HEX_STAGPHASES")) : 2;
   constexpr int TJ = 16, TK = 16, L = 2, NTM = L * TJ * TK, NS = VEC ? 1 : 15, VW = VEC ? 4 : 3;
   int dev = 0, cus = 256;
   NH_CHECK_HIP(hipGetDevice(&dev));
@@ -784,7 +819,10 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
   const size_t ldsm = sizeof(double) * ((L + 2) * (((TJ + 1) * (TK + 1) * NS + 1) & ~1) + (L + 1) * (TJ + 1) * (TK + 1) * VW + 2);
   const i64 units = (i64)p.nbj * p.nbk * (p.pl1 - p.pl0);
   NH_REQUIRE(a->max_workgroups >= 0, "nh_p1hex: negative max_workgroups");
-  const unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
+  unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus, a->max_workgroups) : cus);
+#ifdef NH_ABLATION
+  if (getenv("NH_P1HEX_MAXWG")) grid = std::min<unsigned>(grid, (unsigned)atoi(getenv("NH_P1HEX_MAXWG")));
+#endif
   auto kern = k_p1hex_march<TJ, TK, L, VEC, MASS, COEF>;
   if constexpr (!VEC && L == 2) {  // the matrix goes through the skewed kernel (same tile, same LDS, same launch) unless NH_P1HEX_MARCH=1
     const char *env = getenv("NH_P1HEX_MARCH");  // (read per launch: the tests compare the two kernels within one process)
@@ -794,20 +832,22 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
   NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
 #ifdef NH_ABLATION
   static long long *tdbg = nullptr;
-  if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, 16 * sizeof(long long)));
-  NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, 16 * sizeof(long long), nh_stream(stream)));
+  if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, (16 + 4 * 1024) * sizeof(long long)));
+  NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, (16 + 4 * 1024) * sizeof(long long), nh_stream(stream)));
   p.tdbg = getenv("NH_P1HEX_TIMERS") ? tdbg : nullptr;
 #endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTM), ldsm, nh_stream(stream), p);
   NH_LAUNCH_CHECK();
 #ifdef NH_ABLATION
   if (p.tdbg) {
-    long long h[16];
+    static long long h[16 + 4 * 1024];
     NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
+    if (getenv("NH_P1HEX_WGTIMES"))
+      for (unsigned g = 0; g < grid; ++g) fprintf(stderr, "wg %u cycles %lld fast %lld slow %lld\n", g, h[16 + 4 * g], h[16 + 4 * g + 1], h[16 + 4 * g + 2]);
     const double nw = (double)grid * (NTM / 64);
     if (kern != (void (*)(P1Args))k_p1hex_march<TJ, TK, L, VEC, MASS, COEF>)
-      fprintf(stderr, "p1hex_skew cycles per wave: prologue %.0f | math %.0f | - %.0f | math wait %.0f | flush %.0f | half wait %.0f | zero+stage %.0f | mem wait %.0f\n", h[0] / nw, h[3] / nw, h[1] / nw,
-              h[2] / nw, h[6] / nw, h[7] / nw, h[4] / nw, h[5] / nw);
+      fprintf(stderr, "p1hex_skew cycles per wave: prologue %.0f | math %.0f | - %.0f | math wait %.0f | lds reads %.0f | store issue %.0f | half wait %.0f | zero %.0f | stage %.0f | mem wait %.0f\n", h[0] / nw, h[3] / nw, h[1] / nw,
+              h[2] / nw, h[8] / nw, h[6] / nw, h[7] / nw, h[9] / nw, h[4] / nw, h[5] / nw);
     else
     fprintf(stderr, "p1hex_march cycles per wave: stage+next %.0f | B1 %.0f | load+math %.0f | B2 %.0f | stage+flush %.0f | B3 %.0f | zero %.0f\n", h[0] / nw, h[1] / nw,
             h[2] / nw, h[3] / nw, h[4] / nw, h[5] / nw, h[6] / nw);
@@ -876,6 +916,7 @@ static int fill_p1args(const nh_p1hex_args *a, P1Args &p) {
   p.accumulate = 0;
   p.nbj = p.nbk = 0;
   p.debug = 0;
+  p.stagger = 0, p.stagphases = 2, p.wbnd = 16;
   p.tdbg = nullptr;
   return NH_OK;
 }
