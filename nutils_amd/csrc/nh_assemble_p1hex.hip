@@ -46,8 +46,6 @@ struct P1Args {
   int nbj, nbk;            // column tiles per axis (j, k)
   long long *tdbg;         // phase timers (ablation builds)
   int wbnd;                // cost weight (x16) of a plane of a J-boundary column in the work split of the skewed kernel
-  int stagphases;          // number of phases of the start delay
-  int stagger;             // skewed kernel: start delay in cycles of every second workgroup (de-phases the store bursts of the CUs)
   int debug;               // ablation switches (NH_P1HEX_DEBUG env): 1 = no LDS reduction, 2 = no HBM stores, 4 = no element math
 };
 
@@ -480,12 +478,6 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
   if (tid == 0) *hcnt = 0;
   unsigned htarget = 0;
   const i64 T1 = 3 * (i64)N1 - 2, T2 = 3 * (i64)N2 - 2;
-  if (p.stagger > 0) {
-    const int phase = (blockIdx.x / 8) % p.stagphases;
-    const long long t0 = clock64(), dl = (long long)p.stagger * phase;
-    while (clock64() - t0 < dl) __builtin_amdgcn_s_sleep(8);
-  }
-
   while (u < u1) {
     // run: planes [A, B) of column col; element layers A-1 .. B-1 in slots A-1 .. B-1, plane P flushed in slot P+1
     const int col = (int)(u / NPL), A = p.pl0 + (int)(u % NPL), B = (int)min((i64)p.pl1, A + (u1 - u));
@@ -807,9 +799,7 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
 #ifdef NH_ABLATION
   p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
 #endif
-  p.wbnd = getenv("NH_P1HEX_WBND") ? atoi(getenv("NH_P1HEX_WBND")) : 16;
-  p.stagger = getenv("NH_P1HEX_STAGGER") ? atoi(getenv("NH_P1HEX_STAGGER")) : 0;
-  p.stagphases = getenv("NH_P1HEX_STAGPHASES") ? atoi(getenv("NH_P1HEX_STAGPHASES")) : 2;
+  p.wbnd = getenv("NH_P1HEX_WBND") ? atoi(getenv("NH_P1HEX_WBND")) : 20;  // measured optimum at 128^3 (16 = unweighted: +18 %)
   constexpr int TJ = 16, TK = 16, L = 2, NTM = L * TJ * TK, NS = VEC ? 1 : 15, VW = VEC ? 4 : 3;
   int dev = 0, cus = 256;
   NH_CHECK_HIP(hipGetDevice(&dev));
@@ -916,7 +906,7 @@ static int fill_p1args(const nh_p1hex_args *a, P1Args &p) {
   p.accumulate = 0;
   p.nbj = p.nbk = 0;
   p.debug = 0;
-  p.stagger = 0, p.stagphases = 2, p.wbnd = 16;
+  p.wbnd = 16;
   p.tdbg = nullptr;
   return NH_OK;
 }
