@@ -213,6 +213,67 @@ typedef struct {
 
 int nh_assemble_vector(const nh_vector_args *args, void *stream);
 
+/* ---- fused linear-form assembly: all terms of a residual in ONE element loop ----------
+ * The reference evaluates the derivative of a functional as ONE generated element loop per
+ * block (evaluable.py:6773-6786 with the Inflate/Assemble scatter :3341-3495; solver.py:334-386
+ * assembles the residual of every trial block per Newton step): every term of the integrand
+ * is evaluated at the same points inside that loop.  nh_assemble_terms is that loop:
+ *   r_blk[(m,c)] += sum_q w_q |det J_q| sum_a Dt_blk[q,m,a] sum_{terms t of blk} g_t(q) F_t[q,c,a],
+ *   F_t[q,c,a] = f_t[c][a] + sum_{d,b} C_t[c,a,d,b] U_{field(t)}[q,d,b],
+ *   g_t(q)     = scale_t[e][q] * poly_t(values of up to 4 scalar fields at q)      (each factor optional)
+ * for up to 2 output blocks (test spaces with their own out vector: the residual blocks of a
+ * multi-field system), 6 fields and 32 terms sharing one sample (element list, points,
+ * geometry).  Several elements are processed per workgroup (lanes over (element, point), then
+ * over (element, test function)), so bases with few functions per element do not leave lanes idle
+ * the way the one-wave-per-element kernel of nh_assemble_vector does.  Replaces one
+ * nh_assemble_vector launch per term plus the nh_sample_eval / nh_pointwise_poly passes that
+ * produced their scale arrays. */
+typedef struct {
+  nh_basis basis;
+  const double *u_dev;       /* [ndofs][ncomp] coefficients */
+  int ncomp;
+} nh_field;
+
+typedef struct {
+  nh_basis test;
+  int nct;                   /* components of the test space */
+  double *out_dev;           /* [nrows][nct], accumulated */
+} nh_block;
+
+typedef struct {
+  int nvars, nterms;         /* value = sum_t coeffs[t] prod_v x_v^powers[t][v], x_v = value of component comp[v] of fields[field[v]] at the point */
+  int field[4], comp[4];
+  const double *coeffs_host; /* [nterms] */
+  const int *powers_host;    /* [nterms][nvars] */
+} nh_point_poly;
+
+typedef struct {
+  int block;                 /* output block */
+  int field;                 /* field the form is applied to, -1: source term (f only) */
+  int poly;                  /* pointwise polynomial factor, -1: none */
+  const double *C_host;      /* [nct][S][ncr][S] or NULL */
+  const double *f_host;      /* [nct][S] or NULL */
+  const double *scale_dev;   /* [nelems][nq] (list position with elist_dev) or NULL */
+} nh_term;
+
+typedef struct {
+  int64_t nelems;
+  const int32_t *elist_dev;
+  int ndims, nq;
+  const double *weights_dev;
+  nh_geometry geom;
+  int nfields;
+  const nh_field *fields;
+  int nblocks;
+  const nh_block *blocks;
+  int nterms;
+  const nh_term *terms;
+  int npolys;
+  const nh_point_poly *polys;
+} nh_terms_args;
+
+int nh_assemble_terms(const nh_terms_args *args, void *stream);
+
 /* Sample.eval / bind (sample.py:192-232, _ConcatenatePoints.lower :966-975;
  * LoopConcatenate evaluable.py:5383-5508): values at all quadrature points, element
  * major.  Any output may be NULL.  x[e][q][ndims], detj[e][q],

@@ -52,6 +52,28 @@ class VectorArgs(ctypes.Structure):
                 ('C_host', vp), ('f_host', vp), ('u_dev', vp), ('out_dev', vp), ('f0', ctypes.c_double), ('out_scalar_dev', vp), ('scale_dev', vp)]
 
 
+class Field(ctypes.Structure):
+    _fields_ = [('basis', Basis), ('u_dev', vp), ('ncomp', ctypes.c_int)]
+
+
+class Block(ctypes.Structure):
+    _fields_ = [('test', Basis), ('nct', ctypes.c_int), ('out_dev', vp)]
+
+
+class PointPoly(ctypes.Structure):
+    _fields_ = [('nvars', ctypes.c_int), ('nterms', ctypes.c_int), ('field', ctypes.c_int * 4), ('comp', ctypes.c_int * 4), ('coeffs_host', vp), ('powers_host', vp)]
+
+
+class Term(ctypes.Structure):
+    _fields_ = [('block', ctypes.c_int), ('field', ctypes.c_int), ('poly', ctypes.c_int), ('C_host', vp), ('f_host', vp), ('scale_dev', vp)]
+
+
+class TermsArgs(ctypes.Structure):
+    _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp), ('geom', Geometry),
+                ('nfields', ctypes.c_int), ('fields', ctypes.POINTER(Field)), ('nblocks', ctypes.c_int), ('blocks', ctypes.POINTER(Block)),
+                ('nterms', ctypes.c_int), ('terms', ctypes.POINTER(Term)), ('npolys', ctypes.c_int), ('polys', ctypes.POINTER(PointPoly))]
+
+
 class EvalArgs(ctypes.Structure):
     _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('geom', Geometry), ('trial', Basis),
                 ('ncr', ctypes.c_int), ('points_dev', vp), ('u_dev', vp), ('x_dev', vp), ('detj_dev', vp), ('U_dev', vp)]
@@ -97,6 +119,7 @@ SIGNATURES = {
     'nh_pattern_expand': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
     'nh_assemble_matrix': (ctypes.c_int, [ctypes.POINTER(MatrixArgs), vp]),
     'nh_assemble_vector': (ctypes.c_int, [ctypes.POINTER(VectorArgs), vp]),
+    'nh_assemble_terms': (ctypes.c_int, [ctypes.POINTER(TermsArgs), vp]),
     'nh_sample_eval': (ctypes.c_int, [ctypes.POINTER(EvalArgs), vp]),
     'nh_monomial_csr': (ctypes.c_int, [c_i64, vp, vp, vp, vp, ctypes.c_double, vp, vp]),
     'nh_monomial': (ctypes.c_int, [c_i64, vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, ctypes.c_double, vp, vp]),

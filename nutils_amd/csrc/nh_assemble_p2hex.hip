@@ -78,11 +78,14 @@ struct P2K {
 #endif
 };
 
-#ifdef NH_ABLATION
+#if defined(NH_ABLATION) && !defined(NH_NOTICKS)
 #define TICK(i) do { const long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
-#define DBG(p, bit) ((p).debug & (bit))
 #else
 #define TICK(i) do {} while (0)
+#endif
+#ifdef NH_ABLATION
+#define DBG(p, bit) ((p).debug & (bit))
+#else
 #define DBG(p, bit) 0
 #endif
 
@@ -775,7 +778,15 @@ __global__ __launch_bounds__(NTP4) void k_p2hex_pipe(P2K p) {
   // about one issue slot per MFMA, and the element-ahead work of these roles falls behind the matrix pipe
   if (p.prio) __builtin_amdgcn_s_setprio(3);
   if (wave < 4 + NTW) table_role<NC, S0>(p, lds, lane, tid - 256);
-  else geometry_role<NC>(p, lds, lane);
+  else {
+#ifdef NH_ABLATION
+    const long long t0 = __builtin_readcyclecounter();
+#endif
+    geometry_role<NC>(p, lds, lane);
+#ifdef NH_ABLATION
+    if (p.tdbg && lane == 0) p.tdbg[16 + blockIdx.x] = __builtin_readcyclecounter() - t0;
+#endif
+  }
 }
 
 // closed-form CSR index arrays: one wave per node, rows (node, c) of length len * NC, columns (colnode, d) lexicographic
@@ -918,8 +929,8 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   hipStream_t s = nh_stream(stream);
 #ifdef NH_ABLATION
   static long long *tdbg = nullptr;
-  if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, 8 * sizeof(long long)));
-  NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, 8 * sizeof(long long), s));
+  if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, (16 + 1024) * sizeof(long long)));
+  NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, (16 + 1024) * sizeof(long long), s));
   p.tdbg = getenv("NH_P2HEX_TIMERS") ? tdbg : nullptr;
   p.debug = getenv("NH_P2HEX_DEBUG") ? atoi(getenv("NH_P2HEX_DEBUG")) : 0;
 #endif
@@ -950,9 +961,11 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   NH_LAUNCH_CHECK();
 #ifdef NH_ABLATION
   if (p.tdbg && pipe) {
-    long long h[8];
+    static long long h[16 + 1024];
     NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
     const double g = grid;
+    if (getenv("NH_P2HEX_WGTIMES"))
+      for (unsigned w = 0; w < grid && w < 1024; ++w) fprintf(stderr, "wg %u cycles %lld\n", w, h[16 + w]);
     fprintf(stderr, "p2hex_pipe cycles per wave: MFMA waves: tasks %.0f + barrier %.0f | table waves: D %.0f, flush %.0f + barrier %.0f | geometry wave: geometry %.0f + barrier %.0f | loop head %.0f\n",
               h[0] / (g * 4), h[1] / (g * 4), h[2] / (g * NTW), h[4] / (g * NTW), h[5] / (g * NTW), h[3] / g, h[6] / g, h[7] / (g * 8));
   }

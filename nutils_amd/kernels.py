@@ -141,6 +141,45 @@ def assemble_vector(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     _lib.call('nh_assemble_vector', ctypes.byref(args), device.stream())
 
 
+def assemble_terms(*, nelems, ndims, nq, weights, geom, fields, blocks, terms, polys=(), elist=None):
+    '''All linear-form terms of a residual on one sample in ONE element loop (nh_assemble_terms).
+    fields: [(basis struct, u, ncomp)], blocks: [(test struct, nct, out)], polys: [(vars [(field, comp)], coeffs, powers [nterms][nvars])],
+    terms: [dict(block, field=-1, poly=-1, C=None, f=None, scale=None)].'''
+    S = 1 + ndims
+    keep = []
+    F = (_lib.Field * max(len(fields), 1))()
+    for i, (b, u, nc) in enumerate(fields):
+        F[i] = _lib.Field(b, device.ptr(u), int(nc))
+    B = (_lib.Block * len(blocks))()
+    for i, (b, nct, out) in enumerate(blocks):
+        B[i] = _lib.Block(b, int(nct), device.ptr(out))
+    P = (_lib.PointPoly * max(len(polys), 1))()
+    for i, (vars_, coeffs, powers) in enumerate(polys):
+        cf = numpy.ascontiguousarray(coeffs, dtype=float)
+        pw = numpy.ascontiguousarray(powers, dtype=numpy.int32).reshape(len(cf), len(vars_))
+        keep += [cf, pw]
+        fld = (ctypes.c_int * 4)(*([v[0] for v in vars_] + [0] * (4 - len(vars_))))
+        cmp_ = (ctypes.c_int * 4)(*([v[1] for v in vars_] + [0] * (4 - len(vars_))))
+        P[i] = _lib.PointPoly(len(vars_), len(cf), fld, cmp_, device.host_ptr(cf), pw.ctypes.data if pw.size else None)
+    T = (_lib.Term * len(terms))()
+    for i, t in enumerate(terms):
+        blk, fld = int(t['block']), int(t.get('field', -1))
+        nct = blocks[blk][1]
+        C, f = t.get('C'), t.get('f')
+        if C is not None:
+            C = numpy.ascontiguousarray(C, dtype=float)
+            if fld < 0 or C.shape != (nct, S, fields[fld][2], S):
+                raise ValueError(f'term {i}: coefficient tensor has shape {C.shape}')
+        if f is not None:
+            f = numpy.ascontiguousarray(f, dtype=float)
+            if f.shape != (nct, S):
+                raise ValueError(f'term {i}: source tensor has shape {f.shape}')
+        keep += [C, f]
+        T[i] = _lib.Term(blk, fld, int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(f), device.ptr(t.get('scale')))
+    args = _lib.TermsArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, len(fields), F, len(blocks), B, len(terms), T, len(polys), P)
+    _lib.call('nh_assemble_terms', ctypes.byref(args), device.stream())
+
+
 def sample_eval(*, nelems, ndims, nq, geom, trial=None, ncr=1, points=None, u=None, x=None, detj=None, U=None, elist=None):
     if trial is None:
         trial = _lib.Basis(0, None, None, None, None)

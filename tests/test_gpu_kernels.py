@@ -479,3 +479,100 @@ def test_p1hex_skewed_vs_marching_kernel(monkeypatch):
         written = ~numpy.isnan(got[1])
         assert numpy.array_equal(~numpy.isnan(got[0]), written) and written.any()
         assert numpy.abs(got[0][written] - got[1][written]).max() <= 1e-14 * numpy.abs(got[1][written]).max()
+
+
+# ---- fused linear forms: several elements per workgroup, all terms in one loop (nh_assemble_terms) ---------------------------------
+
+@pytest.mark.parametrize('name', SCALAR)
+def test_terms_scalar_golden(golden, name):
+    '''Laplace residual + mass residual + load vector of the reference in ONE launch = the sum of the three golden vectors.'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    u = device.to_dev(g['u'], 'float64')
+    out = device.zeros(c.ndofs, 'float64')
+    f = numpy.zeros((1, 1 + c.nd))
+    f[0, 0] = 1
+    kernels.assemble_terms(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, fields=[(c.basis, u, 1)], blocks=[(c.basis, 1, out)],
+                           terms=[dict(block=0, field=0, C=oa.laplace_coefficient(c.nd)), dict(block=0, field=0, C=2.5 * oa.mass_coefficient(c.nd)), dict(block=0, f=f)])
+    ref = g['res_laplace'] + 2.5 * g['res_mass'] + g['load_one']
+    close(device.to_host(out), ref, numpy.abs(g['res_laplace']).max() + numpy.abs(ref).max())
+
+
+@pytest.mark.parametrize('name', ELAST)
+def test_terms_elasticity_golden(golden, name):
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    C = oa.elasticity_coefficient(c.nd, float(g['lam']), float(g['mu']))
+    u = device.to_dev(g['u'], 'float64')
+    out = device.zeros(c.ndofs * c.nd, 'float64')
+    kernels.assemble_terms(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, fields=[(c.basis, u, c.nd)], blocks=[(c.basis, c.nd, out)],
+                           terms=[dict(block=0, field=0, C=C)])
+    close(device.to_host(out).reshape(c.ndofs, c.nd), g['res'])
+
+
+@pytest.mark.parametrize('name', ['lap2d_spline2_5x4_iso', 'lap3d_p1_3_iso'])
+def test_terms_two_blocks_polynomial_factor(golden, name):
+    '''Two output blocks, three fields, a pointwise polynomial of two of them and a scale array: equal to one nh_assemble_vector per term
+    with the factors evaluated by nh_sample_eval + nh_pointwise_poly (the path this entry replaces).'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    rng = numpy.random.default_rng(5)
+    nd, S, n = c.nd, 1 + c.nd, c.nelems * c.nq
+    us = [device.to_dev(rng.normal(size=c.ndofs), 'float64') for _ in range(3)]
+    sc = device.to_dev(rng.uniform(.5, 1.5, n), 'float64')
+    f = rng.normal(size=(1, S))
+    Cs = [rng.normal(size=(1, S, 1, S)) for _ in range(3)]
+    coeffs, powers = [.25, -1., .5, 2.], [[2, 0], [0, 1], [1, 3], [0, 0]]
+    out = [device.zeros(c.ndofs, 'float64') for _ in range(2)]
+    kernels.assemble_terms(nelems=c.nelems, ndims=nd, nq=c.nq, weights=c.weights, geom=c.geom, fields=[(c.basis, u, 1) for u in us],
+                           blocks=[(c.basis, 1, o) for o in out], polys=[([(0, 0), (2, 0)], coeffs, powers)],
+                           terms=[dict(block=0, field=0, C=Cs[0]), dict(block=0, field=1, C=Cs[1], poly=0), dict(block=1, field=2, C=Cs[2], scale=sc),
+                                  dict(block=1, f=f, poly=0, scale=sc), dict(block=0, f=2 * f)])
+    # the same through the per-term path
+    U = []
+    for u in us:
+        Ud = device.empty(n * S, 'float64')
+        kernels.sample_eval(nelems=c.nelems, ndims=nd, nq=c.nq, geom=c.geom, trial=c.basis, ncr=1, points=c.points, u=u, U=Ud)
+        U.append(Ud)
+    pv = kernels.pointwise_poly([U[0], U[2]], [S, S], coeffs, powers, n)
+    ref = [device.zeros(c.ndofs, 'float64') for _ in range(2)]
+    kw = dict(nelems=c.nelems, ndims=nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=1, ncr=1)
+    kernels.assemble_vector(C=Cs[0], u=us[0], out=ref[0], **kw)
+    kernels.assemble_vector(C=Cs[1], u=us[1], out=ref[0], scale=pv, **kw)
+    kernels.assemble_vector(C=Cs[2], u=us[2], out=ref[1], scale=sc, **kw)
+    kernels.assemble_vector(f=f, out=ref[1], scale=pv * sc, **kw)
+    kernels.assemble_vector(f=2 * f, out=ref[0], **kw)
+    for o, r in zip(out, ref):
+        close(device.to_host(o), device.to_host(r))
+
+
+def test_terms_ragged_and_errors(golden):
+    '''Ragged bases (functions per element from the offsets) and the argument checks of nh_assemble_terms.'''
+    from nutils_amd import device, kernels, _lib
+    from oracle import assemble as oa
+    g = golden('hier_spline2_2d')
+    pts = device.to_dev(g['gauss_coords'], 'float64')
+    w = device.to_dev(g['gauss_weights'], 'float64')
+    nq = len(g['gauss_weights'])
+    geom = kernels.geometry_box(device.to_dev(g['elem_origin'], 'float64'), device.to_dev(g['elem_size'], 'float64'))
+    off_h = g['t_dof_offsets']
+    ne, ndofs = len(off_h) - 1, int(g['t_ndofs'])
+    dofs = device.to_dev(g['t_dofs'], 'int32')
+    T = kernels.tabulate(device.to_dev(g['t_coeffs'], 'float64'), len(g['t_dofs']), g['t_coeffs'].shape[1], pts, nq, 2)
+    b = kernels.basis(T, dofs, nb=0, off=device.to_dev(off_h, 'int64'))
+    u = device.to_dev(numpy.random.default_rng(1).normal(size=ndofs), 'float64')
+    out, ref = device.zeros(ndofs, 'float64'), device.zeros(ndofs, 'float64')
+    C = oa.laplace_coefficient(2) + oa.mass_coefficient(2)
+    kernels.assemble_terms(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, fields=[(b, u, 1)], blocks=[(b, 1, out)], terms=[dict(block=0, field=0, C=C)])
+    kernels.assemble_vector(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, test=b, trial=b, nct=1, ncr=1, C=C, u=u, out=ref)
+    close(device.to_host(out), device.to_host(ref))
+    with pytest.raises(_lib.NutilsHipError, match='missing block'):
+        kernels.assemble_terms(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, fields=[(b, u, 1)], blocks=[(b, 1, out)], terms=[dict(block=0, field=1, f=numpy.ones((1, 3)))])
+    with pytest.raises(_lib.NutilsHipError, match='neither a form nor a source'):
+        kernels.assemble_terms(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, fields=[(b, u, 1)], blocks=[(b, 1, out)], terms=[dict(block=0, field=0)])
