@@ -274,6 +274,51 @@ typedef struct {
 
 int nh_assemble_terms(const nh_terms_args *args, void *stream);
 
+/* ---- fused bilinear-form assembly: all matrix terms of a block in ONE element loop ----------
+ * Counterpart of nh_assemble_terms for the Jacobian blocks of a Newton step (solver.py:334-386;
+ * derivative of the residual, evaluable.py:5693-5751): all terms share test / trial basis and the
+ * pattern, their coefficient tensors are summed PER POINT inside the kernel,
+ *   A[(m,c),(n,d)] += sum_q w_q |det J_q| sum_{a,b} Dt[q,m,a] Cq[q][c,a,d,b] Dr[q,n,b],  Cq = sum_t g_t(q) C_t(q),
+ * with g_t as in nh_assemble_terms (scale array, pointwise polynomial of field values) and C_t(q)
+ *   kind 0: the constant tensor C_host,
+ *   kind 1: scalar fields, Cq[a][0] += sum_b B[a][b] U_field[q][b]         (product-rule term on the value slot of the trial function)
+ *   kind 2: scalar fields, Cq[a][b] += L[a] sum_x B[x][b] U_field[q][x]    (product-rule term on the test side)
+ * (kinds 1, 2: the per-point tensors that nh_matrix_args.cq_dev takes from the caller, here evaluated in the kernel: the terms
+ * kappa'(u) phi_n grad u . grad phi_m of a quasi-linear Jacobian.)  Several elements per workgroup: lanes over (element, point) for the
+ * pointwise part, over (element, m, n) for the contraction.  values are ACCUMULATED with the layout of nh_assemble_matrix. */
+typedef struct {
+  int kind;                  /* 0, 1, 2 (above) */
+  int field;                 /* kinds 1, 2: the field U; else -1 */
+  int poly;                  /* pointwise polynomial factor, -1: none */
+  const double *C_host;      /* [nct][S][ncr][S]: C (kind 0) or B (kinds 1, 2) */
+  const double *L_host;      /* kind 2: [nct][S] */
+  const double *scale_dev;   /* [nelems][nq] or NULL */
+} nh_matrix_term;
+
+typedef struct {
+  int64_t nelems;
+  const int32_t *elist_dev;
+  int ndims, nq;
+  const double *weights_dev;
+  nh_geometry geom;
+  nh_basis test, trial;
+  int nct, ncr;
+  const unsigned char *mask_host; /* [nct][ncr] block mask used for the pattern, NULL = all */
+  const int64_t *srowptr_dev;
+  const int32_t *emap_dev;
+  const int64_t *eoff_dev;
+  double *values_dev;
+  int flags;                 /* NH_MATRIX_EMAP_BY_ELEMENT */
+  int nfields;
+  const nh_field *fields;
+  int nterms;
+  const nh_matrix_term *terms;
+  int npolys;
+  const nh_point_poly *polys;
+} nh_matrix_terms_args;
+
+int nh_assemble_matrix_terms(const nh_matrix_terms_args *args, void *stream);
+
 /* Sample.eval / bind (sample.py:192-232, _ConcatenatePoints.lower :966-975;
  * LoopConcatenate evaluable.py:5383-5508): values at all quadrature points, element
  * major.  Any output may be NULL.  x[e][q][ndims], detj[e][q],

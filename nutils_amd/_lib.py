@@ -74,6 +74,17 @@ class TermsArgs(ctypes.Structure):
                 ('nterms', ctypes.c_int), ('terms', ctypes.POINTER(Term)), ('npolys', ctypes.c_int), ('polys', ctypes.POINTER(PointPoly))]
 
 
+class MatrixTerm(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int), ('field', ctypes.c_int), ('poly', ctypes.c_int), ('C_host', vp), ('L_host', vp), ('scale_dev', vp)]
+
+
+class MatrixTermsArgs(ctypes.Structure):
+    _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp), ('geom', Geometry),
+                ('test', Basis), ('trial', Basis), ('nct', ctypes.c_int), ('ncr', ctypes.c_int), ('mask_host', vp), ('srowptr_dev', vp), ('emap_dev', vp),
+                ('eoff_dev', vp), ('values_dev', vp), ('flags', ctypes.c_int), ('nfields', ctypes.c_int), ('fields', ctypes.POINTER(Field)),
+                ('nterms', ctypes.c_int), ('terms', ctypes.POINTER(MatrixTerm)), ('npolys', ctypes.c_int), ('polys', ctypes.POINTER(PointPoly))]
+
+
 class EvalArgs(ctypes.Structure):
     _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('geom', Geometry), ('trial', Basis),
                 ('ncr', ctypes.c_int), ('points_dev', vp), ('u_dev', vp), ('x_dev', vp), ('detj_dev', vp), ('U_dev', vp)]
@@ -120,6 +131,7 @@ SIGNATURES = {
     'nh_assemble_matrix': (ctypes.c_int, [ctypes.POINTER(MatrixArgs), vp]),
     'nh_assemble_vector': (ctypes.c_int, [ctypes.POINTER(VectorArgs), vp]),
     'nh_assemble_terms': (ctypes.c_int, [ctypes.POINTER(TermsArgs), vp]),
+    'nh_assemble_matrix_terms': (ctypes.c_int, [ctypes.POINTER(MatrixTermsArgs), vp]),
     'nh_sample_eval': (ctypes.c_int, [ctypes.POINTER(EvalArgs), vp]),
     'nh_monomial_csr': (ctypes.c_int, [c_i64, vp, vp, vp, vp, ctypes.c_double, vp, vp]),
     'nh_monomial': (ctypes.c_int, [c_i64, vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, ctypes.c_double, vp, vp]),

@@ -8,6 +8,7 @@
 // (evaluable.py:6773-6786, Inflate/Assemble scatter :3341-3495) for a list of terms, instead of one launch per term.
 #include "nh_common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -21,6 +22,7 @@ constexpr int MAXCT = 4;   // sum of block components
 constexpr int MAXT = 32;   // terms
 constexpr int MAXP = 4;    // pointwise polynomials
 constexpr int NTB = 256;   // threads per workgroup
+constexpr int NBLK = 3;     // trial functions per lane in the contraction of the matrix kernel
 constexpr int TABARG = 256;  // doubles of the term table that fit the kernel arguments
 
 __device__ __forceinline__ i64 boff(const BasisK &b, i64 e) { return b.off ? b.off[e] : e * (i64)b.nb; }
@@ -31,6 +33,8 @@ struct FieldK {
   BasisK b;
   const double *u;
   int ncomp, c0;  // c0: first slot of this field in the per-point value table
+  int maxnb, ue0; // coefficients of an element staged in LDS: [maxnb][ncomp] at ue0 of the element's record
+  int tsame;      // matrix kernel: the tables are the test tables (staged in LDS)
 };
 struct BlockK {
   BasisK test;
@@ -55,7 +59,88 @@ struct TermsK {
   int tlen;
   double tabarg[TABARG];
   int rowsper;  // sum over blocks of maxnb * nct: output lanes per element
+  int uesz;     // staged field coefficients per element
 };
+
+// coefficients of all fields on the elements of a batch -> LDS, ue[el][uesz]: the gathers u[dofs[...]] are two dependent global loads; here
+// every lane has its own in flight at once, instead of one pair per basis function in the loop over the functions of a point
+__device__ __forceinline__ void stage_coeffs(const FieldK *fields, int nfields, int uesz, double *ue, int eb, i64 b0, i64 nelems, const int32_t *elist,
+                                              int tid) {
+  for (int i = tid; i < eb * uesz; i += NTB) {
+    const int el = i / uesz;
+    int r = i - el * uesz;
+    if (b0 + el >= nelems) continue;
+    const i64 e = elist ? elist[b0 + el] : b0 + el;
+    int f = 0;
+    while (f + 1 < nfields && r >= fields[f + 1].ue0) ++f;
+    const FieldK &F = fields[f];
+    r -= F.ue0;
+    const int n = r / F.ncomp, d = r - n * F.ncomp;
+    if (n < bnb(F.b, e)) ue[i] = F.u[(i64)F.b.dofs[boff(F.b, e) + n] * F.ncomp + d];
+  }
+}
+
+// field values and physical gradients of all fields at point q of element e -> u[fct][S]; ue: staged coefficients of the element,
+// TT: staged test tables of the element (fields with tsame) or NULL
+template <int ND>
+__device__ __forceinline__ void eval_fields(const FieldK *fields, int nfields, i64 e, int q, int nq, const double (&Ji)[ND][ND], const double *ue,
+                                             const double *TT, double *u) {
+  constexpr int S = 1 + ND;
+  for (int f = 0; f < nfields; ++f) {
+    const FieldK &F = fields[f];
+    const int nb = bnb(F.b, e);
+    const double *T = (TT && F.tsame) ? TT + (size_t)q * S : F.b.T + (bfn(F.b, e) * nq + q) * S;
+    const double *c = ue + F.ue0;
+    for (int d = 0; d < F.ncomp; ++d) {
+      double r[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) r[s] = 0;
+#pragma unroll 4
+      for (int n = 0; n < nb; ++n) {
+        const double un = c[n * F.ncomp + d];
+        const double *Tn = T + (size_t)n * nq * S;
+#pragma unroll
+        for (int s = 0; s < S; ++s) r[s] += Tn[s] * un;
+      }
+      double *o = u + (F.c0 + d) * S;
+      o[0] = r[0];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) s += r[1 + j] * Ji[j][i];
+        o[1 + i] = s;
+      }
+    }
+  }
+}
+
+// pointwise polynomials of field values: table entry [nvars, nterms, slot[4], (coeff, power[4]) x nterms]
+template <int S>
+__device__ __forceinline__ void eval_polys(const double *tab, const int *poff, int npolys, const double *u, double (&pv)[MAXP]) {
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    pv[k] = 1.;
+    if (k < npolys) {
+      const double *P = tab + poff[k];
+      const int nv = (int)P[0], nt = (int)P[1];
+      double x[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) x[v] = v < nv ? u[(int)P[2 + v] * S] : 1.;
+      double s = 0;
+      for (int t2 = 0; t2 < nt; ++t2) {
+        const double *M = P + 6 + 5 * t2;
+        double m = M[0];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          for (int k2 = (int)M[1 + v]; k2 > 0; --k2) m *= x[v];
+        s += m;
+      }
+      pv[k] = s;
+    }
+  }
+}
+__device__ __forceinline__ double pick(const double (&pv)[MAXP], int k) { return k == 0 ? pv[0] : k == 1 ? pv[1] : k == 2 ? pv[2] : pv[3]; }
 
 template <int ND>
 __global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
@@ -64,11 +149,14 @@ __global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
   double *tab = lds;                                // term table
   double *G = lds + p.tlen;                         // [eb * nq][ct][S]: integrand, then its reference form times w |J|
   double *U = G + (size_t)p.eb * p.nq * p.ct * S;   // [NTB][fct][S]: field values of this thread's point
+  double *UE = U + (size_t)NTB * p.fct * S;         // [eb][uesz]: field coefficients of the elements of the batch
   const int tid = threadIdx.x;
   for (int i = tid; i < p.tlen; i += NTB) tab[i] = p.table ? p.table[i] : p.tabarg[i];
   const int npts = p.eb * p.nq;
   for (i64 b0 = (i64)blockIdx.x * p.eb; b0 < p.nelems; b0 += (i64)gridDim.x * p.eb) {
     __syncthreads();  // table staged; G of the previous batch consumed
+    stage_coeffs(p.fields, p.nfields, p.uesz, UE, p.eb, b0, p.nelems, p.elist, tid);
+    __syncthreads();
     for (int t = tid; t < npts; t += NTB) {
       const int el = t / p.nq, q = t - el * p.nq;
       const i64 ie = b0 + el;
@@ -78,57 +166,10 @@ __global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
       double Ji[ND][ND], det;
       geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
       const double wdet = p.weights[q] * fabs(det);
-      // field values and physical gradients at the point
       double *u = U + (size_t)tid * p.fct * S;
-      for (int f = 0; f < p.nfields; ++f) {
-        const FieldK &F = p.fields[f];
-        const int nb = bnb(F.b, e);
-        const i64 d0 = boff(F.b, e);
-        const double *T = F.b.T + (bfn(F.b, e) * p.nq + q) * S;
-        for (int d = 0; d < F.ncomp; ++d) {
-          double r[S];
-#pragma unroll
-          for (int s = 0; s < S; ++s) r[s] = 0;
-          for (int n = 0; n < nb; ++n) {
-            const double un = F.u[(i64)F.b.dofs[d0 + n] * F.ncomp + d];
-            const double *Tn = T + (size_t)n * p.nq * S;
-#pragma unroll
-            for (int s = 0; s < S; ++s) r[s] += Tn[s] * un;
-          }
-          double *o = u + (F.c0 + d) * S;
-          o[0] = r[0];
-#pragma unroll
-          for (int i = 0; i < ND; ++i) {
-            double s = 0;
-#pragma unroll
-            for (int j = 0; j < ND; ++j) s += r[1 + j] * Ji[j][i];
-            o[1 + i] = s;
-          }
-        }
-      }
-      // pointwise polynomial factors
+      eval_fields<ND>(p.fields, p.nfields, e, q, p.nq, Ji, UE + (size_t)el * p.uesz, nullptr, u);
       double pv[MAXP];
-#pragma unroll
-      for (int k = 0; k < MAXP; ++k) {
-        pv[k] = 1.;
-        if (k < p.npolys) {
-          const double *P = tab + p.poff[k];
-          const int nv = (int)P[0], nt = (int)P[1];
-          double x[4];
-#pragma unroll
-          for (int v = 0; v < 4; ++v) x[v] = v < nv ? u[(int)P[2 + v] * S] : 1.;
-          double s = 0;
-          for (int t2 = 0; t2 < nt; ++t2) {
-            const double *M = P + 6 + 5 * t2;
-            double m = M[0];
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-              for (int k2 = (int)M[1 + v]; k2 > 0; --k2) m *= x[v];
-            s += m;
-          }
-          pv[k] = s;
-        }
-      }
+      eval_polys<S>(tab, p.poff, p.npolys, u, pv);
       // integrand of every block: sum of the terms
       for (int i = 0; i < p.ct * S; ++i) g[i] = 0.;
       for (int t2 = 0; t2 < p.nterms; ++t2) {
@@ -136,7 +177,7 @@ __global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
         const int blk = (int)H[0], fld = (int)H[1], pol = (int)H[2], hasC = (int)H[3], hasf = (int)H[4];
         const BlockK &B = p.blocks[blk];
         double coef = p.scale[t2] ? p.scale[t2][ie * p.nq + q] : 1.;
-        if (pol >= 0) coef *= pol == 0 ? pv[0] : pol == 1 ? pv[1] : pol == 2 ? pv[2] : pv[3];
+        if (pol >= 0) coef *= pick(pv, pol);
         const double *fv = H + 5, *C = fv + B.nct * S;
         const int ncr = fld >= 0 ? p.fields[fld].ncomp : 0;
         const double *uf = fld >= 0 ? u + p.fields[fld].c0 * S : u;
@@ -191,6 +232,303 @@ __global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
   }
 }
 
+// ---- fused bilinear forms ---------------------------------------------------------------------------------------------------------
+// term table: per term [kind, field, poly, B[nct][S][ncr][S], L[nct][S]]
+#ifdef NH_ABLATION
+#define MDBG(p, bit) ((p).debug & (bit))
+#define MTICK(i) do { if (tid == 0) { const long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define MDBG(p, bit) 0
+#define MTICK(i) do {} while (0)
+#endif
+struct MTermsK {
+  long long *tdbg;  // ablation builds: phase timers
+  int debug;  // ablation builds: 1 = no atomics, 2 = no contraction
+  i64 nelems;
+  const int32_t *elist;
+  int nq, eb;
+  const double *weights;
+  GeomK geom;
+  int nfields, nterms, npolys, fct, uesz;
+  FieldK fields[MAXF];
+  BasisK test, trial;
+  int nct, ncr, maxnbt, maxnbr, same;
+  const i64 *srowptr;
+  const int32_t *emap;
+  const i64 *eoff;
+  double *values;
+  int emap_by_elem;
+  unsigned char mask[3][3];
+  signed char dpos[3][3];
+  int cnt[3], cum[3], tot;
+  const double *scale[MAXT];
+  int toff[MAXT], poff[MAXP];
+  const double *table;
+  int tlen;
+  double tabarg[TABARG];
+};
+
+template <int ND>
+__global__ __launch_bounds__(NTB) void k_mterms(MTermsK p) {
+  constexpr int S = 1 + ND;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int CS = p.nct * S * p.ncr * S;
+  double *tab = lds;
+  double *G = lds + p.tlen;                        // [eb * nq][nct][S][ncr][S]: coefficient tensor in reference form times w |J|
+  double *U = G + (size_t)p.eb * p.nq * CS;        // [NTB][fct][S]
+  i64 *meta = reinterpret_cast<i64 *>(U + (size_t)NTB * p.fct * S);  // [eb][8]: element, first test / trial function, first test dof, element map offset, sizes, table slots
+  double *TT = reinterpret_cast<double *>(meta + 8 * p.eb);  // [eb][maxnbt][nq][S]: the test tables of the batch (global loads in the contraction are L1
+  double *TR = p.same ? TT : TT + (size_t)p.eb * p.maxnbt * p.nq * S;  // hits, but 16 cycles of the texture path each; LDS reads take 4)
+  double *UE = TR + (size_t)p.eb * p.maxnbr * p.nq * S;  // [eb][uesz]: field coefficients
+  const int tid = threadIdx.x;
+  for (int i = tid; i < p.tlen; i += NTB) tab[i] = p.table ? p.table[i] : p.tabarg[i];
+  const int npts = p.eb * p.nq;
+  // The tables of the batch live in eb LDS slots that persist across batches (tag = first function of the table): on a structured mesh
+  // nearly every element uses the table of its predecessor, so most batches stage nothing.  (Test and trial tables that differ get slot sets
+  // of their own.)
+  i64 *tagT = reinterpret_cast<i64 *>(UE + (size_t)p.eb * p.uesz), *tagR = tagT + p.eb;
+  if (tid < 2 * p.eb) tagT[tid] = -1;
+#ifdef NH_ABLATION
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+  for (i64 b0 = (i64)blockIdx.x * p.eb; b0 < p.nelems; b0 += (i64)gridDim.x * p.eb) {
+    __syncthreads();
+    if (tid < p.eb && b0 + tid < p.nelems) {
+      const i64 ie = b0 + tid, e = p.elist ? p.elist[ie] : ie;
+      const int nbt = bnb(p.test, e), nbr = bnb(p.trial, e);
+      i64 *mt = meta + tid * 8;
+      mt[0] = e, mt[1] = bfn(p.test, e), mt[2] = bfn(p.trial, e), mt[3] = boff(p.test, e);
+      mt[4] = p.eoff ? p.eoff[e] : (p.emap_by_elem ? e : ie) * (i64)nbt * nbr;
+      mt[5] = nbt | ((i64)nbr << 16);
+    }
+    __syncthreads();
+    MTICK(0);
+    // the table of element el of a batch lives in slot el and stays there: on a structured mesh element el of the NEXT batch of this workgroup
+    // nearly always uses the same table (tag = first function), and nothing is staged
+    int miss = 0;
+    if (tid < p.eb && b0 + tid < p.nelems) {
+      i64 *mt = meta + tid * 8;
+      const int needT = tagT[tid] != mt[1], needR = !p.same && tagR[tid] != mt[2];
+      tagT[tid] = mt[1];
+      if (!p.same) tagR[tid] = mt[2];
+      mt[6] = tid | (needT ? 0x100 : 0), mt[7] = tid | (needR ? 0x100 : 0);
+      miss = needT | needR;
+    }
+    stage_coeffs(p.fields, p.nfields, p.uesz, UE, p.eb, b0, p.nelems, p.elist, tid);
+    double Ji[ND][ND], det = 0;
+    if (tid < npts && b0 + tid / p.nq < p.nelems) {
+      const int el = tid / p.nq;
+      geometry_at<ND>(p.geom, meta[el * 8], tid - el * p.nq, p.nq, nullptr, Ji, det, nullptr);
+    }
+    miss = __syncthreads_or(miss);
+    MTICK(1);
+    if (miss) {
+      // missing tables -> LDS, eight loads in flight per thread (one load per loop trip is one memory latency per trip)
+      auto stage = [&](double *dst, const double *T, int maxnb, int fs, int ms, int shift) {
+        const int tsz = maxnb * p.nq * S, total = p.eb * tsz;
+        for (int i0 = tid; i0 < total; i0 += 8 * NTB) {
+          double v[8];
+          int at[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * NTB, el = i / tsz, r = i - el * tsz;
+            const bool ok = i < total && b0 + el < p.nelems && (meta[el * 8 + ms] & 0x100) && r < (int)((meta[el * 8 + 5] >> shift) & 0xffff) * p.nq * S;
+            at[u] = ok ? (int)(meta[el * 8 + ms] & 0xff) * tsz + r : -1;
+            v[u] = ok ? T[meta[el * 8 + fs] * p.nq * S + r] : 0.;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (at[u] >= 0) dst[at[u]] = v[u];
+        }
+      };
+      stage(TT, p.test.T, p.maxnbt, 1, 6, 0);
+      if (!p.same) stage(TR, p.trial.T, p.maxnbr, 2, 7, 16);
+    }
+    __syncthreads();
+    MTICK(2);
+    for (int t = tid; t < npts; t += NTB) {
+      const int el = t / p.nq, q = t - el * p.nq;
+      const i64 ie = b0 + el;
+      if (ie >= p.nelems) continue;
+      const i64 e = meta[el * 8];
+      const i64 ip = (p.emap_by_elem ? e : ie) * p.nq + q;  // index of the point in the scale arrays
+      if (t != tid) geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);  // (more points than threads: batches of one element)
+      const double wdet = p.weights[q] * fabs(det);
+      double *u = U + (size_t)tid * p.fct * S;
+      eval_fields<ND>(p.fields, p.nfields, e, q, p.nq, Ji, UE + (size_t)el * p.uesz, TT + (size_t)(meta[el * 8 + 6] & 0xff) * p.maxnbt * p.nq * S, u);
+      double pv[MAXP];
+      eval_polys<S>(tab, p.poff, p.npolys, u, pv);
+      double *g = G + (size_t)t * CS;
+      if (CS <= 16) {
+        // scalar-sized tensors: the sum over the terms stays in registers (an LDS read-modify-write per term and entry is a latency chain)
+        double gr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gr[i] = 0.;
+        for (int t2 = 0; t2 < p.nterms; ++t2) {
+          const double *H = tab + p.toff[t2];
+          const int kind = (int)H[0], fld = (int)H[1], pol = (int)H[2];
+          double coef = p.scale[t2] ? p.scale[t2][ip] : 1.;
+          if (pol >= 0) coef *= pick(pv, pol);
+          const double *B = H + 3;
+          if (kind == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              if (i < CS) gr[i] += coef * B[i];
+          } else {
+            const double *uf = u + p.fields[fld].c0 * S;
+            double ul[S];
+#pragma unroll
+            for (int b = 0; b < S; ++b) ul[b] = uf[b];
+            if (kind == 1) {
+#pragma unroll
+              for (int a = 0; a < S; ++a) {
+                double sum = 0;
+#pragma unroll
+                for (int b = 0; b < S; ++b) sum += B[a * S + b] * ul[b];
+                gr[a * S] += coef * sum;
+              }
+            } else {
+              const double *L = B + CS;
+#pragma unroll
+              for (int b = 0; b < S; ++b) {
+                double sum = 0;
+#pragma unroll
+                for (int x = 0; x < S; ++x) sum += B[x * S + b] * ul[x];
+#pragma unroll
+                for (int a = 0; a < S; ++a) gr[a * S + b] += coef * L[a] * sum;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < CS) g[i] = gr[i];
+      } else {
+        for (int i = 0; i < CS; ++i) g[i] = 0.;
+        for (int t2 = 0; t2 < p.nterms; ++t2) {
+          const double *H = tab + p.toff[t2];
+          const int pol = (int)H[2];
+          double coef = p.scale[t2] ? p.scale[t2][ip] : 1.;
+          if (pol >= 0) coef *= pick(pv, pol);
+          const double *B = H + 3;
+          for (int i = 0; i < CS; ++i) g[i] += coef * B[i];  // (point-dependent kinds are scalar: CS = S * S <= 16)
+        }
+      }
+      // reference form: D[a] = sum_s T[s] X[s][a], X = diag(1, Jinv)  ->  G[c][s][d][t] = w|J| sum_ab X[s][a] Cq[c][a][d][b] X[t][b]
+      for (int c = 0; c < p.nct; ++c)
+        for (int d = 0; d < p.ncr; ++d) {
+          double M[S][S], R[S][S];
+#pragma unroll
+          for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int b = 0; b < S; ++b) M[a][b] = g[((c * S + a) * p.ncr + d) * S + b];
+#pragma unroll
+          for (int b = 0; b < S; ++b) {
+            R[0][b] = M[0][b];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+              double s = 0;
+#pragma unroll
+              for (int i = 0; i < ND; ++i) s += Ji[j][i] * M[1 + i][b];
+              R[1 + j][b] = s;
+            }
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) {
+            g[((c * S + s2) * p.ncr + d) * S] = wdet * R[s2][0];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+              double s = 0;
+#pragma unroll
+              for (int i = 0; i < ND; ++i) s += R[s2][1 + i] * Ji[j][i];
+              g[((c * S + s2) * p.ncr + d) * S + 1 + j] = wdet * s;
+            }
+          }
+        }
+    }
+    __syncthreads();
+    MTICK(3);
+    // Contraction A[m][n] = sum_q sum_t (sum_s Tt[m][q][s] G[q][s][t]) Tr[n][q][t]: every lane owns NBLK consecutive n of one (element, m)
+    // and keeps their sums in registers; per point it forms the S values of the bracket once (S loads of the test table, S * S broadcast reads
+    // of G) and spends S loads + S multiply-adds per entry.  Nothing but G lives in LDS, so several workgroups share a CU.
+    const int nblk = (p.maxnbr + NBLK - 1) / NBLK;
+    for (int k = tid; k < p.eb * p.maxnbt * nblk; k += NTB) {
+      const int el = k / (p.maxnbt * nblk), r = k - el * (p.maxnbt * nblk);
+      if (b0 + el >= p.nelems) continue;
+      const i64 *mt = meta + el * 8;
+      const int m = r / nblk, n0 = (r - m * nblk) * NBLK;
+      const int nbt = (int)(mt[5] & 0xffff), nbr = (int)(mt[5] >> 16);
+      if (m >= nbt || n0 >= nbr) continue;
+      const double *Tt = TT + ((size_t)(mt[6] & 0xff) * p.maxnbt + m) * p.nq * S;
+      const double *Tr[NBLK];
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) Tr[j] = TR + ((size_t)(mt[p.same ? 6 : 7] & 0xff) * p.maxnbr + min(n0 + j, nbr - 1)) * p.nq * S;
+      const i64 row = p.test.dofs[mt[3] + m];
+      const i64 a0 = p.srowptr[row], len = p.srowptr[row + 1] - a0;
+      const int32_t *em = p.emap + mt[4] + m * nbr + n0;
+      const double *g0 = G + (size_t)el * p.nq * CS;
+      for (int c = 0; c < p.nct; ++c)
+        for (int d = 0; d < p.ncr; ++d) {
+          if (!p.mask[c][d]) continue;
+          double acc[NBLK];
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j) acc[j] = 0;
+          // software pipeline: the LDS reads of point q + 1 are issued before the arithmetic of point q (two waves per SIMD do not hide the
+          // ~100 cycles of an LDS read that is waited for right behind its issue)
+          const double *gb = g0 + (c * S * p.ncr + d) * S;
+          double tt[2][S], gg[2][S][S], tr[2][NBLK][S];
+          auto fetch = [&](int q, int b2) {
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) {
+              tt[b2][s2] = Tt[q * S + s2];
+#pragma unroll
+              for (int t2 = 0; t2 < S; ++t2) gg[b2][s2][t2] = gb[(size_t)q * CS + s2 * p.ncr * S + t2];
+            }
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+              for (int t2 = 0; t2 < S; ++t2) tr[b2][j][t2] = Tr[j][q * S + t2];
+          };
+          auto point = [&](int b2) {
+            double w[S];
+#pragma unroll
+            for (int t2 = 0; t2 < S; ++t2) w[t2] = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2)
+#pragma unroll
+              for (int t2 = 0; t2 < S; ++t2) w[t2] += tt[b2][s2] * gg[b2][s2][t2];
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+              for (int t2 = 0; t2 < S; ++t2) acc[j] += w[t2] * tr[b2][j][t2];
+          };
+          const int nqc = MDBG(p, 2) ? 1 : p.nq;
+          fetch(0, 0);
+          int q = 0;
+          for (; q + 2 <= nqc; q += 2) {
+            fetch(q + 1, 1);
+            point(0);
+            if (q + 2 < nqc) fetch(q + 2, 0);
+            point(1);
+          }
+          if (q < nqc) point(0);
+          double *dst = p.values + a0 * p.tot + len * p.cum[c] + p.dpos[c][d];
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j)
+            if (n0 + j < nbr && !MDBG(p, 1)) atomicAdd(dst + (i64)em[j] * p.cnt[c], acc[j]);
+#ifdef NH_ABLATION
+          if (MDBG(p, 1) && acc[0] == 1.2345e300) dst[0] = 1.;
+#endif
+        }
+    }
+    MTICK(4);
+  }
+#ifdef NH_ABLATION
+  if (p.tdbg && tid == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
+#endif
+}
+
 int check_geom2(const nh_geometry &g) {
   if (g.kind == NH_GEOM_ISO) {
     NH_REQUIRE(g.ngb > 0 && g.gT_dev && g.gdofs_dev && g.verts_dev, "isoparametric geometry needs ngb, gT, gdofs, verts");
@@ -218,6 +556,51 @@ int max_nb2(const nh_basis &b, i64 nelems, int *out) {
   return NH_OK;
 }
 
+// polynomial k of the argument list -> term table
+int push_poly(const nh_point_poly &P, const nh_field *fields, int nfields, const FieldK *fk, int k, std::vector<double> &tab, int *off) {
+  NH_REQUIRE(P.nvars >= 0 && P.nvars <= 4 && P.nterms >= 0 && P.nterms <= 64 && (P.nterms == 0 || (P.coeffs_host && (P.nvars == 0 || P.powers_host))), "polynomial %d: at most 4 variables and 64 terms", k);
+  *off = (int)tab.size();
+  tab.push_back(P.nvars), tab.push_back(P.nterms);
+  for (int v = 0; v < 4; ++v) {
+    int slot = 0;
+    if (v < P.nvars) {
+      NH_REQUIRE(P.field[v] >= 0 && P.field[v] < nfields && P.comp[v] >= 0 && P.comp[v] < fields[P.field[v]].ncomp, "polynomial %d: variable %d refers to a missing field component", k, v);
+      slot = fk[P.field[v]].c0 + P.comp[v];
+    }
+    tab.push_back(slot);
+  }
+  for (int t = 0; t < P.nterms; ++t) {
+    tab.push_back(P.coeffs_host[t]);
+    for (int v = 0; v < 4; ++v) {
+      const int pw = v < P.nvars ? P.powers_host[t * P.nvars + v] : 0;
+      NH_REQUIRE(pw >= 0 && pw < 64, "polynomial %d: power out of range", k);
+      tab.push_back(pw);
+    }
+  }
+  return NH_OK;
+}
+
+// small tables travel with the kernel arguments; large ones go through a device buffer owned by the library (the pageable host vector
+// must outlive the copy, and earlier launches on the stream may still read the buffer: synchronous)
+int place_table(const std::vector<double> &tab, double *tabarg, const double **table, hipStream_t s) {
+  if (tab.size() <= (size_t)TABARG) {
+    *table = nullptr;
+    std::copy(tab.begin(), tab.end(), tabarg);
+    return NH_OK;
+  }
+  static double *dtab = nullptr;
+  static size_t dcap = 0;
+  if (tab.size() > dcap) {
+    if (dtab) NH_CHECK_HIP(hipFree(dtab));
+    dcap = 2 * tab.size();
+    NH_CHECK_HIP(hipMalloc((void **)&dtab, dcap * sizeof(double)));
+  }
+  NH_CHECK_HIP(hipStreamSynchronize(s));
+  NH_CHECK_HIP(hipMemcpy(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  *table = dtab;
+  return NH_OK;
+}
+
 }  // namespace
 
 extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
@@ -239,7 +622,7 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
   p.weights = a->weights_dev;
   p.geom = to_k(a->geom);
   p.nfields = a->nfields, p.nblocks = a->nblocks, p.nterms = a->nterms, p.npolys = a->npolys;
-  p.fct = 0;
+  p.fct = 0, p.uesz = 0;
   for (int f = 0; f < a->nfields; ++f) {
     const nh_field &F = a->fields[f];
     NH_REQUIRE(F.basis.T_dev && F.basis.dofs_dev && F.u_dev && F.ncomp >= 1 && F.ncomp <= 3, "nh_assemble_terms: field %d incomplete", f);
@@ -249,6 +632,10 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
     p.fields[f].ncomp = F.ncomp;
     p.fields[f].c0 = p.fct;
     p.fct += F.ncomp;
+    if ((rc = max_nb2(F.basis, a->nelems, &p.fields[f].maxnb)) != NH_OK) return rc;
+    p.fields[f].ue0 = p.uesz;
+    p.fields[f].tsame = 0;
+    p.uesz += p.fields[f].maxnb * F.ncomp;
   }
   NH_REQUIRE(p.fct <= MAXFC, "nh_assemble_terms: more than %d field components", MAXFC);
   p.ct = 0, p.rowsper = 0;
@@ -281,50 +668,15 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
   }
   for (int t = a->nterms; t < MAXT; ++t) p.scale[t] = nullptr, p.toff[t] = 0;
   for (int k = 0; k < MAXP; ++k) p.poff[k] = 0;
-  for (int k = 0; k < a->npolys; ++k) {
-    const nh_point_poly &P = a->polys[k];
-    NH_REQUIRE(P.nvars >= 0 && P.nvars <= 4 && P.nterms >= 0 && P.nterms <= 64 && (P.nterms == 0 || (P.coeffs_host && (P.nvars == 0 || P.powers_host))), "nh_assemble_terms: polynomial %d: at most 4 variables and 64 terms", k);
-    p.poff[k] = (int)tab.size();
-    tab.push_back(P.nvars), tab.push_back(P.nterms);
-    for (int v = 0; v < 4; ++v) {
-      int slot = 0;
-      if (v < P.nvars) {
-        NH_REQUIRE(P.field[v] >= 0 && P.field[v] < a->nfields && P.comp[v] >= 0 && P.comp[v] < a->fields[P.field[v]].ncomp, "nh_assemble_terms: polynomial %d: variable %d refers to a missing field component", k, v);
-        slot = p.fields[P.field[v]].c0 + P.comp[v];
-      }
-      tab.push_back(slot);
-    }
-    for (int t = 0; t < P.nterms; ++t) {
-      tab.push_back(P.coeffs_host[t]);
-      for (int v = 0; v < 4; ++v) {
-        const int pw = v < P.nvars ? P.powers_host[t * P.nvars + v] : 0;
-        NH_REQUIRE(pw >= 0 && pw < 64, "nh_assemble_terms: power out of range");
-        tab.push_back(pw);
-      }
-    }
-  }
+  for (int k = 0; k < a->npolys; ++k)
+    if ((rc = push_poly(a->polys[k], a->fields, a->nfields, p.fields, k, tab, &p.poff[k])) != NH_OK) return rc;
   p.tlen = (int)tab.size();
   // elements per batch: as many as fill the workgroup in the pointwise phase
   p.eb = std::max(1, NTB / a->nq);
-  const size_t lds = sizeof(double) * ((size_t)p.tlen + (size_t)p.eb * a->nq * p.ct * S + (size_t)NTB * std::max(p.fct, 1) * S);
+  const size_t lds = sizeof(double) * ((size_t)p.tlen + (size_t)p.eb * a->nq * p.ct * S + (size_t)NTB * p.fct * S + (size_t)p.eb * p.uesz);
   NH_REQUIRE(lds <= 160 * 1024, "nh_assemble_terms: batch too large for LDS (%zu bytes)", lds);
   hipStream_t s = nh_stream(stream);
-  if (tab.size() <= (size_t)TABARG) {
-    p.table = nullptr;
-    std::copy(tab.begin(), tab.end(), p.tabarg);
-  } else {
-    // large tables go through a device buffer owned by the library; the pageable host vector must outlive the copy: wait for it
-    static double *dtab = nullptr;
-    static size_t dcap = 0;
-    if (tab.size() > dcap) {
-      if (dtab) NH_CHECK_HIP(hipFree(dtab));
-      dcap = 2 * tab.size();
-      NH_CHECK_HIP(hipMalloc((void **)&dtab, dcap * sizeof(double)));
-    }
-    NH_CHECK_HIP(hipStreamSynchronize(s));  // earlier launches on this stream may still read the buffer
-    NH_CHECK_HIP(hipMemcpy(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-    p.table = dtab;
-  }
+  if ((rc = place_table(tab, p.tabarg, &p.table, s)) != NH_OK) return rc;
   const i64 nbatch = (a->nelems + p.eb - 1) / p.eb;
   dim3 grid((unsigned)std::min<i64>(nbatch, 256 * 8)), block(NTB);
 #define LAUNCH(ND)                                                                                                          \
@@ -337,5 +689,125 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
   if (a->ndims == 3) LAUNCH(3);
 #undef LAUNCH
   NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+extern "C" int nh_assemble_matrix_terms(const nh_matrix_terms_args *a, void *stream) {
+  NH_REQUIRE(a, "nh_assemble_matrix_terms: NULL args");
+  NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
+  NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
+  NH_REQUIRE((a->flags & ~NH_MATRIX_EMAP_BY_ELEMENT) == 0, "nh_assemble_matrix_terms: unknown flag bits 0x%x", a->flags & ~NH_MATRIX_EMAP_BY_ELEMENT);
+  NH_REQUIRE(a->srowptr_dev && a->emap_dev && a->values_dev, "nh_assemble_matrix_terms: NULL pattern / values");
+  NH_REQUIRE(a->test.T_dev && a->test.dofs_dev && a->trial.T_dev && a->trial.dofs_dev, "basis tables missing");
+  NH_REQUIRE(a->nct >= 1 && a->nct <= 3 && a->ncr >= 1 && a->ncr <= 3, "component counts must be 1..3 (got %d, %d)", a->nct, a->ncr);
+  NH_REQUIRE(a->nfields >= 0 && a->nfields <= MAXF && (a->nfields == 0 || a->fields), "nh_assemble_matrix_terms: 0..%d fields", MAXF);
+  NH_REQUIRE(a->nterms >= 1 && a->nterms <= MAXT && a->terms, "nh_assemble_matrix_terms: 1..%d terms", MAXT);
+  NH_REQUIRE(a->npolys >= 0 && a->npolys <= MAXP && (a->npolys == 0 || a->polys), "nh_assemble_matrix_terms: 0..%d pointwise polynomials", MAXP);
+  NH_REQUIRE(!a->elist_dev || (a->test.nb && a->trial.nb), "elist with ragged bases is not supported");
+  int rc = check_geom2(a->geom);
+  if (rc) return rc;
+  if (a->nelems == 0) return NH_OK;
+  const int S = 1 + a->ndims, CS = a->nct * S * a->ncr * S;
+  MTermsK p;
+  p.debug = 0;
+  p.tdbg = nullptr;
+#ifdef NH_ABLATION
+  if (getenv("NH_BATCHED_DEBUG")) p.debug = atoi(getenv("NH_BATCHED_DEBUG"));
+  static long long *tdbg = nullptr;
+  if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, 8 * sizeof(long long)));
+  NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, 8 * sizeof(long long), nh_stream(stream)));
+  if (getenv("NH_BATCHED_TIMERS")) p.tdbg = tdbg;
+#endif
+  p.nelems = a->nelems;
+  p.elist = a->elist_dev;
+  p.nq = a->nq;
+  p.weights = a->weights_dev;
+  p.geom = to_k(a->geom);
+  p.nfields = a->nfields, p.nterms = a->nterms, p.npolys = a->npolys;
+  p.fct = 0, p.uesz = 0;
+  for (int f = 0; f < a->nfields; ++f) {
+    const nh_field &F = a->fields[f];
+    NH_REQUIRE(F.basis.T_dev && F.basis.dofs_dev && F.u_dev && F.ncomp >= 1 && F.ncomp <= 3, "nh_assemble_matrix_terms: field %d incomplete", f);
+    NH_REQUIRE(!a->elist_dev || !F.basis.off_dev, "elist with ragged bases is not supported");
+    p.fields[f].b = to_k(F.basis);
+    p.fields[f].u = F.u_dev;
+    p.fields[f].ncomp = F.ncomp;
+    p.fields[f].c0 = p.fct;
+    p.fct += F.ncomp;
+    if ((rc = max_nb2(F.basis, a->nelems, &p.fields[f].maxnb)) != NH_OK) return rc;
+    p.fields[f].ue0 = p.uesz;
+    p.fields[f].tsame = (F.basis.T_dev == a->test.T_dev && F.basis.off_dev == a->test.off_dev && F.basis.tab_dev == a->test.tab_dev && F.basis.nb == a->test.nb);
+    p.uesz += p.fields[f].maxnb * F.ncomp;
+  }
+  NH_REQUIRE(p.fct <= MAXFC, "nh_assemble_matrix_terms: more than %d field components", MAXFC);
+  p.test = to_k(a->test), p.trial = to_k(a->trial);
+  p.nct = a->nct, p.ncr = a->ncr;
+  if ((rc = max_nb2(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
+  if ((rc = max_nb2(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
+  p.srowptr = (const i64 *)a->srowptr_dev;
+  p.emap = a->emap_dev;
+  p.eoff = (const i64 *)a->eoff_dev;
+  p.values = a->values_dev;
+  p.emap_by_elem = (a->flags & NH_MATRIX_EMAP_BY_ELEMENT) != 0;
+  p.tot = 0;
+  for (int c = 0; c < 3; ++c) {
+    p.cum[c] = p.tot, p.cnt[c] = 0;
+    for (int d = 0; d < 3; ++d) {
+      p.mask[c][d] = c < a->nct && d < a->ncr && (a->mask_host ? a->mask_host[c * a->ncr + d] != 0 : 1);
+      p.dpos[c][d] = (signed char)p.cnt[c];
+      p.cnt[c] += p.mask[c][d];
+    }
+    p.tot += p.cnt[c];
+  }
+  std::vector<double> tab;
+  for (int t = 0; t < a->nterms; ++t) {
+    const nh_matrix_term &T = a->terms[t];
+    NH_REQUIRE(T.kind >= 0 && T.kind <= 2 && T.C_host, "nh_assemble_matrix_terms: term %d: kind 0..2 with a coefficient tensor", t);
+    NH_REQUIRE(T.poly >= -1 && T.poly < a->npolys, "nh_assemble_matrix_terms: term %d refers to a missing polynomial", t);
+    if (T.kind) {
+      NH_REQUIRE(a->nct == 1 && a->ncr == 1 && T.field >= 0 && T.field < a->nfields && a->fields[T.field].ncomp == 1, "nh_assemble_matrix_terms: term %d: point-dependent forms are for scalar fields", t);
+      NH_REQUIRE(T.kind != 2 || T.L_host, "nh_assemble_matrix_terms: term %d: kind 2 needs L", t);
+    }
+    p.toff[t] = (int)tab.size();
+    p.scale[t] = T.scale_dev;
+    tab.push_back(T.kind), tab.push_back(T.kind ? T.field : -1), tab.push_back(T.poly);
+    for (int i = 0; i < CS; ++i) tab.push_back(T.C_host[i]);
+    if (T.kind == 2)
+      for (int i = 0; i < a->nct * S; ++i) tab.push_back(T.L_host[i]);
+  }
+  for (int t = a->nterms; t < MAXT; ++t) p.scale[t] = nullptr, p.toff[t] = 0;
+  for (int k = 0; k < MAXP; ++k) p.poff[k] = 0;
+  for (int k = 0; k < a->npolys; ++k)
+    if ((rc = push_poly(a->polys[k], a->fields, a->nfields, p.fields, k, tab, &p.poff[k])) != NH_OK) return rc;
+  p.tlen = (int)tab.size();
+  p.same = (a->test.T_dev == a->trial.T_dev && a->test.off_dev == a->trial.off_dev && a->test.tab_dev == a->trial.tab_dev && a->test.nb == a->trial.nb);
+  // elements per batch: fill the workgroup in the pointwise phase, within an LDS budget that keeps two workgroups per CU
+  const size_t per_elem = sizeof(double) * (a->nq * ((size_t)CS + (size_t)(p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S) + p.uesz);
+  p.eb = std::max(1, std::min(NTB / a->nq, (int)(60 * 1024 / per_elem)));
+  p.eb = std::min(p.eb, 32);  // (slot bookkeeping in a 32-bit mask)
+  const size_t lds = sizeof(double) * ((size_t)p.tlen + (size_t)NTB * p.fct * S + 10 * (size_t)p.eb) + p.eb * per_elem;
+  NH_REQUIRE(lds <= 160 * 1024, "nh_assemble_matrix_terms: batch too large for LDS (%zu bytes)", lds);
+  hipStream_t s = nh_stream(stream);
+  if ((rc = place_table(tab, p.tabarg, &p.table, s)) != NH_OK) return rc;
+  const i64 nbatch = (a->nelems + p.eb - 1) / p.eb;
+  dim3 grid((unsigned)std::min<i64>(nbatch, 256 * 8)), block(NTB);
+#define LAUNCH(ND)                                                                                                          \
+  do {                                                                                                                      \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_mterms<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+    hipLaunchKernelGGL(k_mterms<ND>, grid, block, lds, s, p);                                                               \
+  } while (0)
+  if (a->ndims == 1) LAUNCH(1);
+  if (a->ndims == 2) LAUNCH(2);
+  if (a->ndims == 3) LAUNCH(3);
+#undef LAUNCH
+  NH_LAUNCH_CHECK();
+#ifdef NH_ABLATION
+  if (p.tdbg) {
+    long long h[8];
+    NH_CHECK_HIP(hipMemcpy(h, p.tdbg, sizeof h, hipMemcpyDeviceToHost));
+    const double g = grid.x;
+    fprintf(stderr, "k_mterms cycles per workgroup: meta %.0f | slots+coeffs+geometry %.0f | stage %.0f | pointwise %.0f | contraction %.0f (eb %d, %u workgroups)\n", h[0] / g, h[1] / g, h[2] / g, h[3] / g, h[4] / g, p.eb, grid.x);
+  }
+#endif
   return NH_OK;
 }

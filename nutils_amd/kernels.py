@@ -147,20 +147,10 @@ def assemble_terms(*, nelems, ndims, nq, weights, geom, fields, blocks, terms, p
     terms: [dict(block, field=-1, poly=-1, C=None, f=None, scale=None)].'''
     S = 1 + ndims
     keep = []
-    F = (_lib.Field * max(len(fields), 1))()
-    for i, (b, u, nc) in enumerate(fields):
-        F[i] = _lib.Field(b, device.ptr(u), int(nc))
+    F, P = _fields_polys(fields, polys, keep)
     B = (_lib.Block * len(blocks))()
     for i, (b, nct, out) in enumerate(blocks):
         B[i] = _lib.Block(b, int(nct), device.ptr(out))
-    P = (_lib.PointPoly * max(len(polys), 1))()
-    for i, (vars_, coeffs, powers) in enumerate(polys):
-        cf = numpy.ascontiguousarray(coeffs, dtype=float)
-        pw = numpy.ascontiguousarray(powers, dtype=numpy.int32).reshape(len(cf), len(vars_))
-        keep += [cf, pw]
-        fld = (ctypes.c_int * 4)(*([v[0] for v in vars_] + [0] * (4 - len(vars_))))
-        cmp_ = (ctypes.c_int * 4)(*([v[1] for v in vars_] + [0] * (4 - len(vars_))))
-        P[i] = _lib.PointPoly(len(vars_), len(cf), fld, cmp_, device.host_ptr(cf), pw.ctypes.data if pw.size else None)
     T = (_lib.Term * len(terms))()
     for i, t in enumerate(terms):
         blk, fld = int(t['block']), int(t.get('field', -1))
@@ -178,6 +168,45 @@ def assemble_terms(*, nelems, ndims, nq, weights, geom, fields, blocks, terms, p
         T[i] = _lib.Term(blk, fld, int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(f), device.ptr(t.get('scale')))
     args = _lib.TermsArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, len(fields), F, len(blocks), B, len(terms), T, len(polys), P)
     _lib.call('nh_assemble_terms', ctypes.byref(args), device.stream())
+
+
+def _fields_polys(fields, polys, keep):
+    F = (_lib.Field * max(len(fields), 1))()
+    for i, (b, u, nc) in enumerate(fields):
+        F[i] = _lib.Field(b, device.ptr(u), int(nc))
+    P = (_lib.PointPoly * max(len(polys), 1))()
+    for i, (vars_, coeffs, powers) in enumerate(polys):
+        cf = numpy.ascontiguousarray(coeffs, dtype=float)
+        pw = numpy.ascontiguousarray(powers, dtype=numpy.int32).reshape(len(cf), len(vars_))
+        keep += [cf, pw]
+        fld = (ctypes.c_int * 4)(*([v[0] for v in vars_] + [0] * (4 - len(vars_))))
+        cmp_ = (ctypes.c_int * 4)(*([v[1] for v in vars_] + [0] * (4 - len(vars_))))
+        P[i] = _lib.PointPoly(len(vars_), len(cf), fld, cmp_, device.host_ptr(cf), pw.ctypes.data if pw.size else None)
+    return F, P
+
+
+def assemble_matrix_terms(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, mask, pattern, values, terms, fields=(), polys=(), elist=None, flags=0):
+    '''All bilinear-form terms of a matrix block in ONE element loop, several elements per workgroup (nh_assemble_matrix_terms); accumulates
+    into `values`.  terms: [dict(C, kind=0, field=-1, poly=-1, L=None, scale=None)], fields / polys as in assemble_terms.'''
+    S = 1 + ndims
+    keep = []
+    F, P = _fields_polys(fields, polys, keep)
+    m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
+    T = (_lib.MatrixTerm * len(terms))()
+    for i, t in enumerate(terms):
+        C = numpy.ascontiguousarray(t['C'], dtype=float)
+        if C.shape != (nct, S, ncr, S):
+            raise ValueError(f'term {i}: coefficient tensor has shape {C.shape}, expected {(nct, S, ncr, S)}')
+        L = t.get('L')
+        if L is not None:
+            L = numpy.ascontiguousarray(L, dtype=float)
+            if L.shape != (nct, S):
+                raise ValueError(f'term {i}: L has shape {L.shape}')
+        keep += [C, L]
+        T[i] = _lib.MatrixTerm(int(t.get('kind', 0)), int(t.get('field', -1)), int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(L), device.ptr(t.get('scale')))
+    args = _lib.MatrixTermsArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(m), pattern.srowptr_ptr,
+                                pattern.emap_ptr, pattern.eoff_ptr, device.ptr(values), int(flags), len(fields), F, len(terms), T, len(polys), P)
+    _lib.call('nh_assemble_matrix_terms', ctypes.byref(args), device.stream())
 
 
 def sample_eval(*, nelems, ndims, nq, geom, trial=None, ncr=1, points=None, u=None, x=None, detj=None, U=None, elist=None):

@@ -461,6 +461,80 @@ class _MatrixPlan:
             return None
         return basis.shape, basis.degree + 1
 
+    def _batched(self, terms, values, mask, arguments):
+        '''Bases with few functions per element: ALL terms of the block that share a measure go through one nh_assemble_matrix_terms launch
+        (several elements per workgroup; coefficient functions, polynomial factors of field values and the point-dependent product-rule
+        tensors are evaluated inside the kernel).  Returns the terms that remain for the per-term kernels.'''
+        smp0 = self.smp0
+        tt, tr = smp0.tables(self.test.basis), smp0.tables(self.trial.basis)
+        if not (0 < tt.nb <= 27 and 0 < tr.nb <= 27):
+            return terms
+        if self.test.basis is self.trial.basis and smp0.nlist >= COLOR_THRESHOLD and tt.nb >= 16:
+            return terms  # (the coloured MFMA path)
+        # measured (profiles/r02_c4.md): the fused kernel pays when it replaces several launches -- more than one term, or pointwise factors that
+        # would otherwise be evaluated by nh_sample_eval / nh_pointwise_poly / torch algebra first; one constant-coefficient term of a 3-D basis
+        # is faster through the one-wave-per-element kernel (128^3 trilinear: 4.1 against 9.5 ms)
+        if len(terms) < 2 and not any(itg.fscale is not None or itg.qform is not None for _, itg, _ in terms):
+            return terms
+        nd, nq, S = smp0.ndims, smp0.points.npoints, 1 + smp0.ndims
+        nct, ncr = self.test.ncomp, self.trial.ncomp
+        groups, rest = {}, []
+        for term in terms:
+            smp, itg, fac = term
+            ok = (itg.measure is not None and (itg.geom is None or itg.geom is itg.measure or itg.qform is None)
+                  and (itg.fscale is None or (len(itg.fscale.args) <= 4 and len(itg.fscale.terms) <= 64 and all(a.ncomp == 1 for a in itg.fscale.args)))
+                  and (itg.qform is None or (nct == ncr == 1 and itg.qform[1].ncomp == 1)))
+            (groups.setdefault(id(itg.measure), []) if ok else rest).append(term)
+        for items in groups.values():
+            fkeys, pkeys, tl, ucache = [], [], [], {}
+
+            def fidx(a):
+                for i, k in enumerate(fkeys):
+                    if a.same(k):
+                        return i
+                fkeys.append(a)
+                return len(fkeys) - 1
+
+            left = []
+            for term in items:
+                smp, itg, fac = term
+                need = ([itg.qform[1]] if itg.qform is not None else []) + (list(itg.fscale.args) if itg.fscale is not None and itg.qscalar is None else [])
+                newf = [a for a in need if not any(a.same(k) for k in fkeys)]
+                newp = itg.fscale is not None and itg.qscalar is None and not any(itg.fscale is k for k in pkeys)
+                if len(tl) >= 32 or len(fkeys) + len(newf) > 6 or len(pkeys) + newp > 4:
+                    left.append(term)
+                    continue
+                t = dict(C=numpy.asarray(itg.B, dtype=float) * fac)
+                if itg.qscalar is not None:  # (energy Hessians: the point factor U_t . B . U_r stays a scale array)
+                    t['scale'] = _point_scale(smp, itg, arguments)
+                else:
+                    if itg.scale is not None:
+                        t['scale'] = smp.scale(itg.scale)
+                    if itg.fscale is not None:
+                        if newp:
+                            pkeys.append(itg.fscale)
+                        for a in itg.fscale.args:
+                            fidx(a)
+                        t['poly'] = next(i for i, k in enumerate(pkeys) if k is itg.fscale)
+                if itg.qform is not None:
+                    t['kind'], t['field'] = (1 if itg.qform[0] == 'trial' else 2), fidx(itg.qform[1])
+                    if itg.qform[0] != 'trial':
+                        t['L'] = numpy.asarray(itg.qform[2], dtype=float).reshape(1, S)
+                tl.append(t)
+            rest += left
+            if not tl:
+                continue
+            smp = items[0][0]
+            polys = []
+            for fp in pkeys:
+                keys = list(fp.terms)
+                polys.append(([(fidx(a), 0) for a in fp.args], [fp.terms[k] for k in keys], keys))
+            fields = [(smp.tables(a.basis).struct, device.to_dev(_argument(arguments, a), 'float64'), a.ncomp) for a in fkeys]
+            kernels.assemble_matrix_terms(nelems=smp.nlist, elist=smp._elist_dev, ndims=nd, nq=nq, weights=smp._weights_dev, geom=smp.geometry(items[0][1].measure),
+                                          test=tt.struct, trial=tr.struct, nct=nct, ncr=ncr, mask=mask, pattern=smp.pattern(self.test.basis, self.trial.basis),
+                                          values=values, terms=tl, fields=fields, polys=polys)
+        return rest
+
     def run(self, arguments=None):
         fast = self._p1hex_laplace(arguments)
         if fast is not None and not fast[4]:
@@ -481,6 +555,8 @@ class _MatrixPlan:
             # no zero-fill, no read of the entries that receive a single contribution
             first_touch = self._first_touch(self.terms[0])
             values, terms = (device.empty if first_touch else device.zeros)(colidx.numel(), 'float64'), self.terms
+        if first_touch is None and not os.environ.get('NUTILS_AMD_NO_BATCHED'):
+            terms = self._batched(terms, values, mask, arguments)
         for iterm, (smp, itg, fac) in enumerate(terms):
             if itg.measure is None:
                 raise NotImplementedError('integrand without J(geom): reference-space integrals are outside the accelerated path')
@@ -616,6 +692,119 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
                             f0=float(itg.f0) * fac, out_scalar=scalar[0])
 
 
+def _fusable(itg):
+    '''Linear-form term (test dofs exposed) that nh_assemble_terms takes: a form applied to a bound field or a source, times optional
+    pointwise factors (coefficient function of x, polynomial of field values).'''
+    return (itg.measure is not None and itg.rows and not itg.cols and itg.qform is None and itg.qscalar is None
+            and (itg.B is not None or itg.L is not None) and (itg.fscale is None or (len(itg.fscale.args) <= 4 and len(itg.fscale.terms) <= 64)))
+
+
+def _launch_terms(items, blocks, arguments, ucache):
+    '''items: [(block index, sample, integrand, factor)] on ONE sample and measure; packed into as few nh_assemble_terms launches as the
+    limits of the entry allow (2 blocks / 4 test components, 6 fields / 8 components, 4 polynomials, 32 terms).'''
+    smp = items[0][1]
+    geom = smp.geometry(items[0][2].measure)
+    nd, nq = smp.ndims, smp.points.npoints
+
+    def dev_u(arg):
+        if arg.name not in ucache:
+            ucache[arg.name] = device.to_dev(_argument(arguments, arg), 'float64')
+        return ucache[arg.name]
+
+    pending = list(items)
+    while pending:
+        fkeys, bkeys, pkeys, terms, rest = [], [], [], [], []
+        for it in pending:
+            bi, _, itg, fac = it
+            need = ([itg.trial] if itg.B is not None else []) + (list(itg.fscale.args) if itg.fscale is not None else [])
+            newf = []
+            for a in need:
+                if not any(a.same(k) for k in fkeys + newf):
+                    newf.append(a)
+            newb = bi not in bkeys
+            newp = itg.fscale is not None and not any(itg.fscale is k for k in pkeys)
+            if (len(terms) >= 32 or len(fkeys) + len(newf) > 6 or sum(a.ncomp for a in fkeys + newf) > 8 or len(bkeys) + newb > 2
+                    or sum(blocks[b][0].ncomp for b in bkeys) + (blocks[bi][0].ncomp if newb else 0) > 4 or len(pkeys) + newp > 4):
+                rest.append(it)
+                continue
+            fkeys += newf
+            if newb:
+                bkeys.append(bi)
+            if newp:
+                pkeys.append(itg.fscale)
+            fidx = lambda a: next(i for i, k in enumerate(fkeys) if a.same(k))
+            t = dict(block=bkeys.index(bi), scale=smp.scale(itg.scale) if itg.scale is not None else None)
+            if itg.B is not None:
+                t['field'], t['C'] = fidx(itg.trial), numpy.asarray(itg.B, dtype=float) * fac
+            else:
+                t['f'] = numpy.asarray(itg.L, dtype=float) * fac
+            if itg.fscale is not None:
+                t['poly'] = next(i for i, k in enumerate(pkeys) if k is itg.fscale)
+            terms.append(t)
+        if not terms:  # (a single term beyond the limits: the per-term path takes anything)
+            for bi, smp_, itg, fac in pending:
+                _vector_term(smp_, itg, fac, arguments, blocks[bi][1], None)
+            return
+        fidx = lambda a: next(i for i, k in enumerate(fkeys) if a.same(k))
+        polys = []
+        for fp in pkeys:
+            keys = list(fp.terms)
+            polys.append(([(fidx(a), 0) for a in fp.args], [fp.terms[k] for k in keys], keys))
+        kernels.assemble_terms(nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, elist=smp._elist_dev,
+                               fields=[(smp.tables(a.basis).struct, dev_u(a), a.ncomp) for a in fkeys],
+                               blocks=[(smp.tables(blocks[b][0].basis).struct, blocks[b][0].ncomp, blocks[b][1]) for b in bkeys], terms=terms, polys=polys)
+        pending = rest
+
+
+def _vector_blocks(blocks, arguments, scalar):
+    '''Linear forms of one or more output blocks [(test argument, out tensor, terms)]: the structured P1-hex residual terms go through
+    nh_p1hex_apply, everything else that shares a sample and a measure through ONE fused element loop, the remainder term by term.'''
+    groups, ucache = {}, {}
+    for bi, (a0, out, terms) in enumerate(blocks):
+        for smp, itg, fac in terms:
+            if itg.measure is not None and itg.rows and _p1hex_apply_term(smp, itg, fac, arguments, out):
+                continue
+            if _fusable(itg) and all(a.ncomp == 1 for a in (itg.fscale.args if itg.fscale is not None else ())):
+                groups.setdefault((id(smp), id(itg.measure)), []).append((bi, smp, itg, fac))
+            else:
+                _vector_term(smp, itg, fac, arguments, out, scalar)
+    for items in groups.values():
+        _launch_terms(items, blocks, arguments, ucache)
+
+
+def _exposed_test(f):
+    '''Test argument of a vector-valued integral (all terms expose the same test space), or None.'''
+    exposed = [itg for _, itg, _ in f.terms if itg.rows]
+    if not exposed or len(exposed) != len(f.terms) or any(itg.cols for itg in exposed):
+        return None
+    a0 = exposed[0].test
+    if not all(itg.test.basis is a0.basis and itg.test.ncomp == a0.ncomp for itg in exposed):
+        return None
+    return a0
+
+
+def evaluate_blocks(fs, arguments):
+    '''The residual blocks of a multi-field system in one pass (solver.py:334-386 evaluates them as one compiled function): the terms
+    of all blocks that share a sample go through one element loop.  Integrals that are not plain linear forms are evaluated one by one.'''
+    tests = [_exposed_test(f) if isinstance(f, function.Integral) and f.terms else None for f in fs]
+    blocks, index = [], {}
+    for i, (f, a0) in enumerate(zip(fs, tests)):
+        if a0 is not None:
+            index[i] = len(blocks)
+            blocks.append((a0, device.zeros(a0.basis.ndofs * a0.ncomp, 'float64'), f.terms))
+    if blocks:
+        _vector_blocks(blocks, arguments, [device.zeros(1, 'float64'), 0.])
+    out = []
+    for i, f in enumerate(fs):
+        if i in index:
+            a0, o, _ = blocks[index[i]]
+            res = device.to_host(o)
+            out.append(res.reshape(a0.basis.ndofs, a0.ncomp) if a0.ncomp > 1 else res)
+        else:
+            out.append(evaluate(f, arguments))
+    return out
+
+
 def evaluate(f, arguments):
     '''Evaluate one Integral / as_csr / as_coo wrapper.'''
     from . import factor as _factor0
@@ -654,8 +843,11 @@ def evaluate(f, arguments):
             raise NotImplementedError('vector terms with different test spaces')
         out = device.zeros(a0.basis.ndofs * a0.ncomp, 'float64')
     scalar = [device.zeros(1, 'float64'), 0.]  # device accumulator, host-side addend
-    for smp, itg, fac in f.terms:
-        _vector_term(smp, itg, fac, arguments, out, scalar)
+    if out is not None:
+        _vector_blocks([(a0, out, f.terms)], arguments, scalar)
+    else:
+        for smp, itg, fac in f.terms:
+            _vector_term(smp, itg, fac, arguments, out, scalar)
     if out is not None:
         res = device.to_host(out)
         return res.reshape(a0.basis.ndofs, a0.ncomp) if a0.ncomp > 1 else res

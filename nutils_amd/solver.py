@@ -145,12 +145,19 @@ class System:
         return jac
 
     def assemble_residual(self, arguments):
+        sizes = [int(n) for n in numpy.diff(self.offsets)]
+        try:  # all blocks in one pass: the terms that share a sample go through one element loop (nh_assemble_terms)
+            live = [r for r in self.block_residual if r.terms]
+            vals = iter(_sample.evaluate_blocks(live, arguments))
+            return numpy.concatenate([numpy.asarray(next(vals), dtype=float).ravel() if r.terms else numpy.zeros(n) for r, n in zip(self.block_residual, sizes)])
+        except NotImplementedError:
+            pass
         parts = []
-        for r, size in zip(self.block_residual, numpy.diff(self.offsets)):
+        for r, size in zip(self.block_residual, sizes):
             try:  # all terms of a block share the test space: one device accumulator, one copy back
-                v = numpy.asarray(_sample.evaluate(r, arguments), dtype=float).ravel() if r.terms else numpy.zeros(int(size))
+                v = numpy.asarray(_sample.evaluate(r, arguments), dtype=float).ravel() if r.terms else numpy.zeros(size)
             except NotImplementedError:
-                v = numpy.zeros(int(size))
+                v = numpy.zeros(size)
                 for term in r.terms:
                     v += numpy.asarray(_sample.evaluate(function.Integral([term]), arguments)).ravel()
             parts.append(v)

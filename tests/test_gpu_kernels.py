@@ -576,3 +576,94 @@ def test_terms_ragged_and_errors(golden):
         kernels.assemble_terms(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, fields=[(b, u, 1)], blocks=[(b, 1, out)], terms=[dict(block=0, field=1, f=numpy.ones((1, 3)))])
     with pytest.raises(_lib.NutilsHipError, match='neither a form nor a source'):
         kernels.assemble_terms(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, fields=[(b, u, 1)], blocks=[(b, 1, out)], terms=[dict(block=0, field=0)])
+
+
+# ---- fused bilinear forms (nh_assemble_matrix_terms) ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize('name', SCALAR)
+def test_matrix_terms_scalar_golden(golden, name):
+    '''Stiffness + 2.5 x mass of the reference in ONE launch, several elements per workgroup.'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    rowptr, colidx = c.pattern.expand(1, 1, None)
+    values = device.zeros(colidx.numel(), 'float64')
+    kernels.assemble_matrix_terms(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=1, ncr=1, mask=None,
+                                  pattern=c.pattern, values=values, terms=[dict(C=oa.laplace_coefficient(c.nd)), dict(C=2.5 * oa.mass_coefficient(c.nd))])
+    assert numpy.array_equal(device.to_host(rowptr), g['K_rowptr']) and numpy.array_equal(device.to_host(colidx), g['K_colidx'])
+    assert numpy.array_equal(g['K_colidx'], g['M_colidx'])
+    close(device.to_host(values), g['K_values'] + 2.5 * g['M_values'], numpy.abs(g['K_values']).max())
+
+
+@pytest.mark.parametrize('name', ELAST)
+def test_matrix_terms_elasticity_golden(golden, name):
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    C = oa.elasticity_coefficient(c.nd, float(g['lam']), float(g['mu']))
+    mask = oa.block_mask(C)
+    rowptr, colidx = c.pattern.expand(c.nd, c.nd, mask)
+    values = device.zeros(colidx.numel(), 'float64')
+    kernels.assemble_matrix_terms(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=c.nd, ncr=c.nd, mask=mask,
+                                  pattern=c.pattern, values=values, terms=[dict(C=.25 * C), dict(C=.75 * C)])
+    assert numpy.array_equal(device.to_host(colidx), g['K_colidx'])
+    close(device.to_host(values), g['K_values'])
+
+
+@pytest.mark.parametrize('name', ['lap2d_spline2_5x4_iso', 'lap3d_p1_3_iso', 'lap1d_p1_5'])
+def test_matrix_terms_point_dependent_forms(golden, name):
+    '''Polynomial factor, scale array and the two product-rule kinds against nh_assemble_matrix with per-point tensors (cq_dev) built on the
+    host from nh_sample_eval values: the path (and the torch glue in front of it) that the fused entry replaces.'''
+    from nutils_amd import device, kernels
+    g = golden(name)
+    c = Case(g)
+    rng = numpy.random.default_rng(7)
+    nd, S, n = c.nd, 1 + c.nd, c.nelems * c.nq
+    us = [device.to_dev(rng.normal(size=c.ndofs), 'float64') for _ in range(2)]
+    sc = rng.uniform(.5, 1.5, n)
+    C0, B1, B2 = (rng.normal(size=(1, S, 1, S)) for _ in range(3))
+    L2 = rng.normal(size=(1, S))
+    coeffs, powers = [1.5, -.5, .25], [[1, 0], [0, 2], [2, 1]]
+    rowptr, colidx = c.pattern.expand(1, 1, None)
+    values = device.zeros(colidx.numel(), 'float64')
+    kernels.assemble_matrix_terms(nelems=c.nelems, ndims=nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=1, ncr=1, mask=None,
+                                  pattern=c.pattern, values=values, fields=[(c.basis, u, 1) for u in us], polys=[([(0, 0), (1, 0)], coeffs, powers)],
+                                  terms=[dict(C=C0, poly=0), dict(C=B1, kind=1, field=1, scale=device.to_dev(sc, 'float64')), dict(C=B2, kind=2, field=0, L=L2, poly=0)])
+    U = []
+    for u in us:
+        Ud = device.empty(n * S, 'float64')
+        kernels.sample_eval(nelems=c.nelems, ndims=nd, nq=c.nq, geom=c.geom, trial=c.basis, ncr=1, points=c.points, u=u, U=Ud)
+        U.append(device.to_host(Ud).reshape(n, S))
+    pv = sum(cf * U[0][:, 0] ** p0 * U[1][:, 0] ** p1 for cf, (p0, p1) in zip(coeffs, powers))
+    cq = pv[:, None, None] * C0[0, :, 0, :]
+    cq[:, :, 0] += sc[:, None] * (U[1] @ B1[0, :, 0, :].T)
+    cq += pv[:, None, None] * L2[0][None, :, None] * (U[0] @ B2[0, :, 0, :])[:, None, :]
+    ref = device.zeros(colidx.numel(), 'float64')
+    kernels.assemble_matrix(nelems=c.nelems, ndims=nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=1, ncr=1, C=numpy.ones((1, S, 1, S)),
+                            mask=None, pattern=c.pattern, values=ref, cq=device.to_dev(cq.reshape(-1), 'float64'))
+    close(device.to_host(values), device.to_host(ref))
+
+
+def test_matrix_terms_ragged(golden):
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden('hier_spline2_2d')
+    pts = device.to_dev(g['gauss_coords'], 'float64')
+    w = device.to_dev(g['gauss_weights'], 'float64')
+    nq = len(g['gauss_weights'])
+    geom = kernels.geometry_box(device.to_dev(g['elem_origin'], 'float64'), device.to_dev(g['elem_size'], 'float64'))
+    for key in 'th':
+        off_h = g[key + '_dof_offsets']
+        ne, ndofs = len(off_h) - 1, int(g[key + '_ndofs'])
+        off = device.to_dev(off_h, 'int64')
+        dofs = device.to_dev(g[key + '_dofs'], 'int32')
+        T = kernels.tabulate(device.to_dev(g[key + '_coeffs'], 'float64'), len(g[key + '_dofs']), g[key + '_coeffs'].shape[1], pts, nq, 2)
+        b = kernels.basis(T, dofs, nb=0, off=off)
+        pat = kernels.Pattern(ne, ndofs, ndofs, dofs, dofs, toff=off, roff=off)
+        rowptr, colidx = pat.expand()
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix_terms(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, test=b, trial=b, nct=1, ncr=1, mask=None, pattern=pat, values=values,
+                                      terms=[dict(C=oa.laplace_coefficient(2))])
+        close(device.to_host(values), g[key + 'K_values'])
