@@ -45,7 +45,7 @@ def parse():
     ap.add_argument('--n', '--elements-per-axis', dest='n', type=int, default=None,
                     help='elements per axis (per GPU with weak scaling; use the long form behind torch.distributed.run, whose parser claims --n)')
     ap.add_argument('--variant', choices=['iso', 'uniform'], default='iso')
-    ap.add_argument('--kernel', choices=['auto', 'generic', 'batched', 'fast'], default='auto')
+    ap.add_argument('--kernel', choices=['auto', 'generic', 'gather', 'batched', 'fast'], default='auto')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-graph', dest='graph', action='store_false', help='launch every step eagerly instead of replaying a captured HIP graph')
     a = ap.parse_args()

@@ -185,6 +185,16 @@ typedef struct {
                                         STORED, not added -- the caller does not zero-fill the values, and the ~70 % of the entries that
                                         receive a single contribution are not read */
 
+#define NH_MATRIX_GATHER 64          /* deterministic owner-side reduction instead of atomics (needs `pattern`, all elements of the pattern in one
+                                        call): the local matrices go to a scratch array, element by element, and every CSR entry is then
+                                        summed ONCE over its contributions in ascending (element, m, n) order -- the order in which the
+                                        reference's numpy.add.at / numeric.accumulate adds them (numeric.py:434-460, evaluable.py:603-605),
+                                        so repeated assemblies are bit-identical.  The gather map is built on the first such call and cached
+                                        in the pattern handle (one device sort of the element map). */
+
+#define NH_MATRIX_STORE 128          /* with NH_MATRIX_GATHER: the sums are STORED, values_dev is not read (first term on a fresh array: no
+                                        zero fill, no read-modify-write) */
+
 int nh_assemble_matrix(const nh_matrix_args *args, void *stream);
 
 /* ---- vector / functional assembly, point evaluation --------------------------------

@@ -122,6 +122,7 @@ struct MatK {
   const double *cq;  // per-point coefficient tensors [nelems][nq][nct][S][ncr][S], or NULL
   int use_w;      // pre-multiplied trial table W in LDS (pays when it does not cost occupancy)
   int exclusive;  // NH_MATRIX_EXCLUSIVE: no two elements of this launch share a matrix entry -> plain read-modify-write (deterministic)
+  double *local;  // NH_MATRIX_GATHER: element-major local matrices [emap position][nct * ncr] instead of the scatter
 };
 
 template <int ND>
@@ -220,6 +221,11 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
             for (int q = q0; q < q1; ++q) point(p.cq + ((p.emap_by_elem ? e : ie) * (i64)p.nq + q) * (form.nct * S * form.ncr * S) + coff, q);
           else
             for (int q = q0; q < q1; ++q) point(form.C + coff, q);
+        }
+        if (p.local) {
+          double *dst = p.local + (emap0 + m * nbr + n) * (form.nct * form.ncr) + c * form.ncr + d;
+          *dst = q0 ? *dst + acc : acc;
+          continue;
         }
         const i64 row = p.test.dofs[tdof0 + m];
         const i64 a0 = p.srowptr[row], len = p.srowptr[row + 1] - a0;
@@ -633,8 +639,8 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   NH_REQUIRE(a, "nh_assemble_matrix: NULL args");
   NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
   NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
-  NH_REQUIRE((a->flags & ~(NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_NO_MFMA | NH_MATRIX_FIRST_TOUCH)) == 0,
-             "nh_assemble_matrix: unknown flag bits 0x%x", a->flags & ~(NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_NO_MFMA | NH_MATRIX_FIRST_TOUCH));
+  NH_REQUIRE((a->flags & ~(NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_NO_MFMA | NH_MATRIX_FIRST_TOUCH | NH_MATRIX_GATHER | NH_MATRIX_STORE)) == 0,
+             "nh_assemble_matrix: unknown flag bits 0x%x", a->flags & ~(NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_NO_MFMA | NH_MATRIX_FIRST_TOUCH | NH_MATRIX_GATHER | NH_MATRIX_STORE));
   NH_REQUIRE(a->C_host && a->srowptr_dev && a->emap_dev && a->values_dev, "nh_assemble_matrix: NULL coefficient / pattern / values");
   NH_REQUIRE(a->test.T_dev && a->test.dofs_dev && a->trial.T_dev && a->trial.dofs_dev, "basis tables missing");
   int rc = check_geom(a->geom);
@@ -689,9 +695,37 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
     if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
   }
+  // NH_MATRIX_GATHER: local matrices to scratch, then one deterministic sum per CSR entry
+  p.local = nullptr;
+  const bool gather = (a->flags & NH_MATRIX_GATHER) != 0;
+  i64 local_ld = 0;  // > 0: the scratch is entry-major, local[(m * nbr + n) * ld + list position] (thread-per-element kernel)
+  NH_REQUIRE(gather || !(a->flags & NH_MATRIX_STORE), "NH_MATRIX_STORE is an option of NH_MATRIX_GATHER");
+  if (gather) {
+    NH_REQUIRE(a->pattern && a->pattern->nelems == a->nelems && !(a->flags & (NH_MATRIX_EXCLUSIVE | NH_MATRIX_FIRST_TOUCH)) && !(a->elist_dev && (a->flags & NH_MATRIX_EMAP_BY_ELEMENT)),
+               "NH_MATRIX_GATHER needs the pattern handle and all of its elements in one call");
+    nh_pattern *pat = const_cast<nh_pattern *>(a->pattern);
+    if ((rc = nh_gather_prepare(pat, a->test, nh_stream(stream))) != NH_OK) return rc;
+    double *scratch = nullptr;
+    // (the thread-per-element kernel writes blocks of 64 elements: room for the last, partly filled block)
+    const size_t padded = (size_t)((pat->nelems + 63) / 64 * 64) * std::max(pat->nbt * pat->nbr, 1);
+    if ((rc = nh_gather_scratch(std::max((size_t)pat->emap_len, padded) * a->nct * a->ncr, &scratch)) != NH_OK) return rc;
+    bool done = false;
+    if ((rc = nh_local_scalar(a, scratch, &done, nh_stream(stream))) != NH_OK) return rc;
+    if (done) {
+      GSlots gs;
+      memset(&gs, 0, sizeof gs);
+      gs.nct = form.nct, gs.ncr = form.ncr, gs.tot = form.tot;
+      for (int c = 0; c < MAXC; ++c) {
+        gs.cnt[c] = form.cnt[c], gs.cum[c] = form.cum[c];
+        for (int d = 0; d < MAXC; ++d) gs.dpos[c][d] = form.dpos[c][d], gs.mask[c][d] = form.mask[c][d];
+      }
+      return nh_gather_values(pat, scratch, a->nelems, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream));
+    }
+    p.local = scratch;
+  }
   // MFMA path: uniform shared tables, >= 16 local rows and columns, tile counts we instantiate
   const int Nloc = a->trial.nb * a->ncr;
-  if (!(a->flags & 4) && !a->cq_dev && p.same && a->test.nb >= 16 && Nloc >= 16 && !a->test.off_dev && a->ndims >= 2 && a->geom.kind != 0) {
+  if (!gather && !(a->flags & 4) && !a->cq_dev && p.same && a->test.nb >= 16 && Nloc >= 16 && !a->test.off_dev && a->ndims >= 2 && a->geom.kind != 0) {
     MfmaX x;
     x.nas = 0;
     for (int sa = 0; sa < S; ++sa) {
@@ -777,9 +811,19 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
       q.maxnbr = a->pattern->bucket_nbr[b];
       if ((rc = launch_generic(q)) != NH_OK) return rc;
     }
-    return NH_OK;
+  } else if ((rc = launch_generic(p)) != NH_OK)
+    return rc;
+  if (gather) {
+    GSlots gs;
+    memset(&gs, 0, sizeof gs);
+    gs.nct = form.nct, gs.ncr = form.ncr, gs.tot = form.tot;
+    for (int c = 0; c < MAXC; ++c) {
+      gs.cnt[c] = form.cnt[c], gs.cum[c] = form.cum[c];
+      for (int d = 0; d < MAXC; ++d) gs.dpos[c][d] = form.dpos[c][d], gs.mask[c][d] = form.mask[c][d];
+    }
+    return nh_gather_values(a->pattern, p.local, local_ld, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream));
   }
-  return launch_generic(p);
+  return NH_OK;
 }
 
 int nh_assemble_vector(const nh_vector_args *a, void *stream) {

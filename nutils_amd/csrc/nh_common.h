@@ -76,4 +76,23 @@ struct nh_pattern {
   int32_t *bucket_elist[NH_MAX_BUCKETS];  // views into bucket_store
   int bucket_nbt[NH_MAX_BUCKETS], bucket_nbr[NH_MAX_BUCKETS];
   int32_t *bucket_store;
+  // gather map (nh_gather.hip; built on the first NH_MATRIX_GATHER assembly): for scalar entry k the local-matrix positions
+  // gsrc[gptr[k] .. gptr[k+1]) in ascending order (element, m, n) -- the order numpy.add.at accumulates them in -- and the row of k
+  int32_t *gsrc;
+  i64 *gptr;
+  int32_t *grow;
 };
+
+// component-block layout of an expanded pattern (mirrors FormK of nh_assemble_generic.hip)
+struct GSlots {
+  int nct, ncr, tot;
+  int cnt[4], cum[4];
+  signed char dpos[4][4];
+  unsigned char mask[4][4];
+};
+
+// nh_gather.hip: deterministic two-pass scatter (element-major local matrices, then one sum per CSR entry)
+int nh_gather_prepare(nh_pattern *p, const nh_basis &test, hipStream_t s);
+int nh_gather_scratch(size_t doubles, double **out);
+int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s);
+int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);

@@ -1,0 +1,302 @@
+// Deterministic owner-side reduction for unstructured / ragged connectivity (NH_MATRIX_GATHER, include/nutils_hip.h).
+// The generic element kernels scatter their local matrices with one f64 atomic per entry (134 M for the 128^3 trilinear mesh); here
+//   pass 1  writes the local matrices to a scratch array, element by element (coalesced, no atomics), and
+//   pass 2  sums, for every CSR entry ONCE, its contributions through a gather map in ascending (element, m, n) order --
+// the order in which the reference accumulates them (numpy.add.at / numeric.accumulate over the flattened element loop,
+// numeric.py:434-460; evaluable.py:603-605), so the result does not depend on the scheduling of the element kernel.
+// The map is the stable sort of the element map by CSR entry; it is built once per pattern handle.
+#include "nh_common.h"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+
+namespace {
+
+#include "nh_geom.inc"
+
+__device__ __forceinline__ i64 boff(const BasisK &b, i64 e) { return b.off ? b.off[e] : e * (i64)b.nb; }
+__device__ __forceinline__ int bnb(const BasisK &b, i64 e) { return b.off ? (int)(b.off[e + 1] - b.off[e]) : b.nb; }
+__device__ __forceinline__ i64 bfn(const BasisK &b, i64 e) { return b.off ? b.off[e] : (b.tab ? (i64)b.tab[e] * b.nb : 0); }
+
+// key of local position i = (element, m, n): its scalar CSR entry
+__global__ void k_gather_keys(i64 nelems, BasisK test, int nbr_uniform, const i64 *eoff, const i64 *srowptr, const int32_t *emap, unsigned *keys,
+                              unsigned *vals, int *counts) {
+  for (i64 e = blockIdx.x; e < nelems; e += gridDim.x) {
+    const int nbt = bnb(test, e);
+    if (!nbt) continue;
+    const i64 t0 = boff(test, e);
+    const i64 e0 = eoff ? eoff[e] : e * (i64)nbt * nbr_uniform;
+    const i64 cnt = (eoff ? eoff[e + 1] : e0 + (i64)nbt * nbr_uniform) - e0;
+    const int nbr = (int)(cnt / nbt);
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+      const int m = i / nbr;
+      const i64 k = srowptr[test.dofs[t0 + m]] + emap[e0 + i];
+      keys[e0 + i] = (unsigned)k;
+      vals[e0 + i] = (unsigned)(e0 + i);
+      atomicAdd(counts + k, 1);
+    }
+  }
+}
+
+__global__ void k_rowof(i64 nrows, const i64 *srowptr, int32_t *grow) {
+  for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (i64)gridDim.x * blockDim.x)
+    for (i64 k = srowptr[r]; k < srowptr[r + 1]; ++k) grow[k] = (int32_t)r;
+}
+
+// pass 2: one thread per scalar entry; local: element-major [position][nct * ncr]
+__global__ void k_gather_values(i64 nnz, const i64 *gptr, const int32_t *gsrc, const int32_t *grow, const i64 *srowptr, const double *local, i64 ld, int per,
+                                GSlots gs, double *values, int store) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const i64 b = gptr[k], e = gptr[k + 1];
+  const int ncd = gs.nct * gs.ncr;
+  if (ncd == 1) {  // scalar: the expanded pattern is the scalar one
+    double s = 0;
+    for (i64 i = b; i < e; ++i) s += local[(unsigned)gsrc[i]];
+    values[k] = store ? s : values[k] + s;
+    return;
+  }
+  const i64 r = grow[k], a0 = srowptr[r], len = srowptr[r + 1] - a0, pos = k - a0;
+  for (int c = 0; c < gs.nct; ++c)
+    for (int d = 0; d < gs.ncr; ++d) {
+      if (!gs.mask[c][d]) continue;
+      double s = 0;
+      for (i64 i = b; i < e; ++i) s += local[(i64)(unsigned)gsrc[i] * ncd + c * gs.ncr + d];
+      double *dst = values + a0 * gs.tot + len * gs.cum[c] + pos * gs.cnt[c] + gs.dpos[c][d];
+      *dst = store ? s : *dst + s;
+    }
+}
+
+// ---- pass 1 for small scalar elements: ONE THREAD per element, the local matrix in registers --------------------------------------------
+// (the one-wave-per-element kernel spends ~500 wave instructions on a trilinear element: lanes idle in the pointwise stages, LDS staging,
+// barriers; a thread that keeps the NBT x NBR sums in registers needs ~90 per element and no LDS at all)
+struct LocK {
+  i64 nelems;
+  const int32_t *elist;
+  int nq;
+  const double *weights;
+  GeomK geom;
+  BasisK test, trial;
+  const double *scale;
+  int by_elem;
+  double C[16];  // [a][b]
+  double *local;
+};
+
+template <int ND, int NBT, int NBR>
+__global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
+  constexpr int S = 1 + ND, NG = 1 << ND;
+  const i64 ie = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ie >= p.nelems) return;
+  const i64 e = p.elist ? p.elist[ie] : ie;
+  double A[NBT][NBR];
+#pragma unroll
+  for (int m = 0; m < NBT; ++m)
+#pragma unroll
+    for (int n = 0; n < NBR; ++n) A[m][n] = 0;
+  // multilinear isoparametric geometry: the vertices of the element once, not once per point
+  const bool iso = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG;
+  double X[NG][ND];
+  if (iso) {
+#pragma unroll
+    for (int a = 0; a < NG; ++a) {
+      const i64 v = p.geom.gdofs[e * NG + a];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) X[a][i] = p.geom.verts[v * ND + i];
+    }
+  }
+  const double *Tt = p.test.T + bfn(p.test, e) * p.nq * S, *Tr = p.trial.T + bfn(p.trial, e) * p.nq * S;
+  for (int q = 0; q < p.nq; ++q) {
+    double Ji[ND][ND], det;
+    if (iso) {
+      double J[ND][ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int j = 0; j < ND; ++j) J[i][j] = 0;
+#pragma unroll
+      for (int a = 0; a < NG; ++a) {
+        const double *t = p.geom.gT + ((i64)a * p.nq + q) * S;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) J[i][j] += X[a][i] * t[1 + j];
+      }
+      invert<ND>(J, Ji, det);
+      if (p.geom.bnd_axis >= 0) {
+        double s2 = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+            if (j == p.geom.bnd_axis) s2 += Ji[j][i] * Ji[j][i];
+        det *= sqrt(s2);
+      }
+    } else
+      geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
+    const double w = p.weights[q] * fabs(det) * (p.scale ? p.scale[(p.by_elem ? e : ie) * p.nq + q] : 1.);
+    // trial side premultiplied by the form and the weight: W[n][a] = w sum_b C[a][b] Dr[n][b]
+    double W[NBR][S];
+#pragma unroll
+    for (int n = 0; n < NBR; ++n) {
+      const double *T = Tr + ((size_t)n * p.nq + q) * S;
+      double dr[S];
+      dr[0] = T[0];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) s += T[1 + j] * Ji[j][i];
+        dr[1 + i] = s;
+      }
+#pragma unroll
+      for (int a = 0; a < S; ++a) {
+        double s = 0;
+#pragma unroll
+        for (int b = 0; b < S; ++b) s += p.C[a * S + b] * dr[b];
+        W[n][a] = w * s;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NBT; ++m) {
+      const double *T = Tt + ((size_t)m * p.nq + q) * S;
+      double dt[S];
+      dt[0] = T[0];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) s += T[1 + j] * Ji[j][i];
+        dt[1 + i] = s;
+      }
+#pragma unroll
+      for (int n = 0; n < NBR; ++n)
+#pragma unroll
+        for (int a = 0; a < S; ++a) A[m][n] += dt[a] * W[n][a];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < NBT; ++m)
+#pragma unroll
+    for (int n = 0; n < NBR; ++n) p.local[ie * (NBT * NBR) + m * NBR + n] = A[m][n];  // element-major: the gather of a CSR row reads whole rows of the local matrices
+}
+
+double *g_scratch = nullptr;
+size_t g_scratch_cap = 0;
+
+}  // namespace
+
+int nh_gather_scratch(size_t doubles, double **out) {
+  if (doubles > g_scratch_cap) {
+    if (g_scratch) {
+      NH_CHECK_HIP(hipDeviceSynchronize());
+      NH_CHECK_HIP(hipFree(g_scratch));
+      g_scratch = nullptr, g_scratch_cap = 0;
+    }
+    NH_CHECK_HIP(hipMalloc((void **)&g_scratch, doubles * sizeof(double)));
+    g_scratch_cap = doubles;
+  }
+  *out = g_scratch;
+  return NH_OK;
+}
+
+int nh_gather_prepare(nh_pattern *p, const nh_basis &test, hipStream_t s) {
+  if (p->gsrc) return NH_OK;
+  NH_REQUIRE(p->emap_len < (1ll << 32) && p->nnz < (1ll << 32), "NH_MATRIX_GATHER: pattern too large for 32-bit gather indices");
+  NH_REQUIRE(test.dofs_dev, "NH_MATRIX_GATHER: test dofs missing");
+  const i64 n = p->emap_len, nnz = p->nnz;
+  unsigned *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
+  int *counts = nullptr;
+  void *tmp = nullptr;
+  int rc = NH_OK;
+#define GP_CHECK(expr)                                                                          \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      nh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+      rc = NH_EHIP;                                                                             \
+      goto done;                                                                                \
+    }                                                                                           \
+  } while (0)
+  {
+    GP_CHECK(hipMalloc((void **)&keys, n * 4));
+    GP_CHECK(hipMalloc((void **)&vals, n * 4));
+    GP_CHECK(hipMalloc((void **)&keys2, n * 4));
+    GP_CHECK(hipMalloc((void **)&vals2, n * 4));
+    GP_CHECK(hipMalloc((void **)&counts, (nnz + 1) * 4));
+    GP_CHECK(hipMemsetAsync(counts, 0, (nnz + 1) * 4, s));
+    hipLaunchKernelGGL(k_gather_keys, dim3((unsigned)std::min<i64>(p->nelems, 1 << 20)), dim3(64), 0, s, p->nelems, to_k(test), p->nbr, p->eoff, p->srowptr, p->emap, keys,
+                       vals, counts);
+    GP_CHECK(hipGetLastError());
+    int bits = 1;
+    while ((1ll << bits) < nnz) ++bits;
+    size_t tmpsz = 0;
+    GP_CHECK(rocprim::radix_sort_pairs(nullptr, tmpsz, keys, keys2, vals, vals2, (size_t)n, 0, bits, s));
+    GP_CHECK(hipMalloc(&tmp, tmpsz));
+    GP_CHECK(rocprim::radix_sort_pairs(tmp, tmpsz, keys, keys2, vals, vals2, (size_t)n, 0, bits, s));  // stable: sources stay in (element, m, n) order
+    GP_CHECK(hipMalloc((void **)&p->gptr, (nnz + 1) * sizeof(i64)));
+    if ((rc = nh_scan_exclusive(counts, p->gptr, nnz, s)) != NH_OK) goto done;
+    GP_CHECK(hipMalloc((void **)&p->grow, std::max<i64>(nnz, 1) * 4));
+    hipLaunchKernelGGL(k_rowof, dim3((unsigned)std::min<i64>((p->nrows + 255) / 256, 1 << 16)), dim3(256), 0, s, p->nrows, p->srowptr, p->grow);
+    GP_CHECK(hipGetLastError());
+    GP_CHECK(hipStreamSynchronize(s));
+    p->gsrc = reinterpret_cast<int32_t *>(vals2);
+    vals2 = nullptr;
+  }
+done:
+#undef GP_CHECK
+  hipFree(keys);
+  hipFree(vals);
+  hipFree(keys2);
+  hipFree(vals2);
+  hipFree(counts);
+  hipFree(tmp);
+  if (rc != NH_OK) {
+    hipFree(p->gptr), hipFree(p->grow);
+    p->gptr = nullptr, p->grow = nullptr, p->gsrc = nullptr;
+  }
+  return rc;
+}
+
+int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s) {
+  if (!p->nnz) return NH_OK;
+  hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, ld, p->nbt * p->nbr, slots,
+                     values, store);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+// thread-per-element pass 1 for scalar forms on uniform bases of the instantiated sizes; *done = false: the caller runs the generic kernel
+int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s) {
+  *done = false;
+  if (a->nct != 1 || a->ncr != 1 || a->cq_dev || a->test.off_dev || a->trial.off_dev || !a->test.nb || !a->trial.nb) return NH_OK;
+  const int S = 1 + a->ndims;
+  LocK p;
+  p.nelems = a->nelems;
+  p.elist = a->elist_dev;
+  p.nq = a->nq;
+  p.weights = a->weights_dev;
+  p.geom = to_k(a->geom);
+  p.test = to_k(a->test);
+  p.trial = to_k(a->trial);
+  p.scale = a->scale_dev;
+  p.by_elem = (a->flags & NH_MATRIX_EMAP_BY_ELEMENT) != 0;
+  for (int i = 0; i < 16; ++i) p.C[i] = i < S * S ? a->C_host[i] : 0.;
+  p.local = local;
+  dim3 grid((unsigned)((a->nelems + 127) / 128)), block(128);
+  const int key = a->ndims * 10000 + a->test.nb * 100 + a->trial.nb;
+#define LOC(ND, NBT, NBR) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR>), grid, block, 0, s, p)
+  switch (key) {
+    case 10202: LOC(1, 2, 2); break;
+    case 10303: LOC(1, 3, 3); break;
+    case 20303: LOC(2, 3, 3); break;
+    case 20404: LOC(2, 4, 4); break;
+    case 20909: LOC(2, 9, 9); break;
+    case 30404: LOC(3, 4, 4); break;
+    case 30808: LOC(3, 8, 8); break;
+    default: return NH_OK;
+  }
+#undef LOC
+  NH_LAUNCH_CHECK();
+  *done = true;
+  return NH_OK;
+}

@@ -393,6 +393,9 @@ int nh_pattern_free(nh_pattern *p) {
   hipFree(p->emap);
   hipFree(p->eoff);
   hipFree(p->bucket_store);
+  hipFree(p->gsrc);
+  hipFree(p->gptr);
+  hipFree(p->grow);
   delete p;
   return NH_OK;
 }

@@ -109,8 +109,10 @@ def basis(T, dofs, nb=0, off=None, tab=None):
 
 
 def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0,
-                    cq=None, first_touch=None):
-    '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.  `first_touch=(grid_shape, nodes_per_axis)`: NH_MATRIX_FIRST_TOUCH.'''
+                    cq=None, first_touch=None, gather=None, store=False):
+    '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.  `first_touch=(grid_shape, nodes_per_axis)`: NH_MATRIX_FIRST_TOUCH.
+    gather: NH_MATRIX_GATHER (deterministic owner-side reduction instead of atomics); None = from the second assembly on a pattern on (the gather
+    map costs one device sort of the element map, which a one-off assembly does not earn back).'''
     C = numpy.ascontiguousarray(C, dtype=float)
     if C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
         raise ValueError(f'coefficient tensor has shape {C.shape}, expected {(nct, 1 + ndims, ncr, 1 + ndims)}')
@@ -125,6 +127,18 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
         args.nodes_per_axis = int(first_touch[1])
     if elist is None and emap_offset == 0 and not os.environ.get('NUTILS_AMD_NO_BUCKETS'):
         args.pattern = pattern._handle  # ragged bases: launches per size class of the pattern
+    whole = emap_offset == 0 and not flags and not first_touch and nelems == pattern.nelems
+    if gather is None:
+        gather = whole and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')
+    if whole:
+        pattern._assemblies = getattr(pattern, '_assemblies', 0) + 1
+    if gather:
+        if not whole:
+            raise ValueError('gather needs all elements of the pattern in one call')
+        args.pattern = pattern._handle
+        args.flags |= 64 | (128 if store else 0)
+    elif store:
+        raise ValueError('store is an option of the gather path')
     _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
 
 

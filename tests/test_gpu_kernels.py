@@ -667,3 +667,71 @@ def test_matrix_terms_ragged(golden):
         kernels.assemble_matrix_terms(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, test=b, trial=b, nct=1, ncr=1, mask=None, pattern=pat, values=values,
                                       terms=[dict(C=oa.laplace_coefficient(2))])
         close(device.to_host(values), g[key + 'K_values'])
+
+
+# ---- deterministic owner-side reduction (NH_MATRIX_GATHER) ---------------------------------------------------------------------
+
+@pytest.mark.parametrize('name', SCALAR + ELAST)
+def test_gather_equals_atomics_and_is_reproducible(golden, name):
+    '''Local matrices to scratch + one sum per CSR entry in (element, m, n) order: the golden values of the reference, and bit-identical
+    results for repeated assemblies (the atomic scatter is only reproducible to rounding).'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    if name in ELAST:
+        nc, C = c.nd, oa.elasticity_coefficient(c.nd, float(g['lam']), float(g['mu']))
+        mask = oa.block_mask(C)
+    else:
+        nc, C, mask = 1, oa.laplace_coefficient(c.nd), None
+    rowptr, colidx = c.pattern.expand(nc, nc, mask)
+    out = []
+    for it in range(3):
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=nc, ncr=nc, C=C, mask=mask,
+                                pattern=c.pattern, values=values, gather=True)
+        out.append(device.to_host(values))
+    close(out[0], g['K_values'])
+    assert numpy.array_equal(out[0], out[1]) and numpy.array_equal(out[0], out[2])
+
+
+def test_gather_ragged_and_structured_large(golden):
+    '''Ragged bases (size classes + gather) and a structured trilinear mesh of 24^3 elements against the atomic scatter.'''
+    from nutils_amd import device, kernels, mesh, sample, points
+    from oracle import assemble as oa
+    g = golden('hier_spline2_2d')
+    pts = device.to_dev(g['gauss_coords'], 'float64')
+    w = device.to_dev(g['gauss_weights'], 'float64')
+    nq = len(g['gauss_weights'])
+    geom = kernels.geometry_box(device.to_dev(g['elem_origin'], 'float64'), device.to_dev(g['elem_size'], 'float64'))
+    for key in 'th':
+        off_h = g[key + '_dof_offsets']
+        ne, ndofs = len(off_h) - 1, int(g[key + '_ndofs'])
+        off = device.to_dev(off_h, 'int64')
+        dofs = device.to_dev(g[key + '_dofs'], 'int32')
+        T = kernels.tabulate(device.to_dev(g[key + '_coeffs'], 'float64'), len(g[key + '_dofs']), g[key + '_coeffs'].shape[1], pts, nq, 2)
+        b = kernels.basis(T, dofs, nb=0, off=off)
+        pat = kernels.Pattern(ne, ndofs, ndofs, dofs, dofs, toff=off, roff=off)
+        rowptr, colidx = pat.expand()
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, test=b, trial=b, nct=1, ncr=1, C=oa.laplace_coefficient(2), mask=None, pattern=pat,
+                                values=values, gather=True)
+        close(device.to_host(values), g[key + 'K_values'])
+    # structured: the API path switches to the gather on the second assembly of a pattern
+    from nutils_amd import function
+    rng = numpy.random.default_rng(2)
+    domain, geom0 = mesh.rectilinear([24, 24, 24])
+    basis = domain.basis('std', degree=1)
+    verts = numpy.stack(numpy.meshgrid(*[numpy.arange(25.)] * 3, indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, (len(basis), 3))
+    geomf = basis @ verts
+    K = domain.integral((function.outer(function.grad(basis, geomf)).sum(-1) + 3. * function.outer(basis)) * function.J(geomf), degree=2)
+    import os
+    os.environ['NUTILS_AMD_NO_FAST_PATH'] = '1'
+    try:
+        v0, rp, ci = function.eval(function.as_csr(K))  # first assembly: atomics
+        v1, _, _ = function.eval(function.as_csr(K))    # second: gather
+        v2, _, _ = function.eval(function.as_csr(K))
+    finally:
+        del os.environ['NUTILS_AMD_NO_FAST_PATH']
+    close(v1, v0)
+    assert numpy.array_equal(v1, v2)
