@@ -318,13 +318,16 @@ typedef struct {
   const int32_t *emap_dev;
   const int64_t *eoff_dev;
   double *values_dev;
-  int flags;                 /* NH_MATRIX_EMAP_BY_ELEMENT */
+  int flags;                 /* NH_MATRIX_EMAP_BY_ELEMENT, NH_MATRIX_GATHER, NH_MATRIX_STORE */
   int nfields;
   const nh_field *fields;
   int nterms;
   const nh_matrix_term *terms;
   int npolys;
   const nh_point_poly *polys;
+  const nh_pattern *pattern; /* optional pattern handle: with NH_MATRIX_GATHER (| NH_MATRIX_STORE) in flags, scalar blocks on small uniform bases
+                                (2 x 2 ... 9 x 9 local matrices, at most two scalar fields on the test basis) are assembled by a thread-per-element
+                                pass + the owner-side reduction of nh_assemble_matrix; other blocks ignore NH_MATRIX_GATHER */
 } nh_matrix_terms_args;
 
 int nh_assemble_matrix_terms(const nh_matrix_terms_args *args, void *stream);

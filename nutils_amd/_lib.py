@@ -82,7 +82,7 @@ class MatrixTermsArgs(ctypes.Structure):
     _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp), ('geom', Geometry),
                 ('test', Basis), ('trial', Basis), ('nct', ctypes.c_int), ('ncr', ctypes.c_int), ('mask_host', vp), ('srowptr_dev', vp), ('emap_dev', vp),
                 ('eoff_dev', vp), ('values_dev', vp), ('flags', ctypes.c_int), ('nfields', ctypes.c_int), ('fields', ctypes.POINTER(Field)),
-                ('nterms', ctypes.c_int), ('terms', ctypes.POINTER(MatrixTerm)), ('npolys', ctypes.c_int), ('polys', ctypes.POINTER(PointPoly))]
+                ('nterms', ctypes.c_int), ('terms', ctypes.POINTER(MatrixTerm)), ('npolys', ctypes.c_int), ('polys', ctypes.POINTER(PointPoly)), ('pattern', vp)]
 
 
 class EvalArgs(ctypes.Structure):

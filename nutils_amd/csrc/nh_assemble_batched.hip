@@ -529,6 +529,219 @@ __global__ __launch_bounds__(NTB) void k_mterms(MTermsK p) {
 #endif
 }
 
+// ---- fused bilinear forms, scalar, small uniform bases: rows of the local matrix per THREAD, owner-side reduction -------------------------------
+// (nh_gather.hip: the thread-per-element pass is ~5x cheaper than a workgroup pipeline for local matrices of this size; here with the term
+// list of nh_assemble_matrix_terms evaluated at the point in registers.)  Thread = (element, block of MB test functions); up to NF scalar
+// fields on the test basis, their element coefficients in registers; the local matrix goes to the element-major scratch of NH_MATRIX_GATHER.
+struct LTermsK {
+  i64 nelems;
+  const int32_t *elist;
+  int nq;
+  const double *weights;
+  GeomK geom;
+  BasisK test, trial;
+  int by_elem;
+  int nterms, npolys;
+  const double *u[2];
+  const double *scale[MAXT];
+  int toff[MAXT], poff[MAXP];
+  int tlen;
+  double tabarg[TABARG];
+  double *local;
+};
+
+template <int ND, int NBT, int NBR, int MB, int NF>
+__global__ __launch_bounds__(128) void k_local_terms(LTermsK p) {
+  constexpr int S = 1 + ND, NG = 1 << ND, NMB = NBT / MB;
+  static_assert(NBT % MB == 0, "row blocks");
+  __shared__ double tab[TABARG];
+  for (int i = threadIdx.x; i < p.tlen; i += blockDim.x) tab[i] = p.tabarg[i];
+  __syncthreads();
+  const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 ie = t / NMB;
+  const int mb = (int)(t - ie * NMB) * MB;
+  if (ie >= p.nelems) return;
+  const i64 e = p.elist ? p.elist[ie] : ie;
+  double A[MB][NBR];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int n = 0; n < NBR; ++n) A[m][n] = 0;
+  const bool iso = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG;
+  double X[NG][ND];
+  if (iso) {
+#pragma unroll
+    for (int a = 0; a < NG; ++a) {
+      const i64 v = p.geom.gdofs[e * NG + a];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) X[a][i] = p.geom.verts[v * ND + i];
+    }
+  }
+  double ue[NF > 0 ? NF : 1][NBT];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int n = 0; n < NBT; ++n) ue[f][n] = p.u[f][p.test.dofs[e * (i64)NBT + n]];
+  const double *Tt = p.test.T + bfn(p.test, e) * p.nq * S, *Tr = p.trial.T + bfn(p.trial, e) * p.nq * S;
+  for (int q = 0; q < p.nq; ++q) {
+    double Ji[ND][ND], det;
+    if (iso) {
+      double J[ND][ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int j = 0; j < ND; ++j) J[i][j] = 0;
+#pragma unroll
+      for (int a = 0; a < NG; ++a) {
+        const double *tg = p.geom.gT + ((i64)a * p.nq + q) * S;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) J[i][j] += X[a][i] * tg[1 + j];
+      }
+      invert<ND>(J, Ji, det);
+      if (p.geom.bnd_axis >= 0) {
+        double s2 = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+            if (j == p.geom.bnd_axis) s2 += Ji[j][i] * Ji[j][i];
+        det *= sqrt(s2);
+      }
+    } else
+      geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
+    const double w = p.weights[q] * fabs(det);
+    const i64 ip = (p.by_elem ? e : ie) * p.nq + q;
+    // field values and physical gradients
+    double U[NF > 0 ? NF : 1][S];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      double r[S];
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) r[s2] = 0;
+#pragma unroll
+      for (int n = 0; n < NBT; ++n) {
+        const double *T = Tt + ((size_t)n * p.nq + q) * S;
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) r[s2] += T[s2] * ue[f][n];
+      }
+      U[f][0] = r[0];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        double sum = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) sum += r[1 + j] * Ji[j][i];
+        U[f][1 + i] = sum;
+      }
+    }
+    auto field = [&](int f, int s2) { return NF > 1 && f == 1 ? U[NF > 1 ? 1 : 0][s2] : U[0][s2]; };
+    // pointwise polynomials (variables: field values; slot = field index since the fields are scalar)
+    double pv[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      pv[k] = 1.;
+      if (k < p.npolys) {
+        const double *P = tab + p.poff[k];
+        const int nv = (int)P[0], nt = (int)P[1];
+        double x[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) x[v] = v < nv ? field((int)P[2 + v], 0) : 1.;
+        double sum = 0;
+        for (int t2 = 0; t2 < nt; ++t2) {
+          const double *M = P + 6 + 5 * t2;
+          double mm = M[0];
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            for (int k2 = (int)M[1 + v]; k2 > 0; --k2) mm *= x[v];
+          sum += mm;
+        }
+        pv[k] = sum;
+      }
+    }
+    // coefficient tensor of the point: sum of the terms
+    double Cq[S][S];
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+      for (int b = 0; b < S; ++b) Cq[a][b] = 0;
+    for (int t2 = 0; t2 < p.nterms; ++t2) {
+      const double *H = tab + p.toff[t2];
+      const int kind = (int)H[0], fld = (int)H[1], pol = (int)H[2];
+      double coef = p.scale[t2] ? p.scale[t2][ip] : 1.;
+      if (pol >= 0) coef *= pick(pv, pol);
+      const double *B = H + 3;
+      if (kind == 0) {
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+          for (int b = 0; b < S; ++b) Cq[a][b] += coef * B[a * S + b];
+      } else if (kind == 1) {
+#pragma unroll
+        for (int a = 0; a < S; ++a) {
+          double sum = 0;
+#pragma unroll
+          for (int b = 0; b < S; ++b) sum += B[a * S + b] * field(fld, b);
+          Cq[a][0] += coef * sum;
+        }
+      } else {
+        const double *L = B + S * S;
+#pragma unroll
+        for (int b = 0; b < S; ++b) {
+          double sum = 0;
+#pragma unroll
+          for (int x2 = 0; x2 < S; ++x2) sum += B[x2 * S + b] * field(fld, x2);
+#pragma unroll
+          for (int a = 0; a < S; ++a) Cq[a][b] += coef * L[a] * sum;
+        }
+      }
+    }
+    // trial side premultiplied: W[n][a] = w sum_b Cq[a][b] Dr[n][b]
+    double W[NBR][S];
+#pragma unroll
+    for (int n = 0; n < NBR; ++n) {
+      const double *T = Tr + ((size_t)n * p.nq + q) * S;
+      double dr[S];
+      dr[0] = T[0];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        double sum = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) sum += T[1 + j] * Ji[j][i];
+        dr[1 + i] = sum;
+      }
+#pragma unroll
+      for (int a = 0; a < S; ++a) {
+        double sum = 0;
+#pragma unroll
+        for (int b = 0; b < S; ++b) sum += Cq[a][b] * dr[b];
+        W[n][a] = w * sum;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const double *T = Tt + ((size_t)(mb + m) * p.nq + q) * S;
+      double dt[S];
+      dt[0] = T[0];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        double sum = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) sum += T[1 + j] * Ji[j][i];
+        dt[1 + i] = sum;
+      }
+#pragma unroll
+      for (int n = 0; n < NBR; ++n)
+#pragma unroll
+        for (int a = 0; a < S; ++a) A[m][n] += dt[a] * W[n][a];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int n = 0; n < NBR; ++n) p.local[ie * (NBT * NBR) + (mb + m) * NBR + n] = A[m][n];
+}
+
 int check_geom2(const nh_geometry &g) {
   if (g.kind == NH_GEOM_ISO) {
     NH_REQUIRE(g.ngb > 0 && g.gT_dev && g.gdofs_dev && g.verts_dev, "isoparametric geometry needs ngb, gT, gdofs, verts");
@@ -598,6 +811,66 @@ int place_table(const std::vector<double> &tab, double *tabarg, const double **t
   NH_CHECK_HIP(hipStreamSynchronize(s));
   NH_CHECK_HIP(hipMemcpy(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   *table = dtab;
+  return NH_OK;
+}
+
+// owner-side reduction for scalar blocks on small uniform bases (NH_MATRIX_GATHER): thread-per-element pass + gather; *done = false: not applicable
+int local_terms(const nh_matrix_terms_args *a, const MTermsK &m, const std::vector<double> &tab, bool *done, hipStream_t s) {
+  *done = false;
+  if (!a->pattern || a->pattern->nelems != a->nelems || (a->elist_dev && (a->flags & NH_MATRIX_EMAP_BY_ELEMENT))) return NH_OK;
+  if (a->nct != 1 || a->ncr != 1 || a->test.off_dev || a->trial.off_dev || !a->test.nb || !a->trial.nb || a->nfields > 2 || tab.size() > (size_t)TABARG) return NH_OK;
+  for (int f = 0; f < a->nfields; ++f)
+    if (!m.fields[f].tsame || a->fields[f].ncomp != 1) return NH_OK;
+  LTermsK p;
+  p.nelems = a->nelems, p.elist = a->elist_dev, p.nq = a->nq, p.weights = a->weights_dev;
+  p.geom = m.geom, p.test = m.test, p.trial = m.trial;
+  p.by_elem = m.emap_by_elem;
+  p.nterms = m.nterms, p.npolys = m.npolys;
+  p.u[0] = a->nfields > 0 ? a->fields[0].u_dev : nullptr;
+  p.u[1] = a->nfields > 1 ? a->fields[1].u_dev : nullptr;
+  for (int t = 0; t < MAXT; ++t) p.scale[t] = m.scale[t], p.toff[t] = m.toff[t];
+  for (int k = 0; k < MAXP; ++k) p.poff[k] = m.poff[k];
+  p.tlen = (int)tab.size();
+  std::copy(tab.begin(), tab.end(), p.tabarg);
+  int nmb = 0;
+  const int key = (a->ndims * 100 + a->test.nb) * 100 + a->trial.nb;
+  switch (key) {
+    case 10202: nmb = 1; break;
+    case 10303: nmb = 1; break;
+    case 20404: nmb = 1; break;
+    case 20909: nmb = 3; break;  // (one thread per element, 9 x 9 sums in 256 VGPRs: 0.85 against 0.90 ms on C4 -- not worth the occupancy)
+    case 30808: nmb = 2; break;
+    default: return NH_OK;
+  }
+  nh_pattern *pat = const_cast<nh_pattern *>(a->pattern);
+  int rc;
+  if ((rc = nh_gather_prepare(pat, a->test, s)) != NH_OK) return rc;
+  double *scratch = nullptr;
+  if ((rc = nh_gather_scratch((size_t)pat->emap_len, &scratch)) != NH_OK) return rc;
+  p.local = scratch;
+  const i64 nthreads = a->nelems * nmb;
+  dim3 grid((unsigned)((nthreads + 127) / 128)), block(128);
+#define LT(ND, NBT, NBR, MB)                                                                                  \
+  do {                                                                                                        \
+    if (a->nfields == 0) hipLaunchKernelGGL((k_local_terms<ND, NBT, NBR, MB, 0>), grid, block, 0, s, p);      \
+    else if (a->nfields == 1) hipLaunchKernelGGL((k_local_terms<ND, NBT, NBR, MB, 1>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((k_local_terms<ND, NBT, NBR, MB, 2>), grid, block, 0, s, p);                      \
+  } while (0)
+  switch (key) {
+    case 10202: LT(1, 2, 2, 2); break;
+    case 10303: LT(1, 3, 3, 3); break;
+    case 20404: LT(2, 4, 4, 4); break;
+    case 20909: LT(2, 9, 9, 3); break;
+    case 30808: LT(3, 8, 8, 4); break;
+  }
+#undef LT
+  NH_LAUNCH_CHECK();
+  GSlots gs;
+  memset(&gs, 0, sizeof gs);
+  gs.nct = gs.ncr = gs.tot = 1;
+  gs.cnt[0] = 1, gs.mask[0][0] = 1;
+  if ((rc = nh_gather_values(pat, scratch, 0, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, s)) != NH_OK) return rc;
+  *done = true;
   return NH_OK;
 }
 
@@ -696,7 +969,8 @@ extern "C" int nh_assemble_matrix_terms(const nh_matrix_terms_args *a, void *str
   NH_REQUIRE(a, "nh_assemble_matrix_terms: NULL args");
   NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
   NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
-  NH_REQUIRE((a->flags & ~NH_MATRIX_EMAP_BY_ELEMENT) == 0, "nh_assemble_matrix_terms: unknown flag bits 0x%x", a->flags & ~NH_MATRIX_EMAP_BY_ELEMENT);
+  NH_REQUIRE((a->flags & ~(NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_GATHER | NH_MATRIX_STORE)) == 0, "nh_assemble_matrix_terms: unknown flag bits 0x%x", a->flags & ~(NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_GATHER | NH_MATRIX_STORE));
+  NH_REQUIRE(!(a->flags & NH_MATRIX_STORE) || (a->flags & NH_MATRIX_GATHER), "NH_MATRIX_STORE is an option of NH_MATRIX_GATHER");
   NH_REQUIRE(a->srowptr_dev && a->emap_dev && a->values_dev, "nh_assemble_matrix_terms: NULL pattern / values");
   NH_REQUIRE(a->test.T_dev && a->test.dofs_dev && a->trial.T_dev && a->trial.dofs_dev, "basis tables missing");
   NH_REQUIRE(a->nct >= 1 && a->nct <= 3 && a->ncr >= 1 && a->ncr <= 3, "component counts must be 1..3 (got %d, %d)", a->nct, a->ncr);
@@ -780,6 +1054,12 @@ extern "C" int nh_assemble_matrix_terms(const nh_matrix_terms_args *a, void *str
   for (int k = 0; k < a->npolys; ++k)
     if ((rc = push_poly(a->polys[k], a->fields, a->nfields, p.fields, k, tab, &p.poff[k])) != NH_OK) return rc;
   p.tlen = (int)tab.size();
+  if (a->flags & NH_MATRIX_GATHER) {
+    bool done = false;
+    if ((rc = local_terms(a, p, tab, &done, nh_stream(stream))) != NH_OK) return rc;
+    if (done) return NH_OK;
+    NH_REQUIRE(!(a->flags & NH_MATRIX_STORE), "nh_assemble_matrix_terms: NH_MATRIX_STORE, but this block does not qualify for the owner-side reduction");
+  }
   p.same = (a->test.T_dev == a->trial.T_dev && a->test.off_dev == a->trial.off_dev && a->test.tab_dev == a->trial.tab_dev && a->test.nb == a->trial.nb);
   // elements per batch: fill the workgroup in the pointwise phase, within an LDS budget that keeps two workgroups per CU
   const size_t per_elem = sizeof(double) * (a->nq * ((size_t)CS + (size_t)(p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S) + p.uesz);

@@ -199,7 +199,8 @@ def _fields_polys(fields, polys, keep):
     return F, P
 
 
-def assemble_matrix_terms(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, mask, pattern, values, terms, fields=(), polys=(), elist=None, flags=0):
+def assemble_matrix_terms(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, mask, pattern, values, terms, fields=(), polys=(), elist=None, flags=0,
+                          gather=None):
     '''All bilinear-form terms of a matrix block in ONE element loop, several elements per workgroup (nh_assemble_matrix_terms); accumulates
     into `values`.  terms: [dict(C, kind=0, field=-1, poly=-1, L=None, scale=None)], fields / polys as in assemble_terms.'''
     S = 1 + ndims
@@ -218,8 +219,14 @@ def assemble_matrix_terms(*, nelems, ndims, nq, weights, geom, test, trial, nct,
                 raise ValueError(f'term {i}: L has shape {L.shape}')
         keep += [C, L]
         T[i] = _lib.MatrixTerm(int(t.get('kind', 0)), int(t.get('field', -1)), int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(L), device.ptr(t.get('scale')))
+    whole = not flags and nelems == pattern.nelems
+    if gather is None:  # (as in assemble_matrix: the owner-side reduction from the second assembly on a pattern on; blocks that do not qualify ignore it)
+        gather = whole and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')
+    if whole:
+        pattern._assemblies = getattr(pattern, '_assemblies', 0) + 1
     args = _lib.MatrixTermsArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(m), pattern.srowptr_ptr,
-                                pattern.emap_ptr, pattern.eoff_ptr, device.ptr(values), int(flags), len(fields), F, len(terms), T, len(polys), P)
+                                pattern.emap_ptr, pattern.eoff_ptr, device.ptr(values), int(flags) | (64 if gather and whole else 0), len(fields), F, len(terms), T,
+                                len(polys), P, pattern._handle)
     _lib.call('nh_assemble_matrix_terms', ctypes.byref(args), device.stream())
 
 

@@ -735,3 +735,29 @@ def test_gather_ragged_and_structured_large(golden):
         del os.environ['NUTILS_AMD_NO_FAST_PATH']
     close(v1, v0)
     assert numpy.array_equal(v1, v2)
+
+
+@pytest.mark.parametrize('name', ['lap2d_spline2_5x4_iso', 'lap2d_spline2_4x4', 'lap3d_p1_3_iso', 'lap2d_p1_4x3_iso', 'lap1d_p1_5'])
+def test_matrix_terms_gather_path(golden, name):
+    '''Scalar blocks on small uniform bases: thread-per-element pass + owner-side reduction (NH_MATRIX_GATHER through nh_assemble_matrix_terms)
+    against the workgroup-batched kernel with atomics, with polynomial factors and both product-rule kinds; bit-identical when repeated.'''
+    from nutils_amd import device, kernels
+    g = golden(name)
+    c = Case(g)
+    rng = numpy.random.default_rng(9)
+    nd, S, n = c.nd, 1 + c.nd, c.nelems * c.nq
+    us = [device.to_dev(rng.normal(size=c.ndofs), 'float64') for _ in range(2)]
+    sc = device.to_dev(rng.uniform(.5, 1.5, n), 'float64')
+    C0, B1, B2 = (rng.normal(size=(1, S, 1, S)) for _ in range(3))
+    L2 = rng.normal(size=(1, S))
+    kw = dict(nelems=c.nelems, ndims=nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=1, ncr=1, mask=None, pattern=c.pattern,
+              fields=[(c.basis, u, 1) for u in us], polys=[([(0, 0), (1, 0)], [1.5, -.5, .25], [[1, 0], [0, 2], [2, 1]])],
+              terms=[dict(C=C0, poly=0), dict(C=B1, kind=1, field=1, scale=sc), dict(C=B2, kind=2, field=0, L=L2, poly=0), dict(C=.5 * C0)])
+    rowptr, colidx = c.pattern.expand(1, 1, None)
+    out = []
+    for gather in (False, True, True):
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix_terms(values=values, gather=gather, **kw)
+        out.append(device.to_host(values))
+    close(out[1], out[0])
+    assert numpy.array_equal(out[1], out[2])
