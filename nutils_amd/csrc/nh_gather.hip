@@ -82,9 +82,22 @@ struct LocK {
   double *local;
 };
 
-template <int ND, int NBT, int NBR>
+template <int ND, int NBT, int NBR, bool LDST, bool SYMD>
 __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
+  // SYMD: test == trial basis and a DIAGONAL form tensor (Laplace, mass, reaction-diffusion): the local matrix is symmetric -- the upper triangle is
+  // accumulated and mirrored in the store -- and the trial side costs S multiplies instead of S * S multiply-adds per function
   constexpr int S = 1 + ND, NG = 1 << ND;
+  // LDST: one table for all elements (no tab / off array) -- test, trial and geometry tables are staged in LDS once per workgroup; read from
+  // global memory they are L1 hits, but 96 texture-path loads per point and thread with a wait in front of their first use
+  extern __shared__ __attribute__((aligned(16))) double sT[];
+  if (LDST) {
+    const int nt = NBT * p.nq * S, nr = NBR * p.nq * S, ng = NG * p.nq * S;
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) sT[i] = p.test.T[i];
+    for (int i = threadIdx.x; i < nr; i += blockDim.x) sT[nt + i] = p.trial.T[i];
+    if (p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG)
+      for (int i = threadIdx.x; i < ng; i += blockDim.x) sT[nt + nr + i] = p.geom.gT[i];
+    __syncthreads();
+  }
   const i64 ie = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (ie >= p.nelems) return;
   const i64 e = p.elist ? p.elist[ie] : ie;
@@ -104,7 +117,8 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
       for (int i = 0; i < ND; ++i) X[a][i] = p.geom.verts[v * ND + i];
     }
   }
-  const double *Tt = p.test.T + bfn(p.test, e) * p.nq * S, *Tr = p.trial.T + bfn(p.trial, e) * p.nq * S;
+  const double *Tt = LDST ? sT : p.test.T + bfn(p.test, e) * p.nq * S, *Tr = LDST ? sT + NBT * p.nq * S : p.trial.T + bfn(p.trial, e) * p.nq * S;
+  const double *gT = LDST ? sT + (NBT + NBR) * p.nq * S : p.geom.gT;
   for (int q = 0; q < p.nq; ++q) {
     double Ji[ND][ND], det;
     if (iso) {
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
         for (int j = 0; j < ND; ++j) J[i][j] = 0;
 #pragma unroll
       for (int a = 0; a < NG; ++a) {
-        const double *t = p.geom.gT + ((i64)a * p.nq + q) * S;
+        const double *t = gT + ((i64)a * p.nq + q) * S;
 #pragma unroll
         for (int i = 0; i < ND; ++i)
 #pragma unroll
@@ -135,49 +149,61 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
       geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
     const double w = p.weights[q] * fabs(det) * (p.scale ? p.scale[(p.by_elem ? e : ie) * p.nq + q] : 1.);
     // trial side premultiplied by the form and the weight: W[n][a] = w sum_b C[a][b] Dr[n][b]
-    double W[NBR][S];
+    double W[NBR][S], D[NBR][S];
 #pragma unroll
     for (int n = 0; n < NBR; ++n) {
       const double *T = Tr + ((size_t)n * p.nq + q) * S;
-      double dr[S];
-      dr[0] = T[0];
+      D[n][0] = T[0];
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
         double s = 0;
 #pragma unroll
         for (int j = 0; j < ND; ++j) s += T[1 + j] * Ji[j][i];
-        dr[1 + i] = s;
+        D[n][1 + i] = s;
       }
 #pragma unroll
       for (int a = 0; a < S; ++a) {
-        double s = 0;
+        if (SYMD)
+          W[n][a] = w * p.C[a * S + a] * D[n][a];
+        else {
+          double s = 0;
 #pragma unroll
-        for (int b = 0; b < S; ++b) s += p.C[a * S + b] * dr[b];
-        W[n][a] = w * s;
+          for (int b = 0; b < S; ++b) s += p.C[a * S + b] * D[n][b];
+          W[n][a] = w * s;
+        }
       }
     }
+    if (SYMD) {
 #pragma unroll
-    for (int m = 0; m < NBT; ++m) {
-      const double *T = Tt + ((size_t)m * p.nq + q) * S;
-      double dt[S];
-      dt[0] = T[0];
+      for (int m = 0; m < NBT; ++m)
 #pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        double s = 0;
+        for (int n = m; n < NBR; ++n)
 #pragma unroll
-        for (int j = 0; j < ND; ++j) s += T[1 + j] * Ji[j][i];
-        dt[1 + i] = s;
+          for (int a = 0; a < S; ++a) A[m][n] += D[m][a] * W[n][a];
+    } else {
+#pragma unroll
+      for (int m = 0; m < NBT; ++m) {
+        const double *T = Tt + ((size_t)m * p.nq + q) * S;
+        double dt[S];
+        dt[0] = T[0];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          double s = 0;
+#pragma unroll
+          for (int j = 0; j < ND; ++j) s += T[1 + j] * Ji[j][i];
+          dt[1 + i] = s;
+        }
+#pragma unroll
+        for (int n = 0; n < NBR; ++n)
+#pragma unroll
+          for (int a = 0; a < S; ++a) A[m][n] += dt[a] * W[n][a];
       }
-#pragma unroll
-      for (int n = 0; n < NBR; ++n)
-#pragma unroll
-        for (int a = 0; a < S; ++a) A[m][n] += dt[a] * W[n][a];
     }
   }
 #pragma unroll
   for (int m = 0; m < NBT; ++m)
 #pragma unroll
-    for (int n = 0; n < NBR; ++n) p.local[ie * (NBT * NBR) + m * NBR + n] = A[m][n];  // element-major: the gather of a CSR row reads whole rows of the local matrices
+    for (int n = 0; n < NBR; ++n) p.local[ie * (NBT * NBR) + m * NBR + n] = (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n];  // element-major: the gather of a CSR row reads whole rows of the local matrices
 }
 
 double *g_scratch = nullptr;
@@ -284,7 +310,19 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   p.local = local;
   dim3 grid((unsigned)((a->nelems + 127) / 128)), block(128);
   const int key = a->ndims * 10000 + a->test.nb * 100 + a->trial.nb;
-#define LOC(ND, NBT, NBR) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR>), grid, block, 0, s, p)
+  const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + a->trial.nb + (1 << a->ndims));
+  const bool ldst = !a->test.tab_dev && !a->trial.tab_dev && ldsb <= 32 * 1024;
+  bool symd = a->test.T_dev == a->trial.T_dev && a->test.tab_dev == a->trial.tab_dev && a->test.dofs_dev == a->trial.dofs_dev;
+  for (int i = 0; i < S * S; ++i)
+    if (i / S != i % S && a->C_host[i] != 0.) symd = false;
+#define LOC(ND, NBT, NBR)                                                                         \
+  do {                                                                                            \
+    if (NBT == NBR && symd) {                                                                            \
+      if (ldst) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, true, NBT == NBR>), grid, block, ldsb, s, p);  \
+      else hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, false, NBT == NBR>), grid, block, 0, s, p);  \
+    } else if (ldst) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, true, false>), grid, block, ldsb, s, p);  \
+    else hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, false, false>), grid, block, 0, s, p);         \
+  } while (0)
   switch (key) {
     case 10202: LOC(1, 2, 2); break;
     case 10303: LOC(1, 3, 3); break;
