@@ -756,13 +756,15 @@ int check_geom2(const nh_geometry &g) {
   return NH_OK;
 }
 
-int max_nb2(const nh_basis &b, i64 nelems, int *out) {
+int max_nb2(const nh_basis &b, i64 nelems, int *out, hipStream_t s) {
   if (b.nb > 0 || !b.off_dev) {
     *out = b.nb;
     return NH_OK;
   }
   std::vector<i64> h(nelems + 1);
-  NH_CHECK_HIP(hipMemcpy(h.data(), b.off_dev, sizeof(i64) * (nelems + 1), hipMemcpyDeviceToHost));
+  // (on the caller's stream: offsets produced asynchronously on that stream are complete when read)
+  NH_CHECK_HIP(hipMemcpyAsync(h.data(), b.off_dev, sizeof(i64) * (nelems + 1), hipMemcpyDeviceToHost, s));
+  NH_CHECK_HIP(hipStreamSynchronize(s));
   i64 m = 0;
   for (i64 e = 0; e < nelems; ++e) m = std::max(m, h[e + 1] - h[e]);
   *out = (int)m;
@@ -905,7 +907,7 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
     p.fields[f].ncomp = F.ncomp;
     p.fields[f].c0 = p.fct;
     p.fct += F.ncomp;
-    if ((rc = max_nb2(F.basis, a->nelems, &p.fields[f].maxnb)) != NH_OK) return rc;
+    if ((rc = max_nb2(F.basis, a->nelems, &p.fields[f].maxnb, nh_stream(stream))) != NH_OK) return rc;
     p.fields[f].ue0 = p.uesz;
     p.fields[f].tsame = 0;
     p.uesz += p.fields[f].maxnb * F.ncomp;
@@ -920,7 +922,7 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
     p.blocks[b].out = B.out_dev;
     p.blocks[b].nct = B.nct;
     p.blocks[b].c0 = p.ct;
-    if ((rc = max_nb2(B.test, a->nelems, &p.blocks[b].maxnb)) != NH_OK) return rc;
+    if ((rc = max_nb2(B.test, a->nelems, &p.blocks[b].maxnb, nh_stream(stream))) != NH_OK) return rc;
     p.ct += B.nct;
     p.rowsper += p.blocks[b].maxnb * B.nct;
   }
@@ -1008,7 +1010,7 @@ extern "C" int nh_assemble_matrix_terms(const nh_matrix_terms_args *a, void *str
     p.fields[f].ncomp = F.ncomp;
     p.fields[f].c0 = p.fct;
     p.fct += F.ncomp;
-    if ((rc = max_nb2(F.basis, a->nelems, &p.fields[f].maxnb)) != NH_OK) return rc;
+    if ((rc = max_nb2(F.basis, a->nelems, &p.fields[f].maxnb, nh_stream(stream))) != NH_OK) return rc;
     p.fields[f].ue0 = p.uesz;
     p.fields[f].tsame = (F.basis.T_dev == a->test.T_dev && F.basis.off_dev == a->test.off_dev && F.basis.tab_dev == a->test.tab_dev && F.basis.nb == a->test.nb);
     p.uesz += p.fields[f].maxnb * F.ncomp;
@@ -1016,8 +1018,8 @@ extern "C" int nh_assemble_matrix_terms(const nh_matrix_terms_args *a, void *str
   NH_REQUIRE(p.fct <= MAXFC, "nh_assemble_matrix_terms: more than %d field components", MAXFC);
   p.test = to_k(a->test), p.trial = to_k(a->trial);
   p.nct = a->nct, p.ncr = a->ncr;
-  if ((rc = max_nb2(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
-  if ((rc = max_nb2(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
+  if ((rc = max_nb2(a->test, a->nelems, &p.maxnbt, nh_stream(stream))) != NH_OK) return rc;
+  if ((rc = max_nb2(a->trial, a->nelems, &p.maxnbr, nh_stream(stream))) != NH_OK) return rc;
   p.srowptr = (const i64 *)a->srowptr_dev;
   p.emap = a->emap_dev;
   p.eoff = (const i64 *)a->eoff_dev;

@@ -615,14 +615,16 @@ int check_geom(const nh_geometry &g) {
   return NH_OK;
 }
 
-int max_nb(const nh_basis &b, i64 nelems, int *out) {
+int max_nb(const nh_basis &b, i64 nelems, int *out, hipStream_t s) {
   if (b.nb > 0 || !b.off_dev) {
     *out = b.nb;
     return NH_OK;
   }
   // ragged: scan the offsets on the host (called once per bucket; small)
   std::vector<i64> h(nelems + 1);
-  NH_CHECK_HIP(hipMemcpy(h.data(), b.off_dev, sizeof(i64) * (nelems + 1), hipMemcpyDeviceToHost));
+  // (on the caller's stream: offsets produced asynchronously on that stream are complete when read)
+  NH_CHECK_HIP(hipMemcpyAsync(h.data(), b.off_dev, sizeof(i64) * (nelems + 1), hipMemcpyDeviceToHost, s));
+  NH_CHECK_HIP(hipStreamSynchronize(s));
   i64 m = 0;
   for (i64 e = 0; e < nelems; ++e) m = std::max(m, h[e + 1] - h[e]);
   *out = (int)m;
@@ -692,8 +694,8 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
       p.maxnbr = std::max(p.maxnbr, a->pattern->bucket_nbr[b]);
     }
   } else {
-    if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
-    if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
+    if ((rc = max_nb(a->test, a->nelems, &p.maxnbt, nh_stream(stream))) != NH_OK) return rc;
+    if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr, nh_stream(stream))) != NH_OK) return rc;
   }
   // NH_MATRIX_GATHER: local matrices to scratch, then one deterministic sum per CSR entry
   p.local = nullptr;
@@ -857,8 +859,8 @@ int nh_assemble_vector(const nh_vector_args *a, void *stream) {
   p.f0 = a->f0;
   p.out_scalar = a->out_scalar_dev;
   p.scale = a->scale_dev;
-  if ((rc = max_nb(a->test, a->nelems, &p.maxnbt)) != NH_OK) return rc;
-  if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr)) != NH_OK) return rc;
+  if ((rc = max_nb(a->test, a->nelems, &p.maxnbt, nh_stream(stream))) != NH_OK) return rc;
+  if ((rc = max_nb(a->trial, a->nelems, &p.maxnbr, nh_stream(stream))) != NH_OK) return rc;
   p.cs = std::max(a->nct, a->ncr);
   const int per_q = ((p.same ? p.maxnbt : p.maxnbt + p.maxnbr) * S + 2 * p.cs * S) * (int)sizeof(double);
   p.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / per_q));
