@@ -26,6 +26,9 @@ def structured_dofs(shape, nloc, ndofs_axis, start_concat_dev, elem_begin, nelem
     return out
 
 
+GATHER_SCRATCH_LIMIT = 8 << 30
+
+
 class Pattern:
     '''K6 (nh_pattern_*): scalar sparsity pattern + element map, device resident.'''
 
@@ -129,7 +132,9 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
         args.pattern = pattern._handle  # ragged bases: launches per size class of the pattern
     whole = emap_offset == 0 and not flags and not first_touch and nelems == pattern.nelems
     if gather is None:
-        gather = whole and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')
+        # (automatic only while the scratch of the local matrices stays below GATHER_SCRATCH_LIMIT bytes: 1.07 GB for the 128^3 trilinear mesh)
+        gather = (whole and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')
+                  and 8 * pattern.emap_len * nct * ncr <= GATHER_SCRATCH_LIMIT and pattern.emap_len < 2 ** 32 and pattern.nnz_scalar < 2 ** 32)
     if whole:
         pattern._assemblies = getattr(pattern, '_assemblies', 0) + 1
     if gather:
@@ -221,7 +226,8 @@ def assemble_matrix_terms(*, nelems, ndims, nq, weights, geom, test, trial, nct,
         T[i] = _lib.MatrixTerm(int(t.get('kind', 0)), int(t.get('field', -1)), int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(L), device.ptr(t.get('scale')))
     whole = not flags and nelems == pattern.nelems
     if gather is None:  # (as in assemble_matrix: the owner-side reduction from the second assembly on a pattern on; blocks that do not qualify ignore it)
-        gather = whole and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')
+        gather = (whole and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')
+                  and 8 * pattern.emap_len <= GATHER_SCRATCH_LIMIT and pattern.emap_len < 2 ** 32 and pattern.nnz_scalar < 2 ** 32)
     if whole:
         pattern._assemblies = getattr(pattern, '_assemblies', 0) + 1
     args = _lib.MatrixTermsArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(m), pattern.srowptr_ptr,
