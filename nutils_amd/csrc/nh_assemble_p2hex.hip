@@ -525,7 +525,13 @@ __device__ __forceinline__ void pipe_meta(const P2K &p, const Line &L, double *l
 // / tail element by one lane.  All records are read together, then all data, then the stores: the flushing waves have nothing else
 // to hide an LDS round trip behind.
 template <int NC, int NBLK, int UB = 3>  // UB pairs per thread and block: 125 * 9 / 2 = 563 <= UB * nt
-__device__ __forceinline__ void flush_blocks(const P2K &p, double *lds, int K0, int c0, int t, int nt) {
+__device__ __forceinline__ void flush_blocks(const P2K &p, double *lds, int K0, int c0, int t, int nt, long long *ft = nullptr) {
+#if defined(NH_ABLATION) && !defined(NH_NOTICKS)
+  long long f0 = __builtin_readcyclecounter();
+#define FT(i) do { if (ft) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); ft[i] += t_ - f0; f0 = t_; } } while (0)
+#else
+#define FT(i) do {} while (0)
+#endif
   const int *meta = reinterpret_cast<const int *>(lds + PL<NC>::META);
   const i64 *gm = reinterpret_cast<const i64 *>(lds + PL<NC>::META + 64);
   int2 f[NBLK];
@@ -536,30 +542,25 @@ __device__ __forceinline__ void flush_blocks(const P2K &p, double *lds, int K0, 
     f[b] = *reinterpret_cast<const int2 *>(meta + 64 + s * 2);
     g[b] = gm[s];
   }
+  FT(0);
+  // read-and-clear in ONE LDS round trip per value (ds_wrxchg_rtn_b64): the separate zeroing pass was a second trip through an LDS queue that the
+  // ds_add_f64 stream of the MFMA waves keeps ~40 % busy (1.6 k + 0.9 k cycles per call of 4.0 k)
   v2d v[NBLK][UB];
   double hv[NBLK], tv[NBLK];
+  auto grab = [](double *q) { return __hip_atomic_exchange(q, 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) {
     const int first = __builtin_amdgcn_readfirstlane(f[b].x), w = __builtin_amdgcn_readfirstlane(f[b].y);
     const int np = w & 0x3fffffff;
-    const v2d *lp = reinterpret_cast<const v2d *>(lds + first);
+    double *lp = lds + first;
 #pragma unroll
     for (int u = 0; u < UB; ++u)
-      if (t + u * nt < np) v[b][u] = lp[t + u * nt];
-    if (t == 0 && (w & (1 << 30))) hv[b] = lds[first - 1];
-    if (t == 1 && (w < 0)) tv[b] = lds[first + 2 * np];
+      if (t + u * nt < np) v[b][u] = v2d{grab(lp + 2 * (t + u * nt)), grab(lp + 2 * (t + u * nt) + 1)};
+    if (t == 0 && (w & (1 << 30))) hv[b] = grab(lds + first - 1);
+    if (t == 1 && (w < 0)) tv[b] = grab(lds + first + 2 * np);
   }
-#pragma unroll
-  for (int b = 0; b < NBLK; ++b) {
-    const int first = __builtin_amdgcn_readfirstlane(f[b].x), w = __builtin_amdgcn_readfirstlane(f[b].y);
-    const int np = w & 0x3fffffff;
-    v2d *lp = reinterpret_cast<v2d *>(lds + first);
-#pragma unroll
-    for (int u = 0; u < UB; ++u)
-      if (t + u * nt < np) lp[t + u * nt] = v2d{0., 0.};
-    if (t == 0 && (w & (1 << 30))) lds[first - 1] = 0.;
-    if (t == 1 && (w < 0)) lds[first + 2 * np] = 0.;
-  }
+  FT(1);
+  FT(2);
   if (DBG(p, 1)) return;
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) {
@@ -574,6 +575,8 @@ __device__ __forceinline__ void flush_blocks(const P2K &p, double *lds, int K0, 
     if (t == 0 && head) gb[-1] = hv[b];
     if (t == 1 && (w < 0)) gb[2 * np] = tv[b];
   }
+  FT(3);
+#undef FT
 }
 
 template <int NC, int MODE>
@@ -655,6 +658,10 @@ __device__ __forceinline__ void table_role(const P2K &p, double *lds, int lane, 
     for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(T4[r][s]));
 #ifdef NH_ABLATION
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+  long long ftacc[4] = {0, 0, 0, 0};
+#define FTP ftacc
+#else
+#define FTP nullptr
 #endif
   const int nlines = (p.io1 - p.io0 + 1) * (p.n1 + 1);
   for (int line = blockIdx.x; line < nlines; line += gridDim.x) {
@@ -698,7 +705,7 @@ __device__ __forceinline__ void table_role(const P2K &p, double *lds, int lane, 
         else if (i == nph - 1 && k + 1 < p.n2) build_D(k + 1, nth_visit(vmask, 0), lds + PL<NC>::DT + (((k + 1) * nv) & 1) * PL<NC>::DSZ);
         TICK(2);
         if (k > 0) {  // the planes 2k-2, 2k-1 finished in the previous slice: 8 node blocks, nph phases
-          if (nph == 4) flush_blocks<NC, 2>(p, lds, 2 * k - 2, 2 * i, st, NTW * 64);
+          if (nph == 4) flush_blocks<NC, 2>(p, lds, 2 * k - 2, 2 * i, st, NTW * 64, FTP);
           else flush_blocks<NC, 4>(p, lds, 2 * k - 2, 4 * i, st, NTW * 64);
         }
         TICK(4);
@@ -712,6 +719,10 @@ __device__ __forceinline__ void table_role(const P2K &p, double *lds, int lane, 
     for (int c = 0; c < 12; c += 2) flush_blocks<NC, 2>(p, lds, 2 * p.n2 - 2, c, st, NTW * 64);
     lds_barrier();
   }
+#ifdef NH_ABLATION
+  if (p.tdbg && lane == 0)
+    for (int i = 0; i < 4; ++i) atomicAdd((unsigned long long *)p.tdbg + 8 + i, (unsigned long long)ftacc[i]);
+#endif
 #ifdef NH_ABLATION
   if (p.tdbg && lane == 0)
     for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
@@ -966,6 +977,7 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
     const double g = grid;
     if (getenv("NH_P2HEX_WGTIMES"))
       for (unsigned w = 0; w < grid && w < 1024; ++w) fprintf(stderr, "wg %u cycles %lld\n", w, h[16 + w]);
+    fprintf(stderr, "p2hex flush cycles per table wave: records %.0f | lds reads %.0f | zero %.0f | stores %.0f\n", h[8] / (g * NTW), h[9] / (g * NTW), h[10] / (g * NTW), h[11] / (g * NTW));
     fprintf(stderr, "p2hex_pipe cycles per wave: MFMA waves: tasks %.0f + barrier %.0f | table waves: D %.0f, flush %.0f + barrier %.0f | geometry wave: geometry %.0f + barrier %.0f | loop head %.0f\n",
               h[0] / (g * 4), h[1] / (g * 4), h[2] / (g * NTW), h[4] / (g * NTW), h[5] / (g * NTW), h[3] / g, h[6] / g, h[7] / (g * 8));
   }
