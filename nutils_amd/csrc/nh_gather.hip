@@ -8,6 +8,7 @@
 #include "nh_common.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -69,6 +70,11 @@ __global__ void k_gather_values(i64 nnz, const i64 *gptr, const int32_t *gsrc, c
 // ---- pass 1 for small scalar elements: ONE THREAD per element, the local matrix in registers --------------------------------------------
 // (the one-wave-per-element kernel spends ~500 wave instructions on a trilinear element: lanes idle in the pointwise stages, LDS staging,
 // barriers; a thread that keeps the NBT x NBR sums in registers needs ~90 per element and no LDS at all)
+#ifdef NH_ABLATION
+#define MDBGL(p) ((p).debug)
+#else
+#define MDBGL(p) 0
+#endif
 struct LocK {
   i64 nelems;
   const int32_t *elist;
@@ -80,6 +86,8 @@ struct LocK {
   int by_elem;
   double C[16];  // [a][b]
   double *local;
+  int debug;  // ablation builds: 1 = no stores, 2 = no vertex gather
+  int ldst_doubles;  // staged tables in front of the per-wave transposition buffers
 };
 
 template <int ND, int NBT, int NBR, bool LDST, bool SYMD>
@@ -98,8 +106,8 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
       for (int i = threadIdx.x; i < ng; i += blockDim.x) sT[nt + nr + i] = p.geom.gT[i];
     __syncthreads();
   }
-  const i64 ie = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (ie >= p.nelems) return;
+  const i64 ie0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 ie = min(ie0, p.nelems - 1);  // (lanes behind the last element recompute it: the store below needs whole waves, and skips them)
   const i64 e = p.elist ? p.elist[ie] : ie;
   double A[NBT][NBR];
 #pragma unroll
@@ -112,6 +120,13 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
   if (iso) {
 #pragma unroll
     for (int a = 0; a < NG; ++a) {
+#ifdef NH_ABLATION
+      if (p.debug & 2) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) X[a][i] = ((a >> (ND - 1 - i)) & 1) + 1e-3 * (double)((ie + i) & 7);
+        continue;
+      }
+#endif
       const i64 v = p.geom.gdofs[e * NG + a];
 #pragma unroll
       for (int i = 0; i < ND; ++i) X[a][i] = p.geom.verts[v * ND + i];
@@ -200,10 +215,35 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
       }
     }
   }
+  // Store, element-major (the gather of a CSR row reads whole rows of the local matrices).  A thread's matrix is NBT * NBR * 8 contiguous bytes,
+  // neighbouring lanes are that far apart: stored straight from the registers, every instruction touches 64 lines (0.23 of the 0.61 ms of this
+  // kernel on the 128^3 trilinear mesh).  The wave transposes through LDS instead, CH values per element at a time, so that 64 / CH elements' chunks of
+  // CH * 8 contiguous bytes go out per instruction.
+  constexpr int NE = NBT * NBR, CH = NE % 16 == 0 ? 16 : NE % 9 == 0 ? 9 : NE % 4 == 0 ? 4 : 1, PADW = CH | 1;
+  double *stg = sT + p.ldst_doubles + (threadIdx.x >> 6) * 64 * PADW;
+  const int lane = threadIdx.x & 63;
+  const i64 wave0 = ie0 - lane;  // first element of this wave
 #pragma unroll
-  for (int m = 0; m < NBT; ++m)
+  for (int c0 = 0; c0 < NE; c0 += CH) {
 #pragma unroll
-    for (int n = 0; n < NBR; ++n) p.local[ie * (NBT * NBR) + m * NBR + n] = (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n];  // element-major: the gather of a CSR row reads whole rows of the local matrices
+    for (int j = 0; j < CH; ++j) {
+      const int l = c0 + j, m = l / NBR, n = l % NBR;
+      stg[lane * PADW + j] = (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lanes (el, idx): CH consecutive values of element el; 64 / CH elements per pass (CH = 9: 7 elements, one idle lane)
+    constexpr int EPP = 64 / CH;
+    const int sub = lane / CH, idx = lane - sub * CH;
+#pragma unroll
+    for (int pass = 0; pass < (64 + EPP - 1) / EPP; ++pass) {
+      const int el = pass * EPP + sub;
+      if (sub < EPP && el < 64 && wave0 + el < p.nelems) {
+        const double v = stg[el * PADW + idx];
+        if (!(MDBGL(p) & 1)) p.local[(wave0 + el) * NE + c0 + idx] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 double *g_scratch = nullptr;
@@ -308,6 +348,10 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   p.by_elem = (a->flags & NH_MATRIX_EMAP_BY_ELEMENT) != 0;
   for (int i = 0; i < 16; ++i) p.C[i] = i < S * S ? a->C_host[i] : 0.;
   p.local = local;
+  p.debug = 0;
+#ifdef NH_ABLATION
+  if (getenv("NH_LOCAL_DEBUG")) p.debug = atoi(getenv("NH_LOCAL_DEBUG"));
+#endif
   dim3 grid((unsigned)((a->nelems + 127) / 128)), block(128);
   const int key = a->ndims * 10000 + a->test.nb * 100 + a->trial.nb;
   const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + a->trial.nb + (1 << a->ndims));
@@ -315,13 +359,15 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   bool symd = a->test.T_dev == a->trial.T_dev && a->test.tab_dev == a->trial.tab_dev && a->test.dofs_dev == a->trial.dofs_dev;
   for (int i = 0; i < S * S; ++i)
     if (i / S != i % S && a->C_host[i] != 0.) symd = false;
-#define LOC(ND, NBT, NBR)                                                                         \
-  do {                                                                                            \
-    if (NBT == NBR && symd) {                                                                            \
-      if (ldst) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, true, NBT == NBR>), grid, block, ldsb, s, p);  \
-      else hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, false, NBT == NBR>), grid, block, 0, s, p);  \
-    } else if (ldst) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, true, false>), grid, block, ldsb, s, p);  \
-    else hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, false, false>), grid, block, 0, s, p);         \
+  p.ldst_doubles = ldst ? (int)(ldsb / sizeof(double)) : 0;
+  const size_t ldsx = (ldst ? ldsb : 0) + sizeof(double) * 2 * 64 * 17;  // + two waves' transposition buffers
+#define LOC(ND, NBT, NBR)                                                                                         \
+  do {                                                                                                            \
+    if (NBT == NBR && symd) {                                                                                     \
+      if (ldst) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, true, NBT == NBR>), grid, block, ldsx, s, p);    \
+      else hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, false, NBT == NBR>), grid, block, ldsx, s, p);        \
+    } else if (ldst) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, true, false>), grid, block, ldsx, s, p);    \
+    else hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, false, false>), grid, block, ldsx, s, p);               \
   } while (0)
   switch (key) {
     case 10202: LOC(1, 2, 2); break;
