@@ -22,6 +22,10 @@
  *     dof = scalar_dof * ncomp + comp (function.py:2598-2627).
  *   - thread model: one host thread per device context (the reference never threads;
  *     under NUTILS_NPROCS>1 it forks -- do not initialise before a fork).
+ *   - library-owned scratch: NH_MATRIX_GATHER keeps the local matrices of the last assembly in a
+ *     device buffer that grows to the largest pattern seen (1.07 GB for the 128^3 trilinear mesh) and
+ *     is shared by all calls: assemblies that use it must be issued on ONE stream at a time;
+ *     nh_release_scratch() returns it to the device.
  */
 #ifndef NUTILS_HIP_H
 #define NUTILS_HIP_H
@@ -54,6 +58,7 @@ int nh_memcpy_h2d(void *dev, const void *host, size_t bytes, void *stream);
 int nh_memcpy_d2h(void *host, const void *dev, size_t bytes, void *stream);
 int nh_memset(void *dev, int byte, size_t bytes, void *stream);
 int nh_stream_sync(void *stream);
+int nh_release_scratch(void);  /* frees the library-owned scratch buffers (synchronises the device) */
 
 /* ---- K2: basis tabulation -------------------------------------------------------
  * replaces nutils_poly eval_outer / GradPlan as called from generated code

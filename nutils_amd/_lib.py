@@ -120,6 +120,7 @@ SIGNATURES = {
     'nh_memcpy_d2h': (ctypes.c_int, [vp, vp, ctypes.c_size_t, vp]),
     'nh_memset': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_size_t, vp]),
     'nh_stream_sync': (ctypes.c_int, [vp]),
+    'nh_release_scratch': (ctypes.c_int, []),
     'nh_poly_tabulate': (ctypes.c_int, [vp, c_i64, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     'nh_structured_dofs': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                           ctypes.POINTER(ctypes.c_int), vp, c_i64, c_i64, vp, vp]),

@@ -265,6 +265,15 @@ int nh_gather_scratch(size_t doubles, double **out) {
   return NH_OK;
 }
 
+extern "C" int nh_release_scratch(void) {
+  if (g_scratch) {
+    NH_CHECK_HIP(hipDeviceSynchronize());
+    NH_CHECK_HIP(hipFree(g_scratch));
+    g_scratch = nullptr, g_scratch_cap = 0;
+  }
+  return NH_OK;
+}
+
 int nh_gather_prepare(nh_pattern *p, const nh_basis &test, hipStream_t s) {
   if (p->gsrc) return NH_OK;
   NH_REQUIRE(p->emap_len < (1ll << 32) && p->nnz < (1ll << 32), "NH_MATRIX_GATHER: pattern too large for 32-bit gather indices");
