@@ -62,7 +62,9 @@ def run_oracle(name):
     return out, expect
 
 
-def run_hip(name):
+def run_hip(name, mode='term'):
+    '''mode 'term': nh_assemble_matrix / nh_assemble_vector per term; 'fused': the term-list entries nh_assemble_matrix_terms /
+    nh_assemble_terms; 'gather': matrices with the owner-side reduction (NH_MATRIX_GATHER).'''
     from nutils_amd import device, kernels
     kind, nd, terms, expect = load(name)
     out = None
@@ -89,13 +91,26 @@ def run_hip(name):
             pat = kernels.Pattern(nl, int(t['test_ndofs']), int(t['trial_ndofs']), tdofs, rdofs, nbt=nbt, nbr=nbr)
             rowptr, colidx = pat.expand(nct, ncr, None)
             values = device.zeros(colidx.numel(), 'float64')
-            kernels.assemble_matrix(nelems=nl, ndims=nd, nq=nq, weights=w, geom=geom, test=test, trial=trial, nct=nct, ncr=ncr, C=t['B'] * fac, mask=None,
-                                    pattern=pat, values=values, scale=scale)
+            if mode == 'fused':
+                kernels.assemble_matrix_terms(nelems=nl, ndims=nd, nq=nq, weights=w, geom=geom, test=test, trial=trial, nct=nct, ncr=ncr, mask=None, pattern=pat,
+                                              values=values, terms=[dict(C=t['B'] * fac, scale=scale)], gather=False)
+            else:
+                kernels.assemble_matrix(nelems=nl, ndims=nd, nq=nq, weights=w, geom=geom, test=test, trial=trial, nct=nct, ncr=ncr, C=t['B'] * fac, mask=None,
+                                        pattern=pat, values=values, scale=scale, gather=mode == 'gather')
             out = dict(values=device.to_host(values), rowptr=device.to_host(rowptr), colidx=device.to_host(colidx))
         else:
             if out is None:
                 acc = device.zeros(int(t['test_ndofs']) * nct, 'float64')
                 out = dict(acc=acc)
+            if mode == 'fused':  # form and source of the term in ONE launch
+                fields, tl = [], []
+                if 'B' in t:
+                    fields.append((trial, device.to_dev(t['trial_value'], 'float64'), int(t['trial_ncomp'])))
+                    tl.append(dict(block=0, field=0, C=t['B'] * fac, scale=scale))
+                if 'L' in t:
+                    tl.append(dict(block=0, f=t['L'] * fac, scale=scale))
+                kernels.assemble_terms(nelems=nl, ndims=nd, nq=nq, weights=w, geom=geom, fields=fields, blocks=[(test, nct, out['acc'])], terms=tl)
+                continue
             if 'B' in t:
                 kernels.assemble_vector(nelems=nl, ndims=nd, nq=nq, weights=w, geom=geom, test=test, trial=trial, nct=nct, ncr=int(t['trial_ncomp']), C=t['B'] * fac,
                                         u=device.to_dev(t['trial_value'], 'float64'), out=out['acc'], scale=scale)

@@ -8,7 +8,9 @@ import plan_exec
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('mode', ['term', 'fused', 'gather'])
 @pytest.mark.parametrize('name', plan_exec.names())
-def test_plan_through_the_c_abi(name):
-    out, expect = plan_exec.run_hip(name)
+def test_plan_through_the_c_abi(name, mode):
+    '''per-term entries, the fused term-list entries (nh_assemble_terms / nh_assemble_matrix_terms) and the deterministic owner-side reduction'''
+    out, expect = plan_exec.run_hip(name, mode)
     plan_exec.compare(out, expect, rtol=1e-13)
