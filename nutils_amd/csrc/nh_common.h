@@ -79,7 +79,7 @@ struct nh_pattern {
   // gather map (nh_gather.hip; built on the first NH_MATRIX_GATHER assembly): for scalar entry k the local-matrix positions
   // gsrc[gptr[k] .. gptr[k+1]) in ascending order (element, m, n) -- the order numpy.add.at accumulates them in -- and the row of k
   int32_t *gsrc;
-  i64 *gptr;
+  unsigned *gptr;
   int32_t *grow;
 };
 

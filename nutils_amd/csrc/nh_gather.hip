@@ -38,21 +38,37 @@ __global__ void k_gather_keys(i64 nelems, BasisK test, int nbr_uniform, const i6
   }
 }
 
+__global__ void k_narrow(i64 n, const i64 *in, unsigned *out) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) out[i] = (unsigned)in[i];
+}
+
 __global__ void k_rowof(i64 nrows, const i64 *srowptr, int32_t *grow) {
   for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (i64)gridDim.x * blockDim.x)
     for (i64 k = srowptr[r]; k < srowptr[r + 1]; ++k) grow[k] = (int32_t)r;
 }
 
 // pass 2: one thread per scalar entry; local: element-major [position][nct * ncr]
-__global__ void k_gather_values(i64 nnz, const i64 *gptr, const int32_t *gsrc, const int32_t *grow, const i64 *srowptr, const double *local, i64 ld, int per,
+__global__ void k_gather_values(i64 nnz, const unsigned *gptr, const int32_t *gsrc, const int32_t *grow, const i64 *srowptr, const double *local, i64 ld, int per,
                                 GSlots gs, double *values, int store) {
   const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nnz) return;
-  const i64 b = gptr[k], e = gptr[k + 1];
+  const unsigned b = gptr[k], e = gptr[k + 1];
   const int ncd = gs.nct * gs.ncr;
   if (ncd == 1) {  // scalar: the expanded pattern is the scalar one
+    // eight contributions in flight per thread (index loads, then value loads, then the sum in the order of the map): one at a time, the
+    // kernel waits out two dependent memory latencies per contribution (0.76 -> 0.58 ms on the 128^3 trilinear mesh)
     double s = 0;
-    for (i64 i = b; i < e; ++i) s += local[(unsigned)gsrc[i]];
+    for (unsigned i0 = b; i0 < e; i0 += 8) {
+      unsigned idx[8];
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) idx[u] = i0 + u < e ? (unsigned)gsrc[i0 + u] : 0xffffffffu;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = idx[u] != 0xffffffffu ? local[idx[u]] : 0.;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < e) s += v[u];
+    }
     values[k] = store ? s : values[k] + s;
     return;
   }
@@ -61,7 +77,17 @@ __global__ void k_gather_values(i64 nnz, const i64 *gptr, const int32_t *gsrc, c
     for (int d = 0; d < gs.ncr; ++d) {
       if (!gs.mask[c][d]) continue;
       double s = 0;
-      for (i64 i = b; i < e; ++i) s += local[(i64)(unsigned)gsrc[i] * ncd + c * gs.ncr + d];
+      for (unsigned i0 = b; i0 < e; i0 += 8) {
+        i64 idx[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) idx[u] = i0 + u < e ? (i64)(unsigned)gsrc[i0 + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = idx[u] >= 0 ? local[idx[u] * ncd + c * gs.ncr + d] : 0.;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < e) s += v[u];
+      }
       double *dst = values + a0 * gs.tot + len * gs.cum[c] + pos * gs.cnt[c] + gs.dpos[c][d];
       *dst = store ? s : *dst + s;
     }
@@ -281,6 +307,7 @@ int nh_gather_prepare(nh_pattern *p, const nh_basis &test, hipStream_t s) {
   const i64 n = p->emap_len, nnz = p->nnz;
   unsigned *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
   int *counts = nullptr;
+  i64 *gptr64 = nullptr;
   void *tmp = nullptr;
   int rc = NH_OK;
 #define GP_CHECK(expr)                                                                          \
@@ -308,8 +335,11 @@ int nh_gather_prepare(nh_pattern *p, const nh_basis &test, hipStream_t s) {
     GP_CHECK(rocprim::radix_sort_pairs(nullptr, tmpsz, keys, keys2, vals, vals2, (size_t)n, 0, bits, s));
     GP_CHECK(hipMalloc(&tmp, tmpsz));
     GP_CHECK(rocprim::radix_sort_pairs(tmp, tmpsz, keys, keys2, vals, vals2, (size_t)n, 0, bits, s));  // stable: sources stay in (element, m, n) order
-    GP_CHECK(hipMalloc((void **)&p->gptr, (nnz + 1) * sizeof(i64)));
-    if ((rc = nh_scan_exclusive(counts, p->gptr, nnz, s)) != NH_OK) goto done;
+    GP_CHECK(hipMalloc((void **)&gptr64, (nnz + 1) * sizeof(i64)));
+    if ((rc = nh_scan_exclusive(counts, gptr64, nnz, s)) != NH_OK) goto done;
+    GP_CHECK(hipMalloc((void **)&p->gptr, (nnz + 1) * sizeof(unsigned)));  // (emap_len < 2^32: 32-bit offsets)
+    hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<i64>((nnz + 256) / 256, 1 << 16)), dim3(256), 0, s, nnz + 1, gptr64, p->gptr);
+    GP_CHECK(hipGetLastError());
     GP_CHECK(hipMalloc((void **)&p->grow, std::max<i64>(nnz, 1) * 4));
     hipLaunchKernelGGL(k_rowof, dim3((unsigned)std::min<i64>((p->nrows + 255) / 256, 1 << 16)), dim3(256), 0, s, p->nrows, p->srowptr, p->grow);
     GP_CHECK(hipGetLastError());
@@ -324,6 +354,7 @@ done:
   hipFree(keys2);
   hipFree(vals2);
   hipFree(counts);
+  hipFree(gptr64);
   hipFree(tmp);
   if (rc != NH_OK) {
     hipFree(p->gptr), hipFree(p->grow);
