@@ -190,7 +190,9 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
       geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
     const double w = p.weights[q] * fabs(det) * (p.scale ? p.scale[(p.by_elem ? e : ie) * p.nq + q] : 1.);
     // trial side premultiplied by the form and the weight: W[n][a] = w sum_b C[a][b] Dr[n][b]
-    double W[NBR][S], D[NBR][S];
+    double W[NBR][S], D[NBR][S], wc[S];
+#pragma unroll
+    for (int a = 0; a < S; ++a) wc[a] = w * p.C[a * S + a];
 #pragma unroll
     for (int n = 0; n < NBR; ++n) {
       const double *T = Tr + ((size_t)n * p.nq + q) * S;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
 #pragma unroll
       for (int a = 0; a < S; ++a) {
         if (SYMD)
-          W[n][a] = w * p.C[a * S + a] * D[n][a];
+          W[n][a] = wc[a] * D[n][a];
         else {
           double s = 0;
 #pragma unroll
@@ -215,12 +217,15 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
       }
     }
     if (SYMD) {
+      // (operator slots the form does not use -- the value slot of a Laplace form, the gradient slots of a mass form -- are skipped: uniform branches)
 #pragma unroll
-      for (int m = 0; m < NBT; ++m)
+      for (int a = 0; a < S; ++a)
+        if (p.C[a * S + a] != 0.) {
 #pragma unroll
-        for (int n = m; n < NBR; ++n)
+          for (int m = 0; m < NBT; ++m)
 #pragma unroll
-          for (int a = 0; a < S; ++a) A[m][n] += D[m][a] * W[n][a];
+            for (int n = m; n < NBR; ++n) A[m][n] += D[m][a] * W[n][a];
+        }
     } else {
 #pragma unroll
       for (int m = 0; m < NBT; ++m) {
