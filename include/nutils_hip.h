@@ -269,6 +269,8 @@ typedef struct {
   const double *C_host;      /* [nct][S][ncr][S] or NULL */
   const double *f_host;      /* [nct][S] or NULL */
   const double *scale_dev;   /* [nelems][nq] (list position with elist_dev) or NULL */
+  int qs_field_t, qs_field_r; /* with qs_B_host: the term is also multiplied by s_q = sum_ab B[a][b] U_t[q,a] U_r[q,b] of two scalar fields */
+  const double *qs_B_host;   /* [S][S] or NULL (the point factor of energy Hessians: d2/du2 of kappa(u) |grad u|^2 / 2 and the like) */
 } nh_term;
 
 typedef struct {
@@ -308,6 +310,8 @@ typedef struct {
   const double *C_host;      /* [nct][S][ncr][S]: C (kind 0) or B (kinds 1, 2) */
   const double *L_host;      /* kind 2: [nct][S] */
   const double *scale_dev;   /* [nelems][nq] or NULL */
+  int qs_field_t, qs_field_r; /* as in nh_term */
+  const double *qs_B_host;
 } nh_matrix_term;
 
 typedef struct {

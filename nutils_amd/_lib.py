@@ -65,7 +65,8 @@ class PointPoly(ctypes.Structure):
 
 
 class Term(ctypes.Structure):
-    _fields_ = [('block', ctypes.c_int), ('field', ctypes.c_int), ('poly', ctypes.c_int), ('C_host', vp), ('f_host', vp), ('scale_dev', vp)]
+    _fields_ = [('block', ctypes.c_int), ('field', ctypes.c_int), ('poly', ctypes.c_int), ('C_host', vp), ('f_host', vp), ('scale_dev', vp),
+                ('qs_field_t', ctypes.c_int), ('qs_field_r', ctypes.c_int), ('qs_B_host', vp)]
 
 
 class TermsArgs(ctypes.Structure):
@@ -75,7 +76,8 @@ class TermsArgs(ctypes.Structure):
 
 
 class MatrixTerm(ctypes.Structure):
-    _fields_ = [('kind', ctypes.c_int), ('field', ctypes.c_int), ('poly', ctypes.c_int), ('C_host', vp), ('L_host', vp), ('scale_dev', vp)]
+    _fields_ = [('kind', ctypes.c_int), ('field', ctypes.c_int), ('poly', ctypes.c_int), ('C_host', vp), ('L_host', vp), ('scale_dev', vp),
+                ('qs_field_t', ctypes.c_int), ('qs_field_r', ctypes.c_int), ('qs_B_host', vp)]
 
 
 class MatrixTermsArgs(ctypes.Structure):

@@ -54,7 +54,7 @@ struct TermsK {
   FieldK fields[MAXF];
   BlockK blocks[MAXB];
   const double *scale[MAXT];
-  int toff[MAXT], poff[MAXP];
+  int toff[MAXT], poff[MAXP], qoff[MAXT];  // qoff: 0 or the record [slot_t, slot_r, B[S][S]] of the point factor U_t . B . U_r of the term
   const double *table;  // NULL: the table is tabarg (small tables travel with the kernel arguments: no copy, no buffer to keep alive)
   int tlen;
   double tabarg[TABARG];
@@ -140,6 +140,18 @@ __device__ __forceinline__ void eval_polys(const double *tab, const int *poff, i
     }
   }
 }
+// point factor s = sum_ab B[a][b] U_t[a] U_r[b] of a term (scalar fields; the energy Hessians of quasi-linear problems), record [slot_t, slot_r, B]
+template <int S>
+__device__ __forceinline__ double point_factor(const double *Q, const double *u) {
+  const double *ua = u + (int)Q[0] * S, *ub = u + (int)Q[1] * S;
+  double s = 0;
+#pragma unroll
+  for (int a = 0; a < S; ++a)
+#pragma unroll
+    for (int b = 0; b < S; ++b) s += Q[2 + a * S + b] * ua[a] * ub[b];
+  return s;
+}
+
 __device__ __forceinline__ double pick(const double (&pv)[MAXP], int k) { return k == 0 ? pv[0] : k == 1 ? pv[1] : k == 2 ? pv[2] : pv[3]; }
 
 template <int ND>
@@ -178,6 +190,7 @@ __global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
         const BlockK &B = p.blocks[blk];
         double coef = p.scale[t2] ? p.scale[t2][ie * p.nq + q] : 1.;
         if (pol >= 0) coef *= pick(pv, pol);
+        if (p.qoff[t2]) coef *= point_factor<S>(tab + p.qoff[t2], u);
         const double *fv = H + 5, *C = fv + B.nct * S;
         const int ncr = fld >= 0 ? p.fields[fld].ncomp : 0;
         const double *uf = fld >= 0 ? u + p.fields[fld].c0 * S : u;
@@ -262,7 +275,7 @@ struct MTermsK {
   signed char dpos[3][3];
   int cnt[3], cum[3], tot;
   const double *scale[MAXT];
-  int toff[MAXT], poff[MAXP];
+  int toff[MAXT], poff[MAXP], qoff[MAXT];
   const double *table;
   int tlen;
   double tabarg[TABARG];
@@ -369,6 +382,7 @@ __global__ __launch_bounds__(NTB) void k_mterms(MTermsK p) {
           const int kind = (int)H[0], fld = (int)H[1], pol = (int)H[2];
           double coef = p.scale[t2] ? p.scale[t2][ip] : 1.;
           if (pol >= 0) coef *= pick(pv, pol);
+          if (p.qoff[t2]) coef *= point_factor<S>(tab + p.qoff[t2], u);
           const double *B = H + 3;
           if (kind == 0) {
 #pragma unroll
@@ -410,6 +424,7 @@ __global__ __launch_bounds__(NTB) void k_mterms(MTermsK p) {
           const int pol = (int)H[2];
           double coef = p.scale[t2] ? p.scale[t2][ip] : 1.;
           if (pol >= 0) coef *= pick(pv, pol);
+          if (p.qoff[t2]) coef *= point_factor<S>(tab + p.qoff[t2], u);
           const double *B = H + 3;
           for (int i = 0; i < CS; ++i) g[i] += coef * B[i];  // (point-dependent kinds are scalar: CS = S * S <= 16)
         }
@@ -544,7 +559,7 @@ struct LTermsK {
   int nterms, npolys;
   const double *u[2];
   const double *scale[MAXT];
-  int toff[MAXT], poff[MAXP];
+  int toff[MAXT], poff[MAXP], qoff[MAXT];
   int tlen;
   double tabarg[TABARG];
   double *local;
@@ -670,6 +685,15 @@ __global__ __launch_bounds__(128) void k_local_terms(LTermsK p) {
       const int kind = (int)H[0], fld = (int)H[1], pol = (int)H[2];
       double coef = p.scale[t2] ? p.scale[t2][ip] : 1.;
       if (pol >= 0) coef *= pick(pv, pol);
+      if (p.qoff[t2]) {
+        const double *Q = tab + p.qoff[t2];
+        double sum = 0;
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+          for (int b = 0; b < S; ++b) sum += Q[2 + a * S + b] * field((int)Q[0], a) * field((int)Q[1], b);
+        coef *= sum;
+      }
       const double *B = H + 3;
       if (kind == 0) {
 #pragma unroll
@@ -795,6 +819,17 @@ int push_poly(const nh_point_poly &P, const nh_field *fields, int nfields, const
   return NH_OK;
 }
 
+// point factor record of a term -> table; *off = 0: none
+int push_qs(int ft, int fr, const double *B, int S, const nh_field *fields, int nfields, const FieldK *fk, int t, std::vector<double> &tab, int *off) {
+  *off = 0;
+  if (!B) return NH_OK;
+  NH_REQUIRE(ft >= 0 && ft < nfields && fr >= 0 && fr < nfields && fields[ft].ncomp == 1 && fields[fr].ncomp == 1, "term %d: the point factor U_t . B . U_r needs two scalar fields", t);
+  *off = (int)tab.size();
+  tab.push_back(fk[ft].c0), tab.push_back(fk[fr].c0);
+  for (int i = 0; i < S * S; ++i) tab.push_back(B[i]);
+  return NH_OK;
+}
+
 // small tables travel with the kernel arguments; large ones go through a device buffer owned by the library (the pageable host vector
 // must outlive the copy, and earlier launches on the stream may still read the buffer: synchronous)
 int place_table(const std::vector<double> &tab, double *tabarg, const double **table, hipStream_t s) {
@@ -830,7 +865,7 @@ int local_terms(const nh_matrix_terms_args *a, const MTermsK &m, const std::vect
   p.nterms = m.nterms, p.npolys = m.npolys;
   p.u[0] = a->nfields > 0 ? a->fields[0].u_dev : nullptr;
   p.u[1] = a->nfields > 1 ? a->fields[1].u_dev : nullptr;
-  for (int t = 0; t < MAXT; ++t) p.scale[t] = m.scale[t], p.toff[t] = m.toff[t];
+  for (int t = 0; t < MAXT; ++t) p.scale[t] = m.scale[t], p.toff[t] = m.toff[t], p.qoff[t] = m.qoff[t];
   for (int k = 0; k < MAXP; ++k) p.poff[k] = m.poff[k];
   p.tlen = (int)tab.size();
   std::copy(tab.begin(), tab.end(), p.tabarg);
@@ -940,8 +975,9 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
     for (int i = 0; i < nct * S; ++i) tab.push_back(T.f_host ? T.f_host[i] : 0.);
     if (T.C_host)
       for (int i = 0; i < nct * S * ncr * S; ++i) tab.push_back(T.C_host[i]);
+    if ((rc = push_qs(T.qs_field_t, T.qs_field_r, T.qs_B_host, S, a->fields, a->nfields, p.fields, t, tab, &p.qoff[t])) != NH_OK) return rc;
   }
-  for (int t = a->nterms; t < MAXT; ++t) p.scale[t] = nullptr, p.toff[t] = 0;
+  for (int t = a->nterms; t < MAXT; ++t) p.scale[t] = nullptr, p.toff[t] = 0, p.qoff[t] = 0;
   for (int k = 0; k < MAXP; ++k) p.poff[k] = 0;
   for (int k = 0; k < a->npolys; ++k)
     if ((rc = push_poly(a->polys[k], a->fields, a->nfields, p.fields, k, tab, &p.poff[k])) != NH_OK) return rc;
@@ -1050,8 +1086,9 @@ extern "C" int nh_assemble_matrix_terms(const nh_matrix_terms_args *a, void *str
     for (int i = 0; i < CS; ++i) tab.push_back(T.C_host[i]);
     if (T.kind == 2)
       for (int i = 0; i < a->nct * S; ++i) tab.push_back(T.L_host[i]);
+    if ((rc = push_qs(T.qs_field_t, T.qs_field_r, T.qs_B_host, S, a->fields, a->nfields, p.fields, t, tab, &p.qoff[t])) != NH_OK) return rc;
   }
-  for (int t = a->nterms; t < MAXT; ++t) p.scale[t] = nullptr, p.toff[t] = 0;
+  for (int t = a->nterms; t < MAXT; ++t) p.scale[t] = nullptr, p.toff[t] = 0, p.qoff[t] = 0;
   for (int k = 0; k < MAXP; ++k) p.poff[k] = 0;
   for (int k = 0; k < a->npolys; ++k)
     if ((rc = push_poly(a->polys[k], a->fields, a->nfields, p.fields, k, tab, &p.poff[k])) != NH_OK) return rc;

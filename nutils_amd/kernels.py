@@ -183,10 +183,21 @@ def assemble_terms(*, nelems, ndims, nq, weights, geom, fields, blocks, terms, p
             f = numpy.ascontiguousarray(f, dtype=float)
             if f.shape != (nct, S):
                 raise ValueError(f'term {i}: source tensor has shape {f.shape}')
-        keep += [C, f]
-        T[i] = _lib.Term(blk, fld, int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(f), device.ptr(t.get('scale')))
+        qB, qt, qr = _qs(t.get('qs'), S)
+        keep += [C, f, qB]
+        T[i] = _lib.Term(blk, fld, int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(f), device.ptr(t.get('scale')), qt, qr, device.host_ptr(qB))
     args = _lib.TermsArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, len(fields), F, len(blocks), B, len(terms), T, len(polys), P)
     _lib.call('nh_assemble_terms', ctypes.byref(args), device.stream())
+
+
+def _qs(qs, S):
+    '''term option qs = (B [S][S], field_t, field_r): point factor U_t . B . U_r'''
+    if qs is None:
+        return None, -1, -1
+    B = numpy.ascontiguousarray(qs[0], dtype=float)
+    if B.shape != (S, S):
+        raise ValueError(f'point factor tensor has shape {B.shape}')
+    return B, int(qs[1]), int(qs[2])
 
 
 def _fields_polys(fields, polys, keep):
@@ -222,8 +233,10 @@ def assemble_matrix_terms(*, nelems, ndims, nq, weights, geom, test, trial, nct,
             L = numpy.ascontiguousarray(L, dtype=float)
             if L.shape != (nct, S):
                 raise ValueError(f'term {i}: L has shape {L.shape}')
-        keep += [C, L]
-        T[i] = _lib.MatrixTerm(int(t.get('kind', 0)), int(t.get('field', -1)), int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(L), device.ptr(t.get('scale')))
+        qB, qt, qr = _qs(t.get('qs'), S)
+        keep += [C, L, qB]
+        T[i] = _lib.MatrixTerm(int(t.get('kind', 0)), int(t.get('field', -1)), int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(L), device.ptr(t.get('scale')),
+                               qt, qr, device.host_ptr(qB))
     whole = not flags and nelems == pattern.nelems
     if gather is None:  # (as in assemble_matrix: the owner-side reduction from the second assembly on a pattern on; blocks that do not qualify ignore it)
         gather = (whole and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')

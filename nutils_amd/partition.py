@@ -98,7 +98,11 @@ class HaloPlan:
         if s.recvs:
             if staged:
                 self.recv_buf.copy_(recv)
-            values.index_add_(0, self.recv_idx, self.recv_buf)
+            if values.is_cuda:  # owner-side reduce of the interface rows: nh_monomial with an output index (unique positions), on the current stream
+                from . import kernels
+                kernels.monomial(self.recv_buf, [], [], values, out_index=self.recv_idx)
+            else:  # (CPU tensors: the gloo runs of tests/test_partition.py)
+                values.index_add_(0, self.recv_idx, self.recv_buf)
 
 
 def owned_rows(slab, values, rowptr, colidx):

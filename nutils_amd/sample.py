@@ -474,7 +474,7 @@ class _MatrixPlan:
         # measured (profiles/r02_c4.md): the fused kernel pays when it replaces several launches -- more than one term, or pointwise factors that
         # would otherwise be evaluated by nh_sample_eval / nh_pointwise_poly / torch algebra first; one constant-coefficient term of a 3-D basis
         # is faster through the one-wave-per-element kernel (128^3 trilinear: 4.1 against 9.5 ms)
-        if len(terms) < 2 and not any(itg.fscale is not None or itg.qform is not None for _, itg, _ in terms):
+        if len(terms) < 2 and not any(itg.fscale is not None or itg.qform is not None or itg.qscalar is not None for _, itg, _ in terms):
             return terms
         nd, nq, S = smp0.ndims, smp0.points.npoints, 1 + smp0.ndims
         nct, ncr = self.test.ncomp, self.trial.ncomp
@@ -498,16 +498,24 @@ class _MatrixPlan:
             left = []
             for term in items:
                 smp, itg, fac = term
-                need = ([itg.qform[1]] if itg.qform is not None else []) + (list(itg.fscale.args) if itg.fscale is not None and itg.qscalar is None else [])
-                newf = [a for a in need if not any(a.same(k) for k in fkeys)]
-                newp = itg.fscale is not None and itg.qscalar is None and not any(itg.fscale is k for k in pkeys)
+                qs_ok = itg.qscalar is not None and itg.qscalar[1].ncomp == 1 and itg.qscalar[2].ncomp == 1 and (itg.geom is None or itg.geom is itg.measure)
+                inkernel = itg.qscalar is None or qs_ok  # (else: the point factor stays a scale array from _point_scale)
+                need = (([itg.qform[1]] if itg.qform is not None else []) + (list(itg.fscale.args) if itg.fscale is not None and inkernel else [])
+                        + ([itg.qscalar[1], itg.qscalar[2]] if qs_ok else []))
+                newf = []
+                for a in need:
+                    if not any(a.same(k) for k in fkeys + newf):
+                        newf.append(a)
+                newp = itg.fscale is not None and inkernel and not any(itg.fscale is k for k in pkeys)
                 if len(tl) >= 32 or len(fkeys) + len(newf) > 6 or len(pkeys) + newp > 4:
                     left.append(term)
                     continue
                 t = dict(C=numpy.asarray(itg.B, dtype=float) * fac)
-                if itg.qscalar is not None:  # (energy Hessians: the point factor U_t . B . U_r stays a scale array)
+                if not inkernel:
                     t['scale'] = _point_scale(smp, itg, arguments)
                 else:
+                    if qs_ok:  # energy Hessians: the point factor U_t . B . U_r, evaluated in the kernel
+                        t['qs'] = (numpy.asarray(itg.qscalar[0], dtype=float)[0, :, 0, :], fidx(itg.qscalar[1]), fidx(itg.qscalar[2]))
                     if itg.scale is not None:
                         t['scale'] = smp.scale(itg.scale)
                     if itg.fscale is not None:
@@ -695,7 +703,8 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
 def _fusable(itg):
     '''Linear-form term (test dofs exposed) that nh_assemble_terms takes: a form applied to a bound field or a source, times optional
     pointwise factors (coefficient function of x, polynomial of field values).'''
-    return (itg.measure is not None and itg.rows and not itg.cols and itg.qform is None and itg.qscalar is None
+    return (itg.measure is not None and itg.rows and not itg.cols and itg.qform is None
+            and (itg.qscalar is None or (itg.qscalar[1].ncomp == 1 and itg.qscalar[2].ncomp == 1 and (itg.geom is None or itg.geom is itg.measure)))
             and (itg.B is not None or itg.L is not None) and (itg.fscale is None or (len(itg.fscale.args) <= 4 and len(itg.fscale.terms) <= 64)))
 
 
@@ -716,7 +725,8 @@ def _launch_terms(items, blocks, arguments, ucache):
         fkeys, bkeys, pkeys, terms, rest = [], [], [], [], []
         for it in pending:
             bi, _, itg, fac = it
-            need = ([itg.trial] if itg.B is not None else []) + (list(itg.fscale.args) if itg.fscale is not None else [])
+            need = (([itg.trial] if itg.B is not None else []) + (list(itg.fscale.args) if itg.fscale is not None else [])
+                    + ([itg.qscalar[1], itg.qscalar[2]] if itg.qscalar is not None else []))
             newf = []
             for a in need:
                 if not any(a.same(k) for k in fkeys + newf):
@@ -740,6 +750,8 @@ def _launch_terms(items, blocks, arguments, ucache):
                 t['f'] = numpy.asarray(itg.L, dtype=float) * fac
             if itg.fscale is not None:
                 t['poly'] = next(i for i, k in enumerate(pkeys) if k is itg.fscale)
+            if itg.qscalar is not None:  # point factor U_t . B . U_r, evaluated in the kernel
+                t['qs'] = (numpy.asarray(itg.qscalar[0], dtype=float)[0, :, 0, :], fidx(itg.qscalar[1]), fidx(itg.qscalar[2]))
             terms.append(t)
         if not terms:  # (a single term beyond the limits: the per-term path takes anything)
             for bi, smp_, itg, fac in pending:

@@ -761,3 +761,37 @@ def test_matrix_terms_gather_path(golden, name):
         out.append(device.to_host(values))
     close(out[1], out[0])
     assert numpy.array_equal(out[1], out[2])
+
+
+@pytest.mark.parametrize('name', ['lap2d_spline2_5x4_iso', 'lap3d_p1_3_iso'])
+def test_terms_point_factor(golden, name):
+    '''qs = (B, t, r): the term is multiplied by U_t . B . U_r at the point, in nh_assemble_terms and both paths of nh_assemble_matrix_terms;
+    against the same term with that factor handed over as a scale array (nh_sample_eval values, host algebra).'''
+    from nutils_amd import device, kernels
+    g = golden(name)
+    c = Case(g)
+    rng = numpy.random.default_rng(13)
+    nd, S, n = c.nd, 1 + c.nd, c.nelems * c.nq
+    us = [device.to_dev(rng.normal(size=c.ndofs), 'float64') for _ in range(2)]
+    U = []
+    for u in us:
+        Ud = device.empty(n * S, 'float64')
+        kernels.sample_eval(nelems=c.nelems, ndims=nd, nq=c.nq, geom=c.geom, trial=c.basis, ncr=1, points=c.points, u=u, U=Ud)
+        U.append(device.to_host(Ud).reshape(n, S))
+    B = rng.normal(size=(S, S))
+    sc = device.to_dev(numpy.einsum('qa,ab,qb->q', U[0], B, U[1]), 'float64')
+    C = rng.normal(size=(1, S, 1, S))
+    fields = [(c.basis, u, 1) for u in us]
+    out = [device.zeros(c.ndofs, 'float64') for _ in range(2)]
+    kw = dict(nelems=c.nelems, ndims=nd, nq=c.nq, weights=c.weights, geom=c.geom, fields=fields)
+    kernels.assemble_terms(blocks=[(c.basis, 1, out[0])], terms=[dict(block=0, field=1, C=C, qs=(B, 0, 1))], **kw)
+    kernels.assemble_terms(blocks=[(c.basis, 1, out[1])], terms=[dict(block=0, field=1, C=C, scale=sc)], **kw)
+    close(device.to_host(out[0]), device.to_host(out[1]))
+    rowptr, colidx = c.pattern.expand(1, 1, None)
+    vals = []
+    for terms, gather in (([dict(C=C, qs=(B, 0, 1))], False), ([dict(C=C, qs=(B, 0, 1))], True), ([dict(C=C, scale=sc)], False)):
+        v = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix_terms(test=c.basis, trial=c.basis, nct=1, ncr=1, mask=None, pattern=c.pattern, values=v, terms=terms, gather=gather, **kw)
+        vals.append(device.to_host(v))
+    close(vals[0], vals[2])
+    close(vals[1], vals[2])
