@@ -799,7 +799,9 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
 #ifdef NH_ABLATION
   p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
 #endif
-  p.wbnd = getenv("NH_P1HEX_WBND") ? atoi(getenv("NH_P1HEX_WBND")) : 20;  // measured optimum at 128^3 (16 = unweighted: +18 %)
+  // measured optimum at 64^3 .. 256^3 (16 = unweighted: +7 .. +18 %); the tuning override is read once per process and clamped to a sane range
+  static const int wbnd_env = getenv("NH_P1HEX_WBND") ? std::min(64, std::max(8, atoi(getenv("NH_P1HEX_WBND")))) : 20;
+  p.wbnd = wbnd_env;
   constexpr int TJ = 16, TK = 16, L = 2, NTM = L * TJ * TK, NS = VEC ? 1 : 15, VW = VEC ? 4 : 3;
   int dev = 0, cus = 256;
   NH_CHECK_HIP(hipGetDevice(&dev));
