@@ -776,7 +776,7 @@ def _vector_blocks(blocks, arguments, scalar):
         for smp, itg, fac in terms:
             if itg.measure is not None and itg.rows and _p1hex_apply_term(smp, itg, fac, arguments, out):
                 continue
-            if _fusable(itg) and all(a.ncomp == 1 for a in (itg.fscale.args if itg.fscale is not None else ())):
+            if not os.environ.get('NUTILS_AMD_NO_BATCHED') and _fusable(itg) and all(a.ncomp == 1 for a in (itg.fscale.args if itg.fscale is not None else ())):
                 groups.setdefault((id(smp), id(itg.measure)), []).append((bi, smp, itg, fac))
             else:
                 _vector_term(smp, itg, fac, arguments, out, scalar)
