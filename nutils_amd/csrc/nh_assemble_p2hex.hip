@@ -757,10 +757,20 @@ __device__ __forceinline__ void geometry_role(const P2K &p, double *lds, int lan
 #pragma unroll 1
       for (int i = 0; i < nph; ++i) {
         TICK(7);
-        if (i == 0 && k + 1 < p.n2) {
-          if (lane == 0) pipe_meta<NC>(p, L, lds, 2 * k + 3);
-          if (lane == 1) pipe_meta<NC>(p, L, lds, 2 * k + 4);
-          geometry_slice(k + 1);
+        if (k + 1 < p.n2) {
+          if (i == 0) {
+            if (lane == 0) pipe_meta<NC>(p, L, lds, 2 * k + 3);
+            if (lane == 1) pipe_meta<NC>(p, L, lds, 2 * k + 4);
+          }
+          // the geometry of the next slice in nph parts, one per phase (all of it in the first phase made that phase wait for this wave: 6.5 k cycles
+          // against ~4 k of the other roles); element v of the next slice is first needed by the D-table build one element ahead of it
+          double *Jvs = lds + PL<NC>::JV + ((k + 1) & 1) * PL<NC>::JSZ;
+          // (lines with fewer than four elements -- two or three phases -- keep everything in the first phase: their first element may be any v)
+          if (nph == 4) {
+            if (!DBG(p, 16))
+              for (int q = lane; q < p.nq; q += 64) geometry_point(p, L, i, k + 1, q, Jvs + (i * PNQ + q) * 10);
+          } else if (i == 0)
+            geometry_slice(k + 1);
         }
         TICK(3);
         lds_barrier();
