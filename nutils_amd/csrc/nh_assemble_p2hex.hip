@@ -705,7 +705,13 @@ __device__ __forceinline__ void table_role(const P2K &p, double *lds, int lane, 
         else if (i == nph - 1 && k + 1 < p.n2) build_D(k + 1, nth_visit(vmask, 0), lds + PL<NC>::DT + (((k + 1) * nv) & 1) * PL<NC>::DSZ);
         TICK(2);
         if (k > 0) {  // the planes 2k-2, 2k-1 finished in the previous slice: 8 node blocks, nph phases
-          if (nph == 4) flush_blocks<NC, 2>(p, lds, 2 * k - 2, 2 * i, st, NTW * 64, FTP);
+          if (nph == 4) {
+            // 3 + 2 + 2 + 1 node blocks over the four phases: the matrix waves have 31.5 / 21 / 21 / 10.5 MFMA per phase, and a phase lasts as long as the
+            // slower of the two roles -- an even 2 + 2 + 2 + 2 left the table waves waiting in the first phase and the matrix waves in the last
+            if (i == 0) flush_blocks<NC, 3>(p, lds, 2 * k - 2, 0, st, NTW * 64, FTP);
+            else if (i == 3) flush_blocks<NC, 1>(p, lds, 2 * k - 2, 7, st, NTW * 64, FTP);
+            else flush_blocks<NC, 2>(p, lds, 2 * k - 2, 2 * i + 1, st, NTW * 64, FTP);
+          }
           else flush_blocks<NC, 4>(p, lds, 2 * k - 2, 4 * i, st, NTW * 64);
         }
         TICK(4);
