@@ -164,3 +164,25 @@ def test_c4_full_size_consistency():
     A = jac.core
     assert abs(A - A.T).max() <= 1e-12 * abs(A).max()
     assert A.nnz == 4 * (5 * (n + 2) - 6) ** 2  # four blocks of the 5-wide p=2 spline pattern: (5 N - 6)^2 per block, N = n + 2
+
+
+def test_c2_full_size_generic_gather_path():
+    '''The same 128^3 iso case through the GENERIC entry with the owner-side reduction (thread-per-element pass + gather, NH_MATRIX_GATHER |
+    NH_MATRIX_STORE on a NaN-filled array): index arrays and values equal to the write-once fast path entry by entry, and bit-identical when repeated.'''
+    import torch
+    from nutils_amd import workloads
+    fast = workloads.PoissonSlab(n=128, rank=0, world=1, variant='iso')
+    fast.setup()
+    fast.build_pattern()
+    fast.step()
+    gen = workloads.PoissonSlab(n=128, rank=0, world=1, variant='iso', kernel='gather')
+    gen.setup()
+    gen.build_pattern()
+    assert torch.equal(gen.rowptr, fast.rowptr) and torch.equal(gen.colidx, fast.colidx)
+    gen.values.fill_(float('nan'))
+    gen.step()
+    first = gen.values.clone()
+    gen.values.fill_(float('nan'))
+    gen.step()
+    assert torch.equal(first, gen.values)
+    assert float((gen.values - fast.values).abs().max()) <= 1e-13 * float(fast.values.abs().max())
