@@ -1070,7 +1070,7 @@ int local_terms(const nh_matrix_terms_args *a, const MTermsK &m, const std::vect
   }
   nh_pattern *pat = const_cast<nh_pattern *>(a->pattern);
   int rc;
-  if ((rc = nh_gather_prepare(pat, a->test, s)) != NH_OK) return rc;
+  if ((rc = nh_gather_prepare(pat, a->test, a->elist_dev, s)) != NH_OK) return rc;
   double *scratch = nullptr;
   if ((rc = nh_gather_scratch((size_t)pat->emap_len, &scratch)) != NH_OK) return rc;
   p.local = scratch;

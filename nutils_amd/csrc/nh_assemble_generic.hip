@@ -706,7 +706,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     NH_REQUIRE(a->pattern && a->pattern->nelems == a->nelems && !(a->flags & (NH_MATRIX_EXCLUSIVE | NH_MATRIX_FIRST_TOUCH)) && !(a->elist_dev && (a->flags & NH_MATRIX_EMAP_BY_ELEMENT)),
                "NH_MATRIX_GATHER needs the pattern handle and all of its elements in one call");
     nh_pattern *pat = const_cast<nh_pattern *>(a->pattern);
-    if ((rc = nh_gather_prepare(pat, a->test, nh_stream(stream))) != NH_OK) return rc;
+    if ((rc = nh_gather_prepare(pat, a->test, a->elist_dev, nh_stream(stream))) != NH_OK) return rc;
     double *scratch = nullptr;
     // (the thread-per-element kernel writes blocks of 64 elements: room for the last, partly filled block)
     const size_t padded = (size_t)((pat->nelems + 63) / 64 * 64) * std::max(pat->nbt * pat->nbr, 1);

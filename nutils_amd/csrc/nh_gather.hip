@@ -19,12 +19,13 @@ __device__ __forceinline__ int bnb(const BasisK &b, i64 e) { return b.off ? (int
 __device__ __forceinline__ i64 bfn(const BasisK &b, i64 e) { return b.off ? b.off[e] : (b.tab ? (i64)b.tab[e] * b.nb : 0); }
 
 // key of local position i = (element, m, n): its scalar CSR entry
-__global__ void k_gather_keys(i64 nelems, BasisK test, int nbr_uniform, const i64 *eoff, const i64 *srowptr, const int32_t *emap, unsigned *keys,
-                              unsigned *vals, int *counts) {
+__global__ void k_gather_keys(i64 nelems, const int32_t *elist, BasisK test, int nbr_uniform, const i64 *eoff, const i64 *srowptr, const int32_t *emap,
+                              unsigned *keys, unsigned *vals, int *counts) {
   for (i64 e = blockIdx.x; e < nelems; e += gridDim.x) {
-    const int nbt = bnb(test, e);
+    const i64 eid = elist ? elist[e] : e;  // the pattern of an element list numbers its elements by list position, the basis by element
+    const int nbt = bnb(test, eid);
     if (!nbt) continue;
-    const i64 t0 = boff(test, e);
+    const i64 t0 = boff(test, eid);
     const i64 e0 = eoff ? eoff[e] : e * (i64)nbt * nbr_uniform;
     const i64 cnt = (eoff ? eoff[e + 1] : e0 + (i64)nbt * nbr_uniform) - e0;
     const int nbr = (int)(cnt / nbt);
@@ -305,7 +306,7 @@ extern "C" int nh_release_scratch(void) {
   return NH_OK;
 }
 
-int nh_gather_prepare(nh_pattern *p, const nh_basis &test, hipStream_t s) {
+int nh_gather_prepare(nh_pattern *p, const nh_basis &test, const int32_t *elist, hipStream_t s) {
   if (p->gsrc) return NH_OK;
   NH_REQUIRE(p->emap_len < (1ll << 32) && p->nnz < (1ll << 32), "NH_MATRIX_GATHER: pattern too large for 32-bit gather indices");
   NH_REQUIRE(test.dofs_dev, "NH_MATRIX_GATHER: test dofs missing");
@@ -331,7 +332,7 @@ int nh_gather_prepare(nh_pattern *p, const nh_basis &test, hipStream_t s) {
     GP_CHECK(hipMalloc((void **)&vals2, n * 4));
     GP_CHECK(hipMalloc((void **)&counts, (nnz + 1) * 4));
     GP_CHECK(hipMemsetAsync(counts, 0, (nnz + 1) * 4, s));
-    hipLaunchKernelGGL(k_gather_keys, dim3((unsigned)std::min<i64>(p->nelems, 1 << 20)), dim3(64), 0, s, p->nelems, to_k(test), p->nbr, p->eoff, p->srowptr, p->emap, keys,
+    hipLaunchKernelGGL(k_gather_keys, dim3((unsigned)std::min<i64>(p->nelems, 1 << 20)), dim3(64), 0, s, p->nelems, elist, to_k(test), p->nbr, p->eoff, p->srowptr, p->emap, keys,
                        vals, counts);
     GP_CHECK(hipGetLastError());
     int bits = 1;
