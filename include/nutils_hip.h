@@ -290,6 +290,11 @@ typedef struct {
 } nh_terms_args;
 
 int nh_assemble_terms(const nh_terms_args *args, void *stream);
+/* The term lists of several samples (the volume sample and the sides of the boundary of one residual: the reference fuses all loops of
+ * equal length under one id, evaluable.py:6841-6895, but still runs one loop per sample) in ONE launch: every list gets a range of
+ * workgroups.  Same result as `count` nh_assemble_terms calls (the outputs are accumulated either way); lists of another dimension than
+ * the first and lists of more than 2^20 elements are launched on their own. */
+int nh_assemble_terms_multi(int count, const nh_terms_args *const *lists, void *stream);
 
 /* ---- fused bilinear-form assembly: all matrix terms of a block in ONE element loop ----------
  * Counterpart of nh_assemble_terms for the Jacobian blocks of a Newton step (solver.py:334-386;
@@ -451,6 +456,14 @@ int nh_monomial_csr(int64_t nrows, const int64_t *rowptr_dev, const int64_t *col
                     double alpha, double *y_dev, void *stream);
 int nh_monomial(int64_t n, const double *values_dev, int nargs, const double *const *args_dev, const int64_t *const *indices_dev,
                 const int64_t *out_index_dev, double alpha, double *out_dev, void *stream);
+
+/* ---- block merge / submatrix: indexed copy of CSR values -----------------------------------
+ * dst[dst_index[i]] = src[src_index[i]] (an index array may be NULL: i), plain stores, no accumulation.  The value half of
+ * matrix.assemble_block_csr (matrix/__init__.py:103-151: the positions of every block entry in the merged matrix are fixed once
+ * per system) and of Matrix.submatrix(free, free) (solver.py:332,386).  `dst` is device memory OR page-locked host memory that is
+ * mapped into the device (hipHostMalloc / a pinned torch tensor): a Newton step then sends only the entries of the field-dependent
+ * blocks over PCIe, straight into their places of the host CSR value array. */
+int nh_index_copy(int64_t n, const double *src_dev, const int64_t *src_index_dev, const int64_t *dst_index_dev, double *dst, void *stream);
 
 /* ---- pointwise coefficient functions ------------------------------------------------------
  * out[i] = sum_t coeffs[t] prod_v x_v[i*strides[v]]^powers[t*nvars+v]  (nvars <= 4, nterms <= 32;

@@ -134,10 +134,12 @@ SIGNATURES = {
     'nh_assemble_matrix': (ctypes.c_int, [ctypes.POINTER(MatrixArgs), vp]),
     'nh_assemble_vector': (ctypes.c_int, [ctypes.POINTER(VectorArgs), vp]),
     'nh_assemble_terms': (ctypes.c_int, [ctypes.POINTER(TermsArgs), vp]),
+    'nh_assemble_terms_multi': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.POINTER(TermsArgs)), vp]),
     'nh_assemble_matrix_terms': (ctypes.c_int, [ctypes.POINTER(MatrixTermsArgs), vp]),
     'nh_sample_eval': (ctypes.c_int, [ctypes.POINTER(EvalArgs), vp]),
     'nh_monomial_csr': (ctypes.c_int, [c_i64, vp, vp, vp, vp, ctypes.c_double, vp, vp]),
     'nh_monomial': (ctypes.c_int, [c_i64, vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, ctypes.c_double, vp, vp]),
+    'nh_index_copy': (ctypes.c_int, [c_i64, vp, vp, vp, vp, vp]),
     'nh_pointwise_poly': (ctypes.c_int, [c_i64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int), vp, vp]),
     'nh_rationalize': (ctypes.c_int, [vp, c_i64, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),

@@ -9,6 +9,7 @@
 #include "nh_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -23,6 +24,7 @@ constexpr int MAXT = 32;   // terms
 constexpr int MAXP = 4;    // pointwise polynomials
 constexpr int NTB = 256;   // threads per workgroup
 constexpr int NBLK = 3;     // trial functions per lane in the contraction of the matrix kernel
+constexpr int MAXL = 8;    // term lists of one launch (nh_assemble_terms_multi)
 constexpr int TABARG = 256;  // doubles of the term table that fit the kernel arguments
 
 __device__ __forceinline__ i64 boff(const BasisK &b, i64 e) { return b.off ? b.off[e] : e * (i64)b.nb; }
@@ -155,7 +157,7 @@ __device__ __forceinline__ double point_factor(const double *Q, const double *u)
 __device__ __forceinline__ double pick(const double (&pv)[MAXP], int k) { return k == 0 ? pv[0] : k == 1 ? pv[1] : k == 2 ? pv[2] : pv[3]; }
 
 template <int ND>
-__global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
+__device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, const unsigned nbid) {
   constexpr int S = 1 + ND;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *tab = lds;                                // term table
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
   const int tid = threadIdx.x;
   for (int i = tid; i < p.tlen; i += NTB) tab[i] = p.table ? p.table[i] : p.tabarg[i];
   const int npts = p.eb * p.nq;
-  for (i64 b0 = (i64)blockIdx.x * p.eb; b0 < p.nelems; b0 += (i64)gridDim.x * p.eb) {
+  for (i64 b0 = (i64)bid * p.eb; b0 < p.nelems; b0 += (i64)nbid * p.eb) {
     __syncthreads();  // table staged; G of the previous batch consumed
     stage_coeffs(p.fields, p.nfields, p.uesz, UE, p.eb, b0, p.nelems, p.elist, tid);
     __syncthreads();
@@ -243,6 +245,24 @@ __global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
       atomicAdd(B.out + (i64)B.test.dofs[boff(B.test, e) + m] * B.nct + c, acc);
     }
   }
+}
+
+template <int ND>
+__global__ __launch_bounds__(NTB) void k_terms(TermsK p) {
+  terms_body<ND>(p, blockIdx.x, gridDim.x);
+}
+
+// several term lists (samples: the volume and the sides of the boundary) in ONE launch: list i owns the workgroups first[i] .. first[i+1];
+// the parameter blocks live in device memory (they do not fit the kernel argument segment together), uniform per workgroup
+struct MultiK {
+  int count;
+  unsigned first[MAXL + 1];
+};
+template <int ND>
+__global__ __launch_bounds__(NTB) void k_terms_multi(const TermsK *__restrict__ lists, MultiK m) {
+  int i = 0;
+  while (i + 1 < m.count && blockIdx.x >= m.first[i + 1]) ++i;
+  terms_body<ND>(lists[i], blockIdx.x - m.first[i], m.first[i + 1] - m.first[i]);
 }
 
 // ---- fused bilinear forms ---------------------------------------------------------------------------------------------------------
@@ -1144,9 +1164,8 @@ int local_vterms(const nh_terms_args *a, const TermsK &m, const std::vector<doub
   return NH_OK;
 }
 
-}  // namespace
-
-extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
+// argument checks, parameter block and term table of one term list
+int build_terms(const nh_terms_args *a, hipStream_t stream, TermsK &p, std::vector<double> &tab, size_t *ldsbytes) {
   NH_REQUIRE(a, "nh_assemble_terms: NULL args");
   NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
   NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
@@ -1156,9 +1175,9 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
   NH_REQUIRE(a->npolys >= 0 && a->npolys <= MAXP && (a->npolys == 0 || a->polys), "nh_assemble_terms: 0..%d pointwise polynomials", MAXP);
   int rc = check_geom2(a->geom);
   if (rc) return rc;
+  *ldsbytes = 0;
   if (a->nelems == 0) return NH_OK;
   const int S = 1 + a->ndims;
-  TermsK p;
   p.nelems = a->nelems;
   p.elist = a->elist_dev;
   p.nq = a->nq;
@@ -1175,7 +1194,7 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
     p.fields[f].ncomp = F.ncomp;
     p.fields[f].c0 = p.fct;
     p.fct += F.ncomp;
-    if ((rc = max_nb2(F.basis, a->nelems, &p.fields[f].maxnb, nh_stream(stream))) != NH_OK) return rc;
+    if ((rc = max_nb2(F.basis, a->nelems, &p.fields[f].maxnb, stream)) != NH_OK) return rc;
     p.fields[f].ue0 = p.uesz;
     p.fields[f].tsame = 0;
     p.uesz += p.fields[f].maxnb * F.ncomp;
@@ -1190,12 +1209,12 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
     p.blocks[b].out = B.out_dev;
     p.blocks[b].nct = B.nct;
     p.blocks[b].c0 = p.ct;
-    if ((rc = max_nb2(B.test, a->nelems, &p.blocks[b].maxnb, nh_stream(stream))) != NH_OK) return rc;
+    if ((rc = max_nb2(B.test, a->nelems, &p.blocks[b].maxnb, stream)) != NH_OK) return rc;
     p.ct += B.nct;
     p.rowsper += p.blocks[b].maxnb * B.nct;
   }
   NH_REQUIRE(p.ct <= MAXCT, "nh_assemble_terms: more than %d test components", MAXCT);
-  std::vector<double> tab;
+  tab.clear();
   for (int t = 0; t < a->nterms; ++t) {
     const nh_term &T = a->terms[t];
     NH_REQUIRE(T.block >= 0 && T.block < a->nblocks && T.field >= -1 && T.field < a->nfields && T.poly >= -1 && T.poly < a->npolys, "nh_assemble_terms: term %d refers to a missing block / field / polynomial", t);
@@ -1215,16 +1234,56 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
   for (int k = 0; k < a->npolys; ++k)
     if ((rc = push_poly(a->polys[k], a->fields, a->nfields, p.fields, k, tab, &p.poff[k])) != NH_OK) return rc;
   p.tlen = (int)tab.size();
-  {
-    bool done = false;
-    if ((rc = local_vterms(a, p, tab, &done, nh_stream(stream))) != NH_OK) return rc;
-    if (done) return NH_OK;
-  }
   // elements per batch: as many as fill the workgroup in the pointwise phase
   p.eb = std::max(1, NTB / a->nq);
-  const size_t lds = sizeof(double) * ((size_t)p.tlen + (size_t)p.eb * a->nq * p.ct * S + (size_t)NTB * p.fct * S + (size_t)p.eb * p.uesz);
-  NH_REQUIRE(lds <= 160 * 1024, "nh_assemble_terms: batch too large for LDS (%zu bytes)", lds);
+  *ldsbytes = sizeof(double) * ((size_t)p.tlen + (size_t)p.eb * a->nq * p.ct * S + (size_t)NTB * p.fct * S + (size_t)p.eb * p.uesz);
+  p.table = nullptr;
+  return NH_OK;
+}
+
+// parameter blocks (+ the term tables that do not fit them) of a multi-list launch: page-locked host and device buffer pairs in a ring, so
+// that neither the stream nor the host has to wait for the previous launch
+struct ListSlot {
+  char *host = nullptr, *dev = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;
+  bool used = false;
+};
+int list_slot(size_t bytes, ListSlot **out) {
+  static ListSlot ring[8];
+  static int next = 0;
+  ListSlot &sl = ring[next];
+  next = (next + 1) % 8;
+  if (!sl.done) NH_CHECK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  if (sl.used) NH_CHECK_HIP(hipEventSynchronize(sl.done));
+  if (bytes > sl.cap) {
+    if (sl.host) NH_CHECK_HIP(hipHostFree(sl.host));
+    if (sl.dev) NH_CHECK_HIP(hipFree(sl.dev));
+    sl.host = sl.dev = nullptr, sl.cap = 0;
+    NH_CHECK_HIP(hipHostMalloc((void **)&sl.host, 2 * bytes, hipHostMallocDefault));
+    NH_CHECK_HIP(hipMalloc((void **)&sl.dev, 2 * bytes));
+    sl.cap = 2 * bytes;
+  }
+  *out = &sl;
+  return NH_OK;
+}
+
+}  // namespace
+
+extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
+  TermsK p;
+  std::vector<double> tab;
+  size_t lds;
   hipStream_t s = nh_stream(stream);
+  int rc = build_terms(a, s, p, tab, &lds);
+  if (rc) return rc;
+  if (a->nelems == 0) return NH_OK;
+  {
+    bool done = false;
+    if ((rc = local_vterms(a, p, tab, &done, s)) != NH_OK) return rc;
+    if (done) return NH_OK;
+  }
+  NH_REQUIRE(lds <= 160 * 1024, "nh_assemble_terms: batch too large for LDS (%zu bytes)", lds);
   if ((rc = place_table(tab, p.tabarg, &p.table, s)) != NH_OK) return rc;
   const i64 nbatch = (a->nelems + p.eb - 1) / p.eb;
   dim3 grid((unsigned)std::min<i64>(nbatch, 256 * 8)), block(NTB);
@@ -1238,6 +1297,77 @@ extern "C" int nh_assemble_terms(const nh_terms_args *a, void *stream) {
   if (a->ndims == 3) LAUNCH(3);
 #undef LAUNCH
   NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+extern "C" int nh_assemble_terms_multi(int count, const nh_terms_args *const *lists, void *stream) {
+  NH_REQUIRE(count >= 0 && (count == 0 || lists), "nh_assemble_terms_multi: invalid argument");
+  hipStream_t s = nh_stream(stream);
+  std::vector<TermsK> ps;
+  std::vector<std::vector<double>> tabs;
+  std::vector<i64> nbatch;
+  size_t lds = 0;
+  int ndims = 0, rc, last = -1;
+  for (int i = 0; i < count; ++i) {
+    const nh_terms_args *a = lists[i];
+    // lists that get their own kind of kernel (thread per element on large meshes), other dimensions or more lists than a launch takes: on their own
+    if (a && (a->nelems >= (1 << 20) || (ndims && a->ndims != ndims) || (int)ps.size() == MAXL)) {
+      if ((rc = nh_assemble_terms(a, stream)) != NH_OK) return rc;
+      continue;
+    }
+    TermsK p;
+    std::vector<double> tab;
+    size_t l;
+    if ((rc = build_terms(a, s, p, tab, &l)) != NH_OK) return rc;
+    if (a->nelems == 0) continue;
+    NH_REQUIRE(l <= 160 * 1024, "nh_assemble_terms: batch too large for LDS (%zu bytes)", l);
+    ndims = a->ndims, last = i;
+    lds = std::max(lds, l);
+    nbatch.push_back((a->nelems + p.eb - 1) / p.eb);
+    ps.push_back(p);
+    tabs.push_back(std::move(tab));
+  }
+  if (ps.empty()) return NH_OK;
+  if (ps.size() == 1) return nh_assemble_terms(lists[last], stream);  // nothing to merge: parameters in the kernel arguments
+  // workgroups per list: in proportion to the batches, at least one, 256 * 8 in total when there is that much work
+  i64 total = 0;
+  for (i64 n : nbatch) total += n;
+  MultiK m;
+  m.count = (int)ps.size();
+  m.first[0] = 0;
+  for (int i = 0; i < m.count; ++i) {
+    const i64 share = total <= 256 * 8 ? nbatch[i] : std::max<i64>(1, nbatch[i] * (256 * 8) / total);
+    m.first[i + 1] = m.first[i] + (unsigned)share;
+  }
+  for (int i = m.count; i < MAXL; ++i) m.first[i + 1] = m.first[m.count];
+  size_t bytes = ps.size() * sizeof(TermsK);
+  std::vector<size_t> toff(ps.size(), 0);
+  for (size_t i = 0; i < ps.size(); ++i)
+    if (tabs[i].size() > (size_t)TABARG) toff[i] = bytes, bytes += tabs[i].size() * sizeof(double);
+  ListSlot *sl;
+  if ((rc = list_slot(bytes, &sl)) != NH_OK) return rc;
+  for (size_t i = 0; i < ps.size(); ++i) {
+    if (toff[i]) {
+      std::memcpy(sl->host + toff[i], tabs[i].data(), tabs[i].size() * sizeof(double));
+      ps[i].table = (const double *)(sl->dev + toff[i]);
+    } else
+      std::copy(tabs[i].begin(), tabs[i].end(), ps[i].tabarg);
+    std::memcpy(sl->host + i * sizeof(TermsK), &ps[i], sizeof(TermsK));
+  }
+  NH_CHECK_HIP(hipMemcpyAsync(sl->dev, sl->host, bytes, hipMemcpyHostToDevice, s));
+  dim3 grid(m.first[m.count]), block(NTB);
+#define LAUNCH(ND)                                                                                                                \
+  do {                                                                                                                            \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_terms_multi<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+    hipLaunchKernelGGL(k_terms_multi<ND>, grid, block, lds, s, (const TermsK *)sl->dev, m);                                       \
+  } while (0)
+  if (ndims == 1) LAUNCH(1);
+  if (ndims == 2) LAUNCH(2);
+  if (ndims == 3) LAUNCH(3);
+#undef LAUNCH
+  NH_LAUNCH_CHECK();
+  NH_CHECK_HIP(hipEventRecord(sl->done, s));
+  sl->used = true;
   return NH_OK;
 }
 

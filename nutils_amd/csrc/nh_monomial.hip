@@ -45,9 +45,25 @@ __global__ void k_monomial(MonoK p) {
   }
 }
 
+// dst[didx[i]] = src[sidx[i]]: the value half of the block merge / submatrix selection.  Consecutive i are consecutive entries of a CSR row
+// segment, so the stores of a wave form a few contiguous runs -- also when dst is page-locked host memory and they travel as PCIe writes.
+__global__ void k_index_copy(i64 n, const double *src, const i64 *sidx, const i64 *didx, double *dst) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(src[sidx ? sidx[i] : i], dst + (didx ? didx[i] : i));
+}
+
 }  // namespace
 
 extern "C" {
+
+int nh_index_copy(int64_t n, const double *src_dev, const int64_t *src_index_dev, const int64_t *dst_index_dev, double *dst, void *stream) {
+  NH_REQUIRE(n >= 0 && src_dev && dst, "nh_index_copy: invalid argument");
+  if (!n) return NH_OK;
+  const unsigned grid = (unsigned)std::min<i64>((n + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(k_index_copy, dim3(grid), dim3(256), 0, nh_stream(stream), (i64)n, src_dev, (const i64 *)src_index_dev, (const i64 *)dst_index_dev, dst);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
 
 int nh_monomial_csr(int64_t nrows, const int64_t *rowptr_dev, const int64_t *colidx_dev, const double *values_dev, const double *x_dev,
                     double alpha, double *y_dev, void *stream) {

@@ -160,12 +160,8 @@ def assemble_vector(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     _lib.call('nh_assemble_vector', ctypes.byref(args), device.stream())
 
 
-def assemble_terms(*, nelems, ndims, nq, weights, geom, fields, blocks, terms, polys=(), elist=None):
-    '''All linear-form terms of a residual on one sample in ONE element loop (nh_assemble_terms).
-    fields: [(basis struct, u, ncomp)], blocks: [(test struct, nct, out)], polys: [(vars [(field, comp)], coeffs, powers [nterms][nvars])],
-    terms: [dict(block, field=-1, poly=-1, C=None, f=None, scale=None)].'''
+def _terms_args(keep, *, nelems, ndims, nq, weights, geom, fields, blocks, terms, polys=(), elist=None):
     S = 1 + ndims
-    keep = []
     F, P = _fields_polys(fields, polys, keep)
     B = (_lib.Block * len(blocks))()
     for i, (b, nct, out) in enumerate(blocks):
@@ -186,8 +182,27 @@ def assemble_terms(*, nelems, ndims, nq, weights, geom, fields, blocks, terms, p
         qB, qt, qr = _qs(t.get('qs'), S)
         keep += [C, f, qB]
         T[i] = _lib.Term(blk, fld, int(t.get('poly', -1)), device.host_ptr(C), device.host_ptr(f), device.ptr(t.get('scale')), qt, qr, device.host_ptr(qB))
-    args = _lib.TermsArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, len(fields), F, len(blocks), B, len(terms), T, len(polys), P)
+    keep += [F, P, B, T]
+    return _lib.TermsArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, len(fields), F, len(blocks), B, len(terms), T, len(polys), P)
+
+
+def assemble_terms(**kwargs):
+    '''All linear-form terms of a residual on one sample in ONE element loop (nh_assemble_terms).  Keywords: nelems, ndims, nq, weights, geom, elist=None,
+    fields: [(basis struct, u, ncomp)], blocks: [(test struct, nct, out)], polys: [(vars [(field, comp)], coeffs, powers [nterms][nvars])],
+    terms: [dict(block, field=-1, poly=-1, C=None, f=None, scale=None)].'''
+    keep = []
+    args = _terms_args(keep, **kwargs)
     _lib.call('nh_assemble_terms', ctypes.byref(args), device.stream())
+
+
+def assemble_terms_multi(lists):
+    '''The term lists of several samples (`lists`: keyword dicts of assemble_terms) in one launch (nh_assemble_terms_multi).'''
+    if not lists:
+        return
+    keep = []
+    args = [_terms_args(keep, **kw) for kw in lists]
+    ptrs = (ctypes.POINTER(_lib.TermsArgs) * len(args))(*[ctypes.pointer(a) for a in args])
+    _lib.call('nh_assemble_terms_multi', len(args), ptrs, device.stream())
 
 
 def _qs(qs, S):
@@ -417,6 +432,16 @@ def monomial(values, args, indices, out, out_index=None, alpha=1.):
     A = (ctypes.c_void_p * max(n, 1))(*[a.data_ptr() for a in args])
     I = (ctypes.c_void_p * max(n, 1))(*[i.data_ptr() for i in indices])
     _lib.call('nh_monomial', values.numel(), device.ptr(values), n, A, I, device.ptr(out_index), float(alpha), device.ptr(out), device.stream())
+
+
+def index_copy(src, dst, src_index=None, dst_index=None):
+    '''dst[dst_index[i]] = src[src_index[i]] (nh_index_copy); `dst` is a device tensor or a PINNED host tensor (device-mapped).'''
+    if not (dst.is_cuda or dst.is_pinned()):
+        raise ValueError('index_copy: the destination must be device memory or page-locked host memory')
+    n = (src_index if src_index is not None else dst_index if dst_index is not None else src).numel()
+    if not n:
+        return
+    _lib.call('nh_index_copy', n, device.ptr(src), device.ptr(src_index), device.ptr(dst_index), device.ptr(dst), device.stream())
 
 
 def pointwise_poly(xs, strides, coeffs, powers, n):

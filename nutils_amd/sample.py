@@ -633,22 +633,28 @@ def _p1hex_setting(smp, basis, geom):
     return verts, list(x1), list(w1)
 
 
-def _p1hex_apply_term(smp, itg, fac, arguments, out):
-    '''Residual-type term `(kappa grad(phi_m) . grad(u) + mu phi_m u) J(geom)` of the headline setting: out += K u through nh_p1hex_apply (the
-    element matrices are applied on the fly, no matrix, no global atomics).  Returns False if the term is anything else.'''
+def _p1hex_match(smp, itg, fac):
+    '''(mass, kappa, setting) if the term is `(kappa grad(phi_m) . grad(u) + mu phi_m u) J(geom)` of the headline setting, else None.'''
     if not (itg.B is not None and itg.rows and not itg.cols and itg.test.basis is itg.trial.basis and itg.test.ncomp == itg.trial.ncomp == 1):
-        return False
+        return None
     B = numpy.asarray(itg.B, dtype=float) * fac
     if B.shape != (1, 4, 1, 4):
-        return False
+        return None
     B = B[0, :, 0, :]
     m, k = float(B[0, 0]), float(B[1, 1])
     if not numpy.array_equal(B, numpy.diag([m, k, k, k])):
-        return False
+        return None
     setting = _p1hex_setting(smp, itg.test.basis, itg.measure)
-    if setting is None:
+    return None if setting is None else (m, k, setting)
+
+
+def _p1hex_apply_term(smp, itg, fac, arguments, out):
+    '''Residual-type term of the headline setting: out += K u through nh_p1hex_apply (the element matrices are applied on the fly, no matrix,
+    no global atomics).  Returns False if the term is anything else.'''
+    match = _p1hex_match(smp, itg, fac)
+    if match is None:
         return False
-    verts, x1, w1 = setting
+    m, k, (verts, x1, w1) = match
     u = device.to_dev(_argument(arguments, itg.trial), 'float64')
     sc = _point_scale(smp, itg, arguments)
     kernels.p1hex_apply(shape=itg.test.basis.shape, u=u, out=out, gauss_x=x1, gauss_w=w1, verts=verts, kappa=k, mass=m,
@@ -708,18 +714,14 @@ def _fusable(itg):
             and (itg.B is not None or itg.L is not None) and (itg.fscale is None or (len(itg.fscale.args) <= 4 and len(itg.fscale.terms) <= 64)))
 
 
-def _launch_terms(items, blocks, arguments, ucache):
-    '''items: [(block index, sample, integrand, factor)] on ONE sample and measure; packed into as few nh_assemble_terms launches as the
-    limits of the entry allow (2 blocks / 4 test components, 6 fields / 8 components, 4 polynomials, 32 terms).'''
+def _plan_terms(items, blocks, lists, leftover):
+    '''items: [(block index, sample, integrand, factor)] on ONE sample and measure; packed into as few term lists as the limits of the entry allow
+    (2 blocks / 4 test components, 6 fields / 8 components, 4 polynomials, 32 terms).  Appends TEMPLATES of the keyword dicts of
+    kernels.assemble_terms to `lists` -- fields as (tables, argument, ncomp), blocks as (tables, ncomp, block index): `_vector_blocks` fills in the
+    device arrays of a Newton step -- and what no list takes to `leftover`.'''
     smp = items[0][1]
     geom = smp.geometry(items[0][2].measure)
     nd, nq = smp.ndims, smp.points.npoints
-
-    def dev_u(arg):
-        if arg.name not in ucache:
-            ucache[arg.name] = device.to_dev(_argument(arguments, arg), 'float64')
-        return ucache[arg.name]
-
     pending = list(items)
     while pending:
         fkeys, bkeys, pkeys, terms, rest = [], [], [], [], []
@@ -754,34 +756,62 @@ def _launch_terms(items, blocks, arguments, ucache):
                 t['qs'] = (numpy.asarray(itg.qscalar[0], dtype=float)[0, :, 0, :], fidx(itg.qscalar[1]), fidx(itg.qscalar[2]))
             terms.append(t)
         if not terms:  # (a single term beyond the limits: the per-term path takes anything)
-            for bi, smp_, itg, fac in pending:
-                _vector_term(smp_, itg, fac, arguments, blocks[bi][1], None)
+            leftover += pending
             return
         fidx = lambda a: next(i for i, k in enumerate(fkeys) if a.same(k))
         polys = []
         for fp in pkeys:
             keys = list(fp.terms)
             polys.append(([(fidx(a), 0) for a in fp.args], [fp.terms[k] for k in keys], keys))
-        kernels.assemble_terms(nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, elist=smp._elist_dev,
-                               fields=[(smp.tables(a.basis).struct, dev_u(a), a.ncomp) for a in fkeys],
-                               blocks=[(smp.tables(blocks[b][0].basis).struct, blocks[b][0].ncomp, blocks[b][1]) for b in bkeys], terms=terms, polys=polys)
+        lists.append(dict(nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, elist=smp._elist_dev,
+                          fields=[(smp.tables(a.basis).struct, a, a.ncomp) for a in fkeys],
+                          blocks=[(smp.tables(blocks[b][0].basis).struct, blocks[b][0].ncomp, b) for b in bkeys], terms=terms, polys=polys))
         pending = rest
+
+
+_TERM_PLANS = {}
 
 
 def _vector_blocks(blocks, arguments, scalar):
     '''Linear forms of one or more output blocks [(test argument, out tensor, terms)]: the structured P1-hex residual terms go through
-    nh_p1hex_apply, everything else that shares a sample and a measure through ONE fused element loop, the remainder term by term.'''
-    groups, ucache = {}, {}
-    for bi, (a0, out, terms) in enumerate(blocks):
-        for smp, itg, fac in terms:
-            if itg.measure is not None and itg.rows and _p1hex_apply_term(smp, itg, fac, arguments, out):
-                continue
-            if not os.environ.get('NUTILS_AMD_NO_BATCHED') and _fusable(itg) and all(a.ncomp == 1 for a in (itg.fscale.args if itg.fscale is not None else ())):
-                groups.setdefault((id(smp), id(itg.measure)), []).append((bi, smp, itg, fac))
-            else:
-                _vector_term(smp, itg, fac, arguments, out, scalar)
-    for items in groups.values():
-        _launch_terms(items, blocks, arguments, ucache)
+    nh_p1hex_apply, everything else that shares a sample and a measure through ONE fused element loop -- and the loops of all samples through one
+    launch (nh_assemble_terms_multi) --, the remainder term by term.  The split and the term lists depend on the integrals only: they are kept
+    per tuple of term lists (the reference caches its compiled callables the same way, solver.py:321-331), a Newton step fills in the arrays.'''
+    env = tuple(bool(os.environ.get('NUTILS_AMD_' + name)) for name in ('NO_BATCHED', 'NO_MULTI', 'NO_FAST_PATH'))  # (debugging switches: part of the key)
+    key = tuple(id(terms) for _, _, terms in blocks) + env
+    plan = _TERM_PLANS.get(key)
+    if plan is None or not all(a is b[2] for a, b in zip(plan['terms'], blocks)):
+        groups, single, lists, leftover = {}, [], [], []
+        for bi, (a0, _, terms) in enumerate(blocks):
+            for smp, itg, fac in terms:
+                if (not env[0] and not (itg.measure is not None and itg.rows and _p1hex_match(smp, itg, fac)) and _fusable(itg)
+                        and all(a.ncomp == 1 for a in (itg.fscale.args if itg.fscale is not None else ()))):
+                    groups.setdefault((id(smp), id(itg.measure)), []).append((bi, smp, itg, fac))
+                else:
+                    single.append((bi, smp, itg, fac))
+        for items in groups.values():
+            _plan_terms(items, blocks, lists, leftover)
+        while len(_TERM_PLANS) >= 8:
+            _TERM_PLANS.pop(next(iter(_TERM_PLANS)))
+        plan = _TERM_PLANS[key] = dict(terms=[b[2] for b in blocks], single=single, lists=lists, leftover=leftover)
+    for bi, smp, itg, fac in plan['single']:
+        _vector_term(smp, itg, fac, arguments, blocks[bi][1], scalar)
+    for bi, smp, itg, fac in plan['leftover']:
+        _vector_term(smp, itg, fac, arguments, blocks[bi][1], None)
+    ucache = {}
+
+    def dev_u(arg):
+        if arg.name not in ucache:
+            ucache[arg.name] = device.to_dev(_argument(arguments, arg), 'float64')
+        return ucache[arg.name]
+
+    lists = [dict(tpl, fields=[(t, dev_u(a), nc) for t, a, nc in tpl['fields']], blocks=[(t, nc, blocks[b][1]) for t, nc, b in tpl['blocks']])
+             for tpl in plan['lists']]
+    if env[1]:  # one launch per sample (tests: the merged launch must give the same result)
+        for kw in lists:
+            kernels.assemble_terms(**kw)
+    else:  # all samples of the residual (volume + the sides of the boundary) in one launch
+        kernels.assemble_terms_multi(lists)
 
 
 def _exposed_test(f):
@@ -795,26 +825,32 @@ def _exposed_test(f):
     return a0
 
 
-def evaluate_blocks(fs, arguments):
+def evaluate_blocks(fs, arguments, flat=False):
     '''The residual blocks of a multi-field system in one pass (solver.py:334-386 evaluates them as one compiled function): the terms
-    of all blocks that share a sample go through one element loop.  Integrals that are not plain linear forms are evaluated one by one.'''
+    of all blocks that share a sample go through one element loop, the blocks share one device buffer and one copy to the host.  Integrals
+    that are not plain linear forms are evaluated one by one.  flat: the concatenation of the raveled blocks instead of the list.'''
     tests = [_exposed_test(f) if isinstance(f, function.Integral) and f.terms else None for f in fs]
+    sizes = [a0.basis.ndofs * a0.ncomp if a0 is not None else 0 for a0 in tests]
+    offsets = numpy.cumsum([0] + sizes)
     blocks, index = [], {}
-    for i, (f, a0) in enumerate(zip(fs, tests)):
-        if a0 is not None:
-            index[i] = len(blocks)
-            blocks.append((a0, device.zeros(a0.basis.ndofs * a0.ncomp, 'float64'), f.terms))
-    if blocks:
+    if offsets[-1]:
+        buf = device.zeros(int(offsets[-1]), 'float64')
+        for i, (f, a0) in enumerate(zip(fs, tests)):
+            if a0 is not None:
+                index[i] = len(blocks)
+                blocks.append((a0, buf[int(offsets[i]):int(offsets[i + 1])], f.terms))
         _vector_blocks(blocks, arguments, [device.zeros(1, 'float64'), 0.])
+        host = device.to_host(buf)
+        if flat and len(index) == len(fs):
+            return host
     out = []
-    for i, f in enumerate(fs):
+    for i, (f, a0) in enumerate(zip(fs, tests)):
         if i in index:
-            a0, o, _ = blocks[index[i]]
-            res = device.to_host(o)
+            res = host[offsets[i]:offsets[i + 1]]
             out.append(res.reshape(a0.basis.ndofs, a0.ncomp) if a0.ncomp > 1 else res)
         else:
             out.append(evaluate(f, arguments))
-    return out
+    return numpy.concatenate([numpy.asarray(o, dtype=float).ravel() for o in out]) if flat else out
 
 
 def evaluate(f, arguments):

@@ -21,6 +21,35 @@ def _names(spec):
     return tuple(spec.split(',')) if isinstance(spec, str) else tuple(spec)
 
 
+class _HostMirror:
+    '''The CSR value array of the (merged, possibly reduced) Jacobian in page-locked host memory, kept up to date in place: the first
+    assembly copies everything, a later one lets the device write only the entries of the field-dependent blocks (compact array `dyn`,
+    entries `sel` of it go to positions `out`) through the mapping of the pinned pages (nh_index_copy) -- for Cahn-Hilliard a quarter
+    of the 0.2 GB.  Two buffers alternate, so the matrix of a step stays valid while the next one is assembled, but not longer: the
+    reference hands out fresh arrays (evaluable.py:6813-6815), a caller that keeps older Jacobians has to copy them.'''
+
+    def __init__(self, values_dev, sel, out):
+        from . import device
+        t = device.torch()
+        self.bufs = [t.empty(values_dev.shape, dtype=values_dev.dtype, pin_memory=True) for _ in range(2)]
+        for buf in self.bufs:
+            buf.copy_(values_dev)
+        self.sel, self.out, self.turn = sel, out, 0
+
+    def first(self):
+        self.turn = 1
+        return self.bufs[0].numpy()
+
+    def publish(self, dyn):
+        from . import device, kernels
+        buf = self.bufs[self.turn]
+        self.turn ^= 1
+        if self.out.numel():
+            kernels.index_copy(dyn, buf, src_index=self.sel, dst_index=self.out)
+        device.synchronize()
+        return buf.numpy()
+
+
 class System:
 
     def __init__(self, residual, /, trial, test=None):
@@ -59,10 +88,11 @@ class System:
     def _build_merge_plan(self, arguments):
         '''Symbolic block merge, ONCE per system (the patterns do not change between Newton steps): every (block, sample)
         group of matrix terms is one device assembly; the position of each of its CSR entries in the merged block matrix is
-        precomputed, so a re-assembly is device launches + one scatter-add per group (nh_monomial with an output index) + one
-        D2H copy of the merged values.  Replaces the per-row Python loop of matrix.assemble_block_csr
+        precomputed.  The groups without a coefficient function are assembled here, once, into `_base`; the others (the
+        field-dependent blocks) are re-assembled per step into the compact array of the entries they touch (`_dynpos`), which is
+        all that crosses PCIe afterwards (`_HostMirror`).  Replaces the per-row Python loop of matrix.assemble_block_csr
         (matrix/__init__.py:141-147) on the per-step path.'''
-        from . import device
+        from . import device, kernels
         groups, keys = [], []
         for i, row in enumerate(self.block_jacobian):
             for j, blk in enumerate(row):
@@ -83,40 +113,57 @@ class System:
         rows, cols = numpy.divmod(ukeys, self.size)
         self._merged_rowptr = numpy.searchsorted(rows, numpy.arange(self.size + 1)).astype(numpy.int64)
         self._merged_colidx = cols.astype(numpy.int64)
-        for grp, key in zip(groups, keys):
-            grp['slot'] = device.to_dev(numpy.searchsorted(ukeys, key), 'int64')
-        self._groups = groups
+        slots = [numpy.searchsorted(ukeys, key) for key in keys]
+        dyn = [slot for grp, slot in zip(groups, slots) if not grp['constant']]
+        self._dynpos = numpy.unique(numpy.concatenate(dyn)) if dyn else numpy.zeros(0, dtype=numpy.int64)
+        self._dynpos_dev = device.to_dev(self._dynpos, 'int64')
+        self._base = device.zeros(len(ukeys), 'float64')
+        for grp, slot in zip(groups, slots):
+            if grp['constant']:
+                kernels.monomial(grp.pop('values'), [], [], self._base, out_index=device.to_dev(slot, 'int64'))
+            else:
+                grp['dslot'] = device.to_dev(numpy.searchsorted(self._dynpos, slot), 'int64')
+        self._dyn_base = device.empty(len(self._dynpos), 'float64')
+        kernels.index_copy(self._base, self._dyn_base, src_index=self._dynpos_dev)
+        self._groups = [grp for grp in groups if not grp['constant']]
+        self._mirror = None
+
+    def _dyn_values(self, arguments):
+        '''Values of the merged Jacobian at `_dynpos` (the entries that field-dependent blocks contribute to), on the device.'''
+        from . import kernels
+        dyn = self._dyn_base.clone()
+        for grp in self._groups:
+            kernels.monomial(grp['plan'].run(arguments)[0], [], [], dyn, out_index=grp['dslot'])
+        return dyn
 
     def _merged_values(self, arguments):
         '''Values of the merged block Jacobian on the device (pattern: _merged_rowptr, _merged_colidx).'''
-        from . import device, kernels
-        merged = device.zeros(len(self._merged_colidx), 'float64')
-        for grp in self._groups:
-            values = grp['values'] if grp['constant'] else grp['plan'].run(arguments)[0]
-            kernels.monomial(values, [], [], merged, out_index=grp['slot'])
+        from . import kernels
+        merged = self._base.clone()
+        if len(self._dynpos):
+            kernels.index_copy(self._dyn_values(arguments), merged, dst_index=self._dynpos_dev)
         return merged
 
     def assemble_jacobian(self, arguments):
-        from . import device
         if self._jac is not None and self.is_constant_matrix:
             return self._jac
         if not hasattr(self, '_groups'):
             self._build_merge_plan(arguments)
-        merged = self._merged_values(arguments)
-        if getattr(self, '_pattern_validated', False):
-            jac = _matrix.reassemble_csr(device.to_host(merged), self._merged_rowptr, self._merged_colidx, self.size)
+        if self._mirror is None:
+            self._mirror = _HostMirror(self._merged_values(arguments), None, self._dynpos_dev)
+            values = self._mirror.first()
+            jac = _matrix.assemble_csr(values, self._merged_rowptr, self._merged_colidx, self.size)
         else:
-            jac = _matrix.assemble_csr(device.to_host(merged), self._merged_rowptr, self._merged_colidx, self.size)
-            self._pattern_validated = True
+            jac = _matrix.reassemble_csr(self._mirror.publish(self._dyn_values(arguments)), self._merged_rowptr, self._merged_colidx, self.size)
         if self.is_constant_matrix:
             self._jac = jac
         return jac
 
     def assemble_jacobian_free(self, arguments, free):
         '''jac.submatrix(free, free) of the reference (solver.py:332,386) WITHOUT the host-side slicing: the positions of the free-free
-        entries in the merged value array and the reduced (rowptr, colidx) are computed once per constraint set, a Newton step is
-        the device assembly + one device gather + the copy of the REDUCED values.'''
-        from . import device
+        entries in the merged value array and the reduced (rowptr, colidx) are computed once per constraint set; a Newton step is the
+        device assembly of the field-dependent blocks + the copy of THEIR free-free entries into the host value array.'''
+        from . import device, kernels
         if not hasattr(self, '_groups'):
             self._build_merge_plan(arguments)
         key = free.tobytes()
@@ -124,22 +171,25 @@ class System:
         if plan is None or plan['key'] != key:
             rp, ci = self._merged_rowptr, self._merged_colidx
             rows = numpy.repeat(numpy.arange(self.size, dtype=numpy.int64), numpy.diff(rp))
-            keep = numpy.flatnonzero(free[rows] & free[ci])
+            keepmask = free[rows] & free[ci]
+            keep = numpy.flatnonzero(keepmask)
             newcol = numpy.cumsum(free, dtype=numpy.int64) - 1
             counts = numpy.bincount(rows[keep], minlength=self.size)[free]
             frp = numpy.zeros(len(counts) + 1, dtype=numpy.int64)
             numpy.cumsum(counts, out=frp[1:])
-            plan = self._free_plan = dict(key=key, keep=device.to_dev(keep, 'int64'), rowptr=frp, colidx=newcol[ci[keep]], n=int(free.sum()), validated=False,
-                                          matrix=None)
+            sel = numpy.flatnonzero(keepmask[self._dynpos])  # entries of the compact dynamic array that survive, and where they go
+            newpos = numpy.cumsum(keepmask, dtype=numpy.int64) - 1
+            plan = self._free_plan = dict(key=key, keep=device.to_dev(keep, 'int64'), rowptr=frp, colidx=newcol[ci[keep]], n=int(free.sum()), matrix=None,
+                                          sel=device.to_dev(sel, 'int64'), out=device.to_dev(newpos[self._dynpos[sel]], 'int64'), mirror=None)
         if plan['matrix'] is not None and self.is_constant_matrix:
             return plan['matrix']
-        merged = self._merged_values(arguments)
-        values = device.to_host(merged.index_select(0, plan['keep']))
-        if plan['validated']:
-            jac = _matrix.reassemble_csr(values, plan['rowptr'], plan['colidx'], plan['n'])
+        if plan['mirror'] is None:
+            values = device.empty(len(plan['colidx']), 'float64')
+            kernels.index_copy(self._merged_values(arguments), values, src_index=plan['keep'])
+            plan['mirror'] = _HostMirror(values, plan['sel'], plan['out'])
+            jac = _matrix.assemble_csr(plan['mirror'].first(), plan['rowptr'], plan['colidx'], plan['n'])
         else:
-            jac = _matrix.assemble_csr(values, plan['rowptr'], plan['colidx'], plan['n'])
-            plan['validated'] = True
+            jac = _matrix.reassemble_csr(plan['mirror'].publish(self._dyn_values(arguments)), plan['rowptr'], plan['colidx'], plan['n'])
         if self.is_constant_matrix:
             plan['matrix'] = jac
         return jac
@@ -148,6 +198,8 @@ class System:
         sizes = [int(n) for n in numpy.diff(self.offsets)]
         try:  # all blocks in one pass: the terms that share a sample go through one element loop (nh_assemble_terms)
             live = [r for r in self.block_residual if r.terms]
+            if len(live) == len(sizes):  # one device buffer, one copy: the blocks arrive concatenated
+                return _sample.evaluate_blocks(live, arguments, flat=True)
             vals = iter(_sample.evaluate_blocks(live, arguments))
             return numpy.concatenate([numpy.asarray(next(vals), dtype=float).ravel() if r.terms else numpy.zeros(n) for r, n in zip(self.block_residual, sizes)])
         except NotImplementedError:

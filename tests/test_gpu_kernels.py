@@ -552,6 +552,44 @@ def test_terms_two_blocks_polynomial_factor(golden, name):
         close(device.to_host(o), device.to_host(r))
 
 
+@pytest.mark.parametrize('name', ['lap2d_spline2_5x4_iso', 'lap3d_p1_3_iso'])
+def test_terms_multi_equals_separate_launches(golden, name):
+    '''nh_assemble_terms_multi: three term lists in one launch (all elements with a polynomial factor; an element subset through `elist` with 24 terms,
+    whose table does not fit the parameter block and travels beside it; an empty list) = the same lists through nh_assemble_terms, one launch each.'''
+    from nutils_amd import device, kernels
+    g = golden(name)
+    c = Case(g)
+    rng = numpy.random.default_rng(11)
+    nd, S = c.nd, 1 + c.nd
+    us = [device.to_dev(rng.normal(size=c.ndofs), 'float64') for _ in range(2)]
+    sub = numpy.sort(rng.choice(c.nelems, size=max(2, c.nelems // 3), replace=False)).astype(numpy.int32)
+    elist = device.to_dev(sub, 'int32')
+    sc = device.to_dev(rng.uniform(.5, 1.5, len(sub) * c.nq), 'float64')
+
+    def lists(outs):
+        common = dict(ndims=nd, nq=c.nq, weights=c.weights, geom=c.geom, fields=[(c.basis, u, 1) for u in us])
+        a = dict(nelems=c.nelems, blocks=[(c.basis, 1, o) for o in outs], polys=[([(0, 0), (1, 0)], [.5, -1., 2.], [[2, 0], [1, 1], [0, 0]])],
+                 terms=[dict(block=0, field=0, C=rng0.normal(size=(1, S, 1, S)), poly=0), dict(block=1, field=1, C=rng0.normal(size=(1, S, 1, S))),
+                        dict(block=1, f=rng0.normal(size=(1, S)), poly=0)], **common)
+        b = dict(nelems=len(sub), elist=elist, blocks=[(c.basis, 1, outs[1])],
+                 terms=[dict(block=0, field=k % 2, C=rng0.normal(size=(1, S, 1, S)), f=rng0.normal(size=(1, S)), scale=sc if k % 3 == 0 else None) for k in range(24)], **common)
+        e = dict(nelems=0, blocks=[(c.basis, 1, outs[0])], terms=[dict(block=0, f=numpy.ones((1, S)))], **common)
+        return [a, b, e]
+
+    out = [device.zeros(c.ndofs, 'float64') for _ in range(2)]
+    ref = [device.zeros(c.ndofs, 'float64') for _ in range(2)]
+    rng0 = numpy.random.default_rng(3)
+    for _ in range(3):  # (the ring of parameter buffers is reused)
+        kernels.assemble_terms_multi(lists(out))
+    rng0 = numpy.random.default_rng(3)
+    for _ in range(3):
+        for kw in lists(ref):
+            kernels.assemble_terms(**kw)
+    for o, r in zip(out, ref):
+        assert numpy.abs(device.to_host(r)).max() > 0
+        close(device.to_host(o), device.to_host(r))
+
+
 def test_terms_ragged_and_errors(golden):
     '''Ragged bases (functions per element from the offsets) and the argument checks of nh_assemble_terms.'''
     from nutils_amd import device, kernels, _lib
