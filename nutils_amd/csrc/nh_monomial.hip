@@ -59,7 +59,11 @@ extern "C" {
 int nh_index_copy(int64_t n, const double *src_dev, const int64_t *src_index_dev, const int64_t *dst_index_dev, double *dst, void *stream) {
   NH_REQUIRE(n >= 0 && src_dev && dst, "nh_index_copy: invalid argument");
   if (!n) return NH_OK;
-  const unsigned grid = (unsigned)std::min<i64>((n + 255) / 256, 256 * 32);
+  // host destination: the copy is PCIe bound and usually runs beside the next assembly on another stream -- a few waves per CU keep the link busy
+  hipPointerAttribute_t attr;
+  const bool host = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeHost;
+  if (!host) (void)hipGetLastError();
+  const unsigned grid = (unsigned)std::min<i64>((n + 255) / 256, host ? 256 * 2 : 256 * 32);
   hipLaunchKernelGGL(k_index_copy, dim3(grid), dim3(256), 0, nh_stream(stream), (i64)n, src_dev, (const i64 *)src_index_dev, (const i64 *)dst_index_dev, dst);
   NH_LAUNCH_CHECK();
   return NH_OK;

@@ -34,20 +34,31 @@ class _HostMirror:
         self.bufs = [t.empty(values_dev.shape, dtype=values_dev.dtype, pin_memory=True) for _ in range(2)]
         for buf in self.bufs:
             buf.copy_(values_dev)
-        self.sel, self.out, self.turn = sel, out, 0
+        self.sel, self.out, self.turn, self.side = sel, out, 0, None
 
     def first(self):
         self.turn = 1
         return self.bufs[0].numpy()
 
     def publish(self, dyn):
+        '''Starts the copy of the changed entries on a side stream (the residual of the same Newton step is assembled meanwhile: its kernels
+        run beside the PCIe writes); returns finish() -> host value array.'''
         from . import device, kernels
+        t = device.torch()
         buf = self.bufs[self.turn]
         self.turn ^= 1
-        if self.out.numel():
+        if not self.out.numel():
+            return buf.numpy
+        if self.side is None:
+            self.side = t.cuda.Stream()
+        self.side.wait_stream(t.cuda.current_stream())
+        with t.cuda.stream(self.side):
             kernels.index_copy(dyn, buf, src_index=self.sel, dst_index=self.out)
-        device.synchronize()
-        return buf.numpy()
+
+        def finish(dyn=dyn):  # (holds `dyn` until the side stream is through with it)
+            self.side.synchronize()
+            return buf.numpy()
+        return finish
 
 
 class System:
@@ -145,27 +156,31 @@ class System:
         return merged
 
     def assemble_jacobian(self, arguments):
-        if self._jac is not None and self.is_constant_matrix:
-            return self._jac
-        if not hasattr(self, '_groups'):
-            self._build_merge_plan(arguments)
-        if self._mirror is None:
-            self._mirror = _HostMirror(self._merged_values(arguments), None, self._dynpos_dev)
-            values = self._mirror.first()
-            jac = _matrix.assemble_csr(values, self._merged_rowptr, self._merged_colidx, self.size)
-        else:
-            jac = _matrix.reassemble_csr(self._mirror.publish(self._dyn_values(arguments)), self._merged_rowptr, self._merged_colidx, self.size)
-        if self.is_constant_matrix:
-            self._jac = jac
-        return jac
+        return self._start_jacobian(arguments, None)()
 
     def assemble_jacobian_free(self, arguments, free):
         '''jac.submatrix(free, free) of the reference (solver.py:332,386) WITHOUT the host-side slicing: the positions of the free-free
         entries in the merged value array and the reduced (rowptr, colidx) are computed once per constraint set; a Newton step is the
         device assembly of the field-dependent blocks + the copy of THEIR free-free entries into the host value array.'''
+        return self._start_jacobian(arguments, free)()
+
+    def _start_jacobian(self, arguments, free):
+        '''Launches the device work of a (reduced, if `free` is given) Jacobian and returns finish() -> Matrix.  Between the two calls the
+        changed entries travel to the host on a side stream; `assemble_jacobian_residual` puts the residual of the step there.'''
         from . import device, kernels
+        if free is None and self._jac is not None and self.is_constant_matrix:
+            return lambda: self._jac
         if not hasattr(self, '_groups'):
             self._build_merge_plan(arguments)
+        if free is None:
+            if self._mirror is None:
+                self._mirror = _HostMirror(self._merged_values(arguments), None, self._dynpos_dev)
+                jac = _matrix.assemble_csr(self._mirror.first(), self._merged_rowptr, self._merged_colidx, self.size)
+                if self.is_constant_matrix:
+                    self._jac = jac
+                return lambda: jac
+            pending = self._mirror.publish(self._dyn_values(arguments))
+            return lambda: _matrix.reassemble_csr(pending(), self._merged_rowptr, self._merged_colidx, self.size)
         key = free.tobytes()
         plan = getattr(self, '_free_plan', None)
         if plan is None or plan['key'] != key:
@@ -182,17 +197,17 @@ class System:
             plan = self._free_plan = dict(key=key, keep=device.to_dev(keep, 'int64'), rowptr=frp, colidx=newcol[ci[keep]], n=int(free.sum()), matrix=None,
                                           sel=device.to_dev(sel, 'int64'), out=device.to_dev(newpos[self._dynpos[sel]], 'int64'), mirror=None)
         if plan['matrix'] is not None and self.is_constant_matrix:
-            return plan['matrix']
+            return lambda: plan['matrix']
         if plan['mirror'] is None:
             values = device.empty(len(plan['colidx']), 'float64')
             kernels.index_copy(self._merged_values(arguments), values, src_index=plan['keep'])
             plan['mirror'] = _HostMirror(values, plan['sel'], plan['out'])
             jac = _matrix.assemble_csr(plan['mirror'].first(), plan['rowptr'], plan['colidx'], plan['n'])
-        else:
-            jac = _matrix.reassemble_csr(plan['mirror'].publish(self._dyn_values(arguments)), plan['rowptr'], plan['colidx'], plan['n'])
-        if self.is_constant_matrix:
-            plan['matrix'] = jac
-        return jac
+            if self.is_constant_matrix:
+                plan['matrix'] = jac
+            return lambda: jac
+        pending = plan['mirror'].publish(self._dyn_values(arguments))
+        return lambda: _matrix.reassemble_csr(pending(), plan['rowptr'], plan['colidx'], plan['n'])
 
     def assemble_residual(self, arguments):
         sizes = [int(n) for n in numpy.diff(self.offsets)]
@@ -215,8 +230,12 @@ class System:
             parts.append(v)
         return numpy.concatenate(parts)
 
-    def assemble_jacobian_residual(self, arguments):
-        return self.assemble_jacobian(arguments), self.assemble_residual(arguments)
+    def assemble_jacobian_residual(self, arguments, free=None):
+        '''Jacobian (reduced to the free dofs if `free` is given) and residual of one Newton step, as the reference evaluates them: in one go
+        (solver.py:358-387; its Newton drivers call nothing else, :633,659,751-760).  The residual is assembled while the changed Jacobian entries are on their way to the host.'''
+        finish = self._start_jacobian(arguments, free)
+        res = self.assemble_residual(arguments)
+        return finish(), res
 
     def assemble_value(self, arguments):
         if not self.is_symmetric:
@@ -256,8 +275,12 @@ class System:
         args = self._unpack(dict(arguments or {}), x)
         if not self.is_linear and tol <= 0:
             raise ValueError('iterative solver requires a strictly positive tolerance')
+        sub = None if free.all() else free  # constraint elimination on the device: only the free-free block travels to the host solver
         for it in range(maxiter + 1):
-            res = self.assemble_residual(args)
+            if self.is_linear:
+                res, jac = self.assemble_residual(args), None
+            else:  # residual and Jacobian of the iterate in one go, like the reference (the last Jacobian is not used)
+                jac, res = self.assemble_jacobian_residual(args, sub)
             resnorm = numpy.linalg.norm(res[free])
             if it and (self.is_linear or resnorm <= tol):
                 break
@@ -265,10 +288,12 @@ class System:
                 break
             if it == maxiter:
                 raise SolverError(f'failed to converge in {maxiter} iterations (residual norm {resnorm:.1e})')
-            if free.all():
-                x = x - self.assemble_jacobian(args).solve(res)
-            else:  # constraint elimination on the device: only the free-free block travels to the host solver
-                x[free] -= self.assemble_jacobian_free(args, free).solve(res[free])
+            if jac is None:
+                jac = self._start_jacobian(args, sub)()
+            if sub is None:
+                x = x - jac.solve(res)
+            else:
+                x[free] -= jac.solve(res[free])
             args = self._unpack(args, x)
         return args
 
