@@ -8,6 +8,7 @@
 // (evaluable.py:6773-6786, Inflate/Assemble scatter :3341-3495) for a list of terms, instead of one launch per term.
 #include "nh_common.h"
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -1242,20 +1243,34 @@ int build_terms(const nh_terms_args *a, hipStream_t stream, TermsK &p, std::vect
 }
 
 // parameter blocks (+ the term tables that do not fit them) of a multi-list launch: page-locked host and device buffer pairs in a ring, so
-// that neither the stream nor the host has to wait for the previous launch
+// that neither the stream nor the host has to wait for the previous launch.  A launch whose parameter image equals that of a slot (the same
+// lists on the same arrays: a Newton loop, where the allocator hands out the same blocks step after step) reuses the device copy: no
+// host-to-device transfer in front of the kernel
 struct ListSlot {
   char *host = nullptr, *dev = nullptr;
   size_t cap = 0;
-  hipEvent_t done = nullptr;
+  hipEvent_t done = nullptr, uploaded = nullptr;
   bool used = false;
+  std::vector<char> image;  // what the device copy holds (device addresses of the tables not filled in)
 };
-int list_slot(size_t bytes, ListSlot **out) {
-  static ListSlot ring[8];
+constexpr int NSLOT = 8;
+int list_slot(const std::vector<char> &image, ListSlot **out, bool *hit) {
+  static ListSlot ring[NSLOT];
   static int next = 0;
+  for (ListSlot &sl : ring)
+    if (sl.used && sl.image.size() == image.size() && !std::memcmp(sl.image.data(), image.data(), image.size())) {
+      *out = &sl, *hit = true;
+      return NH_OK;
+    }
   ListSlot &sl = ring[next];
-  next = (next + 1) % 8;
-  if (!sl.done) NH_CHECK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  next = (next + 1) % NSLOT;
+  if (!sl.done) {
+    NH_CHECK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    NH_CHECK_HIP(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+  }
   if (sl.used) NH_CHECK_HIP(hipEventSynchronize(sl.done));
+  sl.used = false;
+  const size_t bytes = image.size();
   if (bytes > sl.cap) {
     if (sl.host) NH_CHECK_HIP(hipHostFree(sl.host));
     if (sl.dev) NH_CHECK_HIP(hipFree(sl.dev));
@@ -1264,7 +1279,8 @@ int list_slot(size_t bytes, ListSlot **out) {
     NH_CHECK_HIP(hipMalloc((void **)&sl.dev, 2 * bytes));
     sl.cap = 2 * bytes;
   }
-  *out = &sl;
+  sl.image = image;
+  *out = &sl, *hit = false;
   return NH_OK;
 }
 
@@ -1316,6 +1332,7 @@ extern "C" int nh_assemble_terms_multi(int count, const nh_terms_args *const *li
       continue;
     }
     TermsK p;
+    std::memset((void *)&p, 0, sizeof p);  // (padding and unused entries: the parameter images are compared byte by byte)
     std::vector<double> tab;
     size_t l;
     if ((rc = build_terms(a, s, p, tab, &l)) != NH_OK) return rc;
@@ -1344,17 +1361,30 @@ extern "C" int nh_assemble_terms_multi(int count, const nh_terms_args *const *li
   std::vector<size_t> toff(ps.size(), 0);
   for (size_t i = 0; i < ps.size(); ++i)
     if (tabs[i].size() > (size_t)TABARG) toff[i] = bytes, bytes += tabs[i].size() * sizeof(double);
-  ListSlot *sl;
-  if ((rc = list_slot(bytes, &sl)) != NH_OK) return rc;
+  std::vector<char> image(bytes, 0);
   for (size_t i = 0; i < ps.size(); ++i) {
-    if (toff[i]) {
-      std::memcpy(sl->host + toff[i], tabs[i].data(), tabs[i].size() * sizeof(double));
-      ps[i].table = (const double *)(sl->dev + toff[i]);
-    } else
+    if (toff[i])
+      std::memcpy(image.data() + toff[i], tabs[i].data(), tabs[i].size() * sizeof(double));
+    else
       std::copy(tabs[i].begin(), tabs[i].end(), ps[i].tabarg);
-    std::memcpy(sl->host + i * sizeof(TermsK), &ps[i], sizeof(TermsK));
+    ps[i].table = nullptr;
+    std::memcpy(image.data() + i * sizeof(TermsK), &ps[i], sizeof(TermsK));
   }
-  NH_CHECK_HIP(hipMemcpyAsync(sl->dev, sl->host, bytes, hipMemcpyHostToDevice, s));
+  ListSlot *sl;
+  bool hit;
+  if ((rc = list_slot(image, &sl, &hit)) != NH_OK) return rc;
+  if (hit) {
+    NH_CHECK_HIP(hipStreamWaitEvent(s, sl->uploaded, 0));  // (the copy may still be queued on the stream of the launch that made it)
+  } else {
+    std::memcpy(sl->host, image.data(), bytes);
+    for (size_t i = 0; i < ps.size(); ++i)
+      if (toff[i]) {
+        const double *table = (const double *)(sl->dev + toff[i]);
+        std::memcpy(sl->host + i * sizeof(TermsK) + offsetof(TermsK, table), &table, sizeof table);
+      }
+    NH_CHECK_HIP(hipMemcpyAsync(sl->dev, sl->host, bytes, hipMemcpyHostToDevice, s));
+    NH_CHECK_HIP(hipEventRecord(sl->uploaded, s));
+  }
   dim3 grid(m.first[m.count]), block(NTB);
 #define LAUNCH(ND)                                                                                                                \
   do {                                                                                                                            \

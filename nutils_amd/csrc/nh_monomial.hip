@@ -5,6 +5,7 @@
 //   * general COO with up to 4 gathered arguments and an optional output index (scalar result if NULL).
 #include "nh_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -63,7 +64,8 @@ int nh_index_copy(int64_t n, const double *src_dev, const int64_t *src_index_dev
   hipPointerAttribute_t attr;
   const bool host = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeHost;
   if (!host) (void)hipGetLastError();
-  const unsigned grid = (unsigned)std::min<i64>((n + 255) / 256, host ? 256 * 2 : 256 * 32);
+  static const int hostwgs = getenv("NH_INDEX_COPY_WGS") ? atoi(getenv("NH_INDEX_COPY_WGS")) : 256 * 2;
+  const unsigned grid = (unsigned)std::min<i64>((n + 255) / 256, host ? hostwgs : 256 * 32);
   hipLaunchKernelGGL(k_index_copy, dim3(grid), dim3(256), 0, nh_stream(stream), (i64)n, src_dev, (const i64 *)src_index_dev, (const i64 *)dst_index_dev, dst);
   NH_LAUNCH_CHECK();
   return NH_OK;

@@ -115,10 +115,10 @@ class Sample:
             nq, nd, ne = self.points.npoints, self.ndims, self.nlist
             xs = []
             for arg in fp.args:
-                u = _argument(arguments or {}, arg)
+                u = _argument_dev(arguments or {}, arg)
                 U = device.empty(ne * nq * (1 + nd), 'float64')
                 kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(_default_geometry(self.topo)), trial=self.tables(arg.basis).struct,
-                                    ncr=1, points=self._points_dev, u=device.to_dev(u, 'float64'), U=U, elist=self._elist_dev)
+                                    ncr=1, points=self._points_dev, u=u, U=U, elist=self._elist_dev)
                 xs.append(U)
             keys = list(fp.terms)
             f = kernels.pointwise_poly(xs, [1 + nd] * len(xs), [fp.terms[k] for k in keys], keys, ne * nq)
@@ -244,6 +244,50 @@ def _argument(arguments, arg):
     return u.reshape(arg.basis.ndofs, arg.ncomp)
 
 
+_UPLOADS = None  # inside an upload_scope: argument name -> (host array, device tensor)
+
+
+class upload_scope:
+    '''Within the scope an argument array is copied to the device once (keyed by its name and the identity of the array): the Jacobian and the
+    residual of one Newton step share the uploads of the fields they both depend on.'''
+
+    def __enter__(self):
+        global _UPLOADS
+        self.outer = _UPLOADS
+        if _UPLOADS is None:
+            _UPLOADS = {}
+
+    def __exit__(self, *exc):
+        global _UPLOADS
+        _UPLOADS = self.outer
+
+
+def prefetch_arguments(integrals, arguments):
+    '''Inside an upload_scope: start the copies of every bound field the terms of `integrals` read, before anything else of the step is enqueued.
+    (A Newton step streams the changed Jacobian entries to the host while the residual is assembled; host-to-device copies issued during that
+    time wait behind the posted PCIe writes.)'''
+    for f in integrals:
+        for _, itg, _ in getattr(f, 'terms', ()):
+            need = [itg.trial if itg.B is not None else None, itg.test if not itg.rows else None]
+            need += list(itg.fscale.args) if itg.fscale is not None else []
+            need += [itg.qscalar[1], itg.qscalar[2]] if itg.qscalar is not None else []
+            for arg in need:
+                if arg is not None and getattr(arg, 'name', None) in arguments:
+                    _argument_dev(arguments, arg)
+
+
+def _argument_dev(arguments, arg):
+    '''Device copy [ndofs][ncomp] of the array bound to `arg`.'''
+    u = _argument(arguments, arg)
+    if _UPLOADS is None:
+        return device.to_dev(u, 'float64')
+    src = arguments[arg.name]
+    hit = _UPLOADS.get(arg.name)
+    if hit is None or hit[0] is not src:
+        hit = _UPLOADS[arg.name] = (src, device.to_dev(u, 'float64'))
+    return hit[1]
+
+
 # Element colouring (structured bases): elements whose multi-indices are congruent modulo the dof-overlap stride share no
 # dof, so one launch per colour may add into the CSR values with plain loads/stores (NH_MATRIX_EXCLUSIVE): deterministic and
 # at HBM rate instead of memory-side f64 atomics.  Used above COLOR_THRESHOLD elements when the local matrix is large enough
@@ -287,7 +331,7 @@ def _field_values(smp, arg, geom, arguments):
     nq, S = smp.points.npoints, 1 + smp.ndims
     U = device.empty(smp.nlist * nq * S, 'float64')
     kernels.sample_eval(nelems=smp.nlist, ndims=smp.ndims, nq=nq, geom=smp.geometry(geom), trial=smp.tables(arg.basis).struct, ncr=1,
-                        points=smp._points_dev, u=device.to_dev(_argument(arguments, arg), 'float64'), U=U, elist=smp._elist_dev)
+                        points=smp._points_dev, u=_argument_dev(arguments, arg), U=U, elist=smp._elist_dev)
     return U.reshape(smp.nlist * nq, S)
 
 
@@ -537,7 +581,7 @@ class _MatrixPlan:
             for fp in pkeys:
                 keys = list(fp.terms)
                 polys.append(([(fidx(a), 0) for a in fp.args], [fp.terms[k] for k in keys], keys))
-            fields = [(smp.tables(a.basis).struct, device.to_dev(_argument(arguments, a), 'float64'), a.ncomp) for a in fkeys]
+            fields = [(smp.tables(a.basis).struct, _argument_dev(arguments, a), a.ncomp) for a in fkeys]
             kernels.assemble_matrix_terms(nelems=smp.nlist, elist=smp._elist_dev, ndims=nd, nq=nq, weights=smp._weights_dev, geom=smp.geometry(items[0][1].measure),
                                           test=tt.struct, trial=tr.struct, nct=nct, ncr=ncr, mask=mask, pattern=smp.pattern(self.test.basis, self.trial.basis),
                                           values=values, terms=tl, fields=fields, polys=polys)
@@ -655,7 +699,7 @@ def _p1hex_apply_term(smp, itg, fac, arguments, out):
     if match is None:
         return False
     m, k, (verts, x1, w1) = match
-    u = device.to_dev(_argument(arguments, itg.trial), 'float64')
+    u = _argument_dev(arguments, itg.trial)
     sc = _point_scale(smp, itg, arguments)
     kernels.p1hex_apply(shape=itg.test.basis.shape, u=u, out=out, gauss_x=x1, gauss_w=w1, verts=verts, kappa=k, mass=m,
                         qscale=sc if k else None, qmass=sc if m else None, accumulate=True)
@@ -672,18 +716,18 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
     if itg.B is not None:
         tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
         if itg.rows and not itg.cols:
-            u = device.to_dev(_argument(arguments, itg.trial), 'float64')
+            u = _argument_dev(arguments, itg.trial)
             kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                     nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=out)
             return
         if not itg.rows and not itg.cols:
             if itg.test.same(itg.trial):
-                u = device.to_dev(_argument(arguments, itg.trial), 'float64')
+                u = _argument_dev(arguments, itg.trial)
                 kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                         nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * (2 * fac), u=u, out_scalar=scalar[0])
             else:
                 tmp = device.zeros(itg.test.basis.ndofs * itg.test.ncomp, 'float64')
-                u = device.to_dev(_argument(arguments, itg.trial), 'float64')
+                u = _argument_dev(arguments, itg.trial)
                 kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tr.struct,
                                         nct=itg.test.ncomp, ncr=itg.trial.ncomp, C=itg.B * fac, u=u, out=tmp)
                 # v . r for two different bound fields: O(ndofs) post-processing on the host
@@ -696,7 +740,7 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
             kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
                                     nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, out=out)
         else:
-            u = device.to_dev(_argument(arguments, itg.test), 'float64')
+            u = _argument_dev(arguments, itg.test)
             kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct, trial=tt.struct,
                                     nct=itg.test.ncomp, ncr=itg.test.ncomp, f=itg.L * fac, u=u, out_scalar=scalar[0])
         return
@@ -802,7 +846,7 @@ def _vector_blocks(blocks, arguments, scalar):
 
     def dev_u(arg):
         if arg.name not in ucache:
-            ucache[arg.name] = device.to_dev(_argument(arguments, arg), 'float64')
+            ucache[arg.name] = _argument_dev(arguments, arg)
         return ucache[arg.name]
 
     lists = [dict(tpl, fields=[(t, dev_u(a), nc) for t, a, nc in tpl['fields']], blocks=[(t, nc, blocks[b][1]) for t, nc, b in tpl['blocks']])
@@ -829,28 +873,45 @@ def evaluate_blocks(fs, arguments, flat=False):
     '''The residual blocks of a multi-field system in one pass (solver.py:334-386 evaluates them as one compiled function): the terms
     of all blocks that share a sample go through one element loop, the blocks share one device buffer and one copy to the host.  Integrals
     that are not plain linear forms are evaluated one by one.  flat: the concatenation of the raveled blocks instead of the list.'''
+    return start_blocks(fs, arguments, flat)()
+
+
+def start_blocks(fs, arguments, flat=False):
+    '''`evaluate_blocks` in two halves: enqueues the device work and the copy to page-locked host memory on the current stream and returns
+    finish() -> result, which waits for that stream.  (A Newton step runs the residual on its own stream beside the Jacobian kernels.)'''
+    t = device.torch()
     tests = [_exposed_test(f) if isinstance(f, function.Integral) and f.terms else None for f in fs]
     sizes = [a0.basis.ndofs * a0.ncomp if a0 is not None else 0 for a0 in tests]
     offsets = numpy.cumsum([0] + sizes)
-    blocks, index = [], {}
+    index, host, stream = {}, None, None
     if offsets[-1]:
+        blocks = []
         buf = device.zeros(int(offsets[-1]), 'float64')
         for i, (f, a0) in enumerate(zip(fs, tests)):
             if a0 is not None:
                 index[i] = len(blocks)
                 blocks.append((a0, buf[int(offsets[i]):int(offsets[i + 1])], f.terms))
         _vector_blocks(blocks, arguments, [device.zeros(1, 'float64'), 0.])
-        host = device.to_host(buf)
+        host = t.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+        host.copy_(buf, non_blocking=True)
+        stream = t.cuda.current_stream()
+    others = {i: evaluate(f, arguments) for i, f in enumerate(fs) if i not in index}
+
+    def finish(buf=buf if offsets[-1] else None):  # (keeps the device buffer until the copy has run)
+        if stream is not None:
+            stream.synchronize()
+        h = host.numpy() if host is not None else None
         if flat and len(index) == len(fs):
-            return host
-    out = []
-    for i, (f, a0) in enumerate(zip(fs, tests)):
-        if i in index:
-            res = host[offsets[i]:offsets[i + 1]]
-            out.append(res.reshape(a0.basis.ndofs, a0.ncomp) if a0.ncomp > 1 else res)
-        else:
-            out.append(evaluate(f, arguments))
-    return numpy.concatenate([numpy.asarray(o, dtype=float).ravel() for o in out]) if flat else out
+            return h
+        out = []
+        for i, a0 in enumerate(tests):
+            if i in index:
+                res = h[offsets[i]:offsets[i + 1]]
+                out.append(res.reshape(a0.basis.ndofs, a0.ncomp) if a0.ncomp > 1 else res)
+            else:
+                out.append(others[i])
+        return numpy.concatenate([numpy.asarray(o, dtype=float).ravel() for o in out]) if flat else out
+    return finish
 
 
 def evaluate(f, arguments):

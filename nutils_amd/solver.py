@@ -210,13 +210,18 @@ class System:
         return lambda: _matrix.reassemble_csr(pending(), plan['rowptr'], plan['colidx'], plan['n'])
 
     def assemble_residual(self, arguments):
+        return self._start_residual(arguments)()
+
+    def _start_residual(self, arguments):
+        '''Enqueues the residual on the current stream, returns finish() -> concatenated residual vector.'''
         sizes = [int(n) for n in numpy.diff(self.offsets)]
         try:  # all blocks in one pass: the terms that share a sample go through one element loop (nh_assemble_terms)
             live = [r for r in self.block_residual if r.terms]
             if len(live) == len(sizes):  # one device buffer, one copy: the blocks arrive concatenated
-                return _sample.evaluate_blocks(live, arguments, flat=True)
+                return _sample.start_blocks(live, arguments, flat=True)
             vals = iter(_sample.evaluate_blocks(live, arguments))
-            return numpy.concatenate([numpy.asarray(next(vals), dtype=float).ravel() if r.terms else numpy.zeros(n) for r, n in zip(self.block_residual, sizes)])
+            res = numpy.concatenate([numpy.asarray(next(vals), dtype=float).ravel() if r.terms else numpy.zeros(n) for r, n in zip(self.block_residual, sizes)])
+            return lambda: res
         except NotImplementedError:
             pass
         parts = []
@@ -228,13 +233,19 @@ class System:
                 for term in r.terms:
                     v += numpy.asarray(_sample.evaluate(function.Integral([term]), arguments)).ravel()
             parts.append(v)
-        return numpy.concatenate(parts)
+        res = numpy.concatenate(parts)
+        return lambda: res
 
     def assemble_jacobian_residual(self, arguments, free=None):
         '''Jacobian (reduced to the free dofs if `free` is given) and residual of one Newton step, as the reference evaluates them: in one go
-        (solver.py:358-387; its Newton drivers call nothing else, :633,659,751-760).  The residual is assembled while the changed Jacobian entries are on their way to the host.'''
-        finish = self._start_jacobian(arguments, free)
-        res = self.assemble_residual(arguments)
+        (solver.py:358-387; its Newton drivers call nothing else, :633,659,751-760).'''
+        with _sample.upload_scope():  # (every field is copied to the device once, before the Jacobian entries start to travel the other way)
+            _sample.prefetch_arguments(self.block_residual, arguments)
+            # Jacobian kernels, then -- while the changed entries are written to the host by a side stream -- the residual.  (Measured alternatives,
+            # profiles/r02_c4.md: the residual on a third stream beside the Jacobian kernels gains nothing, both fill the register files; kernels
+            # next to the host-bound stores run at half speed, the stores back up the write queues of the L2 channels -- still the best order.)
+            finish = self._start_jacobian(arguments, free)
+            res = self.assemble_residual(arguments)
         return finish(), res
 
     def assemble_value(self, arguments):

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+'''C4 Newton steps only (timeline runs); C4 probe (BASELINE.json configs[3]): Cahn-Hilliard 512^2, p=2, nonlinear residual + Jacobian re-assembly per Newton step.'''
+import sys, time
+sys.path.insert(0, '.')
+import numpy, torch
+from nutils_amd import mesh, function, device
+from nutils_amd.solver import System
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+btype = sys.argv[2] if len(sys.argv) > 2 else 'spline'
+size, eps, M, stens, wn, wp, dt = 10., 1., 1., 50., 30., 20., .5
+domain, geom = mesh.rectilinear([numpy.linspace(0, size, n + 1)] * 2)
+phi = domain.field('φ', btype=btype, degree=2)
+phi0 = domain.field('φ0', btype=btype, degree=2)
+eta = domain.field('η', btype=btype, degree=2) * (stens / eps)
+p, p0 = function.value(phi), function.value(phi0)
+dp = p - p0
+psi = .25 * (p ** 2 - 1) ** 2
+dpsi = .25 * dp ** 2 * (1 - p ** 2 + 2 * p * dp / 3 - dp ** 2 / 6)
+dV = function.J(geom)
+grad = lambda w: function.grad(w, geom)
+nrg = domain.integral((psi + dpsi) * (stens / eps) * dV, degree=8) \
+    + domain.integral(.5 * stens * eps * (grad(phi) * grad(phi)).sum(-1) * dV, degree=8) \
+    - domain.integral(eta * phi * dV, degree=8) + domain.integral(eta * phi0 * dV, degree=8) \
+    - domain.integral(.5 * dt * M * (grad(eta) * grad(eta)).sum(-1) * dV, degree=8) \
+    + domain.boundary.integral((wp + wn) / 2 * dV, degree=4) + domain.boundary.integral((wp - wn) / 2 * phi * dV, degree=4)
+system = System(nrg, trial='φ,η')
+nd = len(phi.arg.basis)
+rng = numpy.random.default_rng(0)
+args = {'φ': rng.normal(0, .5, nd), 'φ0': rng.normal(0, .5, nd), 'η': numpy.zeros(nd)}
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = system.assemble_residual(args)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    jac = system.assemble_jacobian(args)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f'n={n} {btype} p=2 nelems={n*n} ndofs/field={nd} nnz={jac.core.nnz}: residual {1e3*(t1-t0):.1f} ms, jacobian (4 blocks, D2H + host block merge) {1e3*(t2-t1):.1f} ms')
+for it in range(3):  # the Newton step as the reference evaluates it (solver.py:358-387): Jacobian and residual in one call
+    args['φ'] = rng.normal(0, .5, nd)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    jac, res = system.assemble_jacobian_residual(args)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f'  assemble_jacobian_residual (residual beside the PCIe copy of the changed Jacobian entries): {1e3*(t1-t0):.1f} ms')
