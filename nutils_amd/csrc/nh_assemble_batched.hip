@@ -1184,6 +1184,13 @@ int build_terms(const nh_terms_args *a, hipStream_t stream, TermsK &p, std::vect
   p.nq = a->nq;
   p.weights = a->weights_dev;
   p.geom = to_k(a->geom);
+  p.geom.nograd = 1;
+  for (int t = 0; t < a->nterms; ++t) {
+    const nh_term &T = a->terms[t];
+    if (T.block < 0 || T.block >= a->nblocks) continue;  // (reported below)
+    const int nct = a->blocks[T.block].nct, ncr = T.field >= 0 && T.field < a->nfields ? a->fields[T.field].ncomp : 0;
+    if ((ncr && uses_gradients(T.C_host, nct, S, ncr)) || uses_gradients(T.f_host, nct, S, 0) || uses_gradients(T.qs_B_host, 1, S, 1)) p.geom.nograd = 0;
+  }
   p.nfields = a->nfields, p.nblocks = a->nblocks, p.nterms = a->nterms, p.npolys = a->npolys;
   p.fct = 0, p.uesz = 0;
   for (int f = 0; f < a->nfields; ++f) {
@@ -1433,6 +1440,11 @@ extern "C" int nh_assemble_matrix_terms(const nh_matrix_terms_args *a, void *str
   p.nq = a->nq;
   p.weights = a->weights_dev;
   p.geom = to_k(a->geom);
+  p.geom.nograd = 1;
+  for (int t = 0; t < a->nterms; ++t) {
+    const nh_matrix_term &T = a->terms[t];
+    if (T.kind != 0 || uses_gradients(T.C_host, a->nct, 1 + a->ndims, a->ncr) || uses_gradients(T.qs_B_host, 1, 1 + a->ndims, 1)) p.geom.nograd = 0;
+  }
   p.nfields = a->nfields, p.nterms = a->nterms, p.npolys = a->npolys;
   p.fct = 0, p.uesz = 0;
   for (int f = 0; f < a->nfields; ++f) {

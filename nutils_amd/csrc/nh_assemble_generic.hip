@@ -658,6 +658,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   p.nq = a->nq;
   p.weights = a->weights_dev;
   p.geom = to_k(a->geom);
+  p.geom.nograd = !a->cq_dev && !uses_gradients(a->C_host, a->nct, 1 + a->ndims, a->ncr);
   p.test = to_k(a->test);
   p.trial = to_k(a->trial);
   p.same = (a->test.T_dev == a->trial.T_dev && a->test.off_dev == a->trial.off_dev && a->test.tab_dev == a->trial.tab_dev &&
@@ -850,6 +851,7 @@ int nh_assemble_vector(const nh_vector_args *a, void *stream) {
   p.nq = a->nq;
   p.weights = a->weights_dev;
   p.geom = to_k(a->geom);
+  p.geom.nograd = !uses_gradients(a->C_host, a->nct, S, a->ncr) && !uses_gradients(a->f_host, a->nct, S, 0);
   p.test = to_k(a->test);
   p.trial = to_k(a->trial);
   p.same = (a->test.T_dev == a->trial.T_dev && a->test.off_dev == a->trial.off_dev && a->test.tab_dev == a->trial.tab_dev &&

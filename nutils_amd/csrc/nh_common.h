@@ -47,6 +47,7 @@ struct GeomK {
   const double *jac;
   const double *x;
   int bnd_axis;
+  int nograd;  // no term of the launch reads a gradient slot (mass matrices, load vectors): the inverse Jacobian is not needed and is set to zero
 };
 
 struct BasisK {
@@ -57,7 +58,26 @@ struct BasisK {
   const int32_t *tab;
 };
 
-static inline GeomK to_k(const nh_geometry &g) { return GeomK{g.kind, g.ngb, g.gT_dev, g.gdofs_dev, g.verts_dev, g.origin_dev, g.size_dev, g.jac_dev, g.x_dev, g.bnd_axis}; }
+static inline GeomK to_k(const nh_geometry &g) { return GeomK{g.kind, g.ngb, g.gT_dev, g.gdofs_dev, g.verts_dev, g.origin_dev, g.size_dev, g.jac_dev, g.x_dev, g.bnd_axis, 0}; }
+// Does a coefficient tensor C[n0][S][n1][S] (or a source f[n0][S]: n1 = 0) have an entry in a gradient slot?  Terms without any never see the
+// inverse Jacobian in the reference (a mass integrand has no gradient node): an exactly singular element, whose inverse is NaN (numeric.py:221-241),
+// must leave them finite -- and 0 * NaN would not.
+static inline bool uses_gradients(const double *A, int n0, int S, int n1) {
+  if (!A) return false;
+  if (n1 == 0) {
+    for (int c = 0; c < n0; ++c)
+      for (int a = 1; a < S; ++a)
+        if (A[c * S + a] != 0.) return true;
+    return false;
+  }
+  for (int c = 0; c < n0; ++c)
+    for (int a = 0; a < S; ++a)
+      for (int d = 0; d < n1; ++d)
+        for (int b = 0; b < S; ++b)
+          if ((a || b) && A[((c * S + a) * n1 + d) * S + b] != 0.) return true;
+  return false;
+}
+
 static inline BasisK to_k(const nh_basis &b) { return BasisK{b.nb, b.T_dev, b.dofs_dev, b.off_dev, b.tab_dev}; }
 
 // sparsity pattern handle (nh_pattern.hip owns it; the element kernels read the size classes of ragged bases from it)

@@ -388,6 +388,7 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   p.nq = a->nq;
   p.weights = a->weights_dev;
   p.geom = to_k(a->geom);
+  p.geom.nograd = !uses_gradients(a->C_host, a->nct, 1 + a->ndims, a->ncr);
   p.test = to_k(a->test);
   p.trial = to_k(a->trial);
   p.scale = a->scale_dev;

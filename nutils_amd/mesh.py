@@ -7,22 +7,24 @@ from . import function, topology
 
 def rectilinear(richshape, periodic=()):
     '''mesh.rectilinear (mesh.py:34-60): each entry of `richshape` is an int (n unit
-    elements: geom = index + xi) or a uniformly spaced vertex array.  Returns
-    (domain, geom).'''
+    elements: geom = index + xi) or a vertex array.  Returns (domain, geom).  Uniformly
+    spaced vertices give the rectilinear geometry the structured fast paths recognise,
+    anything else one axis-aligned box per element.'''
     if periodic:
         raise NotImplementedError('periodic rectilinear meshes are outside the accelerated path')
-    shape, offset, scale = [], [], []
-    for v in richshape:
-        if numpy.ndim(v) == 0:
-            shape.append(int(v)), offset.append(0.), scale.append(1.)
-        else:
-            v = numpy.asarray(v, dtype=float)
-            h = numpy.diff(v)
-            if len(v) < 2 or not numpy.allclose(h, h[0], rtol=1e-14, atol=0):
-                raise NotImplementedError('non-uniform vertex spacing: use an isoparametric geometry')
-            shape.append(len(v) - 1), offset.append(v[0]), scale.append((v[-1] - v[0]) / (len(v) - 1))
+    axes = [numpy.arange(int(v) + 1, dtype=float) if numpy.ndim(v) == 0 else numpy.asarray(v, dtype=float) for v in richshape]
+    if any(v.ndim != 1 or len(v) < 2 for v in axes):
+        raise ValueError('every axis needs at least two vertices')
+    shape = [len(v) - 1 for v in axes]
     domain = topology.StructuredTopology(shape)
-    return domain, function.RectilinearGeometry(domain, offset, scale)
+    steps = [numpy.diff(v) for v in axes]
+    if all(numpy.allclose(h, h[0], rtol=1e-14, atol=0) for h in steps):
+        scale = [1. if numpy.ndim(r) == 0 else (v[-1] - v[0]) / (len(v) - 1) for r, v in zip(richshape, axes)]
+        return domain, function.RectilinearGeometry(domain, [v[0] for v in axes], scale)
+    idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n) for n in shape], indexing='ij'), -1).reshape(-1, len(shape))  # element order: last axis fastest
+    origin = numpy.stack([v[idx[:, i]] for i, v in enumerate(axes)], 1)
+    size = numpy.stack([h[idx[:, i]] for i, h in enumerate(steps)], 1)
+    return domain, function.BoxGeometry(origin, size)
 
 
 def unitsquare(nelems, etype='square'):

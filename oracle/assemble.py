@@ -165,11 +165,28 @@ def geometry_affine(origin, size, points):
     return x, J
 
 
+def inv(A):
+    '''numeric.inv (numeric.py:221-241): numpy.linalg.inv, but exactly singular matrices of the stack give NaN
+    (and one RuntimeWarning 'singular matrix') instead of a LinAlgError.'''
+    try:
+        return numpy.linalg.inv(A)
+    except numpy.linalg.LinAlgError:
+        import warnings
+        warnings.warn('singular matrix', RuntimeWarning)
+        out = numpy.empty(A.shape, dtype=float)
+        for index in numpy.ndindex(A.shape[:-2]):
+            try:
+                out[index] = numpy.linalg.inv(A[index])
+            except numpy.linalg.LinAlgError:
+                out[index] = numpy.nan
+        return out
+
+
 def physical_tables(N, dN, J):
     '''D[e,q,m,0] = N_m, D[e,q,m,1+i] = d N_m / d x_i = sum_j dN[q,m,j] Jinv[j,i]
     (function.py:1221-1231: einsum('Ai,Aij->Aj') with the inverse Jacobian);
     wdet excluded.'''
-    Jinv = numpy.linalg.inv(J)
+    Jinv = inv(J)
     G = numpy.einsum('eqmj,eqji->eqmi', dN, Jinv)
     return numpy.concatenate([N[..., None], G], axis=-1), numpy.abs(numpy.linalg.det(J))
 
@@ -211,7 +228,10 @@ def local_matrices(Dtest, Dtrial, wdet, C):
     '''A[e,m,c,n,d] = sum_q wdet[e,q] sum_ab Dtest[e,q,m,a] C[c,a,d,b] Dtrial[e,q,n,b]
     -- the einsum('B,ABC->AC', weights, integrand) of sample.py:951-956 applied to
     the bilinear integrand (evaluable.py:6414-6505).'''
-    return numpy.einsum('eq,eqma,cadb,eqnb->emcnd', wdet, Dtest, C, Dtrial, optimize=True)
+    C = numpy.asarray(C)
+    sa = slice(None) if C[:, 1:].any() else slice(0, 1)  # slots of the test / trial tables that the integrand contains at all: a mass
+    sb = slice(None) if C[..., 1:].any() else slice(0, 1)  # integrand has no gradient node, NaN gradients of a singular element never enter it
+    return numpy.einsum('eq,eqma,cadb,eqnb->emcnd', wdet, Dtest[..., sa], C[:, sa][..., sb], Dtrial[..., sb], optimize=True)
 
 
 def local_vectors(Dtest, wdet, F):

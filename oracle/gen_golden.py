@@ -15,6 +15,7 @@ Usage:  python oracle/gen_golden.py            (regenerates tests/golden/*.npz)
 
 import os
 import sys
+import warnings
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -111,6 +112,39 @@ def scalar_case(name, shape, btype, degree, iso, seed=0):
     data['eval_gradu'] = smp.eval('∇_i(u)' @ ns, arguments=dict(u=u))
     data['eval_x'] = smp.eval('x_i' @ ns)
     data['eval_detJ'] = smp.eval('dV' @ ns)
+    save(name, **data)
+
+
+def singular_case(name, coords, seed=9):
+    '''Rectilinear mesh with a repeated coordinate: the elements of zero width have an exactly singular dx/dxi, for which
+    numeric.inv (numeric.py:221-241) warns ('singular matrix') and continues with NaN -- the gradients at the points of these
+    elements, hence every stiffness entry and residual component they touch, are NaN; det = 0 keeps the mass matrix finite.'''
+    rng = numpy.random.default_rng(seed)
+    domain, geom = mesh.rectilinear(coords)
+    basis = domain.basis('std', degree=1)
+    data = dict(shape=numpy.array([len(c) - 1 for c in coords]), degree=1, iso=0)
+    for i, c in enumerate(coords):
+        data[f'coords{i}'] = c
+    data.update(basis_tables(basis, len(domain)))
+    gt, smp = gauss_tables(domain, 2)
+    data.update(gt)
+    ns = Namespace()
+    ns.x = geom
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    ns.basis = basis
+    u = rng.normal(size=len(basis))
+    ns.u = function.dotarg('u', basis)
+    data['u'] = u
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        data.update(csr('K', smp.integral('∇_i(basis_m) ∇_i(basis_n) dV' @ ns)))
+        data.update(csr('M', smp.integral('basis_m basis_n dV' @ ns)))
+        data['res_laplace'] = smp.integrate('∇_i(basis_m) ∇_i(u) dV' @ ns, arguments=dict(u=u))
+        data['res_mass'] = smp.integrate('basis_m u dV' @ ns, arguments=dict(u=u))
+        data['eval_gradu'] = smp.eval('∇_i(u)' @ ns, arguments=dict(u=u))
+        data['eval_detJ'] = smp.eval('dV' @ ns)
+    assert any('singular matrix' in str(w.message) for w in caught), 'the reference did not see a singular Jacobian'
+    assert numpy.isnan(data['K_values']).any() and not numpy.isnan(data['M_values']).any()
     save(name, **data)
 
 
@@ -521,6 +555,8 @@ def generate_all():
     scalar_case('lap3d_p2_2_iso', (2, 2, 2), 'std', 2, iso=True)
     scalar_case('lap3d_spline2_3_iso', (3, 3, 3), 'spline', 2, iso=True)
     scalar_case('lap3d_spline3_3', (3, 4, 3), 'spline', 3, iso=False)
+    singular_case('lap2d_p1_singular', [numpy.array([0., 1., 1., 2.5]), numpy.array([0., .5, 2.])])
+    singular_case('lap3d_p1_singular', [numpy.array([0., 1., 3.]), numpy.array([0., .5, .5, 2.]), numpy.array([0., 1., 1.5])])
     elasticity_case('elast2d_p1_3x3', (3, 3), 1, iso=False)
     elasticity_case('elast2d_p2_3x2_iso', (3, 2), 2, iso=True)
     elasticity_case('elast3d_p1_2_iso', (2, 2, 2), 1, iso=True)

@@ -80,6 +80,41 @@ def test_scalar(golden, name):
     close(det.ravel(), g['eval_detJ'])
 
 
+@pytest.mark.parametrize('name', ['lap2d_p1_singular', 'lap3d_p1_singular'])
+def test_singular_jacobian(golden, name):
+    '''Elements of zero width (repeated coordinate of mesh.rectilinear): the oracle follows numeric.inv (numeric.py:221-241) -- a warning and
+    NaN gradients at the points of those elements.  Same NaN entries as the reference, all other entries and the mass matrix to RTOL.'''
+    g = golden(name)
+    shape = tuple(g['shape']); nd = len(shape)
+    dofs, coeffs, ndofs = oa.structured_basis(shape, 'std', 1)
+    assert numpy.array_equal(dofs.ravel(), g['dofs'])
+    pts, w = oa.gauss(2, nd)
+    N, dN = oa.tabulate(coeffs, pts)
+    axes = [g[f'coords{i}'] for i in range(nd)]
+    idx = numpy.array(list(numpy.ndindex(*shape)))
+    origin = numpy.stack([axes[i][idx[:, i]] for i in range(nd)], 1)
+    size = numpy.stack([numpy.diff(axes[i])[idx[:, i]] for i in range(nd)], 1)
+    x, J = oa.geometry_affine(origin, size, pts)
+    with pytest.warns(RuntimeWarning, match='singular matrix'):
+        D, det = oa.physical_tables(N, dN, J)
+    wdet = det * w
+    v, rp, ci = oa.assemble_csr(oa.local_matrices(D, D, wdet, oa.laplace_coefficient(nd)), dofs, dofs, ndofs, ndofs)
+    bad = numpy.isnan(g['K_values'])
+    assert numpy.array_equal(rp, g['K_rowptr']) and numpy.array_equal(ci, g['K_colidx']) and bad.any() and numpy.array_equal(numpy.isnan(v), bad)
+    close(v[~bad], g['K_values'][~bad])
+    v, rp, ci = oa.assemble_csr(oa.local_matrices(D, D, wdet, oa.mass_coefficient(nd)), dofs, dofs, ndofs, ndofs)
+    close(v, g['M_values'])
+    U = oa.field_at_points(D, dofs, g['u'])
+    r = oa.assemble_vector(oa.local_vectors(D, wdet, numpy.einsum('cadb,eqdb->eqca', oa.laplace_coefficient(nd), U)), dofs, ndofs)[:, 0]
+    rbad = numpy.isnan(g['res_laplace'])
+    assert numpy.array_equal(numpy.isnan(r), rbad)
+    close(r[~rbad], g['res_laplace'][~rbad])
+    close(oa.assemble_vector(oa.local_vectors(D[..., :1], wdet, U[..., :1]), dofs, ndofs)[:, 0], g['res_mass'])
+    flat = numpy.abs(g['eval_detJ']) < 1e-15
+    assert numpy.isnan(U[:, :, 0, 1:].reshape(-1, nd)[flat]).all()
+    close(U[:, :, 0, 1:].reshape(-1, nd)[~flat], g['eval_gradu'][~flat])
+
+
 @pytest.mark.parametrize('name', ELAST)
 def test_elasticity(golden, name):
     g = golden(name)
