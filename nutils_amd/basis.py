@@ -50,18 +50,33 @@ def _local_bsplines(lknots):
     return out
 
 
-def spline_axis(n, degree, continuity=-1):
-    '''Per-axis tables for `n` uniform elements (non-periodic, open knot vector):
-    (coeffs list of (p+1,p+1) arrays, start_dofs int array, ndofs).  continuity=-1
-    is the maximally smooth spline, 0 the C0 'std' basis (topology.py:2243-2312).'''
+def spline_axis(n, degree, continuity=-1, periodic=False):
+    '''Per-axis tables for `n` uniform elements: (coeffs list of (p+1,p+1) arrays,
+    start_dofs int array, ndofs).  continuity=-1 is the maximally smooth spline, 0 the
+    C0 'std' basis (topology.py:2243-2312).  Open knot vector, or -- periodic
+    (topology.py:2279-2291) -- the knot vector continued with the period: every
+    element has the interior table, the dof ranges start_dofs[i] + 0..p wrap around
+    modulo ndofs = n (p - c).'''
     p = degree
     c = continuity + p if continuity < 0 else continuity
     if not -1 <= c < max(p, 1):
         raise ValueError('invalid continuity')
-    mult = numpy.full(n + 1, p - c, dtype=int)
-    mult[0] = mult[-1] = p
-    knots = numpy.repeat(numpy.arange(n + 1, dtype=float), mult)
-    start = numpy.cumsum(mult[:n]) - mult[0]
+    step = p - c
+    if periodic and step != p + 1:
+        reps = 1
+        while (reps - 1) * n * step < p - step + 2:  # periods of knots needed behind the last element
+            reps *= 2
+        knots = numpy.repeat(numpy.arange(reps * n, dtype=float), step)
+        if p > step:
+            knots = numpy.concatenate([knots[-(p - step):] - reps * n, knots])
+        start = step * numpy.arange(n)
+        ndofs = n * step
+    else:
+        mult = numpy.full(n + 1, step, dtype=int)
+        mult[0] = mult[-1] = p
+        knots = numpy.repeat(numpy.arange(n + 1, dtype=float), mult)
+        start = numpy.cumsum(mult[:n]) - mult[0]
+        ndofs = int(mult[:n].sum()) + 1
     cache = {}
     coeffs = []
     for o in start:
@@ -70,7 +85,7 @@ def spline_axis(n, degree, continuity=-1):
         if key not in cache:
             cache[key] = _local_bsplines(lk)
         coeffs.append(cache[key])
-    return coeffs, start.astype(numpy.int64), int(mult[:n].sum()) + 1
+    return coeffs, start.astype(numpy.int64), ndofs
 
 
 class Basis:
@@ -118,13 +133,14 @@ class Basis:
 
 class StructuredBasis(Basis):
 
-    def __init__(self, shape, btype, degree):
+    def __init__(self, shape, btype, degree, periodic=()):
         if btype not in ('std', 'spline'):
             raise ValueError(f'unsupported structured basis type {btype!r}')
         self.shape = tuple(int(n) for n in shape)
         self.ndims = len(self.shape)
         self.btype, self.degree = btype, int(degree)
-        axes = [spline_axis(n, self.degree, 0 if btype == 'std' else -1) for n in self.shape]
+        self.periodic = tuple(sorted(int(i) for i in periodic))
+        axes = [spline_axis(n, self.degree, 0 if btype == 'std' else -1, i in self.periodic) for i, n in enumerate(self.shape)]
         self.axis_coeffs = [a[0] for a in axes]
         self.start_dofs = [a[1] for a in axes]
         self.dofs_shape = tuple(a[2] for a in axes)

@@ -298,9 +298,11 @@ COLOR_THRESHOLD = 4096
 def _colors(smp, basis):
     if not isinstance(basis, StructuredBasis) or smp.elist is not None:
         return None
+    stride = 2 if basis.btype == 'std' else basis.degree + 1
+    if any(basis.shape[i] % stride for i in basis.periodic):
+        return None  # (periodic axis: the first and the last elements share dofs; congruent indices are disjoint only if the stride divides n)
     key = 'colors', id(basis)
     if key not in smp._tables:
-        stride = 2 if basis.btype == 'std' else basis.degree + 1
         idx = numpy.arange(basis.nelems, dtype=numpy.int32).reshape(basis.shape)
         lists = []
         for off in numpy.ndindex(*(min(stride, n) for n in basis.shape)):

@@ -48,16 +48,19 @@ class StructuredTopology(Topology):
     '''mesh.rectilinear topology: prod(shape) elements, element index with the last
     axis fastest (transformseq.py:526-620).'''
 
-    def __init__(self, shape):
+    def __init__(self, shape, periodic=()):
         self.shape = tuple(int(n) for n in shape)
         self.ndims = len(self.shape)
         self.nelems = int(numpy.prod(self.shape))
+        self.periodic = tuple(sorted(int(i) for i in periodic))  # axes whose bases wrap around (mesh.rectilinear(periodic=...), mesh.py:34-60)
+        if any(not 0 <= i < self.ndims for i in self.periodic):
+            raise ValueError('periodic axis out of range')
         self._bases = {}
 
     def basis(self, btype, degree=1):
         key = btype, int(degree)
         if key not in self._bases:
-            self._bases[key] = _basis.StructuredBasis(self.shape, btype, degree)
+            self._bases[key] = _basis.StructuredBasis(self.shape, btype, degree, self.periodic)
         return self._bases[key]
 
     @property
@@ -105,7 +108,8 @@ class _Boundary:
         self._cache = {}
 
     def sides(self):
-        return [self[n] for names in _BNAMES[:self.parent.ndims] for n in names]
+        '''(a periodic axis has no boundary: topology.py StructuredTopology.boundary skips it)'''
+        return [self[n] for axis, names in enumerate(_BNAMES[:self.parent.ndims]) if axis not in self.parent.periodic for n in names]
 
     def integral(self, func, degree):
         '''Integral over the whole boundary (domain.boundary.integral): sum over the sides.'''
@@ -118,7 +122,7 @@ class _Boundary:
     def __getitem__(self, name):
         if name not in self._cache:
             for axis, names in enumerate(_BNAMES[:self.parent.ndims]):
-                if name in names:
+                if name in names and axis not in self.parent.periodic:
                     self._cache[name] = BoundaryTopology(self.parent, axis, names.index(name))
                     break
             else:

@@ -74,22 +74,36 @@ def local_spline_coeffs(lknots):
     return out
 
 
-def structured_axis(n, p, continuity):
-    '''Per-axis tables of topology.py:2243-2312 for the non-periodic, uniform-knot
-    case: returns (coeffs[i] (p+1,p+1), start_dofs[i], ndofs_axis).
-    continuity=-1 -> spline (C^{p-1}); continuity=0 -> 'std' (C^0).'''
+def structured_axis(n, p, continuity, periodic=False):
+    '''Per-axis tables of topology.py:2243-2312 for uniform knots: returns
+    (coeffs[i] (p+1,p+1), start_dofs[i], ndofs_axis).  continuity=-1 -> spline
+    (C^{p-1}); continuity=0 -> 'std' (C^0).  periodic (topology.py:2279-2291):
+    no repeated end knots, the knot vector continues with the period, the dof
+    ranges wrap around (ndofs = n (p - c)).'''
     c = continuity + p if continuity < 0 else continuity
     k = numpy.arange(n + 1, dtype=float)
     m = numpy.repeat(p - c, n + 1)
-    m[0] = m[-1] = p
-    ndofs = int(m[:n].sum()) + 1
-    km = numpy.repeat(k, m)
+    if periodic and m[0] != p + 1:
+        dk = k[n] - k[0]
+        m, k = m[:n], k[:n]
+        ndofs = int(m.sum())
+        while m[n:].sum() < p - m[0] + 2:
+            k = numpy.concatenate([k, k + dk])
+            m = numpy.concatenate([m, m])
+            dk *= 2
+        km = numpy.repeat(k, m)
+        if p > m[0]:
+            km = numpy.concatenate([km[-p + m[0]:] - dk, km])
+    else:
+        m[0] = m[-1] = p
+        ndofs = int(m[:n].sum()) + 1
+        km = numpy.repeat(k, m)
     offsets = numpy.cumsum(m[:n]) - m[0]
     coeffs = [local_spline_coeffs(km[o:o + 2 * p]) for o in offsets]
     return coeffs, offsets.astype(numpy.int64), ndofs
 
 
-def structured_basis(shape, btype, degree):
+def structured_basis(shape, btype, degree, periodic=()):
     '''Per-element dof lists and coefficient tables of function.StructuredBasis
     (function.py:3080-3100): element index unravelled with the LAST axis fastest,
     dofs = RavelIndex of per-axis ranges (first axis slowest), coefficients =
@@ -97,7 +111,7 @@ def structured_basis(shape, btype, degree):
     first axis slowest.  Returns dofs (nelems, nb) int64, coeffs (nelems, nb, nc),
     ndofs.'''
     nd = len(shape)
-    axes = [structured_axis(n, degree, -1 if btype == 'spline' else 0) for n in shape]
+    axes = [structured_axis(n, degree, -1 if btype == 'spline' else 0, i in periodic) for i, n in enumerate(shape)]
     dofshape = [a[2] for a in axes]
     nelems = int(numpy.prod(shape))
     nb = (degree + 1) ** nd

@@ -70,15 +70,17 @@ def perturbed(shape, rng):
     return verts + rng.uniform(-.2, .2, verts.shape)
 
 
-def scalar_case(name, shape, btype, degree, iso, seed=0):
+def scalar_case(name, shape, btype, degree, iso, seed=0, periodic=()):
     '''Laplace stiffness, mass matrix, Laplace residual and load vector for a
     scalar basis on mesh.rectilinear(shape); geometry either the exact uniform
     one or an isoparametric P1 map with seeded vertex perturbation.'''
     rng = numpy.random.default_rng(seed)
-    domain, geom0 = mesh.rectilinear(list(shape))
+    domain, geom0 = mesh.rectilinear(list(shape), periodic=periodic)
     nelems = len(domain)
     data = dict(shape=numpy.array(shape), degree=degree, iso=int(iso))
-    gbasis = domain.basis('std', degree=1)
+    if periodic:
+        data['periodic'] = numpy.array(periodic)
+    gbasis = domain.basis('std', degree=1) if not periodic else None  # (periodic: the geometry is the non-periodic rectilinear map)
     if iso:
         verts = perturbed(shape, rng)
         geom = gbasis @ verts
@@ -555,6 +557,10 @@ def generate_all():
     scalar_case('lap3d_p2_2_iso', (2, 2, 2), 'std', 2, iso=True)
     scalar_case('lap3d_spline2_3_iso', (3, 3, 3), 'spline', 2, iso=True)
     scalar_case('lap3d_spline3_3', (3, 4, 3), 'spline', 3, iso=False)
+    scalar_case('lap1d_spline3_6_per0', (6,), 'spline', 3, iso=False, periodic=(0,))
+    scalar_case('lap2d_spline2_5x4_per0', (5, 4), 'spline', 2, iso=False, periodic=(0,))
+    scalar_case('lap2d_p2_4x3_per1', (4, 3), 'std', 2, iso=False, periodic=(1,))
+    scalar_case('lap3d_p1_345_per02', (3, 4, 5), 'std', 1, iso=False, periodic=(0, 2))
     singular_case('lap2d_p1_singular', [numpy.array([0., 1., 1., 2.5]), numpy.array([0., .5, 2.])])
     singular_case('lap3d_p1_singular', [numpy.array([0., 1., 3.]), numpy.array([0., .5, .5, 2.]), numpy.array([0., 1., 1.5])])
     elasticity_case('elast2d_p1_3x3', (3, 3), 1, iso=False)

@@ -347,3 +347,41 @@ def test_poisson_example(golden, nelems):
     args = System(energy, trial='u').solve(constrain=cons)
     ref = golden('examples_poisson')[f'poisson_{nelems}_u']
     assert numpy.abs(args['u'] - ref).max() <= 1e-12 * numpy.abs(ref).max()
+
+
+@pytest.mark.parametrize('btype,degree,n', [('spline', 2, 16), ('std', 1, 24), ('spline', 3, 12)])
+def test_periodic_helmholtz(btype, degree, n):
+    '''-div grad u + u = f on the unit square, periodic in x (mesh.rectilinear(periodic=[0]), mesh.py:34-60: the bases wrap around, the
+    boundary has only the bottom and top sides), homogeneous Neumann in y: the discrete solution converges to
+    u = sin(2 pi x) cos(pi y) at the rate of the basis, the constant is reproduced exactly, and the matrix couples the first and the
+    last element column.'''
+    from nutils_amd import mesh, function
+    from nutils_amd.solver import System
+    errs = []
+    for nel in (n, 2 * n):
+        domain, geom = mesh.rectilinear([numpy.linspace(0, 1, nel + 1)] * 2, periodic=[0])
+        assert [s.axis for s in domain.boundary.sides()] == [1, 1]
+        with pytest.raises(KeyError):
+            domain.boundary['left']
+        u = domain.field('u', btype=btype, degree=degree)
+        v = domain.field('v', btype=btype, degree=degree)
+        assert len(u.arg.basis) == (nel * degree if btype == 'std' else nel) * (nel * degree + 1 if btype == 'std' else nel + degree)
+        dV = function.J(geom)
+        grad = lambda w: function.grad(w, geom)
+        uex = lambda x: numpy.sin(2 * numpy.pi * x[:, 0]) * numpy.cos(numpy.pi * x[:, 1])
+        f = function.PointFunc(lambda x: (1 + 5 * numpy.pi ** 2) * uex(x), geom)
+        res = domain.integral(((grad(v) * grad(u)).sum(-1) + v * u) * dV, degree=2 * degree) - domain.integral(v * f * dV, degree=2 * degree + 2)
+        system = System(res, trial='u', test='v')
+        args = system.solve()
+        ue = function.PointFunc(uex, geom)
+        err2 = function.eval(domain.integral(u * u * dV, degree=2 * degree + 2) - 2 * domain.integral(u * ue * dV, degree=2 * degree + 2)
+                             + domain.integral(ue * ue * dV, degree=2 * degree + 2), args)
+        errs.append(max(err2, 0.) ** .5)
+        K = system.assemble_jacobian(args).export('dense') if nel == n and nel <= 16 else None
+        if K is not None:  # wrap-around coupling: the dofs of the last element column reach the first one
+            nd1 = nel + degree if btype == 'spline' else nel * degree + 1
+            assert numpy.abs(K[:nd1, -nd1:]).max() > 0
+            assert numpy.abs(K - K.T).max() < 1e-12
+            ones = numpy.ones(len(K))
+            assert abs(ones @ K @ ones - 1.) < 1e-12  # int 1 * 1 dV: the constant is in the periodic space
+    assert errs[1] < errs[0] * 2. ** -(degree + 1) * 1.3 and errs[1] < 2e-2

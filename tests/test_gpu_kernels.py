@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-13
 SCALAR = ['lap1d_p1_5', 'lap2d_p1_4x4', 'lap2d_p1_4x3_iso', 'lap2d_p2_3x4_iso', 'lap2d_spline2_4x4', 'lap2d_spline2_5x4_iso',
           'lap3d_p1_2', 'lap3d_p1_3', 'lap3d_p1_4', 'lap3d_p1_234', 'lap3d_p1_3_iso', 'lap3d_p1_543_iso', 'lap3d_p2_2_iso',
-          'lap3d_spline2_3_iso', 'lap3d_spline3_3']
+          'lap3d_spline2_3_iso', 'lap3d_spline3_3',
+          'lap1d_spline3_6_per0', 'lap2d_spline2_5x4_per0', 'lap2d_p2_4x3_per1', 'lap3d_p1_345_per02']  # (last row: periodic axes)
 ELAST = ['elast2d_p1_3x3', 'elast2d_p2_3x2_iso', 'elast3d_p1_2_iso', 'elast3d_p2_2', 'elast3d_p2_2_iso']
 
 

@@ -6,14 +6,15 @@ import pytest
 
 
 @pytest.mark.parametrize('name,btype', [('lap1d_p1_5', 'std'), ('lap2d_spline2_4x4', 'spline'), ('lap3d_p1_234', 'std'), ('lap3d_p2_2_iso', 'std'),
-                                        ('lap3d_spline3_3', 'spline'), ('lap2d_p2_3x4_iso', 'std')])
+                                        ('lap3d_spline3_3', 'spline'), ('lap2d_p2_3x4_iso', 'std'), ('lap1d_spline3_6_per0', 'spline'),
+                                        ('lap2d_spline2_5x4_per0', 'spline'), ('lap2d_p2_4x3_per1', 'std'), ('lap3d_p1_345_per02', 'std')])
 def test_structured_basis_tables(golden, name, btype):
     '''Basis.get_dofs / get_coefficients (function.py:2794-2837) of the product's table producer == the real reference's.'''
     from nutils_amd import mesh, points
     g = golden(name)
     shape = [int(n) for n in g['shape']]
     degree = int(g['degree'])
-    domain, geom = mesh.rectilinear(shape)
+    domain, geom = mesh.rectilinear(shape, periodic=tuple(int(i) for i in g['periodic']) if 'periodic' in g else ())
     basis = domain.basis(btype, degree=degree)
     nb = len(g['dofs']) // len(domain)
     dofs, coeffs = g['dofs'].reshape(len(domain), nb), g['coeffs'].reshape(len(domain), nb, -1)

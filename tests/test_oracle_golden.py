@@ -10,7 +10,8 @@ RTOL = 1e-13
 
 SCALAR = ['lap1d_p1_5', 'lap2d_p1_4x4', 'lap2d_p1_4x3_iso', 'lap2d_p2_3x4_iso', 'lap2d_spline2_4x4', 'lap2d_spline2_5x4_iso',
           'lap3d_p1_2', 'lap3d_p1_3', 'lap3d_p1_4', 'lap3d_p1_234', 'lap3d_p1_3_iso', 'lap3d_p1_543_iso', 'lap3d_p2_2_iso',
-          'lap3d_spline2_3_iso', 'lap3d_spline3_3']
+          'lap3d_spline2_3_iso', 'lap3d_spline3_3',
+          'lap1d_spline3_6_per0', 'lap2d_spline2_5x4_per0', 'lap2d_p2_4x3_per1', 'lap3d_p1_345_per02']  # (last row: periodic axes)
 ELAST = ['elast2d_p1_3x3', 'elast2d_p2_3x2_iso', 'elast3d_p1_2_iso', 'elast3d_p2_2', 'elast3d_p2_2_iso']
 
 
@@ -24,7 +25,7 @@ def close(a, b, scale=None):
 def setup(g, name):
     shape = tuple(g['shape']); nd = len(shape); degree = int(g['degree'])
     btype = 'spline' if 'spline' in name else 'std'
-    dofs, coeffs, ndofs = oa.structured_basis(shape, btype, degree)
+    dofs, coeffs, ndofs = oa.structured_basis(shape, btype, degree, tuple(g['periodic']) if 'periodic' in g else ())
     pts, w = oa.gauss(2 * degree, nd)
     N, dN = oa.tabulate(coeffs, pts)
     if int(g['iso']):
@@ -42,7 +43,7 @@ def setup(g, name):
 def test_tables(golden, name):
     g = golden(name)
     shape = tuple(g['shape']); degree = int(g['degree'])
-    dofs, coeffs, ndofs = oa.structured_basis(shape, 'spline' if 'spline' in name else 'std', degree)
+    dofs, coeffs, ndofs = oa.structured_basis(shape, 'spline' if 'spline' in name else 'std', degree, tuple(g['periodic']) if 'periodic' in g else ())
     assert dofs.dtype == numpy.int64
     assert numpy.array_equal(dofs.ravel(), g['dofs'])
     close(coeffs.reshape(g['coeffs'].shape), g['coeffs'], 1.)
