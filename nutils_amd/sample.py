@@ -199,6 +199,11 @@ class Sample:
         out = tuple(self._eval_one(f, arguments) for f in items)
         return out[0] if single else out
 
+    def bind(self, func, /):
+        '''Bind the sample to a function (sample.py:217-237): `function.eval(sample.bind(f), **args)` and `sample.bind(f).eval(**args)` are
+        `sample.eval(f, **args)`, evaluated when asked for -- together with integrals in one `function.eval` call.'''
+        return _Bound(self, func)
+
     def _eval_one(self, f, arguments):
         nq, nd, ne = self.points.npoints, self.ndims, self.nlist
         n = ne * nq
@@ -226,6 +231,16 @@ class Sample:
             # tiny host contraction with the operand's constant tensor: value[free] = P[free,c,s] U[c,s]
             return numpy.einsum('...cs,ncs->n...', f.P, Uh)
         raise NotImplementedError(f'Sample.eval of {type(f).__name__}')
+
+
+class _Bound:
+    '''sample.bind(func): the values of `func` at all points of `sample` (point axis first), evaluated by function.eval.'''
+
+    def __init__(self, sample, func):
+        self.sample, self.func = sample, func
+
+    def eval(self, arguments=None, **kwargs):
+        return self.sample._eval_one(self.func, dict(arguments or {}, **kwargs))
 
 
 def _default_geometry(topo):
@@ -919,6 +934,8 @@ def start_blocks(fs, arguments, flat=False):
 def evaluate(f, arguments):
     '''Evaluate one Integral / as_csr / as_coo wrapper.'''
     from . import factor as _factor0
+    if isinstance(f, _Bound):
+        return f.eval(arguments)
     if isinstance(f, function._AsCSR) and isinstance(f.integral, _factor0.FactoredMatrix):
         return f.integral.as_csr()
     if isinstance(f, (function._AsCSR, function._AsCOO)):

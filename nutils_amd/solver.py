@@ -253,6 +253,24 @@ class System:
             raise Exception('value is not defined')
         return function.eval(self.value, arguments)
 
+    def assemble_jacobian_residual_value(self, arguments, free=None):
+        '''Jacobian, residual and value of the functional in one call (solver.py:389-425): the functional goes through the same upload
+        scope as the other two, its launches run beside the copy of the Jacobian entries.'''
+        if not self.is_symmetric:
+            raise Exception('value is not defined')
+        with _sample.upload_scope():
+            _sample.prefetch_arguments(self.block_residual, arguments)
+            finish = self._start_jacobian(arguments, free)
+            res = self.assemble_residual(arguments)
+            val = function.eval(self.value, arguments)
+        return finish(), res, val
+
+    def assemble(self, arguments, free=None):
+        '''(jacobian, residual, value or None), solver.py:427-431'''
+        if self.is_symmetric:
+            return self.assemble_jacobian_residual_value(arguments, free)
+        return (*self.assemble_jacobian_residual(arguments, free), None)
+
     # -- argument packing (solver.py:273-315) --
 
     def _pack(self, arguments, constrain):
