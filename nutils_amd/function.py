@@ -53,6 +53,19 @@ class BoxGeometry(Geometry):
         return self.origin, self.size
 
 
+class GradedGeometry(BoxGeometry):
+    '''mesh.rectilinear with non-uniform vertex arrays (mesh.py:34-60): boxes, plus the per-axis vertices for the structured kernels.'''
+
+    def __init__(self, topo, axes):
+        self.topo = topo
+        self.axes = [numpy.asarray(v, dtype=float) for v in axes]
+        idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n) for n in topo.shape], indexing='ij'), -1).reshape(-1, topo.ndims)  # element order: last axis fastest
+        super().__init__(numpy.stack([v[idx[:, i]] for i, v in enumerate(self.axes)], 1), numpy.stack([numpy.diff(v)[idx[:, i]] for i, v in enumerate(self.axes)], 1))
+
+    def vertices(self):
+        return numpy.stack(numpy.meshgrid(*self.axes, indexing='ij'), -1).reshape(-1, self.ndims)
+
+
 class IsoGeometry(Geometry):
     '''x = sum_a N_a(xi) X_a  (``geom = gbasis @ verts`` in a Nutils script).'''
 

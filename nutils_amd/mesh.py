@@ -19,10 +19,7 @@ def rectilinear(richshape, periodic=()):
     if all(numpy.allclose(h, h[0], rtol=1e-14, atol=0) for h in steps):
         scale = [1. if numpy.ndim(r) == 0 else (v[-1] - v[0]) / (len(v) - 1) for r, v in zip(richshape, axes)]
         return domain, function.RectilinearGeometry(domain, [v[0] for v in axes], scale)
-    idx = numpy.stack(numpy.meshgrid(*[numpy.arange(n) for n in shape], indexing='ij'), -1).reshape(-1, len(shape))  # element order: last axis fastest
-    origin = numpy.stack([v[idx[:, i]] for i, v in enumerate(axes)], 1)
-    size = numpy.stack([h[idx[:, i]] for i, h in enumerate(steps)], 1)
-    return domain, function.BoxGeometry(origin, size)
+    return domain, function.GradedGeometry(domain, axes)
 
 
 def unitsquare(nelems, etype='square'):

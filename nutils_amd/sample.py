@@ -457,6 +457,8 @@ class _MatrixPlan:
             origin, scale = tuple(geom.offset), tuple(geom.scale)
             if qscale is not None or qmass is not None:  # element matrices differ: explicit vertices for the isoparametric kernel
                 verts = _cached(smp._p1verts, geom, lambda: _rectilinear_vertices(geom, basis.shape))
+        elif isinstance(geom, function.GradedGeometry) and geom.topo.shape == basis.shape and not basis.periodic and geom.size.all():  # (flat elements: generic path, NaN rules of numeric.inv)
+            verts = _cached(smp._p1verts, geom, lambda: device.to_dev(geom.vertices(), 'float64'))  # graded mesh: the isoparametric kernel on its vertices
         else:
             return None
         key = 'p1hex_pattern', basis.shape
@@ -686,6 +688,8 @@ def _p1hex_setting(smp, basis, geom):
                 return device.to_dev(geom.verts, 'float64')
         elif isinstance(geom, function.RectilinearGeometry) and geom.topo.shape == basis.shape:
             return _rectilinear_vertices(geom, basis.shape)
+        elif isinstance(geom, function.GradedGeometry) and geom.topo.shape == basis.shape and geom.size.all():
+            return device.to_dev(geom.vertices(), 'float64')
         return None
     verts = _cached(smp._p1verts, geom, make)
     if verts is None:
