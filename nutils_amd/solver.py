@@ -28,16 +28,16 @@ class _HostMirror:
     of the 0.2 GB.  Two buffers alternate, so the matrix of a step stays valid while the next one is assembled, but not longer: the
     reference hands out fresh arrays (evaluable.py:6813-6815), a caller that keeps older Jacobians has to copy them.'''
 
-    def __init__(self, values_dev, sel, out):
+    def __init__(self, values_dev, sel, out, copies=2):
         from . import device
         t = device.torch()
-        self.bufs = [t.empty(values_dev.shape, dtype=values_dev.dtype, pin_memory=True) for _ in range(2)]
+        self.bufs = [t.empty(values_dev.shape, dtype=values_dev.dtype, pin_memory=True) for _ in range(copies)]
         for buf in self.bufs:
             buf.copy_(values_dev)
         self.sel, self.out, self.turn, self.side = sel, out, 0, None
 
     def first(self):
-        self.turn = 1
+        self.turn = 1 % len(self.bufs)
         return self.bufs[0].numpy()
 
     def publish(self, dyn):
@@ -46,7 +46,7 @@ class _HostMirror:
         from . import device, kernels
         t = device.torch()
         buf = self.bufs[self.turn]
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % len(self.bufs)
         if not self.out.numel():
             return buf.numpy
         if self.side is None:
@@ -174,7 +174,7 @@ class System:
             self._build_merge_plan(arguments)
         if free is None:
             if self._mirror is None:
-                self._mirror = _HostMirror(self._merged_values(arguments), None, self._dynpos_dev)
+                self._mirror = _HostMirror(self._merged_values(arguments), None, self._dynpos_dev, 1 if self.is_constant_matrix else 2)
                 jac = _matrix.assemble_csr(self._mirror.first(), self._merged_rowptr, self._merged_colidx, self.size)
                 if self.is_constant_matrix:
                     self._jac = jac
@@ -201,7 +201,7 @@ class System:
         if plan['mirror'] is None:
             values = device.empty(len(plan['colidx']), 'float64')
             kernels.index_copy(self._merged_values(arguments), values, src_index=plan['keep'])
-            plan['mirror'] = _HostMirror(values, plan['sel'], plan['out'])
+            plan['mirror'] = _HostMirror(values, plan['sel'], plan['out'], 1 if self.is_constant_matrix else 2)
             jac = _matrix.assemble_csr(plan['mirror'].first(), plan['rowptr'], plan['colidx'], plan['n'])
             if self.is_constant_matrix:
                 plan['matrix'] = jac
