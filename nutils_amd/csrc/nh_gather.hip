@@ -369,6 +369,150 @@ done:
   return rc;
 }
 
+// ---- pass 1 for larger scalar elements (quadratic hexahedra, cubic tensor splines): a thread owns MB ROWS of the local matrix ----------
+// NBT * NBR sums do not fit one thread any more (27 x 27 doubles); the NBT / MB threads of an element sit in neighbouring lanes and repeat only
+// the geometry of the point.  The form and BOTH Jacobian inverses are applied to the MB test rows (tw = w J^-1 C J^-T dt in the reference
+// frame), so the inner loop over the trial functions is the bare contraction A[m][n] += sum_s tw[m][s] T_n[q][s] with the tabulated
+// reference values: MB * S multiply-adds per trial function and point, nothing else.
+template <int ND, int NBT, int NBR, int MB, bool LDST>
+__global__ __launch_bounds__(128) void k_local_rows(LocK p) {
+  constexpr int S = 1 + ND, NG = 1 << ND, NMB = NBT / MB;
+  static_assert(NBT % MB == 0, "row blocks");
+  extern __shared__ __attribute__((aligned(16))) double sT[];
+  if (LDST) {
+    const int nt = NBT * p.nq * S, nr = NBR * p.nq * S, ng = NG * p.nq * S;
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) sT[i] = p.test.T[i];
+    for (int i = threadIdx.x; i < nr; i += blockDim.x) sT[nt + i] = p.trial.T[i];
+    if (p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG)
+      for (int i = threadIdx.x; i < ng; i += blockDim.x) sT[nt + nr + i] = p.geom.gT[i];
+    __syncthreads();
+  }
+  const i64 nthreads = p.nelems * NMB;
+  const i64 t0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 t = min(t0, nthreads - 1);  // (lanes behind the last row block recompute it: the store needs whole waves, and skips them)
+  const i64 ie = t / NMB;
+  const int mb = (int)(t - ie * NMB) * MB;
+  const i64 e = p.elist ? p.elist[ie] : ie;
+  double A[MB][NBR];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int n = 0; n < NBR; ++n) A[m][n] = 0;
+  const bool iso = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG;
+  double X[NG][ND];
+  if (iso) {
+#pragma unroll
+    for (int a = 0; a < NG; ++a) {
+      const i64 v = p.geom.gdofs[e * NG + a];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) X[a][i] = p.geom.verts[v * ND + i];
+    }
+  }
+  const double *Tt = (LDST ? sT : p.test.T + bfn(p.test, e) * p.nq * S) + (size_t)mb * p.nq * S;
+  const double *Tr = LDST ? sT + NBT * p.nq * S : p.trial.T + bfn(p.trial, e) * p.nq * S;
+  const double *gT = LDST ? sT + (NBT + NBR) * p.nq * S : p.geom.gT;
+  for (int q = 0; q < p.nq; ++q) {
+    double Ji[ND][ND], det;
+    if (iso) {
+      double J[ND][ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int j = 0; j < ND; ++j) J[i][j] = 0;
+#pragma unroll
+      for (int a = 0; a < NG; ++a) {
+        const double *tg = gT + ((i64)a * p.nq + q) * S;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) J[i][j] += X[a][i] * tg[1 + j];
+      }
+      invert<ND>(J, Ji, det);
+      if (p.geom.bnd_axis >= 0) {
+        double s2 = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+            if (j == p.geom.bnd_axis) s2 += Ji[j][i] * Ji[j][i];
+        det *= sqrt(s2);
+      }
+      if (p.geom.nograd) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) Ji[i][j] = 0.;
+      }
+    } else
+      geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
+    const double w = p.weights[q] * fabs(det) * (p.scale ? p.scale[(p.by_elem ? e : ie) * p.nq + q] : 1.);
+    // test rows: physical gradients, form, weight, back to the reference frame
+    double tw[MB][S];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const double *T = Tt + ((size_t)m * p.nq + q) * S;
+      double dt[S], cd[S];
+      dt[0] = T[0];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        double sum = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) sum += T[1 + j] * Ji[j][i];
+        dt[1 + i] = sum;
+      }
+#pragma unroll
+      for (int b = 0; b < S; ++b) {
+        double sum = 0;
+#pragma unroll
+        for (int a = 0; a < S; ++a) sum += dt[a] * p.C[a * S + b];
+        cd[b] = w * sum;
+      }
+      tw[m][0] = cd[0];
+#pragma unroll
+      for (int j = 0; j < ND; ++j) {
+        double sum = 0;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) sum += Ji[j][i] * cd[1 + i];
+        tw[m][1 + j] = sum;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NBR; ++n) {
+      const double *T = Tr + ((size_t)n * p.nq + q) * S;
+      double tn[S];
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) tn[s2] = T[s2];
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) A[m][n] += tw[m][s2] * tn[s2];
+    }
+  }
+  // store: the thread's MB rows are MB * NBR contiguous doubles of the element-major scratch, neighbouring lanes hold neighbouring chunks -- through
+  // the per-wave transposition of k_local_scalar, CH values per thread at a time
+  constexpr int NE = MB * NBR, CH = NE % 16 == 0 ? 16 : NE % 9 == 0 ? 9 : NE % 4 == 0 ? 4 : 1, PADW = CH | 1;
+  double *stg = sT + p.ldst_doubles + (threadIdx.x >> 6) * 64 * PADW;
+  const int lane = threadIdx.x & 63;
+  const i64 wave0 = t0 - lane;
+#pragma unroll
+  for (int c0 = 0; c0 < NE; c0 += CH) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int l = c0 + j;
+      stg[lane * PADW + j] = A[l / NBR][l % NBR];
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int EPP = 64 / CH;
+    const int sub = lane / CH, idx = lane - sub * CH;
+#pragma unroll
+    for (int pass = 0; pass < (64 + EPP - 1) / EPP; ++pass) {
+      const int el = pass * EPP + sub;
+      if (sub < EPP && el < 64 && wave0 + el < nthreads) p.local[(wave0 + el) * NE + c0 + idx] = stg[el * PADW + idx];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s) {
   if (!p->nnz) return NH_OK;
   hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, ld, p->nbt * p->nbr, slots,
@@ -402,7 +546,8 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   dim3 grid((unsigned)((a->nelems + 127) / 128)), block(128);
   const int key = a->ndims * 10000 + a->test.nb * 100 + a->trial.nb;
   const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + a->trial.nb + (1 << a->ndims));
-  const bool ldst = !a->test.tab_dev && !a->trial.tab_dev && ldsb <= 32 * 1024;
+  const bool rows = key == 21616 || key == 32727;  // (row-blocked kernel: at most two workgroups per CU by registers, LDS is free)
+  const bool ldst = !a->test.tab_dev && !a->trial.tab_dev && ldsb <= (rows ? 64 : 32) * 1024;
   bool symd = a->test.T_dev == a->trial.T_dev && a->test.tab_dev == a->trial.tab_dev && a->test.dofs_dev == a->trial.dofs_dev;
   for (int i = 0; i < S * S; ++i)
     if (i / S != i % S && a->C_host[i] != 0.) symd = false;
@@ -416,7 +561,18 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
     } else if (ldst) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, true, false>), grid, block, ldsx, s, p);    \
     else hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, false, false>), grid, block, ldsx, s, p);               \
   } while (0)
+#define ROWS(ND, NBT, NBR, MB)                                                                                              \
+  do {                                                                                                                     \
+    dim3 grid2((unsigned)((a->nelems * (NBT / MB) + 127) / 128));                                                         \
+    if (ldst) {                                                                                                            \
+      NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_local_rows<ND, NBT, NBR, MB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx)); \
+      hipLaunchKernelGGL((k_local_rows<ND, NBT, NBR, MB, true>), grid2, block, ldsx, s, p);                                \
+    } else                                                                                                                 \
+      hipLaunchKernelGGL((k_local_rows<ND, NBT, NBR, MB, false>), grid2, block, ldsx, s, p);                               \
+  } while (0)
   switch (key) {
+    case 21616: ROWS(2, 16, 16, 4); break;  // bicubic tensor splines
+    case 32727: ROWS(3, 27, 27, 3); break;  // triquadratic hexahedra / splines
     case 10202: LOC(1, 2, 2); break;
     case 10303: LOC(1, 3, 3); break;
     case 20303: LOC(2, 3, 3); break;
@@ -427,6 +583,7 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
     default: return NH_OK;
   }
 #undef LOC
+#undef ROWS
   NH_LAUNCH_CHECK();
   *done = true;
   return NH_OK;

@@ -520,9 +520,23 @@ class _MatrixPlan:
             return None
         if basis.dofs_shape != tuple(n * basis.degree + 1 for n in basis.shape) or os.environ.get('NUTILS_AMD_NO_FIRST_TOUCH'):
             return None  # (periodic axes: the neighbour across the seam)
-        if not (smp.nlist >= COLOR_THRESHOLD and basis.nb >= 16 and _colors(smp, basis)):
+        if not (smp.nlist >= COLOR_THRESHOLD and basis.nb >= 16 and _colors(smp, basis)) or os.environ.get('NUTILS_AMD_NO_COLORS'):
             return None
+        if self._rows_pass(smp, itg):
+            return None  # (not assembled colour by colour)
         return basis.shape, basis.degree + 1
+
+    def _rows_pass(self, smp, itg):
+        '''Scalar blocks of 27 (3-D quadratic) / 16 (2-D cubic) functions: from the second assembly on, the owner-side reduction with its row-blocked
+        thread pass (k_local_rows) instead of the coloured MFMA launches -- 64^3 triquadratic 3.9 against 13.0 ms, 1024^2 bicubic splines 3.3
+        against 14.4 ms (tools/generic_probe.py).'''
+        if self.test.ncomp != 1 or self.trial.ncomp != 1 or smp.elist is not None or itg.qform is not None or os.environ.get('NUTILS_AMD_NO_GATHER'):
+            return False
+        tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
+        if (smp.ndims, tt.nb, tr.nb) not in ((2, 16, 16), (3, 27, 27)):
+            return False
+        pat = smp.pattern(itg.test.basis, itg.trial.basis)
+        return getattr(pat, '_assemblies', 0) >= 1 and 8 * pat.emap_len <= kernels.GATHER_SCRATCH_LIMIT
 
     def _batched(self, terms, values, mask, arguments):
         '''Bases with few functions per element: ALL terms of the block that share a measure go through one nh_assemble_matrix_terms launch
@@ -653,12 +667,14 @@ class _MatrixPlan:
                 common_q = dict(common, C=numpy.ones((nct, S, ncr, S)))
                 kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, cq=cq.reshape(-1), **common_q)
                 continue
-            if itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16:  # (small local matrices: 8 coloured launches measured slower than atomics, 4.7 vs 4.0 ms)
+            if (itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16 and not self._rows_pass(smp, itg)
+                    and not os.environ.get('NUTILS_AMD_NO_COLORS')):  # (small local matrices: 8 coloured launches measured slower than atomics, 4.7 vs 4.0 ms)
                 colors = _colors(smp, itg.test.basis)
             if colors:
                 ft = first_touch if iterm == 0 and terms is self.terms else None
                 for el in colors:
                     kernels.assemble_matrix(nelems=el.numel(), elist=el, flags=1 | 2, scale=scale, first_touch=ft, **common)
+                common['pattern']._assemblies = getattr(common['pattern'], '_assemblies', 0) + 1  # (a re-assembly may take the gather path: _rows_pass)
             else:
                 kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, scale=scale, **common)
         return values, rowptr, colidx, self.trial.basis.ndofs * ncr

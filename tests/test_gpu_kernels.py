@@ -420,6 +420,7 @@ def test_first_touch_coloured_assembly(case, monkeypatch):
     '''NH_MATRIX_FIRST_TOUCH (no zero-fill, entries untouched by earlier colours are stored): bit-identical to the zero-filled coloured
     assembly, and EVERY value is written -- the value array is handed over full of NaN.'''
     from nutils_amd import mesh, function, device, sample
+    monkeypatch.setenv('NUTILS_AMD_NO_GATHER', '1')  # (16-function scalar blocks take the owner-side reduction from the second assembly on)
     if case == '3d_p2_vector':
         monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')  # this test is about the coloured generic path (the write-once kernel nh_p2hex_matrix would take the form)
         shape = [16, 16, 17]
@@ -732,6 +733,28 @@ def test_gather_equals_atomics_and_is_reproducible(golden, name):
         out.append(device.to_host(values))
     close(out[0], g['K_values'])
     assert numpy.array_equal(out[0], out[1]) and numpy.array_equal(out[0], out[2])
+
+
+@pytest.mark.parametrize('name', ['lap3d_p2_2_iso', 'lap3d_spline2_3_iso', 'lap2d_spline2_5x4_iso', 'lap3d_p1_543_iso'])
+def test_gather_with_a_full_coefficient_tensor(golden, name):
+    '''A dense, non-symmetric form tensor C[a][b] (value and gradient slots mixed) and a scale array through both thread passes of NH_MATRIX_GATHER
+    (k_local_scalar; k_local_rows for the 27-function elements) against the one-wave-per-element kernel with atomics.'''
+    from nutils_amd import device, kernels
+    g = golden(name)
+    c = Case(g)
+    rng = numpy.random.default_rng(17)
+    S = 1 + c.nd
+    C = rng.normal(size=(1, S, 1, S))
+    scale = device.to_dev(rng.uniform(.5, 1.5, c.nelems * c.nq), 'float64')
+    rowptr, colidx = c.pattern.expand(1, 1, None)
+    out = []
+    for gather in (False, True, True):
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=1, ncr=1, C=C, mask=None,
+                                pattern=c.pattern, values=values, gather=gather, scale=scale)
+        out.append(device.to_host(values))
+    close(out[1], out[0])
+    assert numpy.array_equal(out[1], out[2])
 
 
 def test_gather_ragged_and_structured_large(golden):
