@@ -714,6 +714,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     if ((rc = nh_gather_scratch(std::max((size_t)pat->emap_len, padded) * a->nct * a->ncr, &scratch)) != NH_OK) return rc;
     bool done = false;
     if ((rc = nh_local_scalar(a, scratch, &done, nh_stream(stream))) != NH_OK) return rc;
+    if (!done && (rc = nh_local_vector(a, scratch, &done, nh_stream(stream))) != NH_OK) return rc;
     if (done) {
       GSlots gs;
       memset(&gs, 0, sizeof gs);

@@ -114,5 +114,6 @@ struct GSlots {
 // nh_gather.hip: deterministic two-pass scatter (element-major local matrices, then one sum per CSR entry)
 int nh_gather_prepare(nh_pattern *p, const nh_basis &test, const int32_t *elist, hipStream_t s);  // elist: element ids of the pattern's elements, or NULL
 int nh_gather_scratch(size_t doubles, double **out);
+int nh_local_vector(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);
 int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s);
 int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);

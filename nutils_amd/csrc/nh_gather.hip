@@ -73,24 +73,39 @@ __global__ void k_gather_values(i64 nnz, const unsigned *gptr, const int32_t *gs
     values[k] = store ? s : values[k] + s;
     return;
   }
+  // vector-valued: the nct x ncr block of a contribution is contiguous in the scratch -- read once, all components summed in one pass over the
+  // sources (one pass per component re-reads the index list and touches every 72-byte block nine times: 8.0 -> ms on 96^3 trilinear elasticity)
   const i64 r = grow[k], a0 = srowptr[r], len = srowptr[r + 1] - a0, pos = k - a0;
-  for (int c = 0; c < gs.nct; ++c)
-    for (int d = 0; d < gs.ncr; ++d) {
-      if (!gs.mask[c][d]) continue;
-      double s = 0;
-      for (unsigned i0 = b; i0 < e; i0 += 8) {
-        i64 idx[8];
-        double v[8];
+  double sum[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) idx[u] = i0 + u < e ? (i64)(unsigned)gsrc[i0 + u] : -1;
+  for (int j = 0; j < 16; ++j) sum[j] = 0;
+  for (unsigned i0 = b; i0 < e; i0 += 2) {
+    const i64 i1 = (i64)(unsigned)gsrc[i0], i2 = i0 + 1 < e ? (i64)(unsigned)gsrc[i0 + 1] : -1;
+    const double *s1 = local + i1 * ncd, *s2 = local + (i2 >= 0 ? i2 : i1) * ncd;
+    double v1[16], v2[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = idx[u] >= 0 ? local[idx[u] * ncd + c * gs.ncr + d] : 0.;
+    for (int j = 0; j < 16; ++j) {
+      v1[j] = j < ncd ? s1[j] : 0.;
+      v2[j] = j < ncd && i2 >= 0 ? s2[j] : 0.;
+    }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (i0 + u < e) s += v[u];
-      }
+    for (int j = 0; j < 16; ++j) sum[j] += v1[j];
+    if (i2 >= 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum[j] += v2[j];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (c >= gs.nct || d >= gs.ncr || !gs.mask[c][d]) continue;
+      const int j = c * gs.ncr + d;
+      double v = 0;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) v = jj == j ? sum[jj] : v;
       double *dst = values + a0 * gs.tot + len * gs.cum[c] + pos * gs.cnt[c] + gs.dpos[c][d];
-      *dst = store ? s : *dst + s;
+      *dst = store ? v : *dst + v;
     }
 }
 
@@ -513,6 +528,190 @@ __global__ __launch_bounds__(128) void k_local_rows(LocK p) {
   }
 }
 
+// ---- pass 1 for vector-valued blocks on small bases (trilinear / bilinear / biquadratic elasticity): a thread owns ONE test function -----
+// i.e. the NC rows (m, c) of the local matrix with all NB * NC columns, kept as A[n][c][d]: the scratch holds the NC x NC block of every scalar
+// pair (m, n) contiguously (what k_gather_values expects), so the thread's rows are NB * NC * NC contiguous doubles.  Per point: the physical
+// gradient of the test function, then per (c, d) the row vector w J^-1 (C[c][.][d][.]^T dt) in the reference frame (blocks outside the form's
+// mask are skipped), then the bare contraction with the tabulated reference values of the NB trial functions.
+struct LocVK {
+  i64 nelems;
+  const int32_t *elist;
+  int nq;
+  const double *weights;
+  GeomK geom;
+  BasisK test;
+  const double *scale;
+  int by_elem;
+  double C[144];  // [c][a][d][b], NC <= 3, S <= 4
+  unsigned char mask[3][3];
+  double *local;
+  int ldst_doubles;
+};
+
+template <int ND, int NB, int NC, bool LDST>
+__global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
+  constexpr int S = 1 + ND, NG = 1 << ND, NCD = NC * NC;
+  // the form tensor goes to LDS: its NC * S * NC * S doubles do not fit the scalar registers (read from the kernel arguments they were spilled to
+  // VGPR lanes: 600 v_readlane per point, 4.3 ms instead of  ms for 96^3 trilinear elasticity), a uniform ds_read is a broadcast
+  extern __shared__ __attribute__((aligned(16))) double sC[];
+  double *sT = sC + 144;
+  for (int i = threadIdx.x; i < 144; i += blockDim.x) sC[i] = p.C[i];
+  if (LDST) {
+    const int nt = NB * p.nq * S, ng = NG * p.nq * S;
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) sT[i] = p.test.T[i];
+    if (p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG)
+      for (int i = threadIdx.x; i < ng; i += blockDim.x) sT[nt + i] = p.geom.gT[i];
+  }
+  __syncthreads();
+  const i64 nthreads = p.nelems * NB;
+  const i64 t0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 t = min(t0, nthreads - 1);
+  const i64 ie = t / NB;
+  const int m = (int)(t - ie * NB);
+  const i64 e = p.elist ? p.elist[ie] : ie;
+  double A[NB][NC][NC];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int d = 0; d < NC; ++d) A[n][c][d] = 0;
+  const bool iso = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG;
+  // vertices of the element: in registers, or -- when the NB threads of an element never straddle two workgroups -- once per element in LDS (24
+  // doubles that every one of the 8 threads of a trilinear element would hold: with them the kernel shuttles accumulators through AGPRs)
+  constexpr bool XLDS = 128 % NB == 0 && NB >= NG && ND == 3;
+  double X[XLDS ? 1 : NG][ND];
+  double *sX = sT + p.ldst_doubles + 2 * 64 * 17 + (threadIdx.x / NB) * NG * ND;
+  if (iso) {
+    if (XLDS) {
+      if (m < NG) {
+        const i64 v = p.geom.gdofs[e * NG + m];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) sX[m * ND + i] = p.geom.verts[v * ND + i];
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int a = 0; a < NG; ++a) {
+        const i64 v = p.geom.gdofs[e * NG + a];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) X[XLDS ? 0 : a][i] = p.geom.verts[v * ND + i];
+      }
+    }
+  }
+  const double *Tall = LDST ? sT : p.test.T + bfn(p.test, e) * p.nq * S;
+  const double *Tm = Tall + (size_t)m * p.nq * S;
+  const double *gT = LDST ? sT + NB * p.nq * S : p.geom.gT;
+  for (int q = 0; q < p.nq; ++q) {
+    double Ji[ND][ND], det;
+    if (iso) {
+      double J[ND][ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int j = 0; j < ND; ++j) J[i][j] = 0;
+#pragma unroll
+      for (int a = 0; a < NG; ++a) {
+        const double *tg = gT + ((i64)a * p.nq + q) * S;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) J[i][j] += (XLDS ? sX[a * ND + i] : X[XLDS ? 0 : a][i]) * tg[1 + j];
+      }
+      invert<ND>(J, Ji, det);
+      if (p.geom.bnd_axis >= 0) {
+        double s2 = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+            if (j == p.geom.bnd_axis) s2 += Ji[j][i] * Ji[j][i];
+        det *= sqrt(s2);
+      }
+      if (p.geom.nograd) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) Ji[i][j] = 0.;
+      }
+    } else
+      geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
+    const double w = p.weights[q] * fabs(det) * (p.scale ? p.scale[(p.by_elem ? e : ie) * p.nq + q] : 1.);
+    double dt[S];
+    {
+      const double *T = Tm + (size_t)q * S;
+      dt[0] = T[0];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        double sum = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) sum += T[1 + j] * Ji[j][i];
+        dt[1 + i] = sum;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      double tw[NC][S];
+#pragma unroll
+      for (int d = 0; d < NC; ++d) {
+        if (p.mask[c][d]) {  // (uniform)
+          double cd[S];
+#pragma unroll
+          for (int b = 0; b < S; ++b) {
+            double sum = 0;
+#pragma unroll
+            for (int a = 0; a < S; ++a) sum += dt[a] * sC[((c * S + a) * NC + d) * S + b];
+            cd[b] = w * sum;
+          }
+          tw[d][0] = cd[0];
+#pragma unroll
+          for (int j = 0; j < ND; ++j) {
+            double sum = 0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) sum += Ji[j][i] * cd[1 + i];
+            tw[d][1 + j] = sum;
+          }
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) tw[d][s2] = 0.;
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const double *T = Tall + ((size_t)n * p.nq + q) * S;
+        double tn[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) tn[s2] = T[s2];
+#pragma unroll
+        for (int d = 0; d < NC; ++d)
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) A[n][c][d] += tw[d][s2] * tn[s2];
+      }
+    }
+  }
+  constexpr int NE = NB * NCD, CH = NE % 16 == 0 ? 16 : NE % 8 == 0 ? 8 : NE % 9 == 0 ? 9 : NE % 4 == 0 ? 4 : 1, PADW = CH | 1;  // (8: 64-byte chunks, aligned)
+  double *stg = sT + p.ldst_doubles + (threadIdx.x >> 6) * 64 * PADW;
+  const int lane = threadIdx.x & 63;
+  const i64 wave0 = t0 - lane;
+#pragma unroll
+  for (int c0 = 0; c0 < NE; c0 += CH) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int l = c0 + j, n = l / NCD, cd = l % NCD;
+      stg[lane * PADW + j] = A[n][cd / NC][cd % NC];
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int EPP = 64 / CH;
+    const int sub = lane / CH, idx = lane - sub * CH;
+#pragma unroll
+    for (int pass = 0; pass < (64 + EPP - 1) / EPP; ++pass) {
+      const int el = pass * EPP + sub;
+      if (sub < EPP && el < 64 && wave0 + el < nthreads) p.local[(wave0 + el) * NE + c0 + idx] = stg[el * PADW + idx];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s) {
   if (!p->nnz) return NH_OK;
   hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, ld, p->nbt * p->nbr, slots,
@@ -584,6 +783,49 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   }
 #undef LOC
 #undef ROWS
+  NH_LAUNCH_CHECK();
+  *done = true;
+  return NH_OK;
+}
+
+// thread pass for vector-valued blocks (nct == ncr == NC components on ONE uniform basis, test == trial tables); *done = false: not applicable
+int nh_local_vector(const nh_matrix_args *a, double *local, bool *done, hipStream_t s) {
+  *done = false;
+  const int nc = a->nct;
+  if (nc < 2 || nc > 3 || a->ncr != nc || a->cq_dev || a->test.off_dev || a->trial.off_dev || !a->test.nb || a->test.nb != a->trial.nb) return NH_OK;
+  if (a->test.T_dev != a->trial.T_dev || a->test.tab_dev != a->trial.tab_dev || a->test.dofs_dev != a->trial.dofs_dev) return NH_OK;
+  const int S = 1 + a->ndims;
+  LocVK p;
+  p.nelems = a->nelems;
+  p.elist = a->elist_dev;
+  p.nq = a->nq;
+  p.weights = a->weights_dev;
+  p.geom = to_k(a->geom);
+  p.geom.nograd = !uses_gradients(a->C_host, nc, S, nc);
+  p.test = to_k(a->test);
+  p.scale = a->scale_dev;
+  p.by_elem = (a->flags & NH_MATRIX_EMAP_BY_ELEMENT) != 0;
+  for (int i = 0; i < 144; ++i) p.C[i] = i < nc * S * nc * S ? a->C_host[i] : 0.;
+  for (int c = 0; c < 3; ++c)
+    for (int d = 0; d < 3; ++d) p.mask[c][d] = c < nc && d < nc && (!a->mask_host || a->mask_host[c * nc + d]);
+  p.local = local;
+  dim3 grid((unsigned)((a->nelems * a->test.nb + 127) / 128)), block(128);
+  const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + (1 << a->ndims));
+  const bool ldst = !a->test.tab_dev && ldsb <= 64 * 1024;
+  p.ldst_doubles = ldst ? (int)(ldsb / sizeof(double)) : 0;
+  const size_t ldsx = sizeof(double) * 144 + (ldst ? ldsb : 0) + sizeof(double) * 2 * 64 * 17 + sizeof(double) * 128 * 3;  // + vertices of the elements of the workgroup
+#define ROWSV(ND, NB, NC)                                                                                       \
+  do {                                                                                                          \
+    if (ldst) hipLaunchKernelGGL((k_local_rows_v<ND, NB, NC, true>), grid, block, ldsx, s, p);                  \
+    else hipLaunchKernelGGL((k_local_rows_v<ND, NB, NC, false>), grid, block, ldsx, s, p);                      \
+  } while (0)
+  switch (a->ndims * 1000 + a->test.nb * 10 + nc) {
+    case 3083: ROWSV(3, 8, 3); break;  // trilinear hexahedra, 3 components
+    case 2042: ROWSV(2, 4, 2); break;  // bilinear quadrilaterals, 2 components
+    case 2092: ROWSV(2, 9, 2); break;  // biquadratic quadrilaterals / quadratic splines, 2 components
+    default: return NH_OK;
+  }
+#undef ROWSV
   NH_LAUNCH_CHECK();
   *done = true;
   return NH_OK;

@@ -27,6 +27,7 @@ def structured_dofs(shape, nloc, ndofs_axis, start_concat_dev, elem_begin, nelem
 
 
 GATHER_SCRATCH_LIMIT = 8 << 30
+VECTOR_THREAD_PASS = {(3, 8, 3), (2, 4, 2), (2, 9, 2)}  # (ndims, functions per element, components) of nh_local_vector (nh_gather.hip)
 
 
 class Pattern:
@@ -133,7 +134,12 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     whole = emap_offset == 0 and not flags and not first_touch and nelems == pattern.nelems
     if gather is None:
         # (automatic only while the scratch of the local matrices stays below GATHER_SCRATCH_LIMIT bytes: 1.07 GB for the 128^3 trilinear mesh)
-        gather = (whole and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')
+        # and for blocks with a thread pass (scalar blocks; the vector-valued sizes of VECTOR_THREAD_PASS): the local matrices of other vector-valued
+        # blocks go through the one-wave-per-element kernel either way, and writing + gathering them costs more than its atomics -- 96^3 trilinear
+        # elasticity 15.7 against 7.9 ms, 32^3 triquadratic 14.5 against 3.9 ms, tools/generic_probe.py)
+        thread_pass = nct == ncr == 1 or ((ndims, test.nb, nct) in VECTOR_THREAD_PASS and nct == ncr and cq is None and test.nb == trial.nb
+                                          and test.T_dev == trial.T_dev and test.dofs_dev == trial.dofs_dev and test.tab_dev == trial.tab_dev and not test.off_dev)
+        gather = (whole and thread_pass and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')
                   and 8 * pattern.emap_len * nct * ncr <= GATHER_SCRATCH_LIMIT and pattern.emap_len < 2 ** 32 and pattern.nnz_scalar < 2 ** 32)
     if whole:
         pattern._assemblies = getattr(pattern, '_assemblies', 0) + 1

@@ -8,7 +8,10 @@ import numpy, torch
 from nutils_amd import mesh, function, sample
 
 CASES = [('3D P1 128^3', [128] * 3, 'std', 1, 1), ('3D P2 scalar 64^3', [64] * 3, 'std', 2, 1), ('3D spline2 scalar 64^3', [64] * 3, 'spline', 2, 1),
-         ('2D P1 2048^2', [2048] * 2, 'std', 1, 1), ('2D P2 1024^2', [1024] * 2, 'std', 2, 1), ('2D spline3 1024^2', [1024] * 2, 'spline', 3, 1)]
+         ('2D P1 2048^2', [2048] * 2, 'std', 1, 1), ('2D P2 1024^2', [1024] * 2, 'std', 2, 1), ('2D spline3 1024^2', [1024] * 2, 'spline', 3, 1),
+         ('2D spline2 1024^2', [1024] * 2, 'spline', 2, 1), ('3D spline3 32^3', [32] * 3, 'spline', 3, 1), ('2D P3 512^2', [512] * 2, 'std', 3, 1),
+         ('3D P1 elasticity 96^3', [96] * 3, 'std', 1, 3), ('2D P1 elasticity 1024^2', [1024] * 2, 'std', 1, 2), ('2D P2 elasticity 512^2', [512] * 2, 'std', 2, 2),
+         ('3D P2 elasticity 32^3', [32] * 3, 'std', 2, 3)]
 only = sys.argv[1:] 
 for name, shape, btype, degree, nc in CASES:
     if only and not any(o in name for o in only):
@@ -20,8 +23,15 @@ for name, shape, btype, degree, nc in CASES:
     verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, nd) + rng.uniform(-.2, .2, (len(gb), nd))
     X = gb @ verts
     dV = function.J(X)
-    basis = domain.basis(btype, degree=degree)
-    K = domain.integral(function.outer(function.grad(basis, X)).sum(-1) * dV, degree=2 * degree)
+    if nc == 1:
+        basis = domain.basis(btype, degree=degree)
+        K = domain.integral(function.outer(function.grad(basis, X)).sum(-1) * dV, degree=2 * degree)
+    else:
+        u = domain.field('u', btype=btype, degree=degree, shape=[nd])
+        v = domain.field('v', btype=btype, degree=degree, shape=[nd])
+        eps = lambda w: function.symgrad(w, X)
+        sigma = function.div(u, X) * function.eye(nd) + 1.3 * eps(u)
+        K = function.derivative(function.derivative(domain.integral(function.inner(eps(v), sigma) * dV, degree=2 * degree), 'v'), 'u')
     plan = sample._MatrixPlan(K.terms)
     t0 = time.perf_counter(); out = plan.run({}); torch.cuda.synchronize(); t1 = time.perf_counter()
     plan.run({}); torch.cuda.synchronize()
