@@ -745,7 +745,7 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   dim3 grid((unsigned)((a->nelems + 127) / 128)), block(128);
   const int key = a->ndims * 10000 + a->test.nb * 100 + a->trial.nb;
   const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + a->trial.nb + (1 << a->ndims));
-  const bool rows = key == 21616 || key == 32727;  // (row-blocked kernel: at most two workgroups per CU by registers, LDS is free)
+  const bool rows = key == 21616 || key == 32727 || key == 22525 || key == 36464;  // (row-blocked kernel: at most two workgroups per CU by registers, LDS is free)
   const bool ldst = !a->test.tab_dev && !a->trial.tab_dev && ldsb <= (rows ? 64 : 32) * 1024;
   bool symd = a->test.T_dev == a->trial.T_dev && a->test.tab_dev == a->trial.tab_dev && a->test.dofs_dev == a->trial.dofs_dev;
   for (int i = 0; i < S * S; ++i)
@@ -772,6 +772,8 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   switch (key) {
     case 21616: ROWS(2, 16, 16, 4); break;  // bicubic tensor splines
     case 32727: ROWS(3, 27, 27, 3); break;  // triquadratic hexahedra / splines
+    case 22525: ROWS(2, 25, 25, 5); break;  // biquartic
+    case 36464: ROWS(3, 64, 64, 1); break;  // tricubic: one row per thread (the one-wave-per-element kernel needs 64 kB of LDS per wave: 38 ms for 32^3)
     case 10202: LOC(1, 2, 2); break;
     case 10303: LOC(1, 3, 3); break;
     case 20303: LOC(2, 3, 3); break;

@@ -533,7 +533,7 @@ class _MatrixPlan:
         if self.test.ncomp != 1 or self.trial.ncomp != 1 or smp.elist is not None or itg.qform is not None or os.environ.get('NUTILS_AMD_NO_GATHER'):
             return False
         tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
-        if (smp.ndims, tt.nb, tr.nb) not in ((2, 16, 16), (3, 27, 27)):
+        if (smp.ndims, tt.nb, tr.nb) not in ((2, 16, 16), (3, 27, 27), (2, 25, 25), (3, 64, 64)):  # (the instantiations of k_local_rows, nh_gather.hip)
             return False
         pat = smp.pattern(itg.test.basis, itg.trial.basis)
         return getattr(pat, '_assemblies', 0) >= 1 and 8 * pat.emap_len <= kernels.GATHER_SCRATCH_LIMIT

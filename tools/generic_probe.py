@@ -9,7 +9,7 @@ from nutils_amd import mesh, function, sample
 
 CASES = [('3D P1 128^3', [128] * 3, 'std', 1, 1), ('3D P2 scalar 64^3', [64] * 3, 'std', 2, 1), ('3D spline2 scalar 64^3', [64] * 3, 'spline', 2, 1),
          ('2D P1 2048^2', [2048] * 2, 'std', 1, 1), ('2D P2 1024^2', [1024] * 2, 'std', 2, 1), ('2D spline3 1024^2', [1024] * 2, 'spline', 3, 1),
-         ('2D spline2 1024^2', [1024] * 2, 'spline', 2, 1), ('3D spline3 32^3', [32] * 3, 'spline', 3, 1), ('2D P3 512^2', [512] * 2, 'std', 3, 1),
+         ('2D spline2 1024^2', [1024] * 2, 'spline', 2, 1), ('3D spline3 32^3', [32] * 3, 'spline', 3, 1), ('2D P3 512^2', [512] * 2, 'std', 3, 1), ('2D P4 512^2', [512] * 2, 'std', 4, 1),
          ('3D P1 elasticity 96^3', [96] * 3, 'std', 1, 3), ('2D P1 elasticity 1024^2', [1024] * 2, 'std', 1, 2), ('2D P2 elasticity 512^2', [512] * 2, 'std', 2, 2),
          ('3D P2 elasticity 32^3', [32] * 3, 'std', 2, 3)]
 only = sys.argv[1:] 
