@@ -74,7 +74,7 @@ __global__ void k_gather_values(i64 nnz, const unsigned *gptr, const int32_t *gs
     return;
   }
   // vector-valued: the nct x ncr block of a contribution is contiguous in the scratch -- read once, all components summed in one pass over the
-  // sources (one pass per component re-reads the index list and touches every 72-byte block nine times: 8.0 -> ms on 96^3 trilinear elasticity)
+  // sources (one pass per component re-reads the index list and touches every 72-byte block nine times: 8.0 -> 2.85 ms on 96^3 trilinear elasticity; 16-byte loads: 2.0 ms)
   const i64 r = grow[k], a0 = srowptr[r], len = srowptr[r + 1] - a0, pos = k - a0;
   double sum[16];
 #pragma unroll
@@ -83,10 +83,37 @@ __global__ void k_gather_values(i64 nnz, const unsigned *gptr, const int32_t *gs
     const i64 i1 = (i64)(unsigned)gsrc[i0], i2 = i0 + 1 < e ? (i64)(unsigned)gsrc[i0 + 1] : -1;
     const double *s1 = local + i1 * ncd, *s2 = local + (i2 >= 0 ? i2 : i1) * ncd;
     double v1[16], v2[16];
+    if (ncd == 9) {  // 3 x 3 blocks (72 bytes, 8-byte aligned): four 16-byte loads + one instead of nine 8-byte loads per lane
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      v1[j] = j < ncd ? s1[j] : 0.;
-      v2[j] = j < ncd && i2 >= 0 ? s2[j] : 0.;
+      for (int j = 0; j < 8; j += 2) {
+        double2 a, c;
+        __builtin_memcpy(&a, s1 + j, 16);
+        __builtin_memcpy(&c, s2 + j, 16);
+        v1[j] = a.x, v1[j + 1] = a.y, v2[j] = c.x, v2[j + 1] = c.y;
+      }
+      v1[8] = s1[8], v2[8] = s2[8];
+#pragma unroll
+      for (int j = 9; j < 16; ++j) v1[j] = v2[j] = 0.;
+      if (i2 < 0) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v2[j] = 0.;
+      }
+    } else if (ncd == 4) {  // 2 x 2 blocks: two 16-byte loads
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        double2 a, c;
+        __builtin_memcpy(&a, s1 + j, 16);
+        __builtin_memcpy(&c, s2 + j, 16);
+        v1[j] = a.x, v1[j + 1] = a.y, v2[j] = i2 >= 0 ? c.x : 0., v2[j + 1] = i2 >= 0 ? c.y : 0.;
+      }
+#pragma unroll
+      for (int j = 4; j < 16; ++j) v1[j] = v2[j] = 0.;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        v1[j] = j < ncd ? s1[j] : 0.;
+        v2[j] = j < ncd && i2 >= 0 ? s2[j] : 0.;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) sum[j] += v1[j];
@@ -552,7 +579,7 @@ template <int ND, int NB, int NC, bool LDST>
 __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
   constexpr int S = 1 + ND, NG = 1 << ND, NCD = NC * NC;
   // the form tensor goes to LDS: its NC * S * NC * S doubles do not fit the scalar registers (read from the kernel arguments they were spilled to
-  // VGPR lanes: 600 v_readlane per point, 4.3 ms instead of  ms for 96^3 trilinear elasticity), a uniform ds_read is a broadcast
+  // VGPR lanes: 600 v_readlane per point, 4.3 instead of 3.8 ms for 96^3 trilinear elasticity), a uniform ds_read is a broadcast
   extern __shared__ __attribute__((aligned(16))) double sC[];
   double *sT = sC + 144;
   for (int i = threadIdx.x; i < 144; i += blockDim.x) sC[i] = p.C[i];
