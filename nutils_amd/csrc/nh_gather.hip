@@ -629,8 +629,8 @@ __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
   const double *Tall = LDST ? sT : p.test.T + bfn(p.test, e) * p.nq * S;
   const double *Tm = Tall + (size_t)m * p.nq * S;
   const double *gT = LDST ? sT + NB * p.nq * S : p.geom.gT;
-  for (int q = 0; q < p.nq; ++q) {
-    double Ji[ND][ND], det;
+  auto geometry = [&](int q, double (&Ji)[ND][ND], double &w) {
+    double det;
     if (iso) {
       double J[ND][ND];
 #pragma unroll
@@ -663,7 +663,38 @@ __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
       }
     } else
       geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
-    const double w = p.weights[q] * fabs(det) * (p.scale ? p.scale[(p.by_elem ? e : ie) * p.nq + q] : 1.);
+    w = p.weights[q] * fabs(det) * (p.scale ? p.scale[(p.by_elem ? e : ie) * p.nq + q] : 1.);
+  };
+  // The NB threads of an element sit in one wave (NB divides 64): thread m computes the geometry of the points m, m + NB, ... ONCE and leaves the
+  // inverse Jacobian and the weight in LDS for the others -- repeated by every thread it was 2.6 of the 3.7 ms of this kernel on 96^3 trilinear
+  // elasticity (ablation: form, contraction and stores switched off).
+  constexpr bool SHARE = 64 % NB == 0;
+  constexpr int GW = ND * ND + 1;
+  double *sG = sT + p.ldst_doubles + 2 * 64 * 17 + 128 * 3 + (threadIdx.x / NB) * p.nq * GW;
+  if (SHARE) {
+    for (int q = m; q < p.nq; q += NB) {
+      double Ji[ND][ND], w;
+      geometry(q, Ji, w);
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int j = 0; j < ND; ++j) sG[q * GW + i * ND + j] = Ji[i][j];
+      sG[q * GW + ND * ND] = w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  for (int q = 0; q < p.nq; ++q) {
+    double Ji[ND][ND], w;
+    if (SHARE) {
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int j = 0; j < ND; ++j) Ji[i][j] = sG[q * GW + i * ND + j];
+      w = sG[q * GW + ND * ND];
+    } else
+      geometry(q, Ji, w);
     double dt[S];
     {
       const double *T = Tm + (size_t)q * S;
@@ -842,7 +873,8 @@ int nh_local_vector(const nh_matrix_args *a, double *local, bool *done, hipStrea
   const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + (1 << a->ndims));
   const bool ldst = !a->test.tab_dev && ldsb <= 64 * 1024;
   p.ldst_doubles = ldst ? (int)(ldsb / sizeof(double)) : 0;
-  const size_t ldsx = sizeof(double) * 144 + (ldst ? ldsb : 0) + sizeof(double) * 2 * 64 * 17 + sizeof(double) * 128 * 3;  // + vertices of the elements of the workgroup
+  const size_t ldsx = sizeof(double) * 144 + (ldst ? ldsb : 0) + sizeof(double) * 2 * 64 * 17 + sizeof(double) * 128 * 3 +  // + vertices of the elements of the workgroup
+                      sizeof(double) * (128 / a->test.nb + 1) * a->nq * (a->ndims * a->ndims + 1);                      // + inverse Jacobians and weights of their points
 #define ROWSV(ND, NB, NC)                                                                                       \
   do {                                                                                                          \
     if (ldst) hipLaunchKernelGGL((k_local_rows_v<ND, NB, NC, true>), grid, block, ldsx, s, p);                  \
