@@ -54,8 +54,9 @@ __global__ void k_gather_values(i64 nnz, const unsigned *gptr, const int32_t *gs
   const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nnz) return;
   const unsigned b = gptr[k], e = gptr[k + 1];
-  const int ncd = gs.nct * gs.ncr;
-  if (ncd == 1) {  // scalar: the expanded pattern is the scalar one
+  // (scalar blocks: the expanded pattern is the scalar one; vector-valued blocks have their own kernel below -- its 48 accumulator / staging
+  // registers would take the occupancy these latency-bound 8-byte gathers live on: 0.58 -> 0.75 ms on the 128^3 trilinear mesh)
+  {
     // eight contributions in flight per thread (index loads, then value loads, then the sum in the order of the map): one at a time, the
     // kernel waits out two dependent memory latencies per contribution (0.76 -> 0.58 ms on the 128^3 trilinear mesh)
     double s = 0;
@@ -71,8 +72,15 @@ __global__ void k_gather_values(i64 nnz, const unsigned *gptr, const int32_t *gs
         if (i0 + u < e) s += v[u];
     }
     values[k] = store ? s : values[k] + s;
-    return;
   }
+}
+
+__global__ void k_gather_values_v(i64 nnz, const unsigned *gptr, const int32_t *gsrc, const int32_t *grow, const i64 *srowptr, const double *local, GSlots gs,
+                                  double *values, int store) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const unsigned b = gptr[k], e = gptr[k + 1];
+  const int ncd = gs.nct * gs.ncr;
   // vector-valued: the nct x ncr block of a contribution is contiguous in the scratch -- read once, all components summed in one pass over the
   // sources (one pass per component re-reads the index list and touches every 72-byte block nine times: 8.0 -> 2.85 ms on 96^3 trilinear elasticity; 16-byte loads: 2.0 ms)
   const i64 r = grow[k], a0 = srowptr[r], len = srowptr[r + 1] - a0, pos = k - a0;
@@ -772,8 +780,11 @@ __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
 
 int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s) {
   if (!p->nnz) return NH_OK;
-  hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, ld, p->nbt * p->nbr, slots,
-                     values, store);
+  if (slots.nct * slots.ncr == 1)
+    hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, ld, p->nbt * p->nbr, slots,
+                       values, store);
+  else
+    hipLaunchKernelGGL(k_gather_values_v, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, slots, values, store);
   NH_LAUNCH_CHECK();
   return NH_OK;
 }
