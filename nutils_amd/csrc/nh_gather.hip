@@ -425,7 +425,9 @@ done:
 // frame), so the inner loop over the trial functions is the bare contraction A[m][n] += sum_s tw[m][s] T_n[q][s] with the tabulated
 // reference values: MB * S multiply-adds per trial function and point, nothing else.
 template <int ND, int NBT, int NBR, int MB, bool LDST>
-__global__ __launch_bounds__(128) void k_local_rows(LocK p) {
+// (27 functions, tables through L1: two waves per SIMD with 19 spilled doubles beat one wave without, 3.89 -> 3.47 ms for 64^3 quadratic splines; with the tables
+// in LDS the 71 kB workgroups allow one wave per SIMD either way, and the spills cost: 2.62 -> 2.83 ms)
+__global__ __launch_bounds__(128, (ND == 3 && NBT == 27 && !LDST ? 2 : 1)) void k_local_rows(LocK p) {
   constexpr int S = 1 + ND, NG = 1 << ND, NMB = NBT / MB;
   static_assert(NBT % MB == 0, "row blocks");
   extern __shared__ __attribute__((aligned(16))) double sT[];
