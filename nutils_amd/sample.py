@@ -36,9 +36,16 @@ class _BasisTables:
             dofs, coeffs = basis.concatenated()
             self.T = kernels.tabulate(device.to_dev(coeffs, 'float64'), len(coeffs), coeffs.shape[1], pts, nq, nd)
             self.dofs = device.to_dev(dofs, 'int32')
-            self.off = device.to_dev(basis.offsets, 'int64')
-            self.tab = None
-            self.nb = 0
+            sizes = numpy.diff(basis.offsets)
+            if len(sizes) and (sizes == sizes[0]).all() and sizes[0] > 0:
+                # one element type throughout (an unstructured mesh of hexahedra, say): the uniform representation -- nb functions per element, the
+                # table of element e at e * nb -- which the thread-per-element passes and the structured-size kernels take; ragged bases keep offsets
+                self.off, self.nb = None, int(sizes[0])
+                self.tab = device.to_dev(numpy.arange(len(sizes)), 'int32')
+            else:
+                self.off = device.to_dev(basis.offsets, 'int64')
+                self.tab = None
+                self.nb = 0
         elif isinstance(basis, RationalBasis):
             pt = smp.tables(basis.parent)
             ne = basis.nelems
