@@ -528,16 +528,42 @@ __global__ __launch_bounds__(128, (ND == 3 && NBT == 27 && !LDST ? 2 : 1)) void 
         tw[m][1 + j] = sum;
       }
     }
+    // One row per thread and 64 functions: a wave IS an element, and with test == trial tables its lanes have just read the 64 table rows of the
+    // point -- 2 kB apart in the function-major tables.  They are exchanged through LDS instead of read again, row by row, by every lane
+    // (32^3 tricubic splines: 11.9 -> 6.7 ms per assembly).
+    constexpr bool XROW = MB == 1 && NBT == 64 && NBR == 64 && !LDST;
+    if (XROW && Tt - (size_t)mb * p.nq * S == Tr) {  // (uniform: same table for test and trial)
+      double *rowbuf = sT + p.ldst_doubles + (threadIdx.x >> 6) * 64 * 17;  // (LDS pointer: kept apart from the global one, or the loads turn into flat loads)
+      const double *T = Tt + (size_t)q * S;
 #pragma unroll
-    for (int n = 0; n < NBR; ++n) {
-      const double *T = Tr + ((size_t)n * p.nq + q) * S;
-      double tn[S];
+      for (int s2 = 0; s2 < S; ++s2) rowbuf[(threadIdx.x & 63) * S + s2] = T[s2];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int s2 = 0; s2 < S; ++s2) tn[s2] = T[s2];
+      for (int n = 0; n < NBR; ++n) {
+        double tn[S];
 #pragma unroll
-      for (int m = 0; m < MB; ++m)
+        for (int s2 = 0; s2 < S; ++s2) tn[s2] = rowbuf[n * S + s2];
 #pragma unroll
-        for (int s2 = 0; s2 < S; ++s2) A[m][n] += tw[m][s2] * tn[s2];
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) A[m][n] += tw[m][s2] * tn[s2];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // (the rows are overwritten at the next point)
+    } else {
+#pragma unroll
+      for (int n = 0; n < NBR; ++n) {
+        const double *T = Tr + ((size_t)n * p.nq + q) * S;
+        double tn[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) tn[s2] = T[s2];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) A[m][n] += tw[m][s2] * tn[s2];
+      }
     }
   }
   // store: the thread's MB rows are MB * NBR contiguous doubles of the element-major scratch, neighbouring lanes hold neighbouring chunks -- through
