@@ -528,15 +528,18 @@ __global__ __launch_bounds__(128, (ND == 3 && NBT == 27 && !LDST ? 2 : 1)) void 
         tw[m][1 + j] = sum;
       }
     }
-    // One row per thread and 64 functions: a wave IS an element, and with test == trial tables its lanes have just read the 64 table rows of the
-    // point -- 2 kB apart in the function-major tables.  They are exchanged through LDS instead of read again, row by row, by every lane
-    // (32^3 tricubic splines: 11.9 -> 6.7 ms per assembly).
-    constexpr bool XROW = MB == 1 && NBT == 64 && NBR == 64 && !LDST;
+    // The NMB threads of an element sit in one wave (NMB divides 64) and, with test == trial tables, have between them just read all NBT table rows
+    // of the point: they are exchanged through LDS instead of read again, row by row, by every thread -- the rows are nq * S doubles apart in the
+    // function-major tables, 64 lines per load (32^3 tricubic splines: 11.9 -> 6.7 ms per assembly; 1024^2 bicubic splines: 3.3 -> 3.1 ms).
+    constexpr bool XROW = 64 % NMB == 0 && NBT == NBR && !LDST && (64 / NMB) * NBT * S <= 64 * 17;
     if (XROW && Tt - (size_t)mb * p.nq * S == Tr) {  // (uniform: same table for test and trial)
-      double *rowbuf = sT + p.ldst_doubles + (threadIdx.x >> 6) * 64 * 17;  // (LDS pointer: kept apart from the global one, or the loads turn into flat loads)
-      const double *T = Tt + (size_t)q * S;
+      double *rowbuf = sT + p.ldst_doubles + (threadIdx.x >> 6) * 64 * 17 + ((threadIdx.x & 63) / NMB) * NBT * S;  // (LDS pointer: kept apart from the global one, or the loads turn into flat loads)
 #pragma unroll
-      for (int s2 = 0; s2 < S; ++s2) rowbuf[(threadIdx.x & 63) * S + s2] = T[s2];
+      for (int m = 0; m < MB; ++m) {
+        const double *T = Tt + ((size_t)m * p.nq + q) * S;
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) rowbuf[(mb + m) * S + s2] = T[s2];
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
