@@ -431,8 +431,9 @@ __global__ __launch_bounds__(128, (ND == 3 && NBT == 27 && !LDST ? 2 : 1)) void 
   constexpr int S = 1 + ND, NG = 1 << ND, NMB = NBT / MB;
   static_assert(NBT % MB == 0, "row blocks");
   extern __shared__ __attribute__((aligned(16))) double sT[];
-  if (LDST) {
-    const int nt = NBT * p.nq * S, nr = NBR * p.nq * S, ng = NG * p.nq * S;
+  // tables in LDS: test and trial when the basis has one element class (LDST), the geometry tables (one class by construction) in any case
+  {
+    const int nt = LDST ? NBT * p.nq * S : 0, nr = LDST ? NBR * p.nq * S : 0, ng = NG * p.nq * S;
     for (int i = threadIdx.x; i < nt; i += blockDim.x) sT[i] = p.test.T[i];
     for (int i = threadIdx.x; i < nr; i += blockDim.x) sT[nt + i] = p.trial.T[i];
     if (p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG)
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(128, (ND == 3 && NBT == 27 && !LDST ? 2 : 1)) void 
   }
   const double *Tt = (LDST ? sT : p.test.T + bfn(p.test, e) * p.nq * S) + (size_t)mb * p.nq * S;
   const double *Tr = LDST ? sT + NBT * p.nq * S : p.trial.T + bfn(p.trial, e) * p.nq * S;
-  const double *gT = LDST ? sT + (NBT + NBR) * p.nq * S : p.geom.gT;
+  const double *gT = sT + (LDST ? (NBT + NBR) * p.nq * S : 0);
   for (int q = 0; q < p.nq; ++q) {
     double Ji[ND][ND], det;
     if (iso) {
@@ -850,8 +851,9 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   bool symd = a->test.T_dev == a->trial.T_dev && a->test.tab_dev == a->trial.tab_dev && a->test.dofs_dev == a->trial.dofs_dev;
   for (int i = 0; i < S * S; ++i)
     if (i / S != i % S && a->C_host[i] != 0.) symd = false;
-  p.ldst_doubles = ldst ? (int)(ldsb / sizeof(double)) : 0;
-  const size_t ldsx = (ldst ? ldsb : 0) + sizeof(double) * 2 * 64 * 17;  // + two waves' transposition buffers
+  const size_t ldsg = sizeof(double) * (size_t)a->nq * S * (1 << a->ndims);  // geometry tables: staged by the row-split kernel also when the basis tables are not
+  p.ldst_doubles = ldst ? (int)(ldsb / sizeof(double)) : rows ? (int)(ldsg / sizeof(double)) : 0;
+  const size_t ldsx = (ldst ? ldsb : rows ? ldsg : 0) + sizeof(double) * 2 * 64 * 17;  // + two waves' transposition buffers
 #define LOC(ND, NBT, NBR)                                                                                         \
   do {                                                                                                            \
     if (NBT == NBR && symd) {                                                                                     \
