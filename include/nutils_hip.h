@@ -22,10 +22,13 @@
  *     dof = scalar_dof * ncomp + comp (function.py:2598-2627).
  *   - thread model: one host thread per device context (the reference never threads;
  *     under NUTILS_NPROCS>1 it forks -- do not initialise before a fork).
- *   - library-owned scratch: NH_MATRIX_GATHER keeps the local matrices of the last assembly in a
- *     device buffer that grows to the largest pattern seen (1.07 GB for the 128^3 trilinear mesh) and
- *     is shared by all calls: assemblies that use it must be issued on ONE stream at a time;
- *     nh_release_scratch() returns it to the device.
+ *   - library-owned state is per PROCESS, not per stream: the scratch of local matrices of NH_MATRIX_GATHER (grows to
+ *     the largest pattern seen, 1.07 GB for the 128^3 trilinear mesh; nh_release_scratch() returns it), the staged
+ *     basis tables of the thread-per-element passes and the parameter ring of nh_assemble_terms_multi are shared
+ *     by all calls and carry no locks or events.  REQUIREMENT: all assembly entry points (nh_assemble_*, nh_p1hex_*,
+ *     nh_p2hex_*) are issued from ONE host thread onto ONE stream at a time; only nh_index_copy, nh_memcpy_* and
+ *     nh_monomial* (no library state) may run on a second stream beside them -- which is how nutils_amd/solver.py
+ *     overlaps the copy of the Jacobian entries with the residual of the same step.
  */
 #ifndef NUTILS_HIP_H
 #define NUTILS_HIP_H
@@ -474,6 +477,18 @@ int nh_index_copy(int64_t n, const double *src_dev, const int64_t *src_index_dev
  * integrand is re-integrated with the pointwise coefficient. */
 int nh_pointwise_poly(int64_t n, int nvars, const double *const *x_dev, const int *strides, int nterms, const double *coeffs,
                       const int *powers, double *out_dev, void *stream);
+
+/* ---- per-point forms of field values ------------------------------------------------------------
+ * The product-rule coefficients of quasi-linear problems at every quadrature point, from U = (value, gradient w.r.t. x) of
+ * the bound scalar field(s) there (nh_sample_eval; U[npoints][S], S = 1 + ndims):
+ *   kind 0: out[i]       = sc_i sum_ab B[a][b] Ut[i][a] Ur[i][b]         (point factor of an energy: a scale_dev array)
+ *   kind 1: out[i][a][b] = sc_i (b == 0 ? sum_x B[a][x] Ut[i][x] : 0)    (cq_dev of nh_assemble_matrix: g'(u) phi_n B(v, u))
+ *   kind 2: out[i][a][b] = sc_i L[a] sum_x B[x][b] Ut[i][x]              (cq_dev: both one-sided tensors of an energy Hessian)
+ * sc_i = scale_dev[i] or 1.  B_host [S][S], L_host [S] (kind 2).  Replaces what the reference obtains by differentiating the
+ * evaluable graph (evaluable.py: `_derivative` of Multiply / Einsum nodes under function.derivative, function.py:1184-1196)
+ * and evaluating the product inside the generated element loop. */
+int nh_point_forms(int kind, int64_t npoints, int S, const double *Ut_dev, const double *Ur_dev, const double *B_host, const double *L_host,
+                   const double *scale_dev, double *out_dev, void *stream);
 
 /* ---- rational bases (NURBS) ------------------------------------------------------------------
  * In-place transform of per-element tabulated functions T[(e, i)][q][S] (function (e,i) = e*nb+i, or off[e]+i for ragged bases)

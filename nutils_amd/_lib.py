@@ -142,6 +142,7 @@ SIGNATURES = {
     'nh_index_copy': (ctypes.c_int, [c_i64, vp, vp, vp, vp, vp]),
     'nh_pointwise_poly': (ctypes.c_int, [c_i64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int), vp, vp]),
+    'nh_point_forms': (ctypes.c_int, [ctypes.c_int, c_i64, ctypes.c_int, vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), vp, vp, vp]),
     'nh_rationalize': (ctypes.c_int, [vp, c_i64, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     'nh_p1hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64, vp, vp, vp]),
     'nh_p1hex_laplace': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp]),
@@ -184,5 +185,26 @@ def check(status):
         raise NutilsHipError(f'libnutils_hip status {status}: {msg}')
 
 
+TRACE = None  # list of entry-point names while a `trace()` block is active
+
+
+class trace:
+    '''`with _lib.trace() as calls:` records the name of every C-ABI entry point called inside the block (tests assert which kernels an
+    assembly went through, e.g. that a plan reached nh_p1hex_laplace and not the generic nh_assemble_matrix).'''
+
+    def __enter__(self):
+        global TRACE
+        self._outer, TRACE = TRACE, []
+        return TRACE
+
+    def __exit__(self, *exc):
+        global TRACE
+        if self._outer is not None:
+            self._outer.extend(TRACE)
+        TRACE = self._outer
+
+
 def call(name, *args):
+    if TRACE is not None:
+        TRACE.append(name)
     check(getattr(load(), name)(*args))

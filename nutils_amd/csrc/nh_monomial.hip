@@ -165,3 +165,77 @@ extern "C" int nh_pointwise_poly(int64_t n, int nvars, const double *const *x_de
   NH_LAUNCH_CHECK();
   return NH_OK;
 }
+
+// ---- per-point forms of field values ------------------------------------------------------------------------------------
+// The product-rule coefficients of quasi-linear problems (function.derivative of g(u) B(v, u) or of an energy g(u) B(u, u):
+// the reference differentiates the evaluable graph, evaluable.py `derivative` rules of Multiply / Einsum) at every quadrature point,
+// from U = (value, gradient) of the bound scalar field(s) there (nh_sample_eval):
+//   kind 0:  out[i]       = sc_i * sum_ab B[a][b] Ut[i][a] Ur[i][b]           (point factor of an energy Hessian / residual)
+//   kind 1:  out[i][a][b] = sc_i * (b == 0 ? sum_x B[a][x] Ut[i][x] : 0)      (C_q of qform 'trial': result on the value slot)
+//   kind 2:  out[i][a][b] = sc_i * L[a] sum_x B[x][b] Ut[i][x]                (C_q of qform 'test')
+// sc_i = scale[i] or 1.  S = 1 + ndims <= 4.
+namespace {
+struct PFormK {
+  i64 n;
+  int kind, S;
+  const double *Ut, *Ur, *scale;
+  double B[16], L[4];
+  double *out;
+};
+
+__global__ void k_point_forms(PFormK p) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  const int S = p.S;
+  double ut[4], ur[4];
+  for (int a = 0; a < S; ++a) ut[a] = p.Ut[i * S + a];
+  const double sc = p.scale ? p.scale[i] : 1.;
+  if (p.kind == 0) {
+    for (int a = 0; a < S; ++a) ur[a] = p.Ur[i * S + a];
+    double s = 0;
+    for (int a = 0; a < S; ++a) {
+      double t = 0;
+      for (int b = 0; b < S; ++b) t += p.B[a * 4 + b] * ur[b];
+      s += ut[a] * t;
+    }
+    p.out[i] = sc * s;
+    return;
+  }
+  double *o = p.out + i * S * S;
+  if (p.kind == 1) {
+    for (int a = 0; a < S; ++a) {
+      double t = 0;
+      for (int x = 0; x < S; ++x) t += p.B[a * 4 + x] * ut[x];
+      o[a * S] = sc * t;
+      for (int b = 1; b < S; ++b) o[a * S + b] = 0.;
+    }
+  } else {
+    double t[4];
+    for (int b = 0; b < S; ++b) {
+      t[b] = 0;
+      for (int x = 0; x < S; ++x) t[b] += p.B[x * 4 + b] * ut[x];
+    }
+    for (int a = 0; a < S; ++a)
+      for (int b = 0; b < S; ++b) o[a * S + b] = sc * p.L[a] * t[b];
+  }
+}
+}  // namespace
+
+extern "C" int nh_point_forms(int kind, int64_t npoints, int S, const double *Ut_dev, const double *Ur_dev, const double *B_host, const double *L_host,
+                              const double *scale_dev, double *out_dev, void *stream) {
+  NH_REQUIRE(kind >= 0 && kind <= 2 && npoints >= 0 && S >= 2 && S <= 4 && Ut_dev && B_host && out_dev, "nh_point_forms: invalid argument");
+  NH_REQUIRE(kind != 0 || Ur_dev, "nh_point_forms: kind 0 needs both fields");
+  NH_REQUIRE(kind != 2 || L_host, "nh_point_forms: kind 2 needs L");
+  if (!npoints) return NH_OK;
+  PFormK p;
+  memset(&p, 0, sizeof p);
+  p.n = npoints; p.kind = kind; p.S = S;
+  p.Ut = Ut_dev; p.Ur = Ur_dev; p.scale = scale_dev; p.out = out_dev;
+  for (int a = 0; a < S; ++a) {
+    for (int b = 0; b < S; ++b) p.B[a * 4 + b] = B_host[a * S + b];
+    if (L_host) p.L[a] = L_host[a];
+  }
+  hipLaunchKernelGGL(k_point_forms, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, nh_stream(stream), p);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}

@@ -460,3 +460,16 @@ def pointwise_poly(xs, strides, coeffs, powers, n):
     P = (ctypes.c_int * max(nt * nv, 1))(*[int(p) for row in powers for p in row])
     _lib.call('nh_pointwise_poly', n, nv, X, S, nt, C, P, device.ptr(out), device.stream())
     return out
+
+
+def point_forms(kind, Ut, B, Ur=None, L=None, scale=None):
+    '''Per-point forms of field values (nh_point_forms): kind 0 -> [npoints] point factor Ut.B.Ur; kind 1 / 2 -> [npoints][S][S] coefficient
+    tensors of the product-rule terms (sample._MatrixPlan.run).  Ut, Ur: [npoints][S] on the device; B [S][S], L [S] on the host.'''
+    n, S = int(Ut.shape[0]), int(Ut.shape[1])
+    B = numpy.ascontiguousarray(B, dtype=float).reshape(S, S)
+    out = device.empty(n if kind == 0 else n * S * S, 'float64')
+    Bc = (ctypes.c_double * (S * S))(*B.ravel())
+    Lc = (ctypes.c_double * S)(*numpy.asarray(L, dtype=float).ravel()) if L is not None else None
+    _lib.call('nh_point_forms', kind, n, S, device.ptr(Ut), device.ptr(Ur) if Ur is not None else None, Bc, Lc,
+              device.ptr(scale) if scale is not None else None, device.ptr(out), device.stream())
+    return out

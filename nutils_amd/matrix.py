@@ -112,24 +112,32 @@ class _Backend:
 backend = _Backend()
 
 
+def _check_triplet(values, rowptr, colidx, ncols):
+    '''The contract a backend may rely on (the conditions of matrix/__init__.py:47-69, each raising MatrixError): values a vector with
+    one entry per column index; rowptr an integer vector that starts at 0, never decreases and ends at nnz; column indices integers
+    below ncols that do not decrease inside a row.  One pass of numpy per condition.'''
+    nnz = values.shape[0] if values.ndim == 1 else -1
+    if nnz < 0:
+        raise MatrixError(f'values must be a vector, got {values.ndim} axes')
+    if rowptr.ndim != 1 or rowptr.dtype.kind not in 'ui' or not rowptr.size:
+        raise MatrixError('row pointers must be a non-empty integer vector')
+    if rowptr[0] != 0 or rowptr[-1] != nnz or numpy.any(numpy.diff(rowptr) < 0):
+        raise MatrixError(f'row pointers must rise from 0 to the number of values ({nnz})')
+    if colidx.ndim != 1 or colidx.dtype.kind not in 'ui' or colidx.size != nnz:
+        raise MatrixError(f'column indices must be an integer vector of length {nnz}')
+    if nnz and int(colidx.max()) >= ncols:
+        raise MatrixError(f'column index {int(colidx.max())} outside the {ncols} columns')
+    if nnz > 1:
+        drops = numpy.flatnonzero(colidx[1:] < colidx[:-1]) + 1  # allowed only where a new row starts
+        if drops.size and not numpy.isin(drops, rowptr).all():
+            raise MatrixError('column indices decrease inside a row')
+
+
 def assemble_csr(values, rowptr, colidx, ncols):
-    '''Create sparse matrix from CSR sparse data (matrix/__init__.py:30-70).'''
-    values = numpy.asarray(values)
-    rowptr = numpy.asarray(rowptr)
-    colidx = numpy.asarray(colidx)
+    '''Create sparse matrix from CSR sparse data (matrix/__init__.py:30-70): validate, then hand over to the current backend.'''
+    values, rowptr, colidx = numpy.asarray(values), numpy.asarray(rowptr), numpy.asarray(colidx)
     ncols = ncols.__index__()
-    if not values.ndim == 1:
-        raise MatrixError('assemble received invalid values')
-    if not (rowptr.ndim == 1 and rowptr.dtype.kind in 'ui' and len(rowptr) and rowptr[0] == 0
-            and (rowptr[1:] >= rowptr[:-1]).all() and rowptr[-1] == len(values)):
-        raise MatrixError('assemble received invalid row indices')
-    if not (colidx.ndim == 1 and colidx.dtype.kind in 'ui' and len(colidx) == rowptr[-1] and (colidx < ncols).all()):
-        raise MatrixError('assemble received invalid column indices')
-    increasing = numpy.empty(len(colidx) + 1, dtype=bool)
-    numpy.greater_equal(colidx[1:], colidx[:-1], out=increasing[1:-1])
-    increasing[rowptr] = True
-    if not increasing.all():
-        raise MatrixError('column indices are not stricty increasing')
+    _check_triplet(values, rowptr, colidx, ncols)
     return backend.current.assemble(values, rowptr, colidx, ncols)
 
 

@@ -367,9 +367,7 @@ def _point_scale(smp, itg, arguments):
         geom = itg.geom if itg.geom is not None else itg.measure
         Ut = _field_values(smp, at, geom, arguments)
         Ur = Ut if ar is at else _field_values(smp, ar, geom, arguments)
-        Bd = device.to_dev(numpy.ascontiguousarray(Bs[0, :, 0, :]), 'float64')  # scalar fields: [S][S]
-        s = ((Ut @ Bd) * Ur).sum(-1)
-        sc = s if sc is None else sc.reshape(-1) * s
+        sc = kernels.point_forms(0, Ut, Bs[0, :, 0, :], Ur=Ur, scale=None if sc is None else sc.reshape(-1))  # scalar fields: B [S][S]
     return sc
 
 
@@ -497,8 +495,15 @@ class _MatrixPlan:
                 return None
             geom = itg.measure
             C = C + numpy.asarray(itg.B, dtype=float) * fac
-        key = 'p2hex', id(geom), C.tobytes()
-        fn = smp._tables.get(key)
+        # launchers by geometry OBJECT (the entry keeps it alive, so its id cannot be recycled for another geometry while the entry exists;
+        # at most 4 geometries per sample: a script that builds a new one per step does not pile up vertex arrays on the device), then by form
+        if not hasattr(smp, '_p2hex_fns'):
+            smp._p2hex_fns = {}
+        by_form = _cached(smp._p2hex_fns, geom, dict)
+        if len(by_form) >= 8 and C.tobytes() not in by_form:
+            by_form.pop(next(iter(by_form)))
+        key = C.tobytes()
+        fn = by_form.get(key)
         if fn is None:
             try:
                 fn = kernels.P2HexMatrix(shape=basis.shape, nq=smp.points.npoints, weights=smp._weights_dev, geom=smp.geometry(geom), T=smp.tables(basis).T,
@@ -508,9 +513,9 @@ class _MatrixPlan:
             except _lib_error() as e:
                 if 'LDS' not in str(e):
                     raise
-                smp._tables[key] = fn = False
+                by_form[key] = fn = False
             else:
-                smp._tables[key] = fn
+                by_form[key] = fn
                 return probe
         if fn is False:
             return None
@@ -662,17 +667,14 @@ class _MatrixPlan:
                 # per-point coefficient tensors built on the device from U = (value, gradient) of the bound field (scalar fields)
                 nq, S = smp.points.npoints, 1 + smp.ndims
                 U = _field_values(smp, itg.qform[1], itg.geom if itg.geom is not None else itg.measure, arguments)
-                Bd = device.to_dev(numpy.ascontiguousarray(itg.B[0, :, 0, :]) * fac, 'float64')  # [S][S]
-                cq = device.zeros(smp.nlist * nq * S * S, 'float64').reshape(smp.nlist * nq, S, S)
+                Bq = numpy.ascontiguousarray(itg.B[0, :, 0, :]) * fac  # [S][S]
+                sq = None if scale is None else scale.reshape(-1)
                 if itg.qform[0] == 'trial':   # C_q[a][0] = sum_b B[a][b] U[b]
-                    cq[:, :, 0] = U @ Bd.T
+                    cq = kernels.point_forms(1, U, Bq, scale=sq)
                 else:                         # 'test': C_q[a][b] = L[a] sum_x B[x][b] U[x]
-                    Ld = device.to_dev(numpy.ascontiguousarray(itg.qform[2][0]), 'float64')
-                    cq[:, :, :] = Ld.reshape(1, S, 1) * (U @ Bd).reshape(-1, 1, S)
-                if scale is not None:
-                    cq = cq * scale.reshape(-1, 1, 1)
+                    cq = kernels.point_forms(2, U, Bq, L=itg.qform[2][0], scale=sq)
                 common_q = dict(common, C=numpy.ones((nct, S, ncr, S)))
-                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, cq=cq.reshape(-1), **common_q)
+                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, cq=cq, **common_q)
                 continue
             if (itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16 and not self._rows_pass(smp, itg)
                     and not os.environ.get('NUTILS_AMD_NO_COLORS')):  # (small local matrices: 8 coloured launches measured slower than atomics, 4.7 vs 4.0 ms)
@@ -922,7 +924,8 @@ def evaluate_blocks(fs, arguments, flat=False):
 
 def start_blocks(fs, arguments, flat=False):
     '''`evaluate_blocks` in two halves: enqueues the device work and the copy to page-locked host memory on the current stream and returns
-    finish() -> result, which waits for that stream.  (A Newton step runs the residual on its own stream beside the Jacobian kernels.)'''
+    finish() -> result, which waits for that stream.  (All assembly launches of a Newton step share ONE stream -- the library's scratch
+    buffers are not per stream, include/nutils_hip.h --; only the copy of the Jacobian entries to the host runs beside them.)'''
     t = device.torch()
     tests = [_exposed_test(f) if isinstance(f, function.Integral) and f.terms else None for f in fs]
     sizes = [a0.basis.ndofs * a0.ncomp if a0 is not None else 0 for a0 in tests]

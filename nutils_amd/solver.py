@@ -25,8 +25,10 @@ class _HostMirror:
     '''The CSR value array of the (merged, possibly reduced) Jacobian in page-locked host memory, kept up to date in place: the first
     assembly copies everything, a later one lets the device write only the entries of the field-dependent blocks (compact array `dyn`,
     entries `sel` of it go to positions `out`) through the mapping of the pinned pages (nh_index_copy) -- for Cahn-Hilliard a quarter
-    of the 0.2 GB.  Two buffers alternate, so the matrix of a step stays valid while the next one is assembled, but not longer: the
-    reference hands out fresh arrays (evaluable.py:6813-6815), a caller that keeps older Jacobians has to copy them.'''
+    of the 0.2 GB.  Two buffers alternate, so the matrix of a step stays valid while the next one is assembled, but not longer.  That
+    is the contract of the INTERNAL path only (`System._start_jacobian`, used by `solve`, which consumes each Jacobian inside its own
+    iteration): the public `assemble_jacobian*` methods hand out value arrays of their own (`copy=True`), like the reference
+    (evaluable.py:6813-6815: fresh arrays per evaluation).'''
 
     def __init__(self, values_dev, sel, out, copies=2):
         from . import device
@@ -54,11 +56,19 @@ class _HostMirror:
         self.side.wait_stream(t.cuda.current_stream())
         with t.cuda.stream(self.side):
             kernels.index_copy(dyn, buf, src_index=self.sel, dst_index=self.out)
+        # `dyn` comes from the caching allocator of the launch stream: tell it that the side stream reads the block, so that it is
+        # not handed out again (and overwritten) before the copy has run, whether or not finish() is ever called
+        dyn.record_stream(self.side)
 
-        def finish(dyn=dyn):  # (holds `dyn` until the side stream is through with it)
+        def finish():
             self.side.synchronize()
             return buf.numpy()
         return finish
+
+    def drain(self):
+        '''Wait for a copy in flight (error paths: the pinned buffer must not be written behind the caller's back).'''
+        if self.side is not None:
+            self.side.synchronize()
 
 
 class System:
@@ -155,32 +165,48 @@ class System:
             kernels.index_copy(self._dyn_values(arguments), merged, dst_index=self._dynpos_dev)
         return merged
 
-    def assemble_jacobian(self, arguments):
-        return self._start_jacobian(arguments, None)()
+    def assemble_jacobian(self, arguments, copy=True):
+        '''The merged block Jacobian as a Matrix.  `copy=True` (default): the matrix owns its value array, like every evaluation of the
+        reference (fresh arrays, evaluable.py:6813-6815) -- Jacobians of different iterates can be kept side by side.  `copy=False`: the
+        matrix wraps the page-locked array the device writes into; it is overwritten by the assembly after the next one (two arrays
+        alternate), which is all a Newton driver needs and saves a host copy of the values (C4: 0.2 GB).'''
+        return self._finish_jacobian(self._start_jacobian(arguments, None), copy)
 
-    def assemble_jacobian_free(self, arguments, free):
+    def assemble_jacobian_free(self, arguments, free, copy=True):
         '''jac.submatrix(free, free) of the reference (solver.py:332,386) WITHOUT the host-side slicing: the positions of the free-free
         entries in the merged value array and the reduced (rowptr, colidx) are computed once per constraint set; a Newton step is the
-        device assembly of the field-dependent blocks + the copy of THEIR free-free entries into the host value array.'''
-        return self._start_jacobian(arguments, free)()
+        device assembly of the field-dependent blocks + the copy of THEIR free-free entries into the host value array.
+        `copy`: see assemble_jacobian.'''
+        return self._finish_jacobian(self._start_jacobian(arguments, free), copy)
+
+    def _finish_jacobian(self, finish, copy):
+        return finish(copy and not self.is_constant_matrix)  # (a constant matrix is assembled once and never written again)
+
+    def _drain(self):
+        '''Error path of a Newton step: no device copy may still be writing into a host array when the exception reaches the caller.'''
+        for m in (self._mirror, (getattr(self, '_free_plan', None) or {}).get('mirror')):
+            if m is not None:
+                m.drain()
 
     def _start_jacobian(self, arguments, free):
         '''Launches the device work of a (reduced, if `free` is given) Jacobian and returns finish() -> Matrix.  Between the two calls the
         changed entries travel to the host on a side stream; `assemble_jacobian_residual` puts the residual of the step there.'''
         from . import device, kernels
         if free is None and self._jac is not None and self.is_constant_matrix:
-            return lambda: self._jac
+            return lambda copy=False: self._jac
         if not hasattr(self, '_groups'):
             self._build_merge_plan(arguments)
         if free is None:
             if self._mirror is None:
                 self._mirror = _HostMirror(self._merged_values(arguments), None, self._dynpos_dev, 1 if self.is_constant_matrix else 2)
-                jac = _matrix.assemble_csr(self._mirror.first(), self._merged_rowptr, self._merged_colidx, self.size)
+                first = self._mirror.first()
+                jac = _matrix.assemble_csr(first, self._merged_rowptr, self._merged_colidx, self.size)  # (validates the index pair once)
                 if self.is_constant_matrix:
                     self._jac = jac
-                return lambda: jac
+                    return lambda copy=False: jac
+                return lambda copy=False: _matrix.reassemble_csr(numpy.array(first), self._merged_rowptr, self._merged_colidx, self.size) if copy else jac
             pending = self._mirror.publish(self._dyn_values(arguments))
-            return lambda: _matrix.reassemble_csr(pending(), self._merged_rowptr, self._merged_colidx, self.size)
+            return lambda copy=False: _matrix.reassemble_csr(numpy.array(pending()) if copy else pending(), self._merged_rowptr, self._merged_colidx, self.size)
         key = free.tobytes()
         plan = getattr(self, '_free_plan', None)
         if plan is None or plan['key'] != key:
@@ -197,17 +223,19 @@ class System:
             plan = self._free_plan = dict(key=key, keep=device.to_dev(keep, 'int64'), rowptr=frp, colidx=newcol[ci[keep]], n=int(free.sum()), matrix=None,
                                           sel=device.to_dev(sel, 'int64'), out=device.to_dev(newpos[self._dynpos[sel]], 'int64'), mirror=None)
         if plan['matrix'] is not None and self.is_constant_matrix:
-            return lambda: plan['matrix']
+            return lambda copy=False: plan['matrix']
         if plan['mirror'] is None:
             values = device.empty(len(plan['colidx']), 'float64')
             kernels.index_copy(self._merged_values(arguments), values, src_index=plan['keep'])
             plan['mirror'] = _HostMirror(values, plan['sel'], plan['out'], 1 if self.is_constant_matrix else 2)
-            jac = _matrix.assemble_csr(plan['mirror'].first(), plan['rowptr'], plan['colidx'], plan['n'])
+            first = plan['mirror'].first()
+            jac = _matrix.assemble_csr(first, plan['rowptr'], plan['colidx'], plan['n'])
             if self.is_constant_matrix:
                 plan['matrix'] = jac
-            return lambda: jac
+                return lambda copy=False: jac
+            return lambda copy=False: _matrix.reassemble_csr(numpy.array(first), plan['rowptr'], plan['colidx'], plan['n']) if copy else jac
         pending = plan['mirror'].publish(self._dyn_values(arguments))
-        return lambda: _matrix.reassemble_csr(pending(), plan['rowptr'], plan['colidx'], plan['n'])
+        return lambda copy=False: _matrix.reassemble_csr(numpy.array(pending()) if copy else pending(), plan['rowptr'], plan['colidx'], plan['n'])
 
     def assemble_residual(self, arguments):
         return self._start_residual(arguments)()
@@ -236,24 +264,28 @@ class System:
         res = numpy.concatenate(parts)
         return lambda: res
 
-    def assemble_jacobian_residual(self, arguments, free=None):
+    def assemble_jacobian_residual(self, arguments, free=None, copy=True):
         '''Jacobian (reduced to the free dofs if `free` is given) and residual of one Newton step, as the reference evaluates them: in one go
-        (solver.py:358-387; its Newton drivers call nothing else, :633,659,751-760).'''
+        (solver.py:358-387; its Newton drivers call nothing else, :633,659,751-760).  `copy`: see assemble_jacobian (`solve` passes False).'''
         with _sample.upload_scope():  # (every field is copied to the device once, before the Jacobian entries start to travel the other way)
             _sample.prefetch_arguments(self.block_residual, arguments)
             # Jacobian kernels, then -- while the changed entries are written to the host by a side stream -- the residual.  (Measured alternatives,
             # profiles/r02_c4.md: the residual on a third stream beside the Jacobian kernels gains nothing, both fill the register files; kernels
             # next to the host-bound stores run at half speed, the stores back up the write queues of the L2 channels -- still the best order.)
             finish = self._start_jacobian(arguments, free)
-            res = self.assemble_residual(arguments)
-        return finish(), res
+            try:
+                res = self.assemble_residual(arguments)
+            except BaseException:
+                self._drain()
+                raise
+        return self._finish_jacobian(finish, copy), res
 
     def assemble_value(self, arguments):
         if not self.is_symmetric:
             raise Exception('value is not defined')
         return function.eval(self.value, arguments)
 
-    def assemble_jacobian_residual_value(self, arguments, free=None):
+    def assemble_jacobian_residual_value(self, arguments, free=None, copy=True):
         '''Jacobian, residual and value of the functional in one call (solver.py:389-425): the functional goes through the same upload
         scope as the other two, its launches run beside the copy of the Jacobian entries.'''
         if not self.is_symmetric:
@@ -261,15 +293,19 @@ class System:
         with _sample.upload_scope():
             _sample.prefetch_arguments(self.block_residual, arguments)
             finish = self._start_jacobian(arguments, free)
-            res = self.assemble_residual(arguments)
-            val = function.eval(self.value, arguments)
-        return finish(), res, val
+            try:
+                res = self.assemble_residual(arguments)
+                val = function.eval(self.value, arguments)
+            except BaseException:
+                self._drain()
+                raise
+        return self._finish_jacobian(finish, copy), res, val
 
-    def assemble(self, arguments, free=None):
+    def assemble(self, arguments, free=None, copy=True):
         '''(jacobian, residual, value or None), solver.py:427-431'''
         if self.is_symmetric:
-            return self.assemble_jacobian_residual_value(arguments, free)
-        return (*self.assemble_jacobian_residual(arguments, free), None)
+            return self.assemble_jacobian_residual_value(arguments, free, copy)
+        return (*self.assemble_jacobian_residual(arguments, free, copy), None)
 
     # -- argument packing (solver.py:273-315) --
 
@@ -309,7 +345,7 @@ class System:
             if self.is_linear:
                 res, jac = self.assemble_residual(args), None
             else:  # residual and Jacobian of the iterate in one go, like the reference (the last Jacobian is not used)
-                jac, res = self.assemble_jacobian_residual(args, sub)
+                jac, res = self.assemble_jacobian_residual(args, sub, copy=False)  # (consumed before the next assembly)
             resnorm = numpy.linalg.norm(res[free])
             if it and (self.is_linear or resnorm <= tol):
                 break
@@ -318,7 +354,7 @@ class System:
             if it == maxiter:
                 raise SolverError(f'failed to converge in {maxiter} iterations (residual norm {resnorm:.1e})')
             if jac is None:
-                jac = self._start_jacobian(args, sub)()
+                jac = self._start_jacobian(args, sub)()  # (zero-copy: used before the next assembly)
             if sub is None:
                 x = x - jac.solve(res)
             else:

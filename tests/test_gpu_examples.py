@@ -82,8 +82,8 @@ def test_cahnhilliard_residual_jacobian(golden):
     g = golden('cahnhilliard_p2_4')
     domain, nrg = cahnhilliard(g)
     args = {'φ': g['arg_φ'], 'φ0': g['arg_φ0'], 'η': g['arg_η']}
-    tol = lambda ref: 1e-12 * numpy.abs(ref).max()
-    assert abs(function.eval(nrg, args) - float(g['energy'])) < 1e-12 * abs(float(g['energy']))
+    tol = lambda ref: 1e-13 * numpy.abs(ref).max()
+    assert abs(function.eval(nrg, args) - float(g['energy'])) < 1e-13 * abs(float(g['energy']))
     system = System(nrg, trial='φ,η')
     assert not system.is_linear
     res = system.assemble_residual(args)
@@ -127,9 +127,9 @@ def test_nurbs_plate_with_hole(golden):
     res = smp.integral(function.inner(function.grad(v, geom), sigma) * function.J(geom))
     values, rowptr, colidx = function.eval(function.as_csr(function.derivative(function.derivative(res, 'v'), 'u')))
     assert numpy.array_equal(rowptr, g['K_rowptr']) and numpy.array_equal(colidx, g['K_colidx'])
-    assert numpy.abs(values - g['K_values']).max() < 1e-12 * numpy.abs(g['K_values']).max()
+    assert numpy.abs(values - g['K_values']).max() < 1e-13 * numpy.abs(g['K_values']).max()
     r = function.eval(function.derivative(res, 'v'), u=g['u'])
-    assert numpy.abs(r - g['res']).max() < 1e-12 * numpy.abs(g['res']).max()
+    assert numpy.abs(r - g['res']).max() < 1e-13 * numpy.abs(g['res']).max()
     assert abs(smp.integrate(function.J(geom)) - float(g['area'])) < 1e-13
     # same-level NURBS (W = sum_j w_j B_j evaluated by the kernel): partition of unity and zero gradient sum
     nurbs2 = _basis.RationalBasis(bspline, g['weights'])
@@ -163,9 +163,9 @@ def test_iga_plate_p3_ten_levels_one_workload(golden):
     res = smp.integral(function.inner(function.grad(v, geom), sigma) * function.J(geom))
     values, rowptr, colidx = function.eval(function.as_csr(function.derivative(function.derivative(res, 'v'), 'u')))
     assert numpy.array_equal(rowptr, g['K_rowptr']) and numpy.array_equal(colidx, g['K_colidx'])
-    assert numpy.abs(values - g['K_values']).max() < 1e-11 * numpy.abs(g['K_values']).max()
+    assert numpy.abs(values - g['K_values']).max() < 1e-13 * numpy.abs(g['K_values']).max()
     r = function.eval(function.derivative(res, 'v'), u=g['u'])
-    assert numpy.abs(r - g['res']).max() < 1e-11 * numpy.abs(g['res']).max()
+    assert numpy.abs(r - g['res']).max() < 1e-13 * numpy.abs(g['res']).max()
     assert abs(smp.integrate(function.J(geom)) - float(g['area'])) < 1e-13
 
 

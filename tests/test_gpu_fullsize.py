@@ -45,9 +45,10 @@ def test_c2_full_size(variant):
 def test_c3_full_size_rigid_body_modes():
     '''64^3 P2 vector elasticity (6 440 067 dofs, 1.2e9 nonzeros) on the perturbed (isoparametric) mesh: the stiffness matrix
     annihilates the six rigid body modes -- translations and (for the interpolated P2 coordinates) rotations --, is symmetric,
-    and obeys the nnz bound 9 (8 n + 1)^3 of SURVEY 8a; values come from the MFMA kernel with the colour-wise scatter.'''
+    and obeys the nnz bound 9 (8 n + 1)^3 of SURVEY 8a; the values come from the write-once kernel nh_p2hex_matrix (asserted: the front end
+    must not fall back to the generic nh_assemble_matrix for this form).'''
     import torch
-    from nutils_amd import mesh, function, sample, device
+    from nutils_amd import mesh, function, sample, device, _lib
     n = 64
     domain, geom = mesh.rectilinear([n] * 3)
     gb = domain.basis('std', degree=1)
@@ -61,7 +62,9 @@ def test_c3_full_size_rigid_body_modes():
     sigma = lam * function.div(u, geom) * function.eye(3) + 2 * mu * eps(u)
     res = domain.integral(function.inner(eps(v), sigma) * function.J(geom), degree=4)
     jac = function.derivative(function.derivative(res, 'v'), 'u')
-    values, rowptr, colidx, ncols = sample._MatrixPlan(jac.terms).run()
+    with _lib.trace() as calls:
+        values, rowptr, colidx, ncols = sample._MatrixPlan(jac.terms).run()
+    assert 'nh_p2hex_matrix' in calls and 'nh_assemble_matrix' not in calls and 'nh_assemble_matrix_terms' not in calls, calls
     ndofs = 3 * (2 * n + 1) ** 3
     assert ncols == ndofs == len(rowptr) - 1
     assert values.numel() == int(rowptr[-1]) <= 9 * (8 * n + 1) ** 3

@@ -32,12 +32,12 @@ for it in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = system.assemble_residual(args)
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    jac = system.assemble_jacobian(args)
+    jac = system.assemble_jacobian(args, copy=False)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f'n={n} {btype} p=2 nelems={n*n} ndofs/field={nd} nnz={jac.core.nnz}: residual {1e3*(t1-t0):.1f} ms, jacobian (4 blocks, D2H + host block merge) {1e3*(t2-t1):.1f} ms')
 for it in range(3):  # the Newton step as the reference evaluates it (solver.py:358-387): Jacobian and residual in one call
     args['φ'] = rng.normal(0, .5, nd)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    jac, res = system.assemble_jacobian_residual(args)
+    jac, res = system.assemble_jacobian_residual(args, copy=False)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     print(f'  assemble_jacobian_residual (residual beside the PCIe copy of the changed Jacobian entries): {1e3*(t1-t0):.1f} ms')
