@@ -14,9 +14,12 @@ regions of BASELINE.md 3 are reported next to it: `first_assembly_ms` (pattern +
 and `reassembly_host_ready_ms` (values only); the CPU leg times pattern + values on the host, so
 `speedup_vs_cpu_port.first_assembly_host_ready` is the like-for-like ratio.
 
-With --gpus N: `--scaling weak` (default) every rank assembles its own n^3-element slab of an (n N) x n x n mesh;
-`--scaling strong` the ONE n^3 mesh is split into N slabs of n/N element layers.  The shared dof plane
-between neighbouring slabs is reduced over RCCL (point to point, interface rows only).
+With --gpus N (default `--scaling strong`, SURVEY.md 8e / BASELINE.json north_star: "elements are partitioned across the
+GPUs of one node"): the ONE n^3 mesh is split into N slabs of n/N element layers; the line also carries the weak-scaling
+figure of the same launch (`weak`: every rank assembles its own n^3-element slab of an (n N) x n x n mesh).  `--scaling weak`
+makes the weak figure the headline instead.  The shared dof plane between neighbouring slabs is reduced over RCCL (point to
+point, interface rows only).  At N = 1 the default line also carries `variants.c3` (BASELINE.json configs[2], measured in the
+same run: kernel time by HIP events, HBM fraction, CPU port).
 
 Prints ONE JSON line on rank 0.
 '''
@@ -40,13 +43,14 @@ def parse():
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--config', choices=['c2', 'c3'], default='c2', help='c2: 128^3 P1 Poisson (headline); c3: 64^3 P2 vector elasticity')
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default=None, help='default: strong (one mesh split over the GPUs) when the element layers divide evenly, else weak')
     ap.add_argument('--settle', type=int, default=None, help='untimed steps before the warm-up: the first ~50 launches after idle run ~10 %% slower (clock ramp)')
     ap.add_argument('--n', '--elements-per-axis', dest='n', type=int, default=None,
                     help='elements per axis (per GPU with weak scaling; use the long form behind torch.distributed.run, whose parser claims --n)')
     ap.add_argument('--variant', choices=['iso', 'uniform'], default='iso')
     ap.add_argument('--kernel', choices=['auto', 'generic', 'gather', 'batched', 'fast'], default='auto')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--no-c3', action='store_true', help='skip the configs[2] variant of the default line')
     ap.add_argument('--no-graph', dest='graph', action='store_false', help='launch every step eagerly instead of replaying a captured HIP graph')
     a = ap.parse_args()
     c3 = a.config == 'c3'
@@ -54,6 +58,8 @@ def parse():
     a.steps = a.steps if a.steps is not None else (30 if c3 else 200)
     a.warmup = a.warmup if a.warmup is not None else (3 if c3 else 20)
     a.settle = a.settle if a.settle is not None else (10 if c3 else 300)
+    if a.scaling is None:
+        a.scaling = 'strong' if a.n % max(a.gpus, 1) == 0 else 'weak'
     return a
 
 
@@ -238,6 +244,59 @@ def fail(msg, rank, world, dist, metric):
     sys.exit(1)
 
 
+def make_workload(a, config, scaling, rank, world):
+    from nutils_amd import workloads
+    n = a.n if config == a.config else (64 if config == 'c3' else 128)
+    strong = scaling == 'strong' and world > 1
+    if strong and n % world:
+        raise SystemExit(f'--scaling strong: {n} element layers do not split into {world} slabs')
+    layers = n // world if strong else n
+    if config == 'c3':
+        return lambda r=rank, w=world: workloads.ElasticityP2(n=n, layers=layers if w > 1 else n, rank=r, world=w, variant=a.variant)
+    return lambda r=rank, w=world: workloads.PoissonSlab(n=n, layers=layers if w > 1 else n, rank=r, world=w, variant=a.variant, kernel=a.kernel)
+
+
+def settle_and_time(wl, steps, warmup, settle, world, dist, use_graph):
+    """Untimed settle steps (idle power state -> steady clocks), W warm-up steps, then EXACTLY `steps` timed steps."""
+    import torch
+    for _ in range(settle):
+        wl.step()
+    torch.cuda.synchronize()
+    settle_extra = 0
+    if world == 1 and settle:
+        # keep settling while batches of steps still get faster (a box that has idled for long ramps its clocks over more than the fixed
+        # number of steps: one bench run of round 2 read 0.193 ms where three runs on the next box read 0.168): at most 2 s
+        prev, t_end = None, time.perf_counter() + 2.
+        while time.perf_counter() < t_end:
+            t1 = time.perf_counter()
+            for _ in range(max(20, settle // 2)):
+                wl.step()
+            settle_extra += max(20, settle // 2)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            if prev is not None and dt > .99 * prev:
+                break
+            prev = dt
+    for _ in range(warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    elapsed, kernel_ms, launch = timed_steps(wl, steps, world, dist, use_graph)
+    return elapsed, kernel_ms, launch, settle + settle_extra
+
+
+def c3_roofline(wl, kernel_ms, traffic):
+    """configs[2]: the kernel writes 37 kB of CSR values per element once -- it is priced against the HBM peak (the write stream is its floor:
+    9.7 GB / ~6 TB/s); the matrix-pipe share rides along."""
+    bpe = wl.algorithmic_bytes_per_element()
+    gbs = bpe * wl.nelems / (kernel_ms * 1e-3) / 1e9
+    tf = wl.algorithmic_flops_per_element() * wl.nelems / (kernel_ms * 1e-3) / 1e12
+    return {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': traffic,
+            'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bpe,
+            'mfma': {'achieved': tf, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / F64_MFMA_PEAK_TF,
+                     'algorithmic_flops_per_element': wl.algorithmic_flops_per_element(), 'mfma_instructions_per_element': wl.mfma_per_element(),
+                     'matrix_pipe_busy': wl.mfma_per_element() * wl.nelems * 64 / 1024 / (kernel_ms * 1e-3 * 2.4e9)}}
+
+
 def main():
     a = parse()
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: required by RCCL / cross-process device memory on this driver
@@ -263,13 +322,7 @@ def main():
     metric = 'elements assembled/sec (global stiffness K)'
     from nutils_amd import workloads
     strong = a.scaling == 'strong' and world > 1
-    if strong and a.n % world:
-        raise SystemExit(f'--scaling strong: {a.n} element layers do not split into {world} slabs')
-    layers = a.n // world if strong else a.n
-    if a.config == 'c3':
-        make = lambda r=rank, w=world: workloads.ElasticityP2(n=a.n, layers=layers, rank=r, world=w, variant=a.variant)
-    else:
-        make = lambda r=rank, w=world: workloads.PoissonSlab(n=a.n, layers=layers, rank=r, world=w, variant=a.variant, kernel=a.kernel)
+    make = make_workload(a, a.config, a.scaling, rank, world)
     wl = make()
     t0 = time.perf_counter()
     wl.setup()
@@ -279,29 +332,7 @@ def main():
     wl.build_pattern()
     torch.cuda.synchronize()
     pattern_ms = (time.perf_counter() - t0) * 1e3
-
-    for _ in range(a.settle):  # settle: bring the GPU out of its idle power state (untimed, before the W warm-up steps of the contract)
-        wl.step()
-    torch.cuda.synchronize()
-    if world == 1 and a.settle:
-        # ... and keep settling while batches of steps still get faster (a box that has idled for long ramps its clocks over more than
-        # the fixed number of steps: one bench run of this round read 0.193 ms where three runs on the next box read 0.168): at most 2 s
-        prev, t_end = None, time.perf_counter() + 2.
-        settle_extra = 0
-        while time.perf_counter() < t_end:
-            t1 = time.perf_counter()
-            for _ in range(max(20, a.settle // 2)):
-                wl.step()
-            settle_extra += max(20, a.settle // 2)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            if prev is not None and dt > .99 * prev:
-                break
-            prev = dt
-    for _ in range(a.warmup):
-        wl.step()
-    torch.cuda.synchronize()
-    elapsed, kernel_ms, launch = timed_steps(wl, a.steps, world, dist, a.graph)
+    elapsed, kernel_ms, launch, settled = settle_and_time(wl, a.steps, a.warmup, a.settle, world, dist, a.graph)
 
     # size-independent check of the assembled matrix on every rank (rows it owns are complete after the interface reduce)
     wl.finish()
@@ -310,27 +341,45 @@ def main():
     if bad:
         fail(', '.join(f'{k} = {checks[k]:.3e}' for k in bad) + ': the assembled matrix is wrong', rank, world, dist, metric)
 
+    other = None
+    if world > 1:
+        # the other scaling mode of the same launch (secondary figure; fewer settle steps -- the clocks are up)
+        mode2 = 'weak' if strong else 'strong'
+        n = a.n
+        if not (mode2 == 'strong' and n % world):
+            nelems1, layers1, nnz1 = wl.nelems, wl.layers, wl.nnz
+            del wl
+            torch.cuda.empty_cache()
+            w2 = make_workload(a, a.config, mode2, rank, world)()
+            w2.setup()
+            w2.build_pattern()
+            el2, kms2, _, _ = settle_and_time(w2, a.steps, a.warmup, min(a.settle, 50), world, dist, a.graph)
+            w2.finish()
+            c2 = w2.check(world, dist)
+            if not all(v < 1e-10 for v in c2.values()):
+                fail(f'{mode2} scaling: the assembled matrix is wrong ({c2})', rank, world, dist, metric)
+            other = {'scaling': mode2, 'value': w2.nelems * world * a.steps / el2, 'unit': 'elements/s', 'ms_per_step': el2 / a.steps * 1e3, 'kernel_ms': kms2,
+                     'nelems_per_gpu': w2.nelems, 'checks': c2}
+            wl = w2  # (only sizes of the primary run are reported below)
+            wl_nelems, wl_layers, nnz = nelems1, layers1, nnz1
+        else:
+            wl_nelems, wl_layers, nnz = wl.nelems, wl.layers, wl.nnz
+    else:
+        wl_nelems, wl_layers, nnz = wl.nelems, wl.layers, wl.nnz
+
     if rank == 0:
-        nelems_total = wl.nelems * world
+        nelems_total = wl_nelems * world
         value = nelems_total * a.steps / elapsed
         bytes_per_elem = wl.algorithmic_bytes_per_element()
-        gbs = bytes_per_elem * wl.nelems / (kernel_ms * 1e-3) / 1e9
+        gbs = bytes_per_elem * wl_nelems / (kernel_ms * 1e-3) / 1e9
         traffic = measured_traffic(wl.kernel_name, a.n) if world == 1 else None
         if a.config == 'c3':
-            flops = wl.algorithmic_flops_per_element() * wl.nelems
-            tf = flops / (kernel_ms * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'achieved': tf, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / F64_MFMA_PEAK_TF, 'traffic': traffic,
-                        'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_flops_per_element': wl.algorithmic_flops_per_element(),
-                        'mfma_instructions_per_element': wl.mfma_per_element(),
-                        'matrix_pipe_busy': wl.mfma_per_element() * wl.nelems * 64 / 1024 / (kernel_ms * 1e-3 * 2.4e9),
-                        'hbm': {'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes_per_element': bytes_per_elem},
-                        'note': 'Gram-matrix formulation: the quadrature sum needs 336 v_mfma_f64_16x16x4 per element (756 in round 1); matrix_pipe_busy = their 64 cycles '
-                                'each over the kernel time at 2.4 GHz; neither the matrix pipe nor HBM bounds this kernel yet (DESIGN.md 5b)'}
+            roofline = c3_roofline(wl, kernel_ms, traffic)
             workload = f'3D linear elasticity stiffness, {a.n}^3 structured hex, p=2 vector basis (81 local dofs), 3x3x3 Gauss, {a.variant} geometry (BASELINE.json configs[2])'
         else:
             roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': traffic,
                         'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bytes_per_elem}
-            per = f'{layers} x {a.n} x {a.n} per GPU' if world > 1 else f'{a.n}^3'
+            per = f'{wl_layers} x {a.n} x {a.n} per GPU' if world > 1 else f'{a.n}^3'
             workload = f'3D Poisson stiffness, {per} structured hex, p=1, 2x2x2 Gauss, {a.variant} geometry (BASELINE.json configs[1])'
         if traffic is not None:
             roofline['traffic_source'] = TRAFFIC_FILE + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, separate passes; not measured in this run)'
@@ -338,11 +387,13 @@ def main():
             'metric': metric, 'value': value, 'unit': 'elements/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': workload, 'nelems_per_gpu': wl.nelems, 'nnz_per_gpu': wl.nnz, 'kernel': wl.kernel_name,
+            'config': {'workload': workload, 'nelems_per_gpu': wl_nelems, 'nnz_per_gpu': nnz, 'kernel': wl.kernel_name,
                        'parallelism': f'element slabs x{world}, halo-plane reduce' if world > 1 else 'single GPU', 'launch': launch,
-                       'settle_steps': a.settle + (settle_extra if world == 1 and a.settle else 0), 'timed_region': 'device-resident re-assembly of the CSR values (pattern, tables, vertices in HBM)'},
+                       'settle_steps': settled, 'timed_region': 'device-resident re-assembly of the CSR values (pattern, tables, vertices in HBM)'},
             'roofline': roofline, 'pattern_ms': pattern_ms, 'setup_s': setup_s, 'checks': checks,
         }
+        if other is not None:
+            out[other['scaling']] = other
         if world == 1:
             del wl
             torch.cuda.empty_cache()
@@ -376,10 +427,33 @@ def main():
                 torch.cuda.synchronize()
                 nst = max(10, a.steps // 4)
                 el3, kms3, _ = timed_steps(w3, nst, 1, None, False)
+                b3 = w3.algorithmic_bytes_per_element()
                 out['variants']['generic_gather'] = {'value': w3.nelems * nst / el3, 'unit': 'elements/s', 'ms_per_step': el3 / nst * 1e3, 'kernel': w3.kernel_name,
-                                                     'kernel_ms': kms3, 'note': 'nh_assemble_matrix with NH_MATRIX_GATHER | NH_MATRIX_STORE; bit-reproducible'}
+                                                     'kernel_ms': kms3, 'hbm_frac': b3 * w3.nelems / (kms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                     'algorithmic_bytes_per_element': b3,
+                                                     'note': 'nh_assemble_matrix with NH_MATRIX_GATHER | NH_MATRIX_STORE; bit-reproducible'}
                 del w3
                 torch.cuda.empty_cache()
+            if not a.no_c3 and a.n == 128:
+                # BASELINE.json configs[2] in the same run: 64^3 P2 vector elasticity through nh_p2hex_matrix (its own line: --config c3)
+                w4 = workloads.ElasticityP2(n=64, rank=0, world=1, variant='iso')
+                w4.setup()
+                w4.build_pattern()
+                el4, kms4, _, _ = settle_and_time(w4, 10, 3, 10, 1, None, False)
+                c4 = w4.check(1, None)
+                v4 = {'value': w4.nelems * 10 / el4, 'unit': 'elements/s', 'steps': 10, 'ms_per_step': el4 / 10 * 1e3, 'kernel': w4.kernel_name,
+                      'workload': '3D linear elasticity stiffness, 64^3 structured hex, p=2 vector basis, 3x3x3 Gauss, iso geometry (BASELINE.json configs[2])',
+                      'roofline': c3_roofline(w4, kms4, measured_traffic(w4.kernel_name, 64)), 'checks': c4}
+                if not all(x < 1e-10 for x in c4.values()):
+                    v4['error'] = 'correctness gate failed'
+                del w4
+                torch.cuda.empty_cache()
+                if not a.no_cpu:
+                    cb3 = cpu_baseline_c3(workloads.ElasticityP2(n=64, rank=0, world=1, variant='iso'))
+                    if cb3:
+                        v4['cpu_baseline'] = cb3
+                        v4['speedup_vs_cpu_port'] = v4['value'] / cb3['value']
+                out['variants']['c3'] = v4
         if not a.no_cpu and world == 1:
             cb = cpu_baseline_c3(make(0, 1)) if a.config == 'c3' else cpu_baseline_c2(a.variant)
             if cb:

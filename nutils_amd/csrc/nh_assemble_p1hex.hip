@@ -803,9 +803,14 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
   static const int wbnd_env = getenv("NH_P1HEX_WBND") ? std::min(64, std::max(8, atoi(getenv("NH_P1HEX_WBND")))) : 20;
   p.wbnd = wbnd_env;
   constexpr int TJ = 16, TK = 16, L = 2, NTM = L * TJ * TK, NS = VEC ? 1 : 15, VW = VEC ? 4 : 3;
-  int dev = 0, cus = 256;
-  NH_CHECK_HIP(hipGetDevice(&dev));
-  NH_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // (per-step path of a Newton loop / of a multi-GPU slab whose kernel lasts ~20 us: device queries and the LDS attribute once per process)
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 256;
+    NH_CHECK_HIP(hipGetDevice(&dev));
+    NH_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = n;
+  }
   p.nbj = (p.n1 + 1 + TJ - 2) / (TJ - 1);
   p.nbk = (p.n2 + 1 + TK - 2) / (TK - 1);
   const size_t ldsm = sizeof(double) * ((L + 2) * (((TJ + 1) * (TK + 1) * NS + 1) & ~1) + (L + 1) * (TJ + 1) * (TK + 1) * VW + 2);
@@ -821,7 +826,11 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
     const bool march = env && atoi(env);
     if (!march) kern = k_p1hex_skew<TJ, TK, MASS, COEF>;
   }
-  NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+  static const void *attr_set[2] = {nullptr, nullptr};  // (this instantiation: the marching and the skewed kernel)
+  if (attr_set[0] != (const void *)kern && attr_set[1] != (const void *)kern) {
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+    attr_set[attr_set[0] ? 1 : 0] = (const void *)kern;
+  }
 #ifdef NH_ABLATION
   static long long *tdbg = nullptr;
   if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, (16 + 4 * 1024) * sizeof(long long)));

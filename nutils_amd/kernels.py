@@ -356,10 +356,13 @@ class P1HexLaplace:
                                  kwargs.get('scale', (1., 1., 1.)), kwargs.get('kappa', 1.), kwargs.get('layers'), kwargs.get('planes'), kwargs.get('unit_matrix'),
                                  kwargs.get('qscale'), kwargs.get('max_workgroups', 0), kwargs.get('mass', 0.), kwargs.get('qmass'))
         self._ref = ctypes.byref(self._args)
-        self._fn = getattr(_lib.load(), 'nh_p1hex_laplace')
+        self._name = 'nh_p1hex_laplace'
+        self._fn = getattr(_lib.load(), self._name)
 
     def __call__(self, values):
         self._args.values_dev = values.data_ptr()
+        if _lib.TRACE is not None:
+            _lib.TRACE.append(self._name)
         _lib.check(self._fn(self._ref, device.stream()))
 
 
@@ -415,10 +418,13 @@ class P2HexMatrix:
         self._keep = (weights, geom, T, C, scale)
         self._args = a
         self._ref = ctypes.byref(a)
-        self._fn = getattr(_lib.load(), 'nh_p2hex_matrix')
+        self._name = 'nh_p2hex_matrix'
+        self._fn = getattr(_lib.load(), self._name)
 
     def __call__(self, values):
         self._args.values_dev = values.data_ptr()
+        if _lib.TRACE is not None:
+            _lib.TRACE.append(self._name)
         _lib.check(self._fn(self._ref, device.stream()))
 
 

@@ -138,15 +138,19 @@ def test_bench_multiprocess_on_one_gpu(world):
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec['n_gpus'] == world and rec['steps'] == 4 and rec['scaling'] == 'weak'
-    assert rec['config']['nelems_per_gpu'] == 32 ** 3 and rec['value'] > 0
+    # default mode: the ONE mesh split into slabs when the layers divide evenly -- the line then also carries the weak figure
+    strong = 32 % world == 0
+    assert rec['n_gpus'] == world and rec['steps'] == 4 and rec['scaling'] == ('strong' if strong else 'weak')
+    assert rec['config']['nelems_per_gpu'] == (32 ** 3 // world if strong else 32 ** 3) and rec['value'] > 0
     assert rec['checks']['owned_row_sums_rel'] < 1e-12
+    if strong:
+        assert rec['weak']['nelems_per_gpu'] == 32 ** 3 and rec['weak']['value'] > 0 and rec['weak']['checks']['owned_row_sums_rel'] < 1e-12
     assert 'WARNING' not in out.stderr
 
 
-@pytest.mark.parametrize('args,nel', [(['--scaling', 'strong', '--elements-per-axis', '32'], 32 ** 3 // 2),
-                                      (['--config', 'c3', '--elements-per-axis', '8'], 8 ** 3),
-                                      (['--config', 'c3', '--scaling', 'strong', '--elements-per-axis', '8'], 8 ** 3 // 2)])
+@pytest.mark.parametrize('args,nel', [(['--scaling', 'weak', '--elements-per-axis', '32'], 32 ** 3),
+                                      (['--config', 'c3', '--scaling', 'weak', '--elements-per-axis', '8'], 8 ** 3),
+                                      (['--config', 'c3', '--elements-per-axis', '8'], 8 ** 3 // 2)])
 def test_bench_modes_multiprocess_on_one_gpu(args, nel):
     '''strong scaling (one mesh split into slabs) and the configs[2] workload, two ranks on the one GPU of this box'''
     import json, os, subprocess, sys
@@ -157,6 +161,7 @@ def test_bench_modes_multiprocess_on_one_gpu(args, nel):
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][0])
-    assert rec['n_gpus'] == 2 and rec['scaling'] == ('strong' if '--scaling' in args else 'weak')
+    assert rec['n_gpus'] == 2 and rec['scaling'] == ('weak' if '--scaling' in args else 'strong')
+    assert ('strong' if '--scaling' in args else 'weak') in rec  # the other mode rides along
     assert rec['config']['nelems_per_gpu'] == nel and rec['value'] > 0
     assert rec['checks']['owned_row_sums_rel'] < 1e-12
