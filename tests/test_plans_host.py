@@ -1,6 +1,7 @@
-'''Host check of the seam matcher's plans (tools/hip_plan.py): every plan extracted from the unmodified reference examples,
-restated with the numpy oracle, reproduces the reference's own result for the same integral (CSR index arrays bit-exact); and the form
-tensors the matcher read off the reference graph equal what nutils_amd's own front end derives for the same problem.'''
+'''Host check of the seam (nutils_amd/seam.py): every plan that the matcher wrote for arrays of the reference (tools/hip_plan.py: the unmodified
+examples/laplace.py and examples/elasticity.py, and Namespace scripts for BASELINE.json configs[1..4]), evaluated on the CPU by tests/af_oracle.py,
+reproduces the reference's own result stored beside it (CSR index arrays bit-exact, values to 1e-12); the plans describe structure where the
+reference objects have it (structured bases, rectilinear / isoparametric geometry), so that the executor reaches the structured kernels.'''
 import numpy
 import pytest
 
@@ -9,45 +10,50 @@ import plan_exec
 
 @pytest.mark.parametrize('name', plan_exec.names())
 def test_plan_reproduces_the_reference(name):
-    out, expect = plan_exec.run_oracle(name)
+    plan, out, expect = plan_exec.run_oracle(name)
     plan_exec.compare(out, expect, rtol=1e-12)
 
 
-def test_six_or_more_plans_cover_the_required_kinds():
+def test_plans_cover_the_baseline_configurations():
     names = plan_exec.names()
-    assert len(names) >= 6
-    kinds = {n: plan_exec.load(n) for n in names}
-    assert any(k[0] == 'matrix' and int(k[2][0]['test_ncomp']) == 1 for k in kinds.values())   # laplace
-    assert any(k[0] == 'matrix' and int(k[2][0]['test_ncomp']) == 2 for k in kinds.values())   # elasticity
-    assert any(k[0] == 'vector' and any(int(t['bnd_axis']) >= 0 and 'scale' in t for t in k[2]) for k in kinds.values())  # Neumann term with cos(1) cosh(x_1)
-    assert any(k[0] == 'vector' and any('trial_value' in t for t in k[2]) for k in kinds.values())  # residual at a given u
+    plans = {n: plan_exec.load(n)[0] for n in names}
+    for prefix in ('laplace_', 'elasticity_', 'c2_', 'c3_', 'c4_', 'c5_'):
+        assert any(n.startswith(prefix) for n in names), prefix
+    kinds = {p['kind'] for p in plans.values()}
+    assert kinds == {'matrix', 'vector', 'scalar'}
+    # configs[1]: the basis used as an array ('∇_i(basis_m) ∇_i(basis_n) dV' @ ns), 3-D, structural description throughout
+    for n in ('c2_uniform_8_matrix', 'c2_iso_8_matrix', 'c2_iso_12x9x10_matrix'):
+        p = plans[n]
+        assert [t['kind'] for t in p['topos']] == ['structured'] and len(p['topos'][0]['shape']) == 3
+        assert all(b['kind'] == 'structured' and b['btype'] == 'std' and b['degree'] == 1 for b in p['bases'])
+        assert [g['kind'] for g in p['geoms']] == (['rectilinear'] if 'uniform' in n else ['iso'])
+        assert p['args'][0]['name'] is None and p['terms'][0]['rows'] and p['terms'][0]['cols'] and not p['derivs']
+        assert len(p['samples'][0]['weights']) == 8 and p['samples'][0]['elist'] is None
+    # configs[2]: P2 vector field on isoparametric P1 hexahedra, Hessian of the energy
+    p = plans['c3_p2_4x3x5_matrix']
+    assert {(b['btype'], b['degree']) for b in p['bases']} == {('std', 1), ('std', 2)} and p['geoms'][0]['kind'] == 'iso' and p['derivs'] == ['u', 'u']
+    assert p['args'][0]['ncomp'] == 3 and numpy.shape(p['terms'][0]['B']) == (3, 4, 3, 4)
+    # configs[3]: polynomial coefficient functions of field values (the double-well potential), boundary terms on all four sides
+    p = plans['c4_jacobian_φφ']
+    assert any(t['fpoly'] is not None for t in p['terms']) and len({t['sample'] for t in p['terms']}) == 5
+    # configs[4]: ragged (hierarchical) basis with offsets, rational, tabulated NURBS geometry
+    p = plans['c5_nurbs_hier_p3_matrix']
+    kinds = [b['kind'] for b in p['bases']]
+    assert kinds == ['plain', 'rational'] and len(set(numpy.diff(p['bases'][0]['offsets']))) > 1 and p['geoms'][0]['kind'] == 'tab'
+    # the Neumann term of examples/laplace.py: a boundary sample with its coefficient function cos(1) cosh(x_1) tabulated at the points
+    p = plans['laplace_std1_residual']
+    assert any(s['bnd_axis'] >= 0 for s in p['samples']) and any(t['scale'] is not None for t in p['terms'])
 
 
-def test_form_tensors_equal_the_front_end():
-    '''the same integrands written for nutils_amd's front end (nutils_amd/function.py) give the same coefficient tensors'''
-    from nutils_amd import function as af
-
-    class B:  # a basis stand-in: the algebra only needs ndims / ndofs
-        ndims, ndofs = 2, 7
-
-    class G(af.Geometry):
-        ndims = 2
-
-        def __init__(self):
-            pass
-    geom = G()
-    u, v = af.field('u', B(), ()), af.field('v', B(), ())
-    itg = af._as_integrand((af.grad(v, geom) * af.grad(u, geom)).sum(-1) * af.J(geom))
-    kind, nd, terms, _ = plan_exec.load('laplace_std1_matrix')
-    assert numpy.array_equal(terms[0]['B'] * float(terms[0]['fac']), itg.B)
-    lam, mu = 1., .5 / .3 - 1  # examples/elasticity.py defaults: poisson = .3
-    u2 = af.field('u', B(), (2,))
-    eps = af.symgrad(u2, geom)
-    sigma = lam * af.div(u2, geom) * af.eye(2) + 2 * mu * eps
-    E = af._as_integrand(af.inner(eps, sigma) * af.J(geom)) if hasattr(af, 'inner') else None
-    kind, nd, terms, _ = plan_exec.load('elasticity_p1_matrix')
-    Bp = terms[0]['B'] * float(terms[0]['fac'])
-    if E is not None:
-        H = E.B + numpy.moveaxis(E.B, (0, 1, 2, 3), (2, 3, 0, 1))  # second derivative of the quadratic energy
-        assert numpy.allclose(Bp, H, atol=1e-15)
-    assert numpy.allclose(Bp, numpy.moveaxis(Bp, (0, 1, 2, 3), (2, 3, 0, 1)))  # symmetric form
+def test_plan_files_round_trip(tmp_path):
+    from nutils_amd import seam
+    plan, args, expect = plan_exec.load('c4_jacobian_φη')
+    plan.pop('_built', None)
+    seam.save(tmp_path / 'p.npz', plan, dict(expect, **{'arg_' + k: v for k, v in args.items()}))
+    again, expect2 = seam.load(tmp_path / 'p.npz')
+    assert again['derivs'] == plan['derivs'] and len(again['terms']) == len(plan['terms'])
+    for a, b in zip(again['terms'], plan['terms']):
+        for k in b:
+            assert numpy.array_equal(numpy.asarray(a[k], dtype=object if a[k] is None or isinstance(a[k], dict) else None), numpy.asarray(b[k], dtype=object if b[k] is None or isinstance(b[k], dict) else None)) \
+                if not isinstance(b[k], dict) else set(a[k]) == set(b[k])
+    assert numpy.array_equal(expect2['values'], expect['values'])

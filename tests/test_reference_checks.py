@@ -31,9 +31,19 @@ def test_golden_fixtures_reproduce():
     assert ' 0 differences' in out
 
 
-def test_plans_of_the_unmodified_examples_reproduce(tmp_path):
-    '''tools/hip_plan.py walks the function-level graph of the integrals that examples/laplace.py and examples/elasticity.py hand to
-    solver.System (the examples are run unmodified) and must give the committed plans again'''
+def test_seam_installed_in_the_reference():
+    '''nutils_amd.seam.install() patches function.evaluate / as_csr / solver.System of the importable reference; with the CPU evaluator of
+    tests/af_oracle.py as executor the UNMODIFIED examples' own unit tests (embedded golden vectors) pass, their Systems assembled from plans'''
+    out = run('tests/seam_hook_run.py')
+    for name in ('laplace', 'elasticity', 'poisson', 'platewithhole', 'adaptivity'):
+        line = next(l for l in out.splitlines() if l.startswith(name + ':'))
+        assert ' 0 failures, 0 errors' in line and 'from plans: 0;' not in line, line
+    assert 'equal to the reference: True' in out
+
+
+def test_plans_of_the_reference_scripts_reproduce(tmp_path):
+    '''tools/hip_plan.py matches the integrals of the unmodified examples/laplace.py and examples/elasticity.py (captured where they are handed to
+    solver.System) and of the Namespace scripts for BASELINE.json configs[1..4], and must give the committed plans again'''
     import numpy
     out = subprocess.run([sys.executable, 'tools/hip_plan.py'], cwd=ROOT, capture_output=True, text=True, timeout=1500,
                          env=dict(os.environ, NUTILS_AMD_PLAN_OUT=str(tmp_path)))
