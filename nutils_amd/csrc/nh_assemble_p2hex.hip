@@ -372,11 +372,12 @@ __global__ __launch_bounds__(NT) void k_p2hex(P2K p) {
 // once per line, the flush in node blocks with wave-uniform bases from records prepared by the geometry wave.
 constexpr int PKS = 7, PNQ = 4 * PKS;  // k-steps, padded quadrature points
 constexpr int NTP4 = 512, NTW = 3;     // threads; table / flush waves (waves 4 .. 4 + NTW - 1), wave 7: geometry
+constexpr int FLW = (NTW + 1) * 64;    // threads that stream finished rows in the phases in which the geometry wave has nothing else to do
 
 template <int NC>
 struct PL {  // LDS layout in doubles from the start of the dynamic LDS
   static constexpr int ESZ = 320 * NC * NC + 8, OSZ = 192 * NC * NC + 8, DSZ = 3 * PKS * 128, JSZ = 4 * PNQ * 10;
-  static constexpr int O = 3 * ESZ, DT = O + 2 * OSZ, JV = DT + 2 * DSZ, META = JV + 2 * JSZ, END = META + 32 * 3;
+  static constexpr int O = 3 * ESZ, DT = O + 2 * OSZ, JV = DT + 2 * DSZ, META = JV + 2 * JSZ, XV = META + 32 * 3, END = XV + 4 * 8 * 4;
   // meta, per (plane slot K & 7, node j): int2 row {offset of the node's rows, scalar row length}, int2 fl {first whole 16-byte pair,
   // pairs | head << 30 | tail << 31}, i64 element offset of the first row in the value array
   __device__ static __forceinline__ int plane(int K) { return (K & 1) ? O + ((K >> 1) & 1) * OSZ : ((K >> 1) % 3) * ESZ; }
@@ -555,7 +556,13 @@ __device__ __forceinline__ void flush_blocks(const P2K &p, double *lds, int K0, 
     double *lp = lds + first;
 #pragma unroll
     for (int u = 0; u < UB; ++u)
-      if (t + u * nt < np) v[b][u] = v2d{grab(lp + 2 * (t + u * nt)), grab(lp + 2 * (t + u * nt) + 1)};
+      if (t + u * nt < np) {
+        if (DBG(p, 32)) {  // A/B: plain 16-byte read + 16-byte zero store instead of two returning exchanges
+          v[b][u] = *reinterpret_cast<const v2d *>(lp + 2 * (t + u * nt));
+          *reinterpret_cast<v2d *>(lp + 2 * (t + u * nt)) = v2d{0., 0.};
+        } else
+          v[b][u] = v2d{grab(lp + 2 * (t + u * nt)), grab(lp + 2 * (t + u * nt) + 1)};
+      }
     if (t == 0 && (w & (1 << 30))) hv[b] = grab(lds + first - 1);
     if (t == 1 && (w < 0)) tv[b] = grab(lds + first + 2 * np);
   }
@@ -704,13 +711,14 @@ __device__ __forceinline__ void table_role(const P2K &p, double *lds, int lane, 
         if (i + 1 < nv) build_D(k, nth_visit(vmask, i + 1), lds + PL<NC>::DT + ((r + 1) & 1) * PL<NC>::DSZ);
         else if (i == nph - 1 && k + 1 < p.n2) build_D(k + 1, nth_visit(vmask, 0), lds + PL<NC>::DT + (((k + 1) * nv) & 1) * PL<NC>::DSZ);
         TICK(2);
-        if (k > 0) {  // the planes 2k-2, 2k-1 finished in the previous slice: 8 node blocks, nph phases
+        if (k > 0 && !DBG(p, 128)) {  // the planes 2k-2, 2k-1 finished in the previous slice: 8 node blocks, nph phases
           if (nph == 4) {
             // 3 + 2 + 2 + 1 node blocks over the four phases: the matrix waves have 31.5 / 21 / 21 / 10.5 MFMA per phase, and a phase lasts as long as the
-            // slower of the two roles -- an even 2 + 2 + 2 + 2 left the table waves waiting in the first phase and the matrix waves in the last
+            // slower of the two roles -- an even 2 + 2 + 2 + 2 left the table waves waiting in the first phase and the matrix waves in the last.
+            // From the second phase on the geometry wave (done with the next slice by then) streams a quarter of every block: FLW threads.
             if (i == 0) flush_blocks<NC, 3>(p, lds, 2 * k - 2, 0, st, NTW * 64, FTP);
-            else if (i == 3) flush_blocks<NC, 1>(p, lds, 2 * k - 2, 7, st, NTW * 64, FTP);
-            else flush_blocks<NC, 2>(p, lds, 2 * k - 2, 2 * i + 1, st, NTW * 64, FTP);
+            else if (i == 3) flush_blocks<NC, 1>(p, lds, 2 * k - 2, 7, st, FLW, FTP);
+            else flush_blocks<NC, 2>(p, lds, 2 * k - 2, 2 * i + 1, st, FLW, FTP);
           }
           else flush_blocks<NC, 4>(p, lds, 2 * k - 2, 4 * i, st, NTW * 64);
         }
@@ -735,27 +743,161 @@ __device__ __forceinline__ void table_role(const P2K &p, double *lds, int lane, 
 #endif
 }
 
-// wave 7: geometry of the next slice, row records of the planes that enter the ring with it
+// row records of node plane K by FOUR lanes (node j each): the constants of the line are in `LM`, a record costs one 64-bit multiply-add and a few
+// integer operations (the serial per-plane version, one lane doing four nodes with 64-bit products from scratch, was ~2 k cycles of the critical path)
+struct LineMeta {
+  int lenIJ[4];  // scalar row length of node j without its K factor (0: node absent)
+  i64 G0[4];     // element offset of the first row of node j in the value array: G0 + G1 * ax_cum(K)
+  int G1[4];
+};
+
+template <int NC>
+__device__ __forceinline__ LineMeta make_line_meta(const Line &L) {
+  LineMeta M;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ai = j >> 1, aj = j & 1;
+    bool ex = false;  // the node has contributions iff an element that contains it is visited
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (((L.vmask >> v) & 1) && (!(v >> 1) || ai == 0) && (!(v & 1) || aj == 0)) ex = true;
+    M.lenIJ[j] = ex ? L.cntI[ai] * L.cntJ[aj] : 0;
+    M.G0[j] = ((i64)L.cumI[ai] * L.SJ * L.SK + (i64)L.cntI[ai] * ((i64)L.cumJ[aj] * L.SK)) * (NC * NC);
+    M.G1[j] = L.cntI[ai] * L.cntJ[aj] * (NC * NC);
+  }
+  return M;
+}
+
+template <int NC>
+__device__ __forceinline__ void pipe_meta_node(const P2K &p, const LineMeta &M, double *lds, int K, int j) {
+  int *meta = reinterpret_cast<int *>(lds + PL<NC>::META);
+  i64 *gm = reinterpret_cast<i64 *>(lds + PL<NC>::META + 64);
+  const int cK = ax_cnt(K, p.n2), cumK = ax_cum(K, p.n2);
+  int cur = PL<NC>::plane(K), nd = 0, head = 0;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    if (jj <= j) {
+      cur += nd;  // (rows of the previous node)
+      nd = M.lenIJ[jj] * cK * NC * NC;
+      head = nd ? (int)((M.G0[jj] + (i64)M.G1[jj] * cumK) & 1) : 0;
+      cur = ((cur + 1) & ~1) + head;  // blocks never share a 16-byte pair: the flush copies and zeroes whole pairs
+    }
+  }
+  const int s = (K & 7) * 4 + j;
+  meta[s * 2] = cur;
+  meta[s * 2 + 1] = M.lenIJ[j] * cK;
+  meta[64 + s * 2] = cur + head;
+  meta[64 + s * 2 + 1] = ((nd - head) >> 1) | head << 30 | ((nd - head) & 1) << 31;
+  gm[s] = M.G0[j] + (i64)M.G1[j] * cumK;
+}
+
+// wave 7: geometry of the next slice, row records of the planes that enter the ring with it.
+// Trilinear isoparametric geometry (8 geometry functions, the case of configs[2]) takes the cheap route: the 8 vertices of each of the four elements of a slice
+// are fetched ONCE (one lane per vertex, one slice ahead: the index -> coordinate chain of two memory latencies stays off the phase), staged in LDS, and a lane per
+// (element, point) forms J from them with the reference gradients of ITS point held in registers -- the generic geometry_point (per point: 8 index loads, 24
+// coordinate loads, 32 table loads) made this one wave the critical path of every phase (profiles/r03_c3_geometry_role.md).
 template <int NC>
 __device__ __forceinline__ void geometry_role(const P2K &p, double *lds, int lane) {
 #ifdef NH_ABLATION
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
+  const int nq = p.nq;
+  const bool fast = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == 8 && !p.geom.nograd && p.geom.bnd_axis < 0;
+  const int gq = lane < nq ? lane : lane - nq;  // the point of this lane in both rounds: items (v, q) = (2 r + (lane >= nq), gq), r = 0, 1
+  const bool gok = lane < 2 * nq;
+  double dN[8][3], wq = 0.;
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dN[a][j] = 0.;
+  if (fast && gok) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dN[a][j] = p.geom.gT[((i64)a * nq + gq) * 4 + 1 + j];
+    wq = p.weights[gq];
+  }
+  // (pinned here: loads without a use stay pending for the wait-count bookkeeping and would be waited for inside the first slice)
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(dN[a][j]));
+  asm volatile("" : "+v"(wq));
+  double *XV = lds + PL<NC>::XV;  // [4 visits][8 vertices][4]: staged vertex coordinates of one slice
   const int nlines = (p.io1 - p.io0 + 1) * (p.n1 + 1);
   for (int line = blockIdx.x; line < nlines; line += gridDim.x) {
     const Line L = make_line(p, line);
     if (!L.vmask) continue;
+    const LineMeta LM = make_line_meta<NC>(L);
     const int nv = __builtin_popcount(L.vmask), nph = nv < 2 ? 2 : nv;
-    auto geometry_slice = [&](int k) {  // all valid (v, q) of slice k
+    auto geometry_slice = [&](int k) {  // generic route: all valid (v, q) of slice k
       double *Jvs = lds + PL<NC>::JV + (k & 1) * PL<NC>::JSZ;
       for (int i = lane; i < 4 * p.nq; i += 64) {
         const int v = i / p.nq, q = i - v * p.nq;
         if (((L.vmask >> v) & 1) && !DBG(p, 16)) geometry_point(p, L, v, k, q, Jvs + (v * PNQ + q) * 10);
       }
     };
+    // cheap route, lanes 0 .. 31 = (visit, vertex): coordinates of the vertices of slice k into registers
+    const int vv = lane >> 3, va = lane & 7;
+    const bool vok = fast && lane < 32 && ((L.vmask >> vv) & 1);
+    const i64 ecol = ((i64)(L.io - (vv >> 1)) * p.n1 + (L.jo - (vv & 1))) * p.n2;
+    double X0 = 0., X1 = 0., X2 = 0.;
+    auto fetch_vertices = [&](int k) {
+      if (vok && k < p.n2) {
+        const i64 idx = p.geom.gdofs[(ecol + k) * 8 + va];
+        X0 = p.geom.verts[idx * 3];
+        X1 = p.geom.verts[idx * 3 + 1];
+        X2 = p.geom.verts[idx * 3 + 2];
+      }
+    };
+    auto fast_slice = [&](int k) {  // registers -> LDS -> J, J^-1, w |det J| of all valid (v, q) of slice k
+      if (vok) {
+        double *o = XV + lane * 4;
+        *reinterpret_cast<v2d *>(o) = v2d{X0, X1};
+        o[2] = X2;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (same wave writes and reads: no barrier)
+      double *Jvs = lds + PL<NC>::JV + (k & 1) * PL<NC>::JSZ;
+#pragma unroll 1
+      for (int r = 0; r < 2; ++r) {
+        const int v = 2 * r + (lane >= nq ? 1 : 0);
+        if (!gok || !((L.vmask >> v) & 1) || DBG(p, 16)) continue;
+        double J[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) J[i][j] = 0.;
+        const double *Xe = XV + v * 32;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const v2d x01 = *reinterpret_cast<const v2d *>(Xe + a * 4);
+          const double x[3] = {x01[0], x01[1], Xe[a * 4 + 2]};
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) J[i][j] += x[i] * dN[a][j];
+        }
+        double Ji[3][3], det;
+        invert<3>(J, Ji, det);
+        double *o = Jvs + (v * PNQ + gq) * 10;
+        const i64 e = ((i64)(L.io - (v >> 1)) * p.n1 + (L.jo - (v & 1))) * p.n2 + k;
+        const double w = wq * fabs(det) * (p.scale ? p.scale[e * nq + gq] : 1.);
+        // o[j * 3 + i] = Ji[j][i], o[9] = w: five 16-byte stores (a point's record is 80 bytes)
+        *reinterpret_cast<v2d *>(o) = v2d{Ji[0][0], Ji[0][1]};
+        *reinterpret_cast<v2d *>(o + 2) = v2d{Ji[0][2], Ji[1][0]};
+        *reinterpret_cast<v2d *>(o + 4) = v2d{Ji[1][1], Ji[1][2]};
+        *reinterpret_cast<v2d *>(o + 6) = v2d{Ji[2][0], Ji[2][1]};
+        *reinterpret_cast<v2d *>(o + 8) = v2d{Ji[2][2], w};
+      }
+    };
     lds_barrier();  // previous line done
-    if (lane < 3) pipe_meta<NC>(p, L, lds, lane);
-    geometry_slice(0);
+    if (lane < 12) pipe_meta_node<NC>(p, LM, lds, lane >> 2, lane & 3);
+    if (fast) {
+      fetch_vertices(0);
+      fast_slice(0);
+      fetch_vertices(1);  // (in flight until the first phase of slice 0)
+    } else
+      geometry_slice(0);
     lds_barrier();
     lds_barrier();
 #pragma unroll 1
@@ -764,21 +906,26 @@ __device__ __forceinline__ void geometry_role(const P2K &p, double *lds, int lan
       for (int i = 0; i < nph; ++i) {
         TICK(7);
         if (k + 1 < p.n2) {
-          if (i == 0) {
-            if (lane == 0) pipe_meta<NC>(p, L, lds, 2 * k + 3);
-            if (lane == 1) pipe_meta<NC>(p, L, lds, 2 * k + 4);
-          }
-          // the geometry of the next slice in nph parts, one per phase (all of it in the first phase made that phase wait for this wave: 6.5 k cycles
-          // against ~4 k of the other roles); element v of the next slice is first needed by the D-table build one element ahead of it
+          if (i == 0 && !DBG(p, 64) && lane < 8) pipe_meta_node<NC>(p, LM, lds, 2 * k + 3 + (lane >> 2), lane & 3);
           double *Jvs = lds + PL<NC>::JV + ((k + 1) & 1) * PL<NC>::JSZ;
-          // (lines with fewer than four elements -- two or three phases -- keep everything in the first phase: their first element may be any v)
-          if (nph == 4) {
+          if (fast) {
+            // everything in the first phase (the one with the most matrix work): the records of slice k + 1 are first read by the table build of the LAST phase
+            if (i == 0) {
+              fast_slice(k + 1);
+              fetch_vertices(k + 2);
+            }
+          } else if (nph == 4) {
+            // generic route: one element per phase (its table is due one element ahead of it); lines with two or three phases keep everything in the first
             if (!DBG(p, 16))
               for (int q = lane; q < p.nq; q += 64) geometry_point(p, L, i, k + 1, q, Jvs + (i * PNQ + q) * 10);
           } else if (i == 0)
             geometry_slice(k + 1);
         }
         TICK(3);
+        if (nph == 4 && i > 0 && k > 0 && !DBG(p, 128)) {  // the fourth streaming wave of these phases (table_role: the same blocks, FLW threads)
+          if (i == 3) flush_blocks<NC, 1>(p, lds, 2 * k - 2, 7, NTW * 64 + lane, FLW);
+          else flush_blocks<NC, 2>(p, lds, 2 * k - 2, 2 * i + 1, NTW * 64 + lane, FLW);
+        }
         lds_barrier();
         TICK(6);
       }
