@@ -227,6 +227,7 @@ typedef struct {
   double f0;                 /* constant integrand of the functional */
   double *out_scalar_dev;    /* [1] accumulated, or NULL */
   const double *scale_dev;   /* optional pointwise factor [nelems][nq] (list position with elist_dev), NULL = 1 */
+  double *local_dev;         /* NULL, or: local vectors stored element-major instead of atomics into out_dev (see nh_block.local_dev) */
 } nh_vector_args;
 
 int nh_assemble_vector(const nh_vector_args *args, void *stream);
@@ -256,6 +257,8 @@ typedef struct {
   nh_basis test;
   int nct;                   /* components of the test space */
   double *out_dev;           /* [nrows][nct], accumulated */
+  double *local_dev;         /* NULL, or: the local vectors are STORED here, element-major ([position of (e, m) in test.dofs_dev][nct]), instead of
+                                being added into out_dev with atomics -- the first half of the deterministic scatter, see nh_scatter_plan_build */
 } nh_block;
 
 typedef struct {
@@ -477,6 +480,23 @@ int nh_index_copy(int64_t n, const double *src_dev, const int64_t *src_index_dev
  * integrand is re-integrated with the pointwise coefficient. */
 int nh_pointwise_poly(int64_t n, int nvars, const double *const *x_dev, const int *strides, int nterms, const double *coeffs,
                       const int *powers, double *out_dev, void *stream);
+
+/* ---- deterministic vector scatter (owner-side reduction) ------------------------------------------
+ * The reference scatters local vectors with numpy.add.at(out, dofs_e, values_e) element by element (Inflate._compile_with_out,
+ * evaluable.py:3405-3411; numeric.accumulate, numeric.py:434-460): every dof receives its contributions in ascending (element, local
+ * index) order.  Global atomics give the same sum in an arbitrary order, i.e. results that differ in the last bits from run to run.
+ * Two-pass form with the reference's order: (1) the element kernels STORE their local vectors (nh_block.local_dev /
+ * nh_vector_args.local_dev); (2) nh_scatter_gather sums, for every dof, its contributions through a map built once per (basis, element
+ * list): positions of the (e, m) pairs in the local array, grouped by dof, within a dof ascending in (list position, m).
+ * nelems / nb / off_dev / dofs_dev: the connectivity as in nh_basis (nb = 0: ragged with off_dev); elist_dev / nlist: the elements of the
+ * sample in evaluation order (NULL: all nelems).  Several (plan, local) pairs -- the samples of one residual -- are summed in the order
+ * given; accumulate = 0 stores, 1 adds to out_dev[nrows][ncomp]. */
+typedef struct nh_scatter_plan nh_scatter_plan;
+int nh_scatter_plan_build(int64_t nelems, int64_t nrows, int nb, const int32_t *dofs_dev, const int64_t *off_dev, const int32_t *elist_dev,
+                          int64_t nlist, nh_scatter_plan **plan_out, void *stream);
+int nh_scatter_plan_free(nh_scatter_plan *plan);
+int nh_scatter_gather(int count, const nh_scatter_plan *const *plans, const double *const *locals_dev, int ncomp, double *out_dev,
+                      int accumulate, void *stream);
 
 /* ---- per-point forms of field values ------------------------------------------------------------
  * The product-rule coefficients of quasi-linear problems at every quadrature point, from U = (value, gradient w.r.t. x) of

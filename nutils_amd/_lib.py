@@ -49,7 +49,8 @@ class MatrixArgs(ctypes.Structure):
 class VectorArgs(ctypes.Structure):
     _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp),
                 ('geom', Geometry), ('test', Basis), ('trial', Basis), ('nct', ctypes.c_int), ('ncr', ctypes.c_int),
-                ('C_host', vp), ('f_host', vp), ('u_dev', vp), ('out_dev', vp), ('f0', ctypes.c_double), ('out_scalar_dev', vp), ('scale_dev', vp)]
+                ('C_host', vp), ('f_host', vp), ('u_dev', vp), ('out_dev', vp), ('f0', ctypes.c_double), ('out_scalar_dev', vp), ('scale_dev', vp),
+                ('local_dev', vp)]
 
 
 class Field(ctypes.Structure):
@@ -57,7 +58,7 @@ class Field(ctypes.Structure):
 
 
 class Block(ctypes.Structure):
-    _fields_ = [('test', Basis), ('nct', ctypes.c_int), ('out_dev', vp)]
+    _fields_ = [('test', Basis), ('nct', ctypes.c_int), ('out_dev', vp), ('local_dev', vp)]
 
 
 class PointPoly(ctypes.Structure):
@@ -142,6 +143,9 @@ SIGNATURES = {
     'nh_index_copy': (ctypes.c_int, [c_i64, vp, vp, vp, vp, vp]),
     'nh_pointwise_poly': (ctypes.c_int, [c_i64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int), vp, vp]),
+    'nh_scatter_plan_build': (ctypes.c_int, [c_i64, c_i64, ctypes.c_int, vp, vp, vp, c_i64, ctypes.POINTER(vp), vp]),
+    'nh_scatter_plan_free': (ctypes.c_int, [vp]),
+    'nh_scatter_gather': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_int, vp, ctypes.c_int, vp]),
     'nh_point_forms': (ctypes.c_int, [ctypes.c_int, c_i64, ctypes.c_int, vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), vp, vp, vp]),
     'nh_rationalize': (ctypes.c_int, [vp, c_i64, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     'nh_p1hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64, vp, vp, vp]),

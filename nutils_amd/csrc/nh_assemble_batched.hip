@@ -42,6 +42,7 @@ struct FieldK {
 struct BlockK {
   BasisK test;
   double *out;
+  double *local;       // element-major local vectors instead of atomics into out (deterministic scatter, nh_scatter.hip)
   int nct, c0, maxnb;  // c0: first slot in the per-point integrand table
 };
 // term table (doubles, staged in LDS): per term [block, field, poly, hasC, hasf, f[nct][S], C[nct][S][ncr][S]], per polynomial
@@ -243,7 +244,8 @@ __device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, 
 #pragma unroll
         for (int s = 0; s < S; ++s) acc += T[q * S + s] * g[(size_t)q * p.ct * S + s];
       }
-      atomicAdd(B.out + (i64)B.test.dofs[boff(B.test, e) + m] * B.nct + c, acc);
+      if (B.local) B.local[(boff(B.test, e) + m) * B.nct + c] = acc;
+      else atomicAdd(B.out + (i64)B.test.dofs[boff(B.test, e) + m] * B.nct + c, acc);
     }
   }
 }
@@ -801,6 +803,7 @@ struct VTermsK {
   int nterms, npolys, nblocks;
   const double *u[3];
   double *out[2];
+  double *local[2];  // element-major local vectors instead of atomics (deterministic scatter)
   const double *scale[MAXT];
   int toff[MAXT], poff[MAXP], qoff[MAXT];
   int tlen;
@@ -972,7 +975,10 @@ __global__ __launch_bounds__(128) void k_local_vterms(VTermsK p) {
   for (int b = 0; b < 2; ++b) {
     if (b >= p.nblocks) break;
 #pragma unroll
-    for (int m = 0; m < NB; ++m) atomicAdd(p.out[b] + dofs[m], r[b][m]);
+    for (int m = 0; m < NB; ++m) {
+      if (p.local[b]) p.local[b][e * NB + m] = r[b][m];
+      else atomicAdd(p.out[b] + dofs[m], r[b][m]);
+    }
   }
 }
 
@@ -1139,6 +1145,7 @@ int local_vterms(const nh_terms_args *a, const TermsK &m, const std::vector<doub
   p.nterms = m.nterms, p.npolys = m.npolys, p.nblocks = a->nblocks;
   for (int f = 0; f < 3; ++f) p.u[f] = f < a->nfields ? a->fields[f].u_dev : nullptr;
   for (int b = 0; b < 2; ++b) p.out[b] = b < a->nblocks ? a->blocks[b].out_dev : nullptr;
+  for (int b = 0; b < 2; ++b) p.local[b] = b < a->nblocks ? a->blocks[b].local_dev : nullptr;
   for (int t = 0; t < MAXT; ++t) p.scale[t] = m.scale[t], p.toff[t] = m.toff[t], p.qoff[t] = m.qoff[t];
   for (int k = 0; k < MAXP; ++k) p.poff[k] = m.poff[k];
   p.tlen = (int)tab.size();
@@ -1211,10 +1218,11 @@ int build_terms(const nh_terms_args *a, hipStream_t stream, TermsK &p, std::vect
   p.ct = 0, p.rowsper = 0;
   for (int b = 0; b < a->nblocks; ++b) {
     const nh_block &B = a->blocks[b];
-    NH_REQUIRE(B.test.T_dev && B.test.dofs_dev && B.out_dev && B.nct >= 1 && B.nct <= 3, "nh_assemble_terms: block %d incomplete", b);
+    NH_REQUIRE(B.test.T_dev && B.test.dofs_dev && (B.out_dev || B.local_dev) && B.nct >= 1 && B.nct <= 3, "nh_assemble_terms: block %d incomplete", b);
     NH_REQUIRE(!a->elist_dev || !B.test.off_dev, "elist with ragged bases is not supported");
     p.blocks[b].test = to_k(B.test);
     p.blocks[b].out = B.out_dev;
+    p.blocks[b].local = B.local_dev;
     p.blocks[b].nct = B.nct;
     p.blocks[b].c0 = p.ct;
     if ((rc = max_nb2(B.test, a->nelems, &p.blocks[b].maxnb, stream)) != NH_OK) return rc;

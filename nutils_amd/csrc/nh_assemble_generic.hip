@@ -434,6 +434,7 @@ struct VecK {
   int same;
   const double *u;
   double *out;
+  double *local;  // element-major local vectors instead of atomics into out (deterministic scatter, nh_scatter.hip)
   double f0;
   double *out_scalar;
   const double *scale;
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
         F[(ql * p.cs + c) * S + a] = s;
       }
       __syncthreads();
-      if (p.out) {
+      if (p.out || p.local) {
         for (int k = lane; k < nbt * form.nct; k += 64) {
           const int c = k % form.nct, m = k / form.nct;
           double acc = 0;
@@ -501,7 +502,11 @@ __global__ __launch_bounds__(64) void k_vector_generic(VecK p, FormK formarg) {
             for (int a = 0; a < S; ++a) s += Dt[(ql * nbt + m) * S + a] * F[(ql * p.cs + c) * S + a];
             acc += Jw[(q0 + ql) * JW + ND * ND] * s;
           }
-          atomicAdd(p.out + (i64)p.test.dofs[tdof0 + m] * form.nct + c, acc);
+          if (p.local) {  // (the same lane owns (m, c) in every chunk of points: plain accumulation)
+            double *dst = p.local + (tdof0 + m) * form.nct + c;
+            *dst = q0 ? *dst + acc : acc;
+          } else
+            atomicAdd(p.out + (i64)p.test.dofs[tdof0 + m] * form.nct + c, acc);
         }
       }
       if (p.out_scalar) {
@@ -834,7 +839,7 @@ int nh_assemble_vector(const nh_vector_args *a, void *stream) {
   NH_REQUIRE(a, "nh_assemble_vector: NULL args");
   NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
   NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
-  NH_REQUIRE(a->out_dev || a->out_scalar_dev, "nh_assemble_vector: no output");
+  NH_REQUIRE(a->out_dev || a->out_scalar_dev || a->local_dev, "nh_assemble_vector: no output");
   NH_REQUIRE((a->test.nb == 0 && !a->test.off_dev) || (a->test.T_dev && a->test.dofs_dev), "test basis tables missing");
   NH_REQUIRE((a->trial.nb == 0 && !a->trial.off_dev) || (a->trial.T_dev && a->trial.dofs_dev), "trial basis tables missing");
   NH_REQUIRE(!(a->C_host && !a->u_dev), "nh_assemble_vector: coefficient tensor given without field u");
@@ -858,7 +863,8 @@ int nh_assemble_vector(const nh_vector_args *a, void *stream) {
   p.same = (a->test.T_dev == a->trial.T_dev && a->test.off_dev == a->trial.off_dev && a->test.tab_dev == a->trial.tab_dev &&
             a->test.nb == a->trial.nb);
   p.u = a->u_dev;
-  p.out = a->out_dev;
+  p.out = a->local_dev ? nullptr : a->out_dev;
+  p.local = a->local_dev;
   p.f0 = a->f0;
   p.out_scalar = a->out_scalar_dev;
   p.scale = a->scale_dev;

@@ -153,8 +153,37 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
 
 
+class ScatterPlan:
+    '''Map of the deterministic vector scatter (nh_scatter_plan_build): for every dof the positions of its contributions in an element-major
+    array of local vectors, in the order of the reference's loop.  One per (basis tables, element list).'''
+
+    def __init__(self, *, nelems, nrows, nb, dofs, off=None, elist=None, nlist=None):
+        handle = ctypes.c_void_p()
+        _lib.call('nh_scatter_plan_build', int(nelems), int(nrows), int(nb), device.ptr(dofs), device.ptr(off), device.ptr(elist),
+                  int(nelems if elist is None else nlist), ctypes.byref(handle), device.stream())
+        self._handle, self._keep = handle, (dofs, off, elist)
+        self.npositions = int(dofs.numel())  # length of a local array per component
+
+    def __del__(self):
+        h = getattr(self, '_handle', None)
+        if h:
+            try:
+                _lib.load().nh_scatter_plan_free(h)
+            except Exception:
+                pass
+            self._handle = None
+
+
+def scatter_gather(pairs, ncomp, out, accumulate=True):
+    '''out[dof][c] (+)= sum over the (plan, local array) pairs, in order, of the contributions of dof (nh_scatter_gather).'''
+    n = len(pairs)
+    P = (ctypes.c_void_p * n)(*[p._handle.value for p, _ in pairs])
+    L = (ctypes.c_void_p * n)(*[loc.data_ptr() for _, loc in pairs])
+    _lib.call('nh_scatter_gather', n, P, L, int(ncomp), device.ptr(out), int(bool(accumulate)), device.stream())
+
+
 def assemble_vector(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C=None, f=None, u=None, out=None, f0=0., out_scalar=None,
-                    elist=None, scale=None):
+                    elist=None, scale=None, local=None):
     C = None if C is None else numpy.ascontiguousarray(C, dtype=float)
     f = None if f is None else numpy.ascontiguousarray(f, dtype=float)
     if C is not None and C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
@@ -162,7 +191,7 @@ def assemble_vector(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     if f is not None and f.shape != (nct, 1 + ndims):
         raise ValueError(f'source tensor has shape {f.shape}')
     args = _lib.VectorArgs(nelems, device.ptr(elist), ndims, nq, device.ptr(weights), geom, test, trial, nct, ncr, device.host_ptr(C),
-                           device.host_ptr(f), device.ptr(u), device.ptr(out), float(f0), device.ptr(out_scalar), device.ptr(scale))
+                           device.host_ptr(f), device.ptr(u), device.ptr(out), float(f0), device.ptr(out_scalar), device.ptr(scale), device.ptr(local))
     _lib.call('nh_assemble_vector', ctypes.byref(args), device.stream())
 
 
@@ -170,8 +199,8 @@ def _terms_args(keep, *, nelems, ndims, nq, weights, geom, fields, blocks, terms
     S = 1 + ndims
     F, P = _fields_polys(fields, polys, keep)
     B = (_lib.Block * len(blocks))()
-    for i, (b, nct, out) in enumerate(blocks):
-        B[i] = _lib.Block(b, int(nct), device.ptr(out))
+    for i, blk in enumerate(blocks):  # (test struct, nct, out[, local array of the deterministic scatter])
+        B[i] = _lib.Block(blk[0], int(blk[1]), device.ptr(blk[2]), device.ptr(blk[3]) if len(blk) > 3 else None)
     T = (_lib.Term * len(terms))()
     for i, t in enumerate(terms):
         blk, fld = int(t['block']), int(t.get('field', -1))

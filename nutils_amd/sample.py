@@ -764,6 +764,20 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
     if out is not None and _p1hex_apply_term(smp, itg, fac, arguments, out):
         return
     geom = smp.geometry(itg.measure)
+    if out is not None and itg.rows and not itg.cols and _deterministic():
+        # linear form into a vector: local vectors + owner-side reduction instead of atomics
+        tt = smp.tables(itg.test.basis)
+        plan, local = _scatter(smp, itg.test.basis, itg.test.ncomp)
+        common = dict(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=tt.struct,
+                      nct=itg.test.ncomp, local=local)
+        if itg.B is not None:
+            kernels.assemble_vector(trial=smp.tables(itg.trial.basis).struct, ncr=itg.trial.ncomp, C=itg.B * fac, u=_argument_dev(arguments, itg.trial), **common)
+        elif itg.L is not None:
+            kernels.assemble_vector(trial=tt.struct, ncr=itg.test.ncomp, f=itg.L * fac, **common)
+        else:
+            raise NotImplementedError('vector term without a form')
+        kernels.scatter_gather([(plan, local)], itg.test.ncomp, out, accumulate=True)
+        return
     if itg.B is not None:
         tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
         if itg.rows and not itg.cols:
@@ -799,6 +813,27 @@ def _vector_term(smp, itg, fac, arguments, out, scalar):
     none = kernels.basis(None, None)
     kernels.assemble_vector(elist=smp._elist_dev, scale=_point_scale(smp, itg, arguments), nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, test=none, trial=none, nct=1, ncr=1,
                             f0=float(itg.f0) * fac, out_scalar=scalar[0])
+
+
+def _deterministic():
+    '''Residual vectors are scattered with the owner-side reduction (element kernels store local vectors, nh_scatter_gather sums them per dof in the
+    order of the reference's numpy.add.at loop: bit-identical from run to run) unless NUTILS_AMD_ATOMIC_RESIDUALS asks for global atomics.'''
+    return not os.environ.get('NUTILS_AMD_ATOMIC_RESIDUALS')
+
+
+def _scatter(smp, basis, nct, slot=0):
+    '''(plan, local array [positions][nct]) of the deterministic scatter for vectors on `basis` assembled over `smp`; `slot` tells apart
+    the arrays of several launches whose results are gathered together.  Kept with the sample: a Newton step reuses map and array.'''
+    cache = smp.__dict__.setdefault('_scatter_plans', {})
+    t = smp.tables(basis)
+    plan = cache.get(id(basis))
+    if plan is None or plan[0] is not basis:
+        plan = cache[id(basis)] = (basis, kernels.ScatterPlan(nelems=smp.nelems, nrows=basis.ndofs, nb=t.nb, dofs=t.dofs, off=t.off, elist=smp._elist_dev, nlist=smp.nlist))
+    arrays = smp.__dict__.setdefault('_scatter_local', {})
+    key = id(basis), int(nct), slot
+    if key not in arrays:
+        arrays[key] = device.empty(plan[1].npositions * int(nct), 'float64')
+    return plan[1], arrays[key]
 
 
 def _fusable(itg):
@@ -858,7 +893,7 @@ def _plan_terms(items, blocks, lists, leftover):
         for fp in pkeys:
             keys = list(fp.terms)
             polys.append(([(fidx(a), 0) for a in fp.args], [fp.terms[k] for k in keys], keys))
-        lists.append(dict(nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, elist=smp._elist_dev,
+        lists.append(dict(smp=smp, nelems=smp.nlist, ndims=nd, nq=nq, weights=smp._weights_dev, geom=geom, elist=smp._elist_dev,
                           fields=[(smp.tables(a.basis).struct, a, a.ncomp) for a in fkeys],
                           blocks=[(smp.tables(blocks[b][0].basis).struct, blocks[b][0].ncomp, b) for b in bkeys], terms=terms, polys=polys))
         pending = rest
@@ -872,7 +907,7 @@ def _vector_blocks(blocks, arguments, scalar):
     nh_p1hex_apply, everything else that shares a sample and a measure through ONE fused element loop -- and the loops of all samples through one
     launch (nh_assemble_terms_multi) --, the remainder term by term.  The split and the term lists depend on the integrals only: they are kept
     per tuple of term lists (the reference caches its compiled callables the same way, solver.py:321-331), a Newton step fills in the arrays.'''
-    env = tuple(bool(os.environ.get('NUTILS_AMD_' + name)) for name in ('NO_BATCHED', 'NO_MULTI', 'NO_FAST_PATH'))  # (debugging switches: part of the key)
+    env = tuple(bool(os.environ.get('NUTILS_AMD_' + name)) for name in ('NO_BATCHED', 'NO_MULTI', 'NO_FAST_PATH', 'ATOMIC_RESIDUALS'))  # (debugging switches: part of the key)
     key = tuple(id(terms) for _, _, terms in blocks) + env
     plan = _TERM_PLANS.get(key)
     if plan is None or not all(a is b[2] for a, b in zip(plan['terms'], blocks)):
@@ -900,13 +935,28 @@ def _vector_blocks(blocks, arguments, scalar):
             ucache[arg.name] = _argument_dev(arguments, arg)
         return ucache[arg.name]
 
-    lists = [dict(tpl, fields=[(t, dev_u(a), nc) for t, a, nc in tpl['fields']], blocks=[(t, nc, blocks[b][1]) for t, nc, b in tpl['blocks']])
-             for tpl in plan['lists']]
+    det = _deterministic()
+    gathers = {}  # block index -> [(plan, local array)] in list order
+    lists = []
+    for il, tpl in enumerate(plan['lists']):
+        blks = []
+        for t, nc, b in tpl['blocks']:
+            if det:  # the kernel stores the local vectors of this list; they are summed per dof below, lists in order
+                sp, local = _scatter(tpl['smp'], blocks[b][0].basis, nc, slot=(il, b))  # (blocks may share a basis: one array each)
+                gathers.setdefault(b, []).append((sp, local))
+                blks.append((t, nc, None, local))
+            else:
+                blks.append((t, nc, blocks[b][1]))
+        kw = {k: v for k, v in tpl.items() if k != 'smp'}
+        lists.append(dict(kw, fields=[(t, dev_u(a), nc) for t, a, nc in tpl['fields']], blocks=blks))
     if env[1]:  # one launch per sample (tests: the merged launch must give the same result)
         for kw in lists:
             kernels.assemble_terms(**kw)
     else:  # all samples of the residual (volume + the sides of the boundary) in one launch
         kernels.assemble_terms_multi(lists)
+    for b, pairs in gathers.items():
+        for i in range(0, len(pairs), 8):
+            kernels.scatter_gather(pairs[i:i + 8], blocks[b][0].ncomp, blocks[b][1], accumulate=True)
 
 
 def _exposed_test(f):

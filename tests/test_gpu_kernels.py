@@ -735,6 +735,71 @@ def test_gather_equals_atomics_and_is_reproducible(golden, name):
     assert numpy.array_equal(out[0], out[1]) and numpy.array_equal(out[0], out[2])
 
 
+@pytest.mark.parametrize('name', ['lap2d_p1_4x3_iso', 'lap3d_p2_2_iso', 'lap2d_spline2_5x4_iso', 'elast2d_p2_3x2_iso', 'elast3d_p1_2_iso'])
+def test_vector_scatter_equals_the_reference_order_and_is_reproducible(golden, name):
+    '''Residual vectors through the deterministic scatter (local vectors stored element-major + nh_scatter_gather: for every dof its contributions in
+    ascending (element, local index) order, the order of the reference's numpy.add.at loop, evaluable.py:3405-3411): equal to the atomic scatter to
+    rounding, BIT-IDENTICAL to the oracle's add.at restatement of the same local vectors summed in that order, and bit-identical from run to run.'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    nc = c.nd if name in ELAST else 1
+    C = oa.elasticity_coefficient(c.nd, float(g['lam']), float(g['mu'])) if name in ELAST else oa.laplace_coefficient(c.nd)
+    rng = numpy.random.default_rng(23)
+    u = rng.normal(size=(c.ndofs, nc))
+    ud = device.to_dev(u, 'float64')
+    common = dict(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=nc, ncr=nc, C=C, u=ud)
+    atomic = device.zeros(c.ndofs * nc, 'float64')
+    kernels.assemble_vector(out=atomic, **common)
+    plan = kernels.ScatterPlan(nelems=c.nelems, nrows=c.ndofs, nb=c.nb, dofs=c.dofs)
+    outs, locals_ = [], []
+    for it in range(3):
+        local = device.empty(c.nelems * c.nb * nc, 'float64')
+        kernels.assemble_vector(local=local, **common)
+        out = device.zeros(c.ndofs * nc, 'float64')
+        kernels.scatter_gather([(plan, local)], nc, out, accumulate=False)
+        outs.append(device.to_host(out))
+        locals_.append(device.to_host(local))
+    a = device.to_host(atomic)
+    assert numpy.abs(outs[0] - a).max() <= 1e-13 * numpy.abs(a).max()
+    assert numpy.array_equal(outs[0], outs[1]) and numpy.array_equal(outs[0], outs[2])
+    # the reference's scatter of the same local vectors: numpy.add.at element by element (ascending element, then local index)
+    ref = numpy.zeros((c.ndofs, nc))
+    numpy.add.at(ref, g['dofs'].reshape(-1), locals_[0].reshape(-1, nc))
+    assert numpy.array_equal(outs[0].reshape(-1, nc), ref)
+    # two plans / arrays gathered in one call add up in the order given; accumulate adds to what is there
+    out2 = device.zeros(c.ndofs * nc, 'float64')
+    kernels.scatter_gather([(plan, device.to_dev(locals_[0], 'float64')), (plan, device.to_dev(locals_[0], 'float64'))], nc, out2, accumulate=True)
+    ref2 = ref.copy()  # (the second array continues the running sums of the first)
+    numpy.add.at(ref2, g['dofs'].reshape(-1), locals_[0].reshape(-1, nc))
+    assert numpy.array_equal(device.to_host(out2), ref2.reshape(-1))
+
+
+def test_vector_scatter_on_an_element_list_and_a_ragged_basis(golden):
+    '''the map of a boundary-type sample (element list: only the listed elements contribute, in list order) and of a ragged (hierarchical) basis with offsets'''
+    from nutils_amd import device, kernels
+    g = golden('hier_spline2_2d')
+    dofs, off = g['t_dofs'], g['t_dof_offsets']
+    ne, ndofs = len(off) - 1, int(g['t_ndofs'])
+    rng = numpy.random.default_rng(4)
+    local = rng.normal(size=(len(dofs), 2))
+    ddofs, doff = device.to_dev(dofs, 'int32'), device.to_dev(off, 'int64')
+    plan = kernels.ScatterPlan(nelems=ne, nrows=ndofs, nb=0, dofs=ddofs, off=doff)
+    out = device.zeros(ndofs * 2, 'float64')
+    kernels.scatter_gather([(plan, device.to_dev(local, 'float64'))], 2, out, accumulate=False)
+    ref = numpy.zeros((ndofs, 2))
+    numpy.add.at(ref, dofs, local)
+    assert numpy.array_equal(device.to_host(out).reshape(-1, 2), ref)
+    elist = numpy.array([5, 2, 7, 0][:min(4, ne)], dtype=numpy.int32)  # (not ascending: the order of the list is the order of the sum)
+    plan2 = kernels.ScatterPlan(nelems=ne, nrows=ndofs, nb=0, dofs=ddofs, off=doff, elist=device.to_dev(elist, 'int32'), nlist=len(elist))
+    kernels.scatter_gather([(plan2, device.to_dev(local, 'float64'))], 2, out, accumulate=False)
+    ref = numpy.zeros((ndofs, 2))
+    for e in elist:
+        numpy.add.at(ref, dofs[off[e]:off[e + 1]], local[off[e]:off[e + 1]])
+    assert numpy.array_equal(device.to_host(out).reshape(-1, 2), ref)
+
+
 @pytest.mark.parametrize('name', ['lap3d_p2_2_iso', 'lap3d_spline2_3_iso', 'lap2d_spline2_5x4_iso', 'lap3d_p1_543_iso'])
 def test_gather_with_a_full_coefficient_tensor(golden, name):
     '''A dense, non-symmetric form tensor C[a][b] (value and gradient slots mixed) and a scale array through both thread passes of NH_MATRIX_GATHER
