@@ -157,6 +157,10 @@ def test_c4_full_size_consistency():
     shift = lambda s: {'φ': x0['φ'] + s * v['φ'], 'η': x0['η'] + s * v['η'], 'φ0': x0['φ0']}
     vv = numpy.concatenate([v['φ'], v['η']])
     res = system.assemble_residual(x0)
+    # residual vectors take the owner-side reduction (local vectors + nh_scatter_gather, the order of the reference's add.at loop):
+    # bit-identical from run to run -- with global f64 atomics (NUTILS_AMD_ATOMIC_RESIDUALS) equal to rounding only
+    for _ in range(2):
+        assert numpy.array_equal(system.assemble_residual(x0), res)
     jac = system.assemble_jacobian(x0)
     h = 1e-3
     dE = (system.assemble_value(shift(h)) - system.assemble_value(shift(-h))) / (2 * h)
