@@ -385,3 +385,14 @@ def test_periodic_helmholtz(btype, degree, n):
             ones = numpy.ones(len(K))
             assert abs(ones @ K @ ones - 1.) < 1e-12  # int 1 * 1 dV: the constant is in the periodic space
     assert errs[1] < errs[0] * 2. ** -(degree + 1) * 1.3 and errs[1] < 2e-2
+
+
+def test_ragged_rational_workload_tiled():
+    '''BASELINE.json configs[4] at a size that measures something: the reference fixture iga_plate_p3_l10 (p = 3 NURBS, 10 hierarchical levels, ragged) tiled into one
+    mesh of independent plates and assembled in ONE call (tools/ragged_probe.py: every diagonal block must equal the reference's matrix, indices bit-exact, values
+    to 1e-13; the tool asserts it and prints the throughput -- 256 plates = 63 488 elements: profiles/r03_ragged_c4.md)'''
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, 'tools/ragged_probe.py', '12', '2'], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
+    assert '2976 elements' in out.stdout and 'nh_assemble_matrix' in out.stdout
