@@ -783,12 +783,22 @@ __device__ __forceinline__ void pipe_meta_node(const P2K &p, const LineMeta &M, 
       cur = ((cur + 1) & ~1) + head;  // blocks never share a 16-byte pair: the flush copies and zeroes whole pairs
     }
   }
+  // (the constants of node j by compare-and-select: a runtime index into the register arrays would put them into scratch memory)
+  int lenj = 0, g1 = 0;
+  i64 g0 = 0;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+    if (jj == j) {
+      lenj = M.lenIJ[jj];
+      g0 = M.G0[jj];
+      g1 = M.G1[jj];
+    }
   const int s = (K & 7) * 4 + j;
   meta[s * 2] = cur;
-  meta[s * 2 + 1] = M.lenIJ[j] * cK;
+  meta[s * 2 + 1] = lenj * cK;
   meta[64 + s * 2] = cur + head;
   meta[64 + s * 2 + 1] = ((nd - head) >> 1) | head << 30 | ((nd - head) & 1) << 31;
-  gm[s] = M.G0[j] + (i64)M.G1[j] * cumK;
+  gm[s] = g0 + (i64)g1 * cumK;
 }
 
 // wave 7: geometry of the next slice, row records of the planes that enter the ring with it.
