@@ -385,7 +385,7 @@ def main():
             roofline['traffic_source'] = TRAFFIC_FILE + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, separate passes; not measured in this run)'
         out = {
             'metric': metric, 'value': value, 'unit': 'elements/s', 'n_gpus': world,
-            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': a.scaling,  # (one GPU: both modes coincide; the series N = 1, 2, 4, 8 carries one label)
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': workload, 'nelems_per_gpu': wl_nelems, 'nnz_per_gpu': nnz, 'kernel': wl.kernel_name,
                        'parallelism': f'element slabs x{world}, halo-plane reduce' if world > 1 else 'single GPU', 'launch': launch,
