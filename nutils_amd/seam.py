@@ -331,7 +331,11 @@ class Matcher:
         if t == '_Jacobian':
             return [_Mono(numpy.ones(()), [], measure=(self.strip_broadcast(node._geom, 1), node._tip_dim))]
         if not self.has_symbols(node) and not self.basis_dot_constant(node):
-            return self.conv_plain(node)
+            # broadcast wrappers around a coefficient function are processed structurally (below), so that conv_plain sees its core
+            if node.spaces and (t == '_Transpose' or (t == '_Wrapper' and _name(node) == 'InsertAxis')):
+                pass
+            else:
+                return self.conv_plain(node)
         f = self.field(node)
         if f is not None:
             return f
@@ -404,7 +408,15 @@ class Matcher:
         if core.ndim == 0:  # scalar coefficient function, broadcast over the array axes
             m = _Mono(numpy.ones(()), [], pw=[core])
             return [self.rebroadcast(m, node)]
-        raise Unmatched('array-valued coefficient function of the point')
+        if node.size <= 16:
+            # array-valued coefficient function (a normal, a traction vector, ...): one monomial per entry, each with its scalar function
+            out = []
+            for idx in numpy.ndindex(*node.shape):
+                A = numpy.zeros(node.shape)
+                A[idx] = 1.
+                out.append(_Mono(A, [('free', j) for j in range(node.ndim)], pw=[node[idx]]))
+            return out
+        raise Unmatched('large array-valued coefficient function of the point')
 
     def rebroadcast(self, m, node):
         '''a scalar monomial broadcast to the shape of `node`'''
@@ -791,7 +803,8 @@ class Emitter:
 
     # -- basis --
     def basis(self, basis, rational=None, sample=None):
-        key = (id(basis), None if rational is None else (id(rational[1]), id(sample)))
+        '''sample: (reference sample, plan sample index) for rational bases (their weight function is tabulated at its points)'''
+        key = (id(basis), None if rational is None else (id(rational[1]), id(sample[0]), sample[1]))
         if key in self._basis:
             return self._basis[key]
         self._keep.append(basis)
@@ -799,14 +812,18 @@ class Emitter:
             parent = self.basis(basis)
             w, Wnode = rational
             rf = self.M.rf
-            smp = sample
-            si = self.sample(smp, self.basis_transforms(basis))
-            ne, nq = self.plan['samples'][si]['_nl'], len(self.plan['samples'][si]['weights'])
-            if self.plan['samples'][si].get('elist') is not None or self.plan['samples'][si]['_nl'] != self.plan['samples'][si]['_ne']:
-                raise Unmatched('rational basis on a partial sample')
-            xi = rf.transforms_coords(smp.spaces[0], smp.transforms[0])
-            W = numpy.asarray(smp.eval(Wnode), dtype=float).reshape(ne, nq)
-            dW = numpy.asarray(smp.eval(rf.grad(Wnode, xi)), dtype=float).reshape(ne, nq, -1)
+            smp, si = sample
+            sspec = self.plan['samples'][si]
+            nl, nq, ne = sspec['_nl'], len(sspec['weights']), sspec['_ne']
+            xi = rf.transforms_coords(smp.spaces[0], self.basis_transforms(basis))  # coordinates of the parent element
+            nd = int(self.basis_transforms(basis).fromdims)
+            Wl = _point_values(smp, Wnode, sspec)
+            dWl = _point_values(smp, rf.grad(Wnode, xi), sspec, tail=(nd,))
+            if sspec.get('elist') is None:
+                W, dW = Wl, dWl
+            else:  # a sample on part of the topology (boundary faces): tables by element of the topology, the listed elements filled in
+                W, dW = numpy.ones((ne, nq)), numpy.zeros((ne, nq, nd))
+                W[sspec['elist']], dW[sspec['elist']] = Wl, dWl
             spec = dict(kind='rational', parent=parent, weights=numpy.asarray(w, dtype=float), W=W, dW=dW)
         else:
             spec = self.structured_basis(basis)
@@ -977,14 +994,14 @@ class Emitter:
         return self._arg[key]
 
 
-def _point_values(smp, node, s):
+def _point_values(smp, node, s, tail=()):
     v = numpy.asarray(smp.eval(node), dtype=float)
     nq = len(s['weights'])
     if '_pos' in s:
         npts = numpy.cumsum([0] + [smp.points[i].npoints for i in range(len(smp.points))])
         sel = numpy.concatenate([numpy.arange(npts[i], npts[i + 1]) for i in s['_pos']])
         v = v[sel]
-    return v.reshape(s['_nl'], nq)
+    return v.reshape((s['_nl'], nq) + tuple(tail))
 
 
 def match(array, arguments=None):
@@ -1068,10 +1085,17 @@ def match(array, arguments=None):
                 g = next(iter(gnodes.values()))
                 gg = gi if g is gnode else _geom_index(E, g, smp, si, home)
             term = dict(sample=si, fac=float(fac), measure=gi, geom=gg, test=-1, trial=-1, rows=False, cols=False, scale=None, fpoly=None)
+            def on_home(bi):  # every basis of a term must be indexed by the elements of the sample's topology (no field of a coarser level)
+                b = E.plan['bases'][bi]
+                while b['kind'] == 'rational':
+                    b = E.plan['bases'][b['parent']]
+                if b['topo'] != s['topo']:
+                    raise Unmatched('bases of different topologies in one term')
+                return bi
             ai = []
             for i in form:
                 f = facs[i]
-                bi = E.basis(f.basis, f.rational, smp if f.rational is not None else None)
+                bi = on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None))
                 ai.append(E.arg(f.name, bi, f.ncomp))
             if len(form) == 2:
                 Bt = numpy.ascontiguousarray(T)
@@ -1092,7 +1116,7 @@ def match(array, arguments=None):
                 pargs = []
                 for i in poly:
                     f = facs[i]
-                    a = E.arg(f.name, E.basis(f.basis, f.rational, smp if f.rational is not None else None), 1)
+                    a = E.arg(f.name, on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None)), 1)
                     pargs.append(a)
                 uniq = sorted(set(pargs))
                 term['fpoly'] = dict(args=uniq, powers=numpy.array([[pargs.count(a) for a in uniq]]), coeffs=[1.])
@@ -1240,6 +1264,8 @@ def install(executor=None):
                     raise Unmatched('empty integral')
             except Unmatched as e:
                 plan = e
+            except Exception as e:  # (an expression shape the matcher does not know must never break the user's script: reference path)
+                plan = Unmatched(f'{type(e).__name__}: {e}')
             hit = st['plans'][id(array)] = (array, plan)
         return hit[1]
 
@@ -1295,6 +1321,9 @@ def install(executor=None):
             sp = _SystemPlans(self, residual, self.trials, tests, ex)
         except Unmatched as e:
             st['fallback'].append(f'System: {e}')
+            return
+        except Exception as e:  # (see plan_of)
+            st['fallback'].append(f'System: {type(e).__name__}: {e}')
             return
         st['matched'].append('System')
         cache = self._System__cache
