@@ -424,6 +424,45 @@ __device__ __forceinline__ TaskD make_task(const Line &L, int u, int nt, int lan
   return d;
 }
 
+// form tensor + LDS reduction of one lane's (row node, column node) pair: G[a][b] = acc[b][a]; m = row record of the node (offset of its rows in the plane
+// buffer, scalar row length)
+template <int NC, int MODE>
+__device__ __forceinline__ void reduce_pair(const P2K &p, double *lds, const v4d (&acc)[3], const TaskD &d, int2 m, int cK0, int cK2, int dK0) {
+  const int ak = (d.info >> 1) & 3;
+  if ((d.info & 1) && !DBG(p, 2)) {
+    double Kcd[NC][NC];
+    if constexpr (MODE == 1) {  // C[c,a,d,b] = lam d_ca d_db + mu d_cd d_ab + mu2 d_cb d_ad over the three gradient slots
+      const double tr = p.mu * (acc[0][0] + acc[1][1] + acc[2][2]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int dd = 0; dd < NC; ++dd) Kcd[c][dd] = p.lam * acc[dd][c] + p.mu2 * acc[c][dd] + (c == dd ? tr : 0.);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int dd = 0; dd < NC; ++dd) {
+          double sum = 0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) sum += p.C[((c * 3 + a) * NC + dd) * 3 + b] * acc[b][a];
+          Kcd[c][dd] = sum;
+        }
+    }
+    // per-lane constants of the plane by masks (a select chain on ak is turned into a table in scratch by the compiler)
+    const int m1 = -(ak & 1), m2 = -(ak >> 1), m0 = ~(m1 | m2);
+    const int cK = cK0 + (m1 & (3 - cK0)) + (m2 & (cK2 - cK0));
+    const int pos = d.posIJ * cK + ((d.info >> 5) & 3) + (m0 & dK0);
+    double *row = lds + (m.x + pos * NC);
+    const int rs = m.y * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int dd = 0; dd < NC; ++dd) atomicAdd(row + c * rs + dd, Kcd[c][dd]);
+  }
+}
+
 // k-steps [K0, K1) of one (unit, column tile) product + the form tensor + the LDS reduction.
 // cK0 / cK2: columns along K of a row of plane 2k / 2k+2 (3 in a boundary plane, else 5; plane 2k+1: 3); dK0 = 2k - first column of
 // a row of plane 2k; m0 = meta slot of plane 2k
@@ -457,39 +496,7 @@ __device__ __forceinline__ void run_task(const P2K &p, double *lds, int cK0, int
       for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[b], acc[b], 0, 0, 0);
     }
   }
-  // this lane: G[a][b] = acc[b][a] of its (row node, column node) pair
-  if ((d.info & 1) && !DBG(p, 2)) {
-    double Kcd[NC][NC];
-    if constexpr (MODE == 1) {  // C[c,a,d,b] = lam d_ca d_db + mu d_cd d_ab + mu2 d_cb d_ad over the three gradient slots
-      const double tr = p.mu * (acc[0][0] + acc[1][1] + acc[2][2]);
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int dd = 0; dd < NC; ++dd) Kcd[c][dd] = p.lam * acc[dd][c] + p.mu2 * acc[c][dd] + (c == dd ? tr : 0.);
-    } else {
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int dd = 0; dd < NC; ++dd) {
-          double sum = 0;
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) sum += p.C[((c * 3 + a) * NC + dd) * 3 + b] * acc[b][a];
-          Kcd[c][dd] = sum;
-        }
-    }
-    // per-lane constants of the plane by masks (a select chain on ak is turned into a table in scratch by the compiler)
-    const int m1 = -(ak & 1), m2 = -(ak >> 1), m0 = ~(m1 | m2);
-    const int cK = cK0 + (m1 & (3 - cK0)) + (m2 & (cK2 - cK0));
-    const int pos = d.posIJ * cK + ((d.info >> 5) & 3) + (m0 & dK0);
-    double *row = lds + (m.x + pos * NC);
-    const int rs = m.y * NC;
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-      for (int dd = 0; dd < NC; ++dd) atomicAdd(row + c * rs + dd, Kcd[c][dd]);
-  }
+  reduce_pair<NC, MODE>(p, lds, acc, d, m, cK0, cK2, dK0);
 }
 
 // one thread: the records of the 4 nodes (ai, aj) of node plane K
@@ -973,6 +980,371 @@ __global__ __launch_bounds__(NTP4) void k_p2hex_pipe(P2K p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_p2hex_inreg: the MFMA operands are formed IN REGISTERS, no D tables.  Waves 0..3 (one per SIMD) own a (visit group, column tile) each: wave w takes
+// column tile w >> 1 of the elements of visits {0, 3} (w even: 3 + 1 units of 4 row nodes) or {1, 2} (w odd: 2 + 2 units) -- 84 MFMA per wave and slice, the
+// B operand of a k-step formed once and used by all units of the element.  Per k-step a lane reads ONE double of the point's record ([J^-1 sqrt(w |J|)] row
+// major, 12 doubles per point, lane li of the 16 lanes of a point reads entry li) and the products with the reference gradients of ITS column node (28 doubles
+// in registers for the whole kernel) take the multiplicand from lane N of the row: v_fmac_f64_dpp row_newbcast:N (tools/ubench/dpp_bcast.hip: the rate of a plain
+// v_fmac_f64).  The A operand (row node mu, slot a) reads column a of the record and the reference gradients of its node from a 25 kB table in LDS.  What the
+// D tables cost is gone: their build (2187 entries per element, four times per element), ~45 kB of LDS, and the barrier per ELEMENT that handed them over -- the
+// roles meet once per SLICE.  Waves 4..7: wave 4 + v evaluates the geometry of visit v one slice ahead (27 lanes: one per point; 8 lanes fetch the vertices
+// another slice ahead), all four stream the two planes finished in the previous slice (256 threads, 13 pair slots per thread for NC = 3).
+// sqrt(w |J|) is folded into J^-1 (both operands carry it): forms with a signed scale array keep k_p2hex_pipe.
+constexpr int RJ = 12;                       // doubles per point record: [0..8] J^-1[j][i] sqrt(w |J|) at 3 j + i, [9] sqrt(w |J|), [10], [11] zero
+constexpr int RJSZ = 4 * PNQ * RJ;           // one slice: [visit][point]
+constexpr int RTSZ = 28 * PNQ * 4;           // reference table of the A side: [node (27: zero row)][point][dN/dxi_0, dN/dxi_1, dN/dxi_2, N]
+template <int NC>
+struct PR {  // the D-table and J regions of PL hold the two record buffers and the A-side table
+  static constexpr int JV = PL<NC>::DT, TT = JV + 2 * RJSZ;
+  static_assert(TT + RTSZ <= PL<NC>::META, "LDS layout");
+};
+
+template <int N>
+__device__ __forceinline__ void fmac_bc(double &acc, double x, double t) {  // acc += (x of lane N of this lane's row of 16) * t
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(t), "n"(N));
+}
+
+// B operand of the three active slots S0 .. S0 + 2 of this lane's column node at its point: tb = {N, dN/dxi_0..2}, xr = this lane's entry of the point record
+template <int S0>
+__device__ __forceinline__ void form_B(double xr, const double (&tb)[4], double (&B)[3]) {
+  B[0] = B[1] = B[2] = 0.;
+  if constexpr (S0 == 1) {
+    fmac_bc<0>(B[0], xr, tb[1]); fmac_bc<1>(B[1], xr, tb[1]); fmac_bc<2>(B[2], xr, tb[1]);
+    fmac_bc<3>(B[0], xr, tb[2]); fmac_bc<4>(B[1], xr, tb[2]); fmac_bc<5>(B[2], xr, tb[2]);
+    fmac_bc<6>(B[0], xr, tb[3]); fmac_bc<7>(B[1], xr, tb[3]); fmac_bc<8>(B[2], xr, tb[3]);
+  } else {
+    fmac_bc<9>(B[0], xr, tb[0]);
+    fmac_bc<0>(B[1], xr, tb[1]); fmac_bc<1>(B[2], xr, tb[1]);
+    fmac_bc<3>(B[1], xr, tb[2]); fmac_bc<4>(B[2], xr, tb[2]);
+    fmac_bc<6>(B[1], xr, tb[3]); fmac_bc<7>(B[2], xr, tb[3]);
+  }
+  // a VALU f64 write needs two wait states before a v_mfma_f64 reads the register (tools/ubench/dpp_mfma_hazard.hip); the compiler inserts them for the
+  // instructions it knows, not for the inline assembly above
+  asm("s_nop 1" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]));
+}
+
+struct LaneK {   // per-lane constants of the operand fetch
+  int xoff;      // entry of the point record this lane holds for the broadcasts
+  int aoff[3];   // entries J^-1[j][a] of the A side (value-slot lanes: a zero entry)
+  int awoff;     // S0 = 0: sqrt(w |J|) for the value-slot lanes, a zero entry for the others
+};
+
+// all units of one element for one column tile: 7 k-steps, then form tensor + LDS reduction of every unit
+template <int NC, int S0, int MODE, int NU>
+__device__ __forceinline__ void element_task(const P2K &p, double *lds, const double *jv, const double (&TB)[PKS][4], const LaneK &lc, const int (&taoff)[NU],
+                                             const TaskD (&d)[NU], int cK0, int cK2, int dK0, int m0s) {
+  int2 m[NU];  // where the rows live: read ahead of the MFMA chain
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int ak = (d[u].info >> 1) & 3, j = (d[u].info >> 3) & 3;
+    m[u] = *reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(lds + PL<NC>::META) + ((((m0s + ak) & 7) * 4 + j) * 2));
+  }
+  v4d acc[NU][3];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[u][b] = v4d{0., 0., 0., 0.};
+  const double *TT = lds + PR<NC>::TT;
+  struct Ops {
+    double xr, ac[3], aw;
+    v2d ta[NU][2];
+  };
+  auto fetch = [&](int ks, Ops &o) {
+    const double *r = jv + ks * (4 * RJ);
+    o.xr = r[lc.xoff];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o.ac[j] = r[lc.aoff[j]];
+    o.aw = S0 == 0 ? r[lc.awoff] : 0.;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      o.ta[u][0] = *reinterpret_cast<const v2d *>(TT + taoff[u] + ks * 16);
+      o.ta[u][1] = *reinterpret_cast<const v2d *>(TT + taoff[u] + ks * 16 + 2);
+    }
+  };
+  if (!DBG(p, 4)) {
+    Ops cur, nxt;
+    fetch(0, cur);
+    asm volatile("s_nop 4");  // (exec written by the branch above -> first DPP read)
+#pragma unroll
+    for (int ks = 0; ks < PKS; ++ks) {
+      if (ks + 1 < PKS) fetch(ks + 1, nxt);  // operands of the next k-step are in flight while the matrix pipe works
+      double B[3], A[NU];
+      form_B<S0>(cur.xr, TB[ks], B);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        A[u] = cur.ta[u][0][0] * cur.ac[0] + cur.ta[u][0][1] * cur.ac[1] + cur.ta[u][1][0] * cur.ac[2];
+        if constexpr (S0 == 0) A[u] += cur.ta[u][1][1] * cur.aw;
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[u][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[u], B[b], acc[u][b], 0, 0, 0);
+      if (ks + 1 < PKS) cur = nxt;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) reduce_pair<NC, MODE>(p, lds, acc[u], d[u], m[u], cK0, cK2, dK0);
+}
+
+// offset (doubles) in the A-side table of the entry of this lane's A row (node mu = li & 3 of unit u of visit V, slot li >> 2) at the point of k-step 0
+template <int V>
+__device__ __forceinline__ int ta_offset(int u, int lane) {
+  const int lk = lane >> 4, li = lane & 15;
+  int ai, aj, ak;
+  const bool ok = unit_node<V>(u, li & 3, ai, aj, ak) && (li >> 2) < 3;
+  const int node = ok ? (ai * 3 + aj) * 3 + ak : 27;
+  return (node * PNQ + lk) * 4;
+}
+
+template <int NC, int S0, int MODE, int VA, int NUA, int VB, int NUB>
+__device__ __forceinline__ void inreg_mfma_lines(const P2K &p, double *lds, const double (&TB)[PKS][4], const LaneK &lc, int nt, int lane) {
+  const int lk = lane >> 4;
+  int taA[NUA], taB[NUB];
+#pragma unroll
+  for (int u = 0; u < NUA; ++u) taA[u] = ta_offset<VA>(u, lane);
+#pragma unroll
+  for (int u = 0; u < NUB; ++u) taB[u] = ta_offset<VB>(u, lane);
+  const int nlines = (p.io1 - p.io0 + 1) * (p.n1 + 1);
+  for (int line = blockIdx.x; line < nlines; line += gridDim.x) {
+    const Line L = make_line(p, line);
+    if (!L.vmask) continue;
+    TaskD dA[NUA], dB[NUB];
+#pragma unroll
+    for (int u = 0; u < NUA; ++u) dA[u] = make_task<VA>(L, u, nt, lane);
+#pragma unroll
+    for (int u = 0; u < NUB; ++u) dB[u] = make_task<VB>(L, u, nt, lane);
+    const bool hasA = (L.vmask >> VA) & 1, hasB = (L.vmask >> VB) & 1;
+    lds_barrier();  // the last planes of the previous line are out
+    lds_barrier();  // records and geometry of slice 0
+#pragma unroll 1
+    for (int k = 0; k < p.n2; ++k) {
+      const int cK0 = ax_cnt(2 * k, p.n2), cK2 = ax_cnt(2 * k + 2, p.n2), dK0 = k > 0 ? 2 : 0, m0s = (2 * k) & 7;
+      const double *jvs = lds + PR<NC>::JV + (k & 1) * RJSZ + lk * RJ;
+      if (hasA) element_task<NC, S0, MODE, NUA>(p, lds, jvs + VA * PNQ * RJ, TB, lc, taA, dA, cK0, cK2, dK0, m0s);
+      if (hasB) element_task<NC, S0, MODE, NUB>(p, lds, jvs + VB * PNQ * RJ, TB, lc, taB, dB, cK0, cK2, dK0, m0s);
+      lds_barrier();
+    }
+  }
+}
+
+template <int NC, int S0, int MODE>
+__device__ __forceinline__ void inreg_mfma_role(const P2K &p, double *lds, int wave, int lane) {
+  const int lk = lane >> 4, li = lane & 15, nt = wave >> 1;
+  double TB[PKS][4];  // reference values of this lane's column node at its point of every k-step
+  {
+    const int n = nt * 16 + li;
+#pragma unroll
+    for (int ks = 0; ks < PKS; ++ks) {
+      const int q = 4 * ks + lk;
+      const bool ok = n < NB && q < p.nq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) TB[ks][i] = ok ? p.T[((i64)n * p.nq + q) * 4 + i] : 0.;
+    }
+    // (pinned: loads without a use stay pending for the wait-count bookkeeping)
+#pragma unroll
+    for (int ks = 0; ks < PKS; ++ks)
+#pragma unroll
+      for (int i = (S0 == 1 ? 1 : 0); i < 4; ++i) asm volatile("" : "+v"(TB[ks][i]));
+  }
+  LaneK lc;
+  {
+    const int aslot = li >> 2;
+    lc.xoff = li < RJ ? li : RJ - 1;
+    if constexpr (S0 == 1) {
+      const int col = aslot < 3 ? aslot : 0;  // (rows of slot 3: the table row of node 27 is zero)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) lc.aoff[j] = 3 * j + col;
+      lc.awoff = 10;
+    } else {
+      const bool val = aslot == 0;
+      const int col = aslot == 2 ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) lc.aoff[j] = val ? 10 : 3 * j + col;
+      lc.awoff = val ? 9 : 10;
+    }
+  }
+  if (wave & 1) inreg_mfma_lines<NC, S0, MODE, 1, 2, 2, 2>(p, lds, TB, lc, nt, lane);
+  else inreg_mfma_lines<NC, S0, MODE, 0, 3, 3, 1>(p, lds, TB, lc, nt, lane);
+}
+
+// pair slots per thread (256 threads) of node block b of a pair of planes: blocks 0..3 the even plane, 4..7 the odd one; interior row lengths are the maxima
+__host__ __device__ constexpr int inreg_ub(int b, int nc) {
+  constexpr int LEN[8] = {125, 75, 75, 45, 75, 45, 45, 27};
+  return ((LEN[b] * nc * nc + 1) / 2 + 1 + 255) / 256;
+}
+
+// stream the finished rows of node blocks 0 .. NBLK - 1 of planes K0 (blocks 0..3) and K0 + 1 (4..7) to the value array and zero them in the buffers; thread t of 256.
+// As flush_blocks, with the slot count of every block fitted to its size.
+template <int NC, int NBLK>
+__device__ __forceinline__ void inreg_flush(const P2K &p, double *lds, int K0, int t) {
+  if (DBG(p, 128)) return;
+  const int *meta = reinterpret_cast<const int *>(lds + PL<NC>::META);
+  const i64 *gm = reinterpret_cast<const i64 *>(lds + PL<NC>::META + 64);
+  int2 f[NBLK];
+  i64 g[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int s = ((K0 + (b >> 2)) & 7) * 4 + (b & 3);
+    f[b] = *reinterpret_cast<const int2 *>(meta + 64 + s * 2);
+    g[b] = gm[s];
+  }
+  constexpr int UBM = inreg_ub(0, NC);
+  v2d v[NBLK][UBM];
+  double hv[NBLK], tv[NBLK];
+  auto grab = [](double *q) { return __hip_atomic_exchange(q, 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int first = __builtin_amdgcn_readfirstlane(f[b].x), w = __builtin_amdgcn_readfirstlane(f[b].y);
+    const int np = w & 0x3fffffff;
+    double *lp = lds + first;
+#pragma unroll
+    for (int u = 0; u < UBM; ++u)
+      if (u < inreg_ub(b, NC) && t + u * 256 < np) v[b][u] = v2d{grab(lp + 2 * (t + u * 256)), grab(lp + 2 * (t + u * 256) + 1)};
+    if (t == 0 && (w & (1 << 30))) hv[b] = grab(lds + first - 1);
+    if (t == 1 && (w < 0)) tv[b] = grab(lds + first + 2 * np);
+  }
+  if (DBG(p, 1)) return;
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) {
+    const int w = __builtin_amdgcn_readfirstlane(f[b].y);
+    const int np = w & 0x3fffffff, head = (w >> 30) & 1;
+    const i64 goff = ((i64)__builtin_amdgcn_readfirstlane((int)(g[b] >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g[b]);
+    double *gb = p.values + goff + head;
+    v2d *gp = reinterpret_cast<v2d *>(gb);
+#pragma unroll
+    for (int u = 0; u < UBM; ++u)
+      if (u < inreg_ub(b, NC) && t + u * 256 < np) gp[t + u * 256] = v[b][u];
+    if (t == 0 && head) gb[-1] = hv[b];
+    if (t == 1 && (w < 0)) gb[2 * np] = tv[b];
+  }
+}
+
+// waves 4..7: wave 4 + V evaluates the geometry of visit V one slice ahead; all stream the planes finished in the previous slice
+template <int NC>
+__device__ __forceinline__ void inreg_service_role(const P2K &p, double *lds, int V, int lane) {
+  const int st = V * 64 + lane, nq = p.nq;
+  const bool fast = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == 8 && !p.geom.nograd && p.geom.bnd_axis < 0;
+  const bool gok = lane < nq;
+  double dN[8][3], wq = 0.;
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dN[a][j] = 0.;
+  if (gok) {
+    if (fast) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dN[a][j] = p.geom.gT[((i64)a * nq + lane) * 4 + 1 + j];
+    }
+    wq = p.weights[lane];
+  }
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(dN[a][j]));
+  asm volatile("" : "+v"(wq));
+  double *XV = lds + PL<NC>::XV + V * 32;  // [8 vertices][4]: staged vertex coordinates of this wave's element
+  const int nlines = (p.io1 - p.io0 + 1) * (p.n1 + 1);
+  for (int line = blockIdx.x; line < nlines; line += gridDim.x) {
+    const Line L = make_line(p, line);
+    if (!L.vmask) continue;
+    const LineMeta LM = make_line_meta<NC>(L);
+    const bool has = (L.vmask >> V) & 1;
+    const i64 ecol = ((i64)(L.io - (V >> 1)) * p.n1 + (L.jo - (V & 1))) * p.n2;
+    const bool vlane = fast && has && lane >= 32 && lane < 40;
+    double X0 = 0., X1 = 0., X2 = 0.;
+    auto fetch_vertices = [&](int k) {
+      if (vlane && k < p.n2) {
+        const i64 idx = p.geom.gdofs[(ecol + k) * 8 + (lane - 32)];
+        X0 = p.geom.verts[idx * 3];
+        X1 = p.geom.verts[idx * 3 + 1];
+        X2 = p.geom.verts[idx * 3 + 2];
+      }
+    };
+    auto geometry = [&](int k) {  // records of the points of element (V, k)
+      if (!has || DBG(p, 16)) return;
+      double Ji[3][3], det;
+      if (fast) {
+        if (vlane) {
+          double *o = XV + (lane - 32) * 4;
+          *reinterpret_cast<v2d *>(o) = v2d{X0, X1};
+          o[2] = X2;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (same wave writes and reads: no barrier)
+        if (!gok) return;
+        double J[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) J[i][j] = 0.;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const v2d x01 = *reinterpret_cast<const v2d *>(XV + a * 4);
+          const double x[3] = {x01[0], x01[1], XV[a * 4 + 2]};
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) J[i][j] += x[i] * dN[a][j];
+        }
+        invert<3>(J, Ji, det);
+      } else {
+        if (!gok) return;
+        geometry_at<3>(p.geom, ecol + k, lane, nq, nullptr, Ji, det, nullptr);
+      }
+      const double sq = sqrt(wq * fabs(det));
+      double *o = lds + PR<NC>::JV + (k & 1) * RJSZ + (V * PNQ + lane) * RJ;
+      *reinterpret_cast<v2d *>(o) = v2d{Ji[0][0] * sq, Ji[0][1] * sq};
+      *reinterpret_cast<v2d *>(o + 2) = v2d{Ji[0][2] * sq, Ji[1][0] * sq};
+      *reinterpret_cast<v2d *>(o + 4) = v2d{Ji[1][1] * sq, Ji[1][2] * sq};
+      *reinterpret_cast<v2d *>(o + 6) = v2d{Ji[2][0] * sq, Ji[2][1] * sq};
+      *reinterpret_cast<v2d *>(o + 8) = v2d{Ji[2][2] * sq, sq};
+    };
+    lds_barrier();  // (the last planes of the previous line are out: their records may go)
+    if (V == 0 && lane < 12) pipe_meta_node<NC>(p, LM, lds, lane >> 2, lane & 3);
+    fetch_vertices(0);
+    geometry(0);
+    fetch_vertices(1);  // (in flight during slice 0)
+    lds_barrier();
+#pragma unroll 1
+    for (int k = 0; k < p.n2; ++k) {
+      if (k + 1 < p.n2) {
+        geometry(k + 1);
+        fetch_vertices(k + 2);
+        if (V == 0 && lane < 8 && !DBG(p, 64)) pipe_meta_node<NC>(p, LM, lds, 2 * k + 3 + (lane >> 2), lane & 3);
+      }
+      if (k > 0) inreg_flush<NC, 8>(p, lds, 2 * k - 2, st);
+      lds_barrier();
+    }
+    inreg_flush<NC, 8>(p, lds, 2 * p.n2 - 2, st);
+    inreg_flush<NC, 4>(p, lds, 2 * p.n2, st);
+  }
+}
+
+template <int NC, int S0, int MODE>
+__global__ __launch_bounds__(NTP4) void k_p2hex_inreg(P2K p) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // row buffers are re-zeroed by the flush; the records of the pad points stay zero
+  for (int i = tid; i < PR<NC>::TT; i += NTP4) lds[i] = 0.;
+  for (int i = tid; i < 28 * PNQ; i += NTP4) {
+    const int node = i / PNQ, q = i - node * PNQ;
+    const bool ok = node < NB && q < p.nq;
+    const double *Tp = p.T + ((i64)(ok ? node : 0) * p.nq + (ok ? q : 0)) * 4;
+    double *o = lds + PR<NC>::TT + i * 4;
+    *reinterpret_cast<v2d *>(o) = ok ? v2d{Tp[1], Tp[2]} : v2d{0., 0.};
+    *reinterpret_cast<v2d *>(o + 2) = ok ? v2d{Tp[3], Tp[0]} : v2d{0., 0.};
+  }
+  for (int i = PL<NC>::META + tid; i < PL<NC>::END; i += NTP4) lds[i] = 0.;
+  if (wave < 4) {
+    inreg_mfma_role<NC, S0, MODE>(p, lds, wave, lane);
+    return;
+  }
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
+  inreg_service_role<NC>(p, lds, wave - 4, lane);
+}
+
 // closed-form CSR index arrays: one wave per node, rows (node, c) of length len * NC, columns (colnode, d) lexicographic
 __global__ __launch_bounds__(256) void k_p2hex_pattern(int n0, int n1, int n2, int nc, i64 *rowptr, i64 *colidx) {
   const i64 N1 = 2 * n1 + 1, N2 = 2 * n2 + 1, nnodes = (2 * (i64)n0 + 1) * N1 * N2;
@@ -996,8 +1368,8 @@ __global__ __launch_bounds__(256) void k_p2hex_pattern(int n0, int n1, int n2, i
 }
 
 template <int NC, int S0, int MODE>
-hipError_t launch_pipe(unsigned grid, size_t ldsb, hipStream_t s, const P2K &p) {
-  auto kern = k_p2hex_pipe<NC, S0, MODE>;
+hipError_t launch_pipe(unsigned grid, size_t ldsb, hipStream_t s, const P2K &p, bool inreg) {
+  auto kern = inreg ? k_p2hex_inreg<NC, S0, MODE> : k_p2hex_pipe<NC, S0, MODE>;
   hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTP4), ldsb, s, p);
@@ -1094,7 +1466,9 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   auto lds_lock = [&](int ndb) { return fixed + sizeof(double) * ((size_t)ndb * p.dsz + 4 * p.nq * 10); };
   bool pipe = NS == 3 && p.ks == PKS && lds_pipe <= 160 * 1024;
   p.prio = 1;
+  bool inreg = pipe && !a->scale_dev;  // sqrt(w |J|) on both operands: not with a signed scale array
 #ifdef NH_ABLATION  // A/B switches of the ablation build only
+  if (getenv("NH_P2HEX_PIPE") && atoi(getenv("NH_P2HEX_PIPE"))) inreg = false;
   if (getenv("NH_P2HEX_LOCKSTEP") && atoi(getenv("NH_P2HEX_LOCKSTEP"))) pipe = false;
   if (getenv("NH_P2HEX_PRIO")) p.prio = atoi(getenv("NH_P2HEX_PRIO"));
 #endif
@@ -1122,9 +1496,9 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   do {                                                                                                                                \
     if (pipe) {                                                                                                                       \
       if (S0)                                                                                                                         \
-        NH_CHECK_HIP((launch_pipe<NC, 1, MODE>(grid, ldsb, s, p)));                                                                   \
+        NH_CHECK_HIP((launch_pipe<NC, 1, MODE>(grid, ldsb, s, p, inreg)));                                                                   \
       else                                                                                                                            \
-        NH_CHECK_HIP((launch_pipe<NC, 0, 0>(grid, ldsb, s, p)));                                                                      \
+        NH_CHECK_HIP((launch_pipe<NC, 0, 0>(grid, ldsb, s, p, inreg)));                                                                      \
     } else {                                                                                                                          \
       NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_p2hex<NC, NS_, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));  \
       hipLaunchKernelGGL((k_p2hex<NC, NS_, MODE>), dim3(grid), dim3(NT), ldsb, s, p);                                                 \
