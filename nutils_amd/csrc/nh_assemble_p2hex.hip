@@ -436,7 +436,10 @@ __device__ __forceinline__ void reduce_pair(const P2K &p, double *lds, const v4d
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int dd = 0; dd < NC; ++dd) Kcd[c][dd] = p.lam * acc[dd][c] + p.mu2 * acc[c][dd] + (c == dd ? tr : 0.);
+        for (int dd = 0; dd < NC; ++dd) {
+          Kcd[c][dd] = p.lam * acc[dd][c] + p.mu2 * acc[c][dd];
+          if (c == dd) Kcd[c][dd] += tr;  // (not "+ (c == dd ? tr : 0.)": x + 0. is an instruction, -0. + 0. = +0.)
+        }
     } else {
 #pragma unroll
       for (int c = 0; c < NC; ++c)
@@ -1100,6 +1103,9 @@ __device__ __forceinline__ int ta_offset(int u, int lane) {
 template <int NC, int S0, int MODE, int VA, int NUA, int VB, int NUB>
 __device__ __forceinline__ void inreg_mfma_lines(const P2K &p, double *lds, const double (&TB)[PKS][4], const LaneK &lc, int nt, int lane) {
   const int lk = lane >> 4;
+#ifdef NH_ABLATION
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
   int taA[NUA], taB[NUB];
 #pragma unroll
   for (int u = 0; u < NUA; ++u) taA[u] = ta_offset<VA>(u, lane);
@@ -1123,9 +1129,16 @@ __device__ __forceinline__ void inreg_mfma_lines(const P2K &p, double *lds, cons
       const double *jvs = lds + PR<NC>::JV + (k & 1) * RJSZ + lk * RJ;
       if (hasA) element_task<NC, S0, MODE, NUA>(p, lds, jvs + VA * PNQ * RJ, TB, lc, taA, dA, cK0, cK2, dK0, m0s);
       if (hasB) element_task<NC, S0, MODE, NUB>(p, lds, jvs + VB * PNQ * RJ, TB, lc, taB, dB, cK0, cK2, dK0, m0s);
+      TICK(0);
       lds_barrier();
+      TICK(1);
     }
+    TICK(7);
   }
+#ifdef NH_ABLATION
+  if (p.tdbg && lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)p.tdbg + i, (unsigned long long)tacc[i]);
+#endif
 }
 
 template <int NC, int S0, int MODE>
@@ -1246,6 +1259,9 @@ __device__ __forceinline__ void inreg_service_role(const P2K &p, double *lds, in
     for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(dN[a][j]));
   asm volatile("" : "+v"(wq));
   double *XV = lds + PL<NC>::XV + V * 32;  // [8 vertices][4]: staged vertex coordinates of this wave's element
+#ifdef NH_ABLATION
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
   const int nlines = (p.io1 - p.io0 + 1) * (p.n1 + 1);
   for (int line = blockIdx.x; line < nlines; line += gridDim.x) {
     const Line L = make_line(p, line);
@@ -1314,12 +1330,20 @@ __device__ __forceinline__ void inreg_service_role(const P2K &p, double *lds, in
         fetch_vertices(k + 2);
         if (V == 0 && lane < 8 && !DBG(p, 64)) pipe_meta_node<NC>(p, LM, lds, 2 * k + 3 + (lane >> 2), lane & 3);
       }
+      TICK(3);
       if (k > 0) inreg_flush<NC, 8>(p, lds, 2 * k - 2, st);
+      TICK(4);
       lds_barrier();
+      TICK(5);
     }
     inreg_flush<NC, 8>(p, lds, 2 * p.n2 - 2, st);
     inreg_flush<NC, 4>(p, lds, 2 * p.n2, st);
+    TICK(2);
   }
+#ifdef NH_ABLATION
+  if (p.tdbg && lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)p.tdbg + 8 + i, (unsigned long long)tacc[i]);
+#endif
 }
 
 template <int NC, int S0, int MODE>
@@ -1369,7 +1393,10 @@ __global__ __launch_bounds__(256) void k_p2hex_pattern(int n0, int n1, int n2, i
 
 template <int NC, int S0, int MODE>
 hipError_t launch_pipe(unsigned grid, size_t ldsb, hipStream_t s, const P2K &p, bool inreg) {
-  auto kern = inreg ? k_p2hex_inreg<NC, S0, MODE> : k_p2hex_pipe<NC, S0, MODE>;
+  auto kern = k_p2hex_pipe<NC, S0, MODE>;
+  // (three components with the value slot and a dense form tensor: the in-register variant spills, the table kernel keeps it)
+  if constexpr (!(NC == 3 && S0 == 0))
+    if (inreg) kern = k_p2hex_inreg<NC, S0, MODE>;
   hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTP4), ldsb, s, p);
@@ -1518,7 +1545,13 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
 #undef LAUNCH
   NH_LAUNCH_CHECK();
 #ifdef NH_ABLATION
-  if (p.tdbg && pipe) {
+  if (p.tdbg && inreg) {
+    static long long h[16 + 1024];
+    NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
+    const double g = grid * 4.;
+    fprintf(stderr, "p2hex_inreg cycles per wave: MFMA waves: tasks %.0f + barrier %.0f + line setup %.0f | service waves: geometry %.0f, flush %.0f + barrier %.0f, line end / start %.0f\n",
+            h[0] / g, h[1] / g, h[7] / g, h[8 + 3] / g, h[8 + 4] / g, h[8 + 5] / g, h[8 + 2] / g);
+  } else if (p.tdbg && pipe) {
     static long long h[16 + 1024];
     NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
     const double g = grid;

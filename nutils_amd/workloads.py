@@ -227,7 +227,7 @@ class ElasticityP2:
         self.n, self.rank, self.world, self.variant, self.seed = int(n), int(rank), int(world), variant, seed
         self.layers = int(layers) if layers else self.n
         self.C = self.form_tensor(lam, mu)
-        self.kernel_name = 'k_p2hex_pipe<3,1,1>'
+        self.kernel_name = 'k_p2hex_inreg<3,1,1>'
         self.slab = partition.Slab(self.layers, self.rank, self.world, shape_jk=(self.n, self.n), degree=2, ncomp=3)
 
     @staticmethod

@@ -7,5 +7,5 @@ python tools/rocpd_summary.py $(find gpurun_out/prof_r3_final -name "*results.db
 tail -c 1500 gpurun_out/prof_r3_final.json
 for c in FETCH_SIZE WRITE_SIZE; do
   bash tools/pmc.sh r3c2_$c $c -- python tools/c2_time.py 2>&1 | grep -A3 "k_p1hex_skew"
-  bash tools/pmc.sh r3c3_$c $c -- python tools/c3_bench.py 64 5 2>&1 | grep -A3 "k_p2hex_pipe"
+  bash tools/pmc.sh r3c3_$c $c -- python tools/c3_bench.py 64 5 2>&1 | grep -A3 "k_p2hex_inreg"
 done
