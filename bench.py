@@ -48,7 +48,7 @@ def parse():
     ap.add_argument('--n', '--elements-per-axis', dest='n', type=int, default=None,
                     help='elements per axis (per GPU with weak scaling; use the long form behind torch.distributed.run, whose parser claims --n)')
     ap.add_argument('--variant', choices=['iso', 'uniform'], default='iso')
-    ap.add_argument('--kernel', choices=['auto', 'generic', 'gather', 'batched', 'fast'], default='auto')
+    ap.add_argument('--kernel', choices=['auto', 'generic', 'gather', 'fused', 'batched', 'fast'], default='auto')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-c3', action='store_true', help='skip the configs[2] variant of the default line')
     ap.add_argument('--no-graph', dest='graph', action='store_false', help='launch every step eagerly instead of replaying a captured HIP graph')
@@ -430,9 +430,24 @@ def main():
                 b3 = w3.algorithmic_bytes_per_element()
                 out['variants']['generic_gather'] = {'value': w3.nelems * nst / el3, 'unit': 'elements/s', 'ms_per_step': el3 / nst * 1e3, 'kernel': w3.kernel_name,
                                                      'kernel_ms': kms3, 'hbm_frac': b3 * w3.nelems / (kms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                     'algorithmic_bytes_per_element': b3,
+                                                     'algorithmic_bytes_per_element': b3, 'traffic': measured_traffic(w3.kernel_name, a.n),
                                                      'note': 'nh_assemble_matrix with NH_MATRIX_GATHER | NH_MATRIX_STORE; bit-reproducible'}
                 del w3
+                torch.cuda.empty_cache()
+                # ... and through the owner blocks of NH_MATRIX_FUSED: one pass, no scratch, no global atomics (not bit-reproducible)
+                w5 = workloads.PoissonSlab(n=a.n, rank=0, world=1, variant='iso', kernel='fused')
+                w5.setup()
+                w5.build_pattern()
+                for _ in range(20):
+                    w5.step()
+                torch.cuda.synchronize()
+                el5, kms5, _ = timed_steps(w5, nst, 1, None, False)
+                out['variants']['generic_fused'] = {'value': w5.nelems * nst / el5, 'unit': 'elements/s', 'ms_per_step': el5 / nst * 1e3, 'kernel': w5.kernel_name,
+                                                    'kernel_ms': kms5, 'hbm_frac': b3 * w5.nelems / (kms5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                    'algorithmic_bytes_per_element': b3, 'traffic': measured_traffic(w5.kernel_name, a.n),
+                                                    'owner_blocks': dict(zip(('blocks', 'rows_per_block', 'element_visits'), w5.pattern.fused_info())),
+                                                    'note': 'nh_assemble_matrix with NH_MATRIX_FUSED | NH_MATRIX_STORE'}
+                del w5
                 torch.cuda.empty_cache()
             if not a.no_c3 and a.n == 128:
                 # BASELINE.json configs[2] in the same run: 64^3 P2 vector elasticity through nh_p2hex_matrix (its own line: --config c3)

@@ -646,8 +646,8 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   NH_REQUIRE(a, "nh_assemble_matrix: NULL args");
   NH_REQUIRE(a->ndims >= 1 && a->ndims <= 3, "ndims must be 1..3");
   NH_REQUIRE(a->nq >= 1 && a->weights_dev, "quadrature missing");
-  NH_REQUIRE((a->flags & ~(NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_NO_MFMA | NH_MATRIX_FIRST_TOUCH | NH_MATRIX_GATHER | NH_MATRIX_STORE)) == 0,
-             "nh_assemble_matrix: unknown flag bits 0x%x", a->flags & ~(NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_NO_MFMA | NH_MATRIX_FIRST_TOUCH | NH_MATRIX_GATHER | NH_MATRIX_STORE));
+  constexpr int known_flags = NH_MATRIX_EXCLUSIVE | NH_MATRIX_EMAP_BY_ELEMENT | NH_MATRIX_NO_MFMA | NH_MATRIX_FIRST_TOUCH | NH_MATRIX_GATHER | NH_MATRIX_STORE | NH_MATRIX_FUSED;
+  NH_REQUIRE((a->flags & ~known_flags) == 0, "nh_assemble_matrix: unknown flag bits 0x%x", a->flags & ~known_flags);
   NH_REQUIRE(a->C_host && a->srowptr_dev && a->emap_dev && a->values_dev, "nh_assemble_matrix: NULL coefficient / pattern / values");
   NH_REQUIRE(a->test.T_dev && a->test.dofs_dev && a->trial.T_dev && a->trial.dofs_dev, "basis tables missing");
   int rc = check_geom(a->geom);
@@ -707,7 +707,18 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   p.local = nullptr;
   const bool gather = (a->flags & NH_MATRIX_GATHER) != 0;
   i64 local_ld = 0;  // > 0: the scratch is entry-major, local[(m * nbr + n) * ld + list position] (thread-per-element kernel)
-  NH_REQUIRE(gather || !(a->flags & NH_MATRIX_STORE), "NH_MATRIX_STORE is an option of NH_MATRIX_GATHER");
+  const bool fused = (a->flags & NH_MATRIX_FUSED) != 0;
+  NH_REQUIRE(gather || fused || !(a->flags & NH_MATRIX_STORE), "NH_MATRIX_STORE is an option of NH_MATRIX_GATHER / NH_MATRIX_FUSED");
+  if (fused) {  // owner blocks: one pass, no scratch, no global atomics
+    NH_REQUIRE(!gather && !(a->flags & (NH_MATRIX_EXCLUSIVE | NH_MATRIX_FIRST_TOUCH)), "NH_MATRIX_FUSED excludes NH_MATRIX_GATHER / EXCLUSIVE / FIRST_TOUCH");
+    bool done = false;
+    if ((rc = nh_fused_scalar(a, &done, nh_stream(stream))) != NH_OK) return rc;
+    if (done) return NH_OK;
+    if (a->flags & NH_MATRIX_STORE) {  // not applicable to this launch: the default path adds, so the block starts from zero
+      NH_REQUIRE(a->pattern && a->nct == 1 && a->ncr == 1, "NH_MATRIX_FUSED | NH_MATRIX_STORE: scalar blocks with a pattern handle only");
+      NH_CHECK_HIP(hipMemsetAsync(a->values_dev, 0, sizeof(double) * (size_t)a->pattern->nnz, nh_stream(stream)));
+    }
+  }
   if (gather) {
     NH_REQUIRE(a->pattern && a->pattern->nelems == a->nelems && !(a->flags & (NH_MATRIX_EXCLUSIVE | NH_MATRIX_FIRST_TOUCH)) && !(a->elist_dev && (a->flags & NH_MATRIX_EMAP_BY_ELEMENT)),
                "NH_MATRIX_GATHER needs the pattern handle and all of its elements in one call");

@@ -82,6 +82,22 @@ static inline BasisK to_k(const nh_basis &b) { return BasisK{b.nb, b.T_dev, b.do
 
 // sparsity pattern handle (nh_pattern.hip owns it; the element kernels read the size classes of ragged bases from it)
 constexpr int NH_MAX_BUCKETS = 9;
+// owner blocks of NH_MATRIX_FUSED (nh_gather.hip): rows clustered into blocks whose CSR rows fit the LDS of a workgroup; a block recomputes every element
+// that touches one of its rows and writes its rows once
+struct nh_fused_plan {
+  int nblocks, rows_per_block;
+  int max_blen;       // doubles of the largest block accumulator
+  i64 nvisits;
+  int32_t *order;     // [nrows]: dof at rank position i (block b = positions b * rows_per_block ...)
+  int32_t *loff;      // [nrows], by rank position: offset of the row in the accumulator of its block
+  i64 *rstart;        // [nrows], by rank position: first entry of the row in the value array
+  int32_t *blen;      // [nblocks]: doubles of the block's accumulator
+  i64 *vptr;          // [nblocks + 1]: visits of block b
+  int32_t *vlist;     // [nvisits]: element
+  uint16_t *vrow;     // [nvisits][nbt]: accumulator offset of the row of local function m, 0xffff: the row belongs to another block
+  uint8_t *cpos;      // [nelems][nbt * nbr]: position of entry (m, n) within its CSR row
+};
+
 struct nh_pattern {
   i64 nelems, nrows, ncols, nnz;
   int nbt, nbr;
@@ -101,6 +117,8 @@ struct nh_pattern {
   int32_t *gsrc;
   unsigned *gptr;
   int32_t *grow;
+  nh_fused_plan *fused;  // NH_MATRIX_FUSED: built on the first such assembly
+  int fused_failed;      // the plan cannot be built for this pattern: do not try again
 };
 
 // component-block layout of an expanded pattern (mirrors FormK of nh_assemble_generic.hip)
@@ -117,3 +135,6 @@ int nh_gather_scratch(size_t doubles, double **out);
 int nh_local_vector(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);
 int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s);
 int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);
+// owner-block assembly (NH_MATRIX_FUSED); *done = false: not applicable to this launch, nothing was written
+int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s);
+void nh_fused_free(nh_fused_plan *f);

@@ -167,26 +167,10 @@ struct LocK {
   int ldst_doubles;  // staged tables in front of the per-wave transposition buffers
 };
 
+// local matrix of element e (list position ie) of a scalar form on small uniform bases, one thread: A[m][n] (SYMD: the upper triangle n >= m only)
 template <int ND, int NBT, int NBR, bool LDST, bool SYMD>
-__global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
-  // SYMD: test == trial basis and a DIAGONAL form tensor (Laplace, mass, reaction-diffusion): the local matrix is symmetric -- the upper triangle is
-  // accumulated and mirrored in the store -- and the trial side costs S multiplies instead of S * S multiply-adds per function
+__device__ __forceinline__ void local_scalar_matrix(const LocK &p, const double *sT, i64 e, i64 ie, double (&A)[NBT][NBR]) {
   constexpr int S = 1 + ND, NG = 1 << ND;
-  // LDST: one table for all elements (no tab / off array) -- test, trial and geometry tables are staged in LDS once per workgroup; read from
-  // global memory they are L1 hits, but 96 texture-path loads per point and thread with a wait in front of their first use
-  extern __shared__ __attribute__((aligned(16))) double sT[];
-  if (LDST) {
-    const int nt = NBT * p.nq * S, nr = NBR * p.nq * S, ng = NG * p.nq * S;
-    for (int i = threadIdx.x; i < nt; i += blockDim.x) sT[i] = p.test.T[i];
-    for (int i = threadIdx.x; i < nr; i += blockDim.x) sT[nt + i] = p.trial.T[i];
-    if (p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG)
-      for (int i = threadIdx.x; i < ng; i += blockDim.x) sT[nt + nr + i] = p.geom.gT[i];
-    __syncthreads();
-  }
-  const i64 ie0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  const i64 ie = min(ie0, p.nelems - 1);  // (lanes behind the last element recompute it: the store below needs whole waves, and skips them)
-  const i64 e = p.elist ? p.elist[ie] : ie;
-  double A[NBT][NBR];
 #pragma unroll
   for (int m = 0; m < NBT; ++m)
 #pragma unroll
@@ -297,6 +281,29 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
       }
     }
   }
+}
+
+template <int ND, int NBT, int NBR, bool LDST, bool SYMD>
+__global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
+  // SYMD: test == trial basis and a DIAGONAL form tensor (Laplace, mass, reaction-diffusion): the local matrix is symmetric -- the upper triangle is
+  // accumulated and mirrored in the store -- and the trial side costs S multiplies instead of S * S multiply-adds per function
+  constexpr int S = 1 + ND, NG = 1 << ND;
+  // LDST: one table for all elements (no tab / off array) -- test, trial and geometry tables are staged in LDS once per workgroup; read from
+  // global memory they are L1 hits, but 96 texture-path loads per point and thread with a wait in front of their first use
+  extern __shared__ __attribute__((aligned(16))) double sT[];
+  if (LDST) {
+    const int nt = NBT * p.nq * S, nr = NBR * p.nq * S, ng = NG * p.nq * S;
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) sT[i] = p.test.T[i];
+    for (int i = threadIdx.x; i < nr; i += blockDim.x) sT[nt + i] = p.trial.T[i];
+    if (p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG)
+      for (int i = threadIdx.x; i < ng; i += blockDim.x) sT[nt + nr + i] = p.geom.gT[i];
+    __syncthreads();
+  }
+  const i64 ie0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 ie = min(ie0, p.nelems - 1);  // (lanes behind the last element recompute it: the store below needs whole waves, and skips them)
+  const i64 e = p.elist ? p.elist[ie] : ie;
+  double A[NBT][NBR];
+  local_scalar_matrix<ND, NBT, NBR, LDST, SYMD>(p, sT, e, ie, A);
   // Store, element-major (the gather of a CSR row reads whole rows of the local matrices).  A thread's matrix is NBT * NBR * 8 contiguous bytes,
   // neighbouring lanes are that far apart: stored straight from the registers, every instruction touches 64 lines (0.23 of the 0.61 ms of this
   // kernel on the 128^3 trilinear mesh).  The wave transposes through LDS instead, CH values per element at a time, so that 64 / CH elements' chunks of
@@ -325,6 +332,238 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- owner blocks (NH_MATRIX_FUSED): one pass, no scratch, no global atomics ------------------------------------------------------------------
+// The two-pass reduction above moves every local matrix through HBM twice and reads a 4-byte source index per contribution: 4.6 x the algorithmic bytes
+// on the 128^3 trilinear mesh.  Here the ROWS are clustered: dofs are sorted by the Morton code of the centroid of the first element that contains them, runs
+// of R consecutive dofs form a block whose CSR rows fit the LDS of a workgroup, and a block recomputes every element that touches one of its rows (8 x 8 x 8
+// node bricks on a structured mesh: 1.42 x the element arithmetic), adds the entries of ITS rows in LDS (ds_add_f64) and writes each row once.  Read per visit:
+// element id, 2 bytes per local row (accumulator offset or "not mine"), 1 byte per local entry (position within its CSR row), the geometry.  The sums are formed in
+// the order the waves arrive: NOT bit-reproducible (NH_MATRIX_GATHER is), same 1e-13 parity.
+// Block size (128^3 trilinear mesh, rows x threads -> ms, tools/fused_probe.py): 512 x 384 0.91 | 384 x 384 0.86 | 320 x 320 0.96 | 288 x 256 0.72 | 256 x 256 0.75 | 192 x 192 0.86 |
+// 128 x 128 0.77: two workgroups per CU (one streams its rows while the other computes) beat the smaller halo of one large block.
+constexpr int FUSED_CAP = 27 * 288;  // doubles of a block accumulator (62 kB: with staged tables and row tables two workgroups fit the 160 kB of a CU)
+constexpr int FUSED_NT = 256;        // threads of a block (~470 visits of a 288-row block: two rounds)
+constexpr int FUSED_NT_MAX = 384;    // launch bound (ablation builds may launch more threads)
+
+__device__ __forceinline__ unsigned long long ord64(double x) {  // order-preserving map to unsigned
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unord64(unsigned long long u) {
+  return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
+}
+
+// centroid of every element (a point inside it, for clustering only) + bounding box
+__global__ void k_fp_centroid(i64 nelems, GeomK g, int nd, int nq, double *cent, unsigned long long *mm) {
+  const i64 e0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 e = min(e0, nelems - 1);
+  double c[3] = {0., 0., 0.};
+  if (g.kind == NH_GEOM_ISO) {
+    for (int a = 0; a < g.ngb; ++a) {
+      const i64 v = g.gdofs[e * g.ngb + a];
+      for (int i = 0; i < nd; ++i) c[i] += g.verts[v * nd + i];
+    }
+    for (int i = 0; i < nd; ++i) c[i] /= g.ngb;
+  } else if (g.kind == NH_GEOM_TAB) {
+    if (g.x)
+      for (int i = 0; i < nd; ++i) c[i] = g.x[(e * nq) * nd + i];
+    else
+      c[0] = (double)e;  // (no positions: the element order is all there is)
+  } else {
+    for (int i = 0; i < nd; ++i) c[i] = g.origin[e * nd + i] + .5 * g.size[e * nd + i];
+  }
+  if (e0 < nelems)
+    for (int i = 0; i < 3; ++i) cent[e * 3 + i] = c[i];
+  for (int i = 0; i < 3; ++i) {
+    unsigned long long lo = ord64(c[i]), hi = lo;
+    for (int d = 32; d; d >>= 1) {
+      const unsigned long long ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+      lo = ol < lo ? ol : lo;
+      hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(mm + i, lo);
+      atomicMax(mm + 3 + i, hi);
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned spread10(unsigned x) {  // 10 bits -> every third bit
+  x &= 1023;
+  x = (x | (x << 16)) & 0x030000ff;
+  x = (x | (x << 8)) & 0x0300f00f;
+  x = (x | (x << 4)) & 0x030c30c3;
+  x = (x | (x << 2)) & 0x09249249;
+  return x;
+}
+
+__global__ void k_fp_ekey(i64 nelems, const double *cent, const unsigned long long *mm, unsigned *ekey) {
+  const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nelems) return;
+  unsigned k = 0;
+  for (int i = 0; i < 3; ++i) {
+    const double lo = unord64(mm[i]), hi = unord64(mm[3 + i]);
+    const double t = hi > lo ? (cent[e * 3 + i] - lo) / (hi - lo) : 0.;
+    k |= spread10((unsigned)min(1023., max(0., t * 1024.))) << i;
+  }
+  ekey[e] = k;
+}
+
+__global__ void k_fp_fill(i64 n, unsigned *keys, unsigned v, unsigned *iota) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    if (keys) keys[i] = v;
+    if (iota) iota[i] = (unsigned)i;
+  }
+}
+
+__global__ void k_fp_nodekey(i64 nelems, int nbt, const int32_t *dofs, const unsigned *ekey, unsigned *nkey) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nelems * nbt) return;
+  atomicMin(nkey + dofs[i], ekey[i / nbt]);
+}
+
+// rank of every dof; length of the longest row
+__global__ void k_fp_rank(i64 nrows, const unsigned *order, const i64 *srowptr, int32_t *rank, int *maxlen) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  int len = 0;
+  if (i < nrows) {
+    rank[order[i]] = (int32_t)i;
+    len = (int)(srowptr[i + 1] - srowptr[i]);
+  }
+  for (int d = 32; d; d >>= 1) len = max(len, __shfl_xor(len, d));
+  if ((threadIdx.x & 63) == 0 && len) atomicMax(maxlen, len);
+}
+
+// offsets of the rows in the accumulator of their block (one thread per block)
+__global__ void k_fp_loff(i64 nrows, int R, int nblocks, const unsigned *order, const i64 *srowptr, int32_t *loff, i64 *rstart, int32_t *blen, int *max_blen) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  int cur = 0;
+  for (i64 i = (i64)b * R; i < min((i64)(b + 1) * R, nrows); ++i) {
+    const i64 r = order[i];
+    loff[i] = cur;
+    rstart[i] = srowptr[r];
+    cur += (int)(srowptr[r + 1] - srowptr[r]);
+  }
+  blen[b] = cur;
+  atomicMax(max_blen, cur);
+}
+
+// distinct blocks among the rows of an element -> visits; FILL: write them
+template <bool FILL>
+__global__ void k_fp_visits(i64 nelems, int nbt, int R, const int32_t *dofs, const int32_t *rank, int32_t *cnt, const i64 *voff, unsigned *vkey, unsigned *vval, int32_t *bcount) {
+  const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nelems) return;
+  int nd = 0;
+  for (int m = 0; m < nbt; ++m) {
+    const int b = rank[dofs[e * nbt + m]] / R;
+    bool seen = false;
+    for (int k = 0; k < m; ++k) seen |= rank[dofs[e * nbt + k]] / R == b;
+    if (seen) continue;
+    if (FILL) {
+      vkey[voff[e] + nd] = (unsigned)b;
+      vval[voff[e] + nd] = (unsigned)e;
+      atomicAdd(bcount + b, 1);
+    }
+    ++nd;
+  }
+  if (!FILL) cnt[e] = nd;
+}
+
+__global__ void k_fp_vrow(i64 nvisits, int nbt, int R, const int32_t *dofs, const int32_t *rank, const int32_t *loff, const unsigned *vkey, const unsigned *vlist, uint16_t *vrow) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvisits * nbt) return;
+  const i64 v = i / nbt;
+  const int r = rank[dofs[(i64)vlist[v] * nbt + (i - v * nbt)]];
+  vrow[i] = r / R == (int)vkey[v] ? (uint16_t)loff[r] : (uint16_t)0xffff;
+}
+
+// the element map (position of entry (m, n) within the CSR row of its test dof) narrowed to a byte
+__global__ void k_fp_cpos(i64 n, const int32_t *emap, uint8_t *cpos, int *bad) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int d = emap[i];
+  if (d < 0 || d > 255) atomicOr(bad, 1);
+  cpos[i] = (uint8_t)d;
+}
+
+struct FusK {
+  LocK loc;
+  const i64 *srowptr;
+  double *values;
+  int store;
+  i64 nrows;
+  int R, max_blen;
+  const int32_t *loff, *blen, *vlist;
+  const i64 *vptr, *rstart;
+  const uint16_t *vrow;
+  const uint8_t *cpos;
+};
+
+template <int ND, int NBT, int NBR, bool LDST, bool SYMD>
+__global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_scalar(FusK p) {
+  constexpr int S = 1 + ND, NG = 1 << ND, NE = NBT * NBR;
+  extern __shared__ __attribute__((aligned(16))) double sT[];
+  // LDS: [staged tables][row starts of the block in the value array: R x i64][accumulator offsets of its rows: R + 1 ints, padded][accumulator]
+  i64 *rstartS = reinterpret_cast<i64 *>(sT + p.loc.ldst_doubles);
+  int *loffS = reinterpret_cast<int *>(rstartS + p.R);
+  double *acc = reinterpret_cast<double *>(rstartS + p.R) + (p.R + 2) / 2;
+  const int b = blockIdx.x, NT = blockDim.x;
+  const i64 r0 = (i64)b * p.R;
+  const int nr = (int)min((i64)p.R, p.nrows - r0);
+  if (LDST) {
+    const int nt = NBT * p.loc.nq * S, ntr = NBR * p.loc.nq * S, ng = NG * p.loc.nq * S;
+    for (int i = threadIdx.x; i < nt; i += NT) sT[i] = p.loc.test.T[i];
+    for (int i = threadIdx.x; i < ntr; i += NT) sT[nt + i] = p.loc.trial.T[i];
+    if (p.loc.geom.kind == NH_GEOM_ISO && p.loc.geom.ngb == NG)
+      for (int i = threadIdx.x; i < ng; i += NT) sT[nt + ntr + i] = p.loc.geom.gT[i];
+  }
+  for (int i = threadIdx.x; i < nr; i += NT) {
+    rstartS[i] = p.rstart[r0 + i];
+    loffS[i] = p.loff[r0 + i];
+  }
+  for (int i = threadIdx.x; i < p.max_blen; i += NT) acc[i] = 0.;
+  __syncthreads();
+  for (i64 i = p.vptr[b] + threadIdx.x; i < p.vptr[b + 1]; i += NT) {
+    const i64 e = p.vlist[i];
+    // accumulator offsets of the element's rows and the positions of its entries within them: whole words where the sizes allow
+    uint16_t vr[NBT];
+    uint8_t cp[NE];
+    if constexpr (NBT % 8 == 0) {
+#pragma unroll
+      for (int k = 0; k < NBT / 8; ++k) *reinterpret_cast<uint4 *>(vr + 8 * k) = reinterpret_cast<const uint4 *>(p.vrow + i * NBT)[k];
+    } else {
+#pragma unroll
+      for (int m = 0; m < NBT; ++m) vr[m] = p.vrow[i * NBT + m];
+    }
+    if constexpr (NE % 16 == 0) {
+#pragma unroll
+      for (int k = 0; k < NE / 16; ++k) *reinterpret_cast<uint4 *>(cp + 16 * k) = reinterpret_cast<const uint4 *>(p.cpos + e * NE)[k];
+    } else {
+#pragma unroll
+      for (int l = 0; l < NE; ++l) cp[l] = p.cpos[e * NE + l];
+    }
+    double A[NBT][NBR];
+    local_scalar_matrix<ND, NBT, NBR, LDST, SYMD>(p.loc, sT, e, e, A);
+#pragma unroll
+    for (int m = 0; m < NBT; ++m) {
+      const int base = vr[m];
+      if (base == 0xffff) continue;
+#pragma unroll
+      for (int n = 0; n < NBR; ++n) atomicAdd(acc + base + cp[m * NBR + n], (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n]);
+    }
+  }
+  __syncthreads();
+  // the rows of the block, half a wave per row (row starts and offsets are staged: no chain of dependent global loads); a row is one contiguous piece of the
+  // value array
+  const int hl = threadIdx.x & 31;
+  for (int i = threadIdx.x >> 5; i < nr; i += NT >> 5) {
+    const int lo = loffS[i], len = (i + 1 < nr ? loffS[i + 1] : p.blen[b]) - lo;
+    double *dst = p.values + rstartS[i];
+    for (int l = hl; l < len; l += 32) dst[l] = p.store ? acc[lo + l] : dst[l] + acc[lo + l];
   }
 }
 
@@ -818,6 +1057,220 @@ int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSl
   else
     hipLaunchKernelGGL(k_gather_values_v, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, slots, values, store);
   NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+void nh_fused_free(nh_fused_plan *f) {
+  if (!f) return;
+  hipFree(f->order), hipFree(f->loff), hipFree(f->rstart), hipFree(f->blen), hipFree(f->vptr), hipFree(f->vlist), hipFree(f->vrow), hipFree(f->cpos);
+  delete f;
+}
+
+// the owner blocks of a pattern (once per pattern handle)
+static int nh_fused_prepare(nh_pattern *p, const nh_matrix_args *a, hipStream_t s) {
+  const i64 ne = p->nelems, nrows = p->nrows;
+  const int nbt = p->nbt, nbr = p->nbr;
+  NH_REQUIRE(ne < (1ll << 31) && nrows < (1ll << 31) && p->emap_len == ne * nbt * nbr, "NH_MATRIX_FUSED: pattern too large / not uniform");
+  const int32_t *dofs = a->test.dofs_dev;
+  nh_fused_plan *f = new nh_fused_plan();
+  memset(f, 0, sizeof *f);
+  double *cent = nullptr;
+  unsigned long long *mm = nullptr;
+  unsigned *ekey = nullptr, *nkey = nullptr, *iota = nullptr, *nkey2 = nullptr, *order = nullptr, *vkey = nullptr, *vval = nullptr, *vkey2 = nullptr, *vval2 = nullptr;
+  int32_t *rank = nullptr, *cnt = nullptr, *bcount = nullptr;
+  int *flags = nullptr;  // [0] longest row, [1] largest block accumulator, [2] bad column position
+  i64 *voff = nullptr;
+  void *tmp = nullptr;
+  int rc = NH_OK, hflags[3] = {0, 0, 0};
+#define FP_CHECK(expr)                                                                          \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      nh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+      rc = NH_EHIP;                                                                             \
+      goto done;                                                                                \
+    }                                                                                           \
+  } while (0)
+  {
+    const unsigned long long mm0[6] = {~0ull, ~0ull, ~0ull, 0, 0, 0};
+    const unsigned ge = (unsigned)((ne + 255) / 256), gr = (unsigned)((nrows + 255) / 256);
+    FP_CHECK(hipMalloc((void **)&cent, ne * 3 * sizeof(double)));
+    FP_CHECK(hipMalloc((void **)&mm, sizeof mm0));
+    FP_CHECK(hipMemcpyAsync(mm, mm0, sizeof mm0, hipMemcpyHostToDevice, s));
+    FP_CHECK(hipMalloc((void **)&flags, 3 * sizeof(int)));
+    FP_CHECK(hipMemsetAsync(flags, 0, 3 * sizeof(int), s));
+    hipLaunchKernelGGL(k_fp_centroid, dim3(ge), dim3(256), 0, s, ne, to_k(a->geom), a->ndims, a->nq, cent, mm);
+    FP_CHECK(hipMalloc((void **)&ekey, ne * 4));
+    hipLaunchKernelGGL(k_fp_ekey, dim3(ge), dim3(256), 0, s, ne, cent, mm, ekey);
+    FP_CHECK(hipMalloc((void **)&nkey, nrows * 4));
+    FP_CHECK(hipMalloc((void **)&iota, nrows * 4));
+    FP_CHECK(hipMalloc((void **)&nkey2, nrows * 4));
+    FP_CHECK(hipMalloc((void **)&order, nrows * 4));
+    hipLaunchKernelGGL(k_fp_fill, dim3(1024), dim3(256), 0, s, nrows, nkey, 0xffffffffu, iota);
+    hipLaunchKernelGGL(k_fp_nodekey, dim3((unsigned)((ne * nbt + 255) / 256)), dim3(256), 0, s, ne, nbt, dofs, ekey, nkey);
+    FP_CHECK(hipGetLastError());
+    size_t tmpsz = 0, tmpsz2 = 0;
+    FP_CHECK(rocprim::radix_sort_pairs(nullptr, tmpsz, nkey, nkey2, iota, order, (size_t)nrows, 0, 32, s));
+    FP_CHECK(hipMalloc(&tmp, tmpsz));
+    FP_CHECK(rocprim::radix_sort_pairs(tmp, tmpsz, nkey, nkey2, iota, order, (size_t)nrows, 0, 32, s));  // stable: ties in dof order
+    FP_CHECK(hipMalloc((void **)&rank, nrows * 4));
+    hipLaunchKernelGGL(k_fp_rank, dim3(gr), dim3(256), 0, s, nrows, order, p->srowptr, rank, flags);
+    FP_CHECK(hipMemcpyAsync(hflags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    FP_CHECK(hipStreamSynchronize(s));
+    const int maxlen = std::max(hflags[0], 1);
+    int R = std::min(512, FUSED_CAP / maxlen);
+#ifdef NH_ABLATION
+    if (getenv("NH_FUSED_ROWS")) R = std::min(512, std::max(64, atoi(getenv("NH_FUSED_ROWS"))));
+#endif
+    if (R < 64) {  // (rows too long for a useful block: the caller keeps its other paths)
+      rc = NH_ELIMIT;
+      goto done;
+    }
+    const int nblocks = (int)((nrows + R - 1) / R);
+    f->rows_per_block = R;
+    f->nblocks = nblocks;
+    FP_CHECK(hipMalloc((void **)&f->loff, nrows * 4));
+    FP_CHECK(hipMalloc((void **)&f->rstart, nrows * sizeof(i64)));
+    FP_CHECK(hipMalloc((void **)&f->blen, nblocks * 4));
+    hipLaunchKernelGGL(k_fp_loff, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nrows, R, nblocks, order, p->srowptr, f->loff, f->rstart, f->blen, flags + 1);
+    FP_CHECK(hipMalloc((void **)&cnt, (ne + 1) * 4));
+    FP_CHECK(hipMalloc((void **)&voff, (ne + 1) * sizeof(i64)));
+    hipLaunchKernelGGL((k_fp_visits<false>), dim3(ge), dim3(256), 0, s, ne, nbt, R, dofs, rank, cnt, (const i64 *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, (int32_t *)nullptr);
+    FP_CHECK(hipGetLastError());
+    if ((rc = nh_scan_exclusive(cnt, voff, ne, s)) != NH_OK) goto done;
+    i64 nvisits = 0;
+    FP_CHECK(hipMemcpyAsync(&nvisits, voff + ne, sizeof(i64), hipMemcpyDeviceToHost, s));
+    FP_CHECK(hipStreamSynchronize(s));
+    f->nvisits = nvisits;
+    FP_CHECK(hipMalloc((void **)&vkey, nvisits * 4));
+    FP_CHECK(hipMalloc((void **)&vval, nvisits * 4));
+    FP_CHECK(hipMalloc((void **)&vkey2, nvisits * 4));
+    FP_CHECK(hipMalloc((void **)&vval2, nvisits * 4));
+    FP_CHECK(hipMalloc((void **)&bcount, (nblocks + 1) * 4));
+    FP_CHECK(hipMemsetAsync(bcount, 0, (nblocks + 1) * 4, s));
+    hipLaunchKernelGGL((k_fp_visits<true>), dim3(ge), dim3(256), 0, s, ne, nbt, R, dofs, rank, (int32_t *)nullptr, voff, vkey, vval, bcount);
+    FP_CHECK(hipGetLastError());
+    int bits = 1;
+    while ((1ll << bits) < nblocks) ++bits;
+    FP_CHECK(rocprim::radix_sort_pairs(nullptr, tmpsz2, vkey, vkey2, vval, vval2, (size_t)nvisits, 0, bits, s));
+    if (tmpsz2 > tmpsz) {
+      hipFree(tmp);
+      tmp = nullptr;
+      FP_CHECK(hipMalloc(&tmp, tmpsz2));
+    }
+    FP_CHECK(rocprim::radix_sort_pairs(tmp, tmpsz2, vkey, vkey2, vval, vval2, (size_t)nvisits, 0, bits, s));  // stable: the visits of a block in element order
+    FP_CHECK(hipMalloc((void **)&f->vptr, (nblocks + 1) * sizeof(i64)));
+    if ((rc = nh_scan_exclusive(bcount, f->vptr, nblocks, s)) != NH_OK) goto done;
+    FP_CHECK(hipMalloc((void **)&f->vrow, std::max<i64>(nvisits * nbt, 1) * sizeof(uint16_t)));
+    hipLaunchKernelGGL(k_fp_vrow, dim3((unsigned)((nvisits * nbt + 255) / 256)), dim3(256), 0, s, nvisits, nbt, R, dofs, rank, f->loff, vkey2, vval2, f->vrow);
+    FP_CHECK(hipMalloc((void **)&f->cpos, p->emap_len));
+    hipLaunchKernelGGL(k_fp_cpos, dim3((unsigned)((p->emap_len + 255) / 256)), dim3(256), 0, s, p->emap_len, p->emap, f->cpos, flags + 2);
+    FP_CHECK(hipGetLastError());
+    FP_CHECK(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+    FP_CHECK(hipStreamSynchronize(s));
+    if (hflags[2] || hflags[1] > 27 * 512 || hflags[1] >= 0xffff) {
+      rc = NH_ELIMIT;
+      goto done;
+    }
+    f->max_blen = hflags[1];
+    f->order = reinterpret_cast<int32_t *>(order);
+    order = nullptr;
+    f->vlist = reinterpret_cast<int32_t *>(vval2);
+    vval2 = nullptr;
+  }
+done:
+#undef FP_CHECK
+  hipFree(cent), hipFree(mm), hipFree(ekey), hipFree(nkey), hipFree(iota), hipFree(nkey2), hipFree(order), hipFree(vkey), hipFree(vval), hipFree(vkey2), hipFree(vval2);
+  hipFree(rank), hipFree(cnt), hipFree(bcount), hipFree(flags), hipFree(voff), hipFree(tmp);
+  if (rc != NH_OK) {
+    nh_fused_free(f);
+    return rc;
+  }
+  p->fused = f;
+  return NH_OK;
+}
+
+int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s) {
+  *done = false;
+  if (a->nct != 1 || a->ncr != 1 || a->cq_dev || a->test.off_dev || a->trial.off_dev || !a->test.nb || !a->trial.nb || a->elist_dev) return NH_OK;
+  if (a->test.dofs_dev != a->trial.dofs_dev) return NH_OK;  // (the pattern's column positions are taken per test row; one dof array keeps the plan simple)
+  nh_pattern *pat = const_cast<nh_pattern *>(a->pattern);
+  if (!pat || pat->nelems != a->nelems || pat->eoff || pat->fused_failed || pat->nbt != a->test.nb || pat->nbr != a->trial.nb) return NH_OK;
+  const int key = a->ndims * 10000 + a->test.nb * 100 + a->trial.nb;
+  switch (key) {
+    case 10202: case 10303: case 20303: case 20404: case 20909: case 30404: case 30808: break;
+    default: return NH_OK;
+  }
+  if (!pat->fused) {
+    const int rc = nh_fused_prepare(pat, a, s);
+    if (rc == NH_ELIMIT) {
+      pat->fused_failed = 1;
+      return NH_OK;
+    }
+    if (rc != NH_OK) return rc;
+  }
+  const nh_fused_plan *f = pat->fused;
+  const int S = 1 + a->ndims;
+  FusK p;
+  LocK &l = p.loc;
+  l.nelems = a->nelems;
+  l.elist = nullptr;
+  l.nq = a->nq;
+  l.weights = a->weights_dev;
+  l.geom = to_k(a->geom);
+  l.geom.nograd = !uses_gradients(a->C_host, a->nct, 1 + a->ndims, a->ncr);
+  l.test = to_k(a->test);
+  l.trial = to_k(a->trial);
+  l.scale = a->scale_dev;
+  l.by_elem = 1;
+  for (int i = 0; i < 16; ++i) l.C[i] = i < S * S ? a->C_host[i] : 0.;
+  l.local = nullptr;
+  l.debug = 0;
+  const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + a->trial.nb + (1 << a->ndims));
+  const bool ldst = !a->test.tab_dev && !a->trial.tab_dev && ldsb <= 32 * 1024;
+  bool symd = a->test.T_dev == a->trial.T_dev && a->test.tab_dev == a->trial.tab_dev;
+  for (int i = 0; i < S * S; ++i)
+    if (i / S != i % S && a->C_host[i] != 0.) symd = false;
+  l.ldst_doubles = ldst ? (int)(ldsb / sizeof(double)) : 0;
+  p.srowptr = pat->srowptr;
+  p.values = a->values_dev;
+  p.store = (a->flags & NH_MATRIX_STORE) != 0;
+  p.nrows = pat->nrows;
+  p.R = f->rows_per_block;
+  p.max_blen = f->max_blen;
+  p.loff = f->loff, p.blen = f->blen, p.rstart = f->rstart, p.vlist = f->vlist, p.vptr = f->vptr, p.vrow = f->vrow, p.cpos = f->cpos;
+  const size_t ldsx = (ldst ? ldsb : 0) + sizeof(double) * ((size_t)f->max_blen + f->rows_per_block + (f->rows_per_block + 2) / 2);
+  int nt = FUSED_NT;
+#ifdef NH_ABLATION
+  if (getenv("NH_FUSED_NT")) nt = std::min(FUSED_NT_MAX, std::max(64, atoi(getenv("NH_FUSED_NT")) & ~63));
+#endif
+  dim3 grid((unsigned)f->nblocks), block(nt);
+#define FUS2(ND, NBT, NBR, LD, SY)                                                                                                        \
+  do {                                                                                                                                    \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_fused_scalar<ND, NBT, NBR, LD, SY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx)); \
+    hipLaunchKernelGGL((k_fused_scalar<ND, NBT, NBR, LD, SY>), grid, block, ldsx, s, p);                                                  \
+  } while (0)
+#define FUS(ND, NBT, NBR)                                   \
+  do {                                                      \
+    if (NBT == NBR && symd) {                               \
+      if (ldst) FUS2(ND, NBT, NBR, true, NBT == NBR);       \
+      else FUS2(ND, NBT, NBR, false, NBT == NBR);           \
+    } else if (ldst) FUS2(ND, NBT, NBR, true, false);       \
+    else FUS2(ND, NBT, NBR, false, false);                  \
+  } while (0)
+  switch (key) {
+    case 10202: FUS(1, 2, 2); break;
+    case 10303: FUS(1, 3, 3); break;
+    case 20303: FUS(2, 3, 3); break;
+    case 20404: FUS(2, 4, 4); break;
+    case 20909: FUS(2, 9, 9); break;
+    case 30404: FUS(3, 4, 4); break;
+    case 30808: FUS(3, 8, 8); break;
+  }
+#undef FUS
+#undef FUS2
+  NH_LAUNCH_CHECK();
+  *done = true;
   return NH_OK;
 }
 

@@ -396,7 +396,16 @@ int nh_pattern_free(nh_pattern *p) {
   hipFree(p->gsrc);
   hipFree(p->gptr);
   hipFree(p->grow);
+  nh_fused_free(p->fused);
   delete p;
+  return NH_OK;
+}
+
+int nh_pattern_fused_info(const nh_pattern *p, int *nblocks, int *rows_per_block, int64_t *nvisits) {
+  NH_REQUIRE(p, "nh_pattern_fused_info: NULL pattern");
+  if (nblocks) *nblocks = p->fused ? p->fused->nblocks : 0;
+  if (rows_per_block) *rows_per_block = p->fused ? p->fused->rows_per_block : 0;
+  if (nvisits) *nvisits = p->fused ? p->fused->nvisits : 0;
   return NH_OK;
 }
 

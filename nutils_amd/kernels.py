@@ -49,6 +49,12 @@ class Pattern:
         self.srowptr_ptr, self.scol_ptr, self.emap_ptr, self.eoff_ptr = srowptr, scol, emap, eoff
         self.emap_len = emap_len.value
 
+    def fused_info(self):
+        '''(row blocks, rows per block, element visits) of the owner blocks built for NH_MATRIX_FUSED so far; (0, 0, 0): none'''
+        nb, rpb, nv = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        _lib.call('nh_pattern_fused_info', self._handle, ctypes.byref(nb), ctypes.byref(rpb), ctypes.byref(nv))
+        return nb.value, rpb.value, nv.value
+
     def expanded_nnz(self, nct, ncr, mask=None):
         nnz = ctypes.c_int64()
         m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
@@ -113,10 +119,11 @@ def basis(T, dofs, nb=0, off=None, tab=None):
 
 
 def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0,
-                    cq=None, first_touch=None, gather=None, store=False):
+                    cq=None, first_touch=None, gather=None, store=False, fused=False):
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.  `first_touch=(grid_shape, nodes_per_axis)`: NH_MATRIX_FIRST_TOUCH.
     gather: NH_MATRIX_GATHER (deterministic owner-side reduction instead of atomics); None = from the second assembly on a pattern on (the gather
-    map costs one device sort of the element map, which a one-off assembly does not earn back).'''
+    map costs one device sort of the element map, which a one-off assembly does not earn back).  fused: NH_MATRIX_FUSED (owner blocks: one pass
+    without scratch or global atomics for scalar blocks on small uniform bases, not bit-reproducible; excludes gather).'''
     C = numpy.ascontiguousarray(C, dtype=float)
     if C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
         raise ValueError(f'coefficient tensor has shape {C.shape}, expected {(nct, 1 + ndims, ncr, 1 + ndims)}')
@@ -132,6 +139,14 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     if elist is None and emap_offset == 0 and not os.environ.get('NUTILS_AMD_NO_BUCKETS'):
         args.pattern = pattern._handle  # ragged bases: launches per size class of the pattern
     whole = emap_offset == 0 and not flags and not first_touch and nelems == pattern.nelems
+    if not fused and gather is None and os.environ.get('NUTILS_AMD_FUSED') and whole and nct == ncr == 1 and cq is None:
+        fused = True  # (opt-in: faster than the gather from the first assembly on, but the sums are not bit-reproducible)
+    if fused:
+        if not whole:
+            raise ValueError('fused needs all elements of the pattern in one call')
+        if gather:
+            raise ValueError('fused excludes gather')
+        gather = False
     if gather is None:
         # (automatic only while the scratch of the local matrices stays below GATHER_SCRATCH_LIMIT bytes: 1.07 GB for the 128^3 trilinear mesh)
         # and for blocks with a thread pass (scalar blocks; the vector-valued sizes of VECTOR_THREAD_PASS): the local matrices of other vector-valued
@@ -148,8 +163,11 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
             raise ValueError('gather needs all elements of the pattern in one call')
         args.pattern = pattern._handle
         args.flags |= 64 | (128 if store else 0)
+    elif fused:
+        args.pattern = pattern._handle
+        args.flags |= 256 | (128 if store else 0)
     elif store:
-        raise ValueError('store is an option of the gather path')
+        raise ValueError('store is an option of the gather and fused paths')
     _lib.call('nh_assemble_matrix', ctypes.byref(args), device.stream())
 
 

@@ -64,7 +64,7 @@ class PoissonSlab:
         else:
             self.pattern = self.smp.pattern(self.basis, self.basis)
             self.rowptr, self.colidx = self.pattern.expand()
-            self.kernel_name = {'batched': 'k_mterms<3>', 'gather': 'k_local_scalar<3,8,8> + k_gather_values'}.get(self.kernel, 'k_matrix_generic<3>')
+            self.kernel_name = {'batched': 'k_mterms<3>', 'gather': 'k_local_scalar<3,8,8> + k_gather_values', 'fused': 'k_fused_scalar<3,8,8>'}.get(self.kernel, 'k_matrix_generic<3>')
         self.values = device.zeros(self.colidx.numel(), 'float64')  # rows of a ghost plane are never written: keep them zero
         self.nnz = int(self.colidx.numel())
         self.halo = partition.HaloPlan(self.slab, self.rowptr) if self.world > 1 else None
@@ -161,8 +161,9 @@ class PoissonSlab:
             return
         test, g, e0 = self._own_views()
         gather = self.kernel == 'gather' and e0 == 0 and self.nelems == self.pattern.nelems
-        if not gather:
-            self.values.zero_()  # (the gather path stores every entry: NH_MATRIX_STORE)
+        fused = self.kernel == 'fused' and e0 == 0 and self.nelems == self.pattern.nelems
+        if not gather and not fused:
+            self.values.zero_()  # (the gather and fused paths store every entry: NH_MATRIX_STORE)
         if kernel_events:
             kernel_events[0].record()
         if self.kernel == 'batched' and e0 == 0:
@@ -171,7 +172,7 @@ class PoissonSlab:
         else:
             kernels.assemble_matrix(nelems=self.nelems, ndims=3, nq=8, weights=self.smp._weights_dev, geom=g, test=test, trial=test, nct=1, ncr=1,
                                     C=self.C, mask=None, pattern=self.pattern, values=self.values, emap_offset=e0 * 64,
-                                    gather=gather, store=gather)
+                                    gather=gather, fused=fused, store=gather or fused)
         if kernel_events:
             kernel_events[1].record()
         self._end_step(slot, exchange)

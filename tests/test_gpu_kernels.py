@@ -922,3 +922,92 @@ def test_terms_point_factor(golden, name):
         vals.append(device.to_host(v))
     close(vals[0], vals[2])
     close(vals[1], vals[2])
+
+
+# ---- owner blocks (NH_MATRIX_FUSED) ------------------------------------------------------------------------------------------------------
+
+FUSED_SIZES = {(1, 2), (1, 3), (2, 3), (2, 4), (2, 9), (3, 4), (3, 8)}  # (dimension, functions per element) with a thread pass
+
+
+@pytest.mark.parametrize('name', SCALAR)
+def test_fused_owner_blocks_equal_the_reference(golden, name):
+    '''One pass without scratch or global atomics: the golden values of the reference, accumulating into a zeroed array and STORING into a poisoned one; the
+    block plan exists exactly for the element sizes that have a thread pass (the others take the default path behind the same flag).'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden(name)
+    c = Case(g)
+    C = oa.laplace_coefficient(c.nd)
+    rowptr, colidx = c.pattern.expand(1, 1, None)
+    for store in (False, True):
+        values = device.to_dev(numpy.full(colidx.numel(), numpy.nan), 'float64') if store else device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=1, ncr=1, C=C, mask=None,
+                                pattern=c.pattern, values=values, fused=True, store=store)
+        close(device.to_host(values), g['K_values'])
+    nblocks, rpb, nvisits = c.pattern.fused_info()
+    if (c.nd, c.nb) in FUSED_SIZES:
+        assert nblocks >= 1 and nvisits >= c.nelems, (nblocks, rpb, nvisits)
+    else:
+        assert nblocks == 0
+
+
+@pytest.mark.parametrize('name', ['lap2d_p1_4x3_iso', 'lap2d_spline2_5x4_iso', 'lap3d_p1_543_iso'])
+def test_fused_with_a_full_coefficient_tensor(golden, name):
+    '''A dense, non-symmetric form tensor (value and gradient slots mixed) and a scale array: the general instantiation of the fused kernel against the
+    one-wave-per-element kernel with atomics.'''
+    from nutils_amd import device, kernels
+    g = golden(name)
+    c = Case(g)
+    rng = numpy.random.default_rng(17)
+    S = 1 + c.nd
+    C = rng.normal(size=(1, S, 1, S))
+    scale = device.to_dev(rng.uniform(.5, 1.5, c.nelems * c.nq), 'float64')
+    rowptr, colidx = c.pattern.expand(1, 1, None)
+    out = []
+    for fused in (False, True):
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=1, ncr=1, C=C, mask=None,
+                                pattern=c.pattern, values=values, fused=fused, gather=False, scale=scale)
+        out.append(device.to_host(values))
+    assert c.pattern.fused_info()[0] >= 1
+    close(out[1], out[0])
+
+
+@pytest.mark.parametrize('shuffle', [False, True])
+def test_fused_many_blocks_any_numbering(shuffle):
+    '''28^3 trilinear elements on a perturbed mesh (24 389 rows: ~48 owner blocks, elements on block borders recomputed) against the deterministic gather path --
+    with the natural numbering and with elements AND dofs renumbered at random (the clustering sees coordinates, not numbers).'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    n = 28
+    rng = numpy.random.default_rng(5)
+    dofs, coeffs, ndofs = oa.structured_basis((n, n, n), 'std', 1)
+    verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.)] * 3, indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, (ndofs, 3))
+    dofs = numpy.asarray(dofs).reshape(-1, 8)
+    if shuffle:
+        perm = rng.permutation(ndofs)          # new number of old dof i
+        dofs = perm[dofs][rng.permutation(len(dofs))]
+        v2 = numpy.empty_like(verts)
+        v2[perm] = verts
+        verts = v2
+    ne = len(dofs)
+    pts, w = oa.gauss(2, 3)
+    p = device.to_dev(pts, 'float64')
+    T = kernels.tabulate(device.to_dev(coeffs[0], 'float64'), 8, coeffs.shape[2], p, len(pts), 3)
+    d = device.to_dev(dofs.ravel(), 'int32')
+    basis = kernels.basis(T, d, nb=8)
+    geom = kernels.geometry_iso(8, T, d, device.to_dev(verts, 'float64'))
+    pattern = kernels.Pattern(ne, ndofs, ndofs, d, d, nbt=8, nbr=8)
+    rowptr, colidx = pattern.expand(1, 1, None)
+    C = oa.laplace_coefficient(3) + 2. * oa.mass_coefficient(3)
+    out = []
+    for kw in (dict(gather=True), dict(fused=True, store=True), dict(fused=True, store=True)):
+        values = device.to_dev(numpy.full(colidx.numel(), numpy.nan), 'float64') if kw.get('store') else device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=ne, ndims=3, nq=len(pts), weights=device.to_dev(w, 'float64'), geom=geom, test=basis, trial=basis, nct=1, ncr=1, C=C, mask=None,
+                                pattern=pattern, values=values, **kw)
+        out.append(device.to_host(values))
+    nblocks, rpb, nvisits = pattern.fused_info()
+    assert nblocks == -(-ndofs // rpb) and nblocks > 40, (nblocks, rpb)
+    assert ne < nvisits < 2.2 * ne, nvisits / ne  # bricks of ~8^3 nodes: (9/8)^3 = 1.42 in the interior, more at this size
+    close(out[1], out[0])
+    close(out[2], out[0])
