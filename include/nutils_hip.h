@@ -211,7 +211,7 @@ typedef struct {
                                         one call, no elist).  The dofs are clustered by the Morton code of the centroid of the first element
                                         that contains them; a block of rows that fits the LDS of a workgroup recomputes every element touching
                                         one of its rows (1.4 x the element arithmetic for 8 x 8 x 8 node bricks), reduces the entries of its
-                                        rows in LDS and writes each CSR row once: ~1.7 x the algorithmic bytes instead of 4.6 x with
+                                        rows in LDS and writes each CSR row once: 1.5 x the algorithmic bytes instead of 4.6 x with
                                         NH_MATRIX_GATHER.  The order of the floating-point sums follows the arrival of the waves: NOT
                                         bit-reproducible (NH_MATRIX_GATHER is).  The block plan is built on the first such call and cached in the
                                         pattern handle.  Launches the flag does not apply to take the default path (atomics; with
