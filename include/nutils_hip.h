@@ -111,8 +111,10 @@ int nh_pattern_info(const nh_pattern *p, int64_t *nnz_scalar, const int64_t **sr
  * matrix/__init__.py:30-70 (assemble_csr) -- indices int64, rows sorted, cols strictly
  * increasing within a row. */
 /* owner blocks of NH_MATRIX_FUSED built for this pattern so far: number of row blocks (0: none yet, or the plan does not apply), rows per
- * block, element visits over all blocks (>= nelems: elements on block borders are recomputed) */
-int nh_pattern_fused_info(const nh_pattern *p, int *nblocks, int *rows_per_block, int64_t *nvisits);
+ * block, element visits over all blocks (>= nelems: elements on block borders are recomputed), and the element routine of the last fused
+ * launch: -1 none yet, 0 the tabulated any-element routine, 1 / 2 the sum-factorised routine for trilinear hexahedra at the 2 x 2 x 2 Gauss
+ * points (recognised from the tables of the launch; 2: with a mass term) */
+int nh_pattern_fused_info(const nh_pattern *p, int *nblocks, int *rows_per_block, int64_t *nvisits, int *routine);
 int nh_pattern_expanded_nnz(const nh_pattern *p, int nct, int ncr, const unsigned char *mask, int64_t *nnz);
 int nh_pattern_expand(const nh_pattern *p, int nct, int ncr, const unsigned char *mask, int64_t *rowptr_dev,
                       int64_t *colidx_dev, void *stream);
@@ -210,9 +212,12 @@ typedef struct {
                                         (2 .. 9 functions per element, test and trial on one dof array; needs `pattern`, all of its elements in
                                         one call, no elist).  The dofs are clustered by the Morton code of the centroid of the first element
                                         that contains them; a block of rows that fits the LDS of a workgroup recomputes every element touching
-                                        one of its rows (1.4 x the element arithmetic for 8 x 8 x 8 node bricks), reduces the entries of its
+                                        one of its rows (1.7 x the element arithmetic for blocks of 288 rows), reduces the entries of its
                                         rows in LDS and writes each CSR row once: 1.5 x the algorithmic bytes instead of 4.6 x with
-                                        NH_MATRIX_GATHER.  The order of the floating-point sums follows the arrival of the waves: NOT
+                                        NH_MATRIX_GATHER.  Trilinear hexahedra at the 2 x 2 x 2 Gauss points with a form kappa grad.grad +
+                                        mass phi phi (recognised from the tables passed) take the sum-factorised element routine of
+                                        nh_p1hex_laplace (an exactly singular element then gives inf / NaN instead of numeric.inv's all-NaN
+                                        inverse).  The order of the floating-point sums follows the arrival of the waves: NOT
                                         bit-reproducible (NH_MATRIX_GATHER is).  The block plan is built on the first such call and cached in the
                                         pattern handle.  Launches the flag does not apply to take the default path (atomics; with
                                         NH_MATRIX_STORE after a zero fill of a scalar block's values). */

@@ -96,6 +96,11 @@ struct nh_fused_plan {
   int32_t *vlist;     // [nvisits]: element
   uint16_t *vrow;     // [nvisits][nbt]: accumulator offset of the row of local function m, 0xffff: the row belongs to another block
   uint8_t *cpos;      // [nelems][nbt * nbr]: position of entry (m, n) within its CSR row
+  // trilinear hexahedra at the 2 x 2 x 2 Gauss points (recognised from the tables of a launch): -1 not looked at, 0 no, 1 yes, 2 yes with a mass term
+  int p1hex;
+  const void *p1hex_key[4];  // table pointers and ...
+  double p1hex_C[16];        // ... form the answer belongs to
+  double p1hex_tab[32];      // tables of the sum-factorised routine (P1Tab of nh_gather.hip)
 };
 
 struct nh_pattern {

@@ -401,8 +401,9 @@ int nh_pattern_free(nh_pattern *p) {
   return NH_OK;
 }
 
-int nh_pattern_fused_info(const nh_pattern *p, int *nblocks, int *rows_per_block, int64_t *nvisits) {
+int nh_pattern_fused_info(const nh_pattern *p, int *nblocks, int *rows_per_block, int64_t *nvisits, int *routine) {
   NH_REQUIRE(p, "nh_pattern_fused_info: NULL pattern");
+  if (routine) *routine = p->fused ? p->fused->p1hex : -1;
   if (nblocks) *nblocks = p->fused ? p->fused->nblocks : 0;
   if (rows_per_block) *rows_per_block = p->fused ? p->fused->rows_per_block : 0;
   if (nvisits) *nvisits = p->fused ? p->fused->nvisits : 0;

@@ -51,8 +51,9 @@ class Pattern:
 
     def fused_info(self):
         '''(row blocks, rows per block, element visits) of the owner blocks built for NH_MATRIX_FUSED so far; (0, 0, 0): none'''
-        nb, rpb, nv = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
-        _lib.call('nh_pattern_fused_info', self._handle, ctypes.byref(nb), ctypes.byref(rpb), ctypes.byref(nv))
+        nb, rpb, nv, rt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64(), ctypes.c_int()
+        _lib.call('nh_pattern_fused_info', self._handle, ctypes.byref(nb), ctypes.byref(rpb), ctypes.byref(nv), ctypes.byref(rt))
+        self.fused_routine = rt.value  # -1 none yet, 0 tabulated any-element routine, 1 / 2 sum-factorised trilinear routine (2: with a mass term)
         return nb.value, rpb.value, nv.value
 
     def expanded_nnz(self, nct, ncr, mask=None):

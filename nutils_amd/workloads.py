@@ -64,7 +64,7 @@ class PoissonSlab:
         else:
             self.pattern = self.smp.pattern(self.basis, self.basis)
             self.rowptr, self.colidx = self.pattern.expand()
-            self.kernel_name = {'batched': 'k_mterms<3>', 'gather': 'k_local_scalar<3,8,8> + k_gather_values', 'fused': 'k_fused_scalar<3,8,8>'}.get(self.kernel, 'k_matrix_generic<3>')
+            self.kernel_name = {'batched': 'k_mterms<3>', 'gather': 'k_local_scalar<3,8,8> + k_gather_values', 'fused': 'k_fused_p1hex<false>'}.get(self.kernel, 'k_matrix_generic<3>')
         self.values = device.zeros(self.colidx.numel(), 'float64')  # rows of a ghost plane are never written: keep them zero
         self.nnz = int(self.colidx.numel())
         self.halo = partition.HaloPlan(self.slab, self.rowptr) if self.world > 1 else None

@@ -947,6 +947,7 @@ def test_fused_owner_blocks_equal_the_reference(golden, name):
     nblocks, rpb, nvisits = c.pattern.fused_info()
     if (c.nd, c.nb) in FUSED_SIZES:
         assert nblocks >= 1 and nvisits >= c.nelems, (nblocks, rpb, nvisits)
+        assert c.pattern.fused_routine == 0  # (Case passes per-element tables: the tabulated any-element routine; the trilinear one is tested below)
     else:
         assert nblocks == 0
 
@@ -1007,7 +1008,49 @@ def test_fused_many_blocks_any_numbering(shuffle):
                                 pattern=pattern, values=values, **kw)
         out.append(device.to_host(values))
     nblocks, rpb, nvisits = pattern.fused_info()
+    assert pattern.fused_routine == 2  # (stiffness + mass on trilinear hexahedra: the sum-factorised routine with the mass term)
     assert nblocks == -(-ndofs // rpb) and nblocks > 40, (nblocks, rpb)
     assert ne < nvisits < 2.2 * ne, nvisits / ne  # bricks of ~8^3 nodes: (9/8)^3 = 1.42 in the interior, more at this size
     close(out[1], out[0])
     close(out[2], out[0])
+
+
+def test_fused_trilinear_routine_equals_the_tabulated_one(monkeypatch):
+    '''The sum-factorised routine for trilinear hexahedra (chosen from the tables of the launch) against the tabulated any-element routine of the same owner blocks, with a
+    coefficient array at the Gauss points, on an unstructured numbering; and forms the routine does not cover (anisotropic diffusion) keep the tabulated one.'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    n = 12
+    rng = numpy.random.default_rng(11)
+    dofs, coeffs, ndofs = oa.structured_basis((n, n, n), 'std', 1)
+    verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.)] * 3, indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, (ndofs, 3))
+    perm = rng.permutation(ndofs)
+    dofs = perm[numpy.asarray(dofs).reshape(-1, 8)][rng.permutation(n ** 3)]
+    v2 = numpy.empty_like(verts)
+    v2[perm] = verts
+    ne = len(dofs)
+    pts, w = oa.gauss(2, 3)
+    T = kernels.tabulate(device.to_dev(coeffs[0], 'float64'), 8, coeffs.shape[2], device.to_dev(pts, 'float64'), len(pts), 3)
+    d = device.to_dev(dofs.ravel(), 'int32')
+    basis = kernels.basis(T, d, nb=8)
+    geom = kernels.geometry_iso(8, T, d, device.to_dev(v2, 'float64'))
+    scale = device.to_dev(rng.uniform(.5, 1.5, ne * 8), 'float64')
+    wd = device.to_dev(w, 'float64')
+    aniso = oa.laplace_coefficient(3).copy()
+    aniso[0, 1, 0, 1] = 2.
+    for C, routine in ((oa.laplace_coefficient(3), 1), (3. * oa.laplace_coefficient(3) + .5 * oa.mass_coefficient(3), 2), (aniso, 0)):
+        out = []
+        for no_fast in (False, True):
+            if no_fast:
+                monkeypatch.setenv('NUTILS_AMD_NO_FUSED_P1HEX', '1')
+            else:
+                monkeypatch.delenv('NUTILS_AMD_NO_FUSED_P1HEX', raising=False)
+            pattern = kernels.Pattern(ne, ndofs, ndofs, d, d, nbt=8, nbr=8)
+            rowptr, colidx = pattern.expand(1, 1, None)
+            values = device.to_dev(numpy.full(colidx.numel(), numpy.nan), 'float64')
+            kernels.assemble_matrix(nelems=ne, ndims=3, nq=8, weights=wd, geom=geom, test=basis, trial=basis, nct=1, ncr=1, C=C, mask=None, pattern=pattern, values=values,
+                                    fused=True, store=True, scale=scale)
+            pattern.fused_info()
+            assert pattern.fused_routine == (0 if no_fast else routine)
+            out.append(device.to_host(values))
+        close(out[0], out[1])
