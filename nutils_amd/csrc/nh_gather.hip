@@ -377,6 +377,7 @@ __global__ void k_fp_centroid(i64 nelems, GeomK g, int nd, int nq, double *cent,
   }
   if (e0 < nelems)
     for (int i = 0; i < 3; ++i) cent[e * 3 + i] = c[i];
+  __shared__ unsigned long long red[4][6];  // (256 threads: wave results, then six atomics per workgroup -- one per wave were 2 ms of contention at 2 M elements)
   for (int i = 0; i < 3; ++i) {
     unsigned long long lo = ord64(c[i]), hi = lo;
     for (int d = 32; d; d >>= 1) {
@@ -384,10 +385,14 @@ __global__ void k_fp_centroid(i64 nelems, GeomK g, int nd, int nq, double *cent,
       lo = ol < lo ? ol : lo;
       hi = oh > hi ? oh : hi;
     }
-    if ((threadIdx.x & 63) == 0) {
-      atomicMin(mm + i, lo);
-      atomicMax(mm + 3 + i, hi);
-    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = lo, red[threadIdx.x >> 6][3 + i] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    unsigned long long v = red[0][threadIdx.x];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = threadIdx.x < 3 ? (red[w][threadIdx.x] < v ? red[w][threadIdx.x] : v) : (red[w][threadIdx.x] > v ? red[w][threadIdx.x] : v);
+    if (threadIdx.x < 3) atomicMin(mm + threadIdx.x, v);
+    else atomicMax(mm + threadIdx.x, v);
   }
 }
 
