@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
       // trial side pre-multiplied by the form and the quadrature weight, once per (q, n, d, c):
       //   W[q][n][d][c][a] = w_q |J_q| sum_b C[c][a][d][b] Dr[q][n][b]
       // so that an entry costs S multiply-adds per point instead of S*S
-      if (p.use_w) {
+      if (p.use_w) {  // (never set for the blocks that take the Gram path below)
         const int ncd = form.ncr * form.nct;
         for (int t = lane; t < (q1 - q0) * nbr * ncd; t += 64) {
           int r = t;
@@ -187,6 +187,57 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
         }
         __syncthreads();
       }
+      // Vector-valued blocks with a constant form: the quadrature sum of a node pair does not depend on the components -- G[a][b] = sum_q w_q |J_q| Dt[q][m][a] Dr[q][n][b]
+      // (S x S accumulators per lane, 2 S + 1 LDS reads and S (S + 1) multiply-adds per point) and the form tensor is applied once per pair,
+      // K[c][d] = sum_ab C[c][a][d][b] G[a][b], instead of S (S + 1) multiply-adds and 2 S + S S reads per point for EACH of the nct x ncr entries.
+      const bool gram = !p.cq && form.nct * form.ncr > 1;
+      if (gram) {
+        for (int k = lane; k < nbt * nbr; k += 64) {
+          const int m = k / nbr, n = k - m * nbr;
+          double G[S][S];
+#pragma unroll
+          for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int b = 0; b < S; ++b) G[a][b] = 0.;
+          for (int q = q0; q < q1; ++q) {
+            const double *dt = Dt + ((q - q0) * nbt + m) * S;
+            const double *dr = Dr + ((q - q0) * nbr + n) * S;
+            const double wq = Jw[q * JW + ND * ND];
+            double drv[S];
+#pragma unroll
+            for (int b = 0; b < S; ++b) drv[b] = dr[b];
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+              const double wa = wq * dt[a];
+#pragma unroll
+              for (int b = 0; b < S; ++b) G[a][b] += wa * drv[b];
+            }
+          }
+          const i64 row = p.test.dofs[tdof0 + m];
+          const i64 a0 = p.srowptr[row], len = p.srowptr[row + 1] - a0;
+          const i64 pos = p.emap[emap0 + m * nbr + n];
+          const int both = p.exclusive ? ft_node<ND>(p.ft, m) & ft_node<ND>(p.ft, n) : 0;
+          const bool first = p.exclusive && p.ft.on && q0 == 0 && !((both & ftlo) | ((both >> 3) & fthi));
+          for (int c = 0; c < form.nct; ++c)
+            for (int d = 0; d < form.ncr; ++d) {
+              if (!form.mask[c][d]) continue;
+              const double *Cc = form.C + ((c * S) * form.ncr + d) * S;  // C[c][a][d][b] = Cc[a * ncr * S + b]
+              double acc = 0;
+#pragma unroll
+              for (int a = 0; a < S; ++a)
+#pragma unroll
+                for (int b = 0; b < S; ++b) acc += Cc[a * form.ncr * S + b] * G[a][b];
+              if (p.local) {
+                double *dst = p.local + (emap0 + m * nbr + n) * (form.nct * form.ncr) + c * form.ncr + d;
+                *dst = q0 ? *dst + acc : acc;
+                continue;
+              }
+              const i64 slot = a0 * form.tot + len * form.cum[c] + pos * form.cnt[c] + form.dpos[c][d];
+              if (p.exclusive) p.values[slot] = first ? acc : p.values[slot] + acc;
+              else atomicAdd(p.values + slot, acc);
+            }
+        }
+      } else
       for (int k = lane; k < nentries; k += 64) {
         int r = k;
         const int d = r % form.ncr; r /= form.ncr;
@@ -800,7 +851,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     const size_t fixed = sizeof(double) * ((size_t)form.formd + (size_t)a->nq * JW);
     // the W table trades S*S for S multiply-adds per entry and point; these one-wave workgroups are latency bound, so it is only
     // used while the workgroup stays small enough for >= 16 of them per CU (measured: 3-D P1 4.8 -> 3.8 ms, 2-D p2 0.96 -> 1.1 ms)
-    q.use_w = fixed + (size_t)a->nq * per_qw <= 10 * 1024;
+    q.use_w = fixed + (size_t)a->nq * per_qw <= 10 * 1024 && !(!a->cq_dev && a->nct * a->ncr > 1);  // (vector-valued constant forms: the Gram path needs no W table)
     const int per_q = q.use_w ? per_qw : per_q0;
     q.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / std::max(per_q, 1)));
     const size_t lds = fixed + (size_t)q.qchunk * per_q;
