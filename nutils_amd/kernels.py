@@ -119,6 +119,9 @@ def basis(T, dofs, nb=0, off=None, tab=None):
     return b
 
 
+FUSED_SIZES = {(1, 2), (1, 3), (2, 3), (2, 4), (2, 9), (3, 4), (3, 8)}  # (dimension, functions per element) of the owner-block kernels (NH_MATRIX_FUSED)
+
+
 def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0,
                     cq=None, first_touch=None, gather=None, store=False, fused=False):
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.  `first_touch=(grid_shape, nodes_per_axis)`: NH_MATRIX_FIRST_TOUCH.
@@ -140,8 +143,9 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     if elist is None and emap_offset == 0 and not os.environ.get('NUTILS_AMD_NO_BUCKETS'):
         args.pattern = pattern._handle  # ragged bases: launches per size class of the pattern
     whole = emap_offset == 0 and not flags and not first_touch and nelems == pattern.nelems
-    if not fused and gather is None and os.environ.get('NUTILS_AMD_FUSED') and whole and nct == ncr == 1 and cq is None:
-        fused = True  # (opt-in: faster than the gather from the first assembly on, but the sums are not bit-reproducible)
+    if (not fused and gather is None and os.environ.get('NUTILS_AMD_FUSED') and whole and nct == ncr == 1 and cq is None and (ndims, test.nb) in FUSED_SIZES
+            and test.nb == trial.nb and test.dofs_dev == trial.dofs_dev and not test.off_dev):
+        fused = True  # (opt-in, for the blocks the owner-block kernels cover: faster than the gather from the first assembly on, but the sums are not bit-reproducible)
     if fused:
         if not whole:
             raise ValueError('fused needs all elements of the pattern in one call')
