@@ -192,3 +192,15 @@ def test_elasticity_20_cubed_entrywise_vs_c_port():
         got = Dev(inp).fast(C, 3)
     assert 'nh_p2hex_matrix' in calls
     _check(got, (vo, rpo, cio))
+
+
+@pytest.mark.parametrize('nc', [1, 2, 3])
+def test_value_slot_window_vs_oracle(nc):
+    '''Forms on the slot window {value, d/dx, d/dy} (no d/dz anywhere): the S0 = 0 instantiations -- in-register operands for one and two components (the value slot rides on
+    sqrt(w |J|) itself), the table kernel for three (where the in-register variant would spill).'''
+    from oracle import assemble as oa
+    inp = _inputs((3, 2, 4), True, seed=4)
+    rng = numpy.random.default_rng(9)
+    C = numpy.zeros((nc, 4, nc, 4))
+    C[:, :3, :, :3] = rng.normal(size=(nc, 3, nc, 3))
+    _check(Dev(inp).fast(C, nc), _oracle(inp, C))
