@@ -159,9 +159,10 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
         # elasticity 15.7 against 7.9 ms, 32^3 triquadratic 14.5 against 3.9 ms, tools/generic_probe.py)
         thread_pass = nct == ncr == 1 or ((ndims, test.nb, nct) in VECTOR_THREAD_PASS and nct == ncr and cq is None and test.nb == trial.nb
                                           and test.T_dev == trial.T_dev and test.dofs_dev == trial.dofs_dev and test.tab_dev == trial.tab_dev and not test.off_dev)
-        # ... and ragged vector-valued blocks with a constant form: their element kernel sums Gram matrices per node pair (nh_assemble_generic.hip), which leaves the
-        # global atomics as its bound -- 63 488 rational hierarchical elements 2.36 ms with atomics, 1.76 ms through the gather (tools/ragged_probe.py)
-        thread_pass = thread_pass or bool(test.off_dev and nct * ncr > 1 and cq is None)
+        # ... and blocks on ragged bases with a constant form.  Vector-valued: the element kernel sums Gram matrices per node pair (nh_assemble_generic.hip), which leaves
+        # the global atomics as its bound -- 63 488 rational hierarchical elements 2.36 ms with atomics, 1.76 ms through the gather.  Scalar: 1.20 against 1.22 ms -- the
+        # same time, and the sums become bit-reproducible (tools/ragged_probe.py, RAGGED_PROBE_SCALAR=1)
+        thread_pass = thread_pass or bool(test.off_dev and cq is None)
         gather = (whole and thread_pass and getattr(pattern, '_assemblies', 0) >= 1 and not os.environ.get('NUTILS_AMD_NO_GATHER')
                   and 8 * pattern.emap_len * nct * ncr <= GATHER_SCRATCH_LIMIT and pattern.emap_len < 2 ** 32 and pattern.nnz_scalar < 2 ** 32)
     if whole:

@@ -1054,3 +1054,30 @@ def test_fused_trilinear_routine_equals_the_tabulated_one(monkeypatch):
             assert pattern.fused_routine == (0 if no_fast else routine)
             out.append(device.to_host(values))
         close(out[0], out[1])
+
+
+def test_ragged_blocks_become_reproducible_from_the_second_assembly(golden):
+    '''Ragged bases (truncated hierarchical splines): the automatic choice of kernels.assemble_matrix takes the owner-side gather from the second assembly of a pattern on --
+    the values of the reference every time, bit-identical from then on.'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    g = golden('hier_spline2_2d')
+    pts = device.to_dev(g['gauss_coords'], 'float64')
+    w = device.to_dev(g['gauss_weights'], 'float64')
+    nq = len(g['gauss_weights'])
+    geom = kernels.geometry_box(device.to_dev(g['elem_origin'], 'float64'), device.to_dev(g['elem_size'], 'float64'))
+    off_h = g['t_dof_offsets']
+    ne, ndofs = len(off_h) - 1, int(g['t_ndofs'])
+    off = device.to_dev(off_h, 'int64')
+    dofs = device.to_dev(g['t_dofs'], 'int32')
+    T = kernels.tabulate(device.to_dev(g['t_coeffs'], 'float64'), len(g['t_dofs']), g['t_coeffs'].shape[1], pts, nq, 2)
+    b = kernels.basis(T, dofs, nb=0, off=off)
+    pat = kernels.Pattern(ne, ndofs, ndofs, dofs, dofs, toff=off, roff=off)
+    rowptr, colidx = pat.expand()
+    out = []
+    for it in range(4):
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=ne, ndims=2, nq=nq, weights=w, geom=geom, test=b, trial=b, nct=1, ncr=1, C=oa.laplace_coefficient(2), mask=None, pattern=pat, values=values)
+        out.append(device.to_host(values))
+        close(out[-1], g['tK_values'])
+    assert numpy.array_equal(out[1], out[2]) and numpy.array_equal(out[2], out[3])

@@ -24,10 +24,15 @@ hb = topo.plain_basis(coeffs1 * copies, [d + c * nd1 for c in range(copies) for 
 size = tile(g['elem_size'])
 nurbs = _basis.RationalBasis(hb, tile(g['weights']), W=tile(g['W']), dW=tile(g['dW_dparam']) * size[:, None, :])
 geom = function.TabulatedGeometry(tile(g['x']), tile(g['dx_dparam']) * size[:, None, None, :])
-u, v = function.field('u', nurbs, shape=[2]), function.field('v', nurbs, shape=[2])
-lam, mu = float(g['lam']), float(g['mu'])
-sigma = lam * function.div(u, geom) * function.eye(2) + 2 * mu * function.symgrad(u, geom)
-res = smp.integral(function.inner(function.grad(v, geom), sigma) * function.J(geom))
+SCALAR = os.environ.get('RAGGED_PROBE_SCALAR') == '1'  # (a scalar Laplace form on the same basis: timing only, the fixture holds the elasticity matrix)
+if SCALAR:
+    u, v = function.field('u', nurbs), function.field('v', nurbs)
+    res = smp.integral(function.inner(function.grad(v, geom), function.grad(u, geom)) * function.J(geom))
+else:
+    u, v = function.field('u', nurbs, shape=[2]), function.field('v', nurbs, shape=[2])
+    lam, mu = float(g['lam']), float(g['mu'])
+    sigma = lam * function.div(u, geom) * function.eye(2) + 2 * mu * function.symgrad(u, geom)
+    res = smp.integral(function.inner(function.grad(v, geom), sigma) * function.J(geom))
 jac = function.derivative(function.derivative(res, 'v'), 'u')
 plan = _sample._MatrixPlan(jac.terms)
 t0 = time.perf_counter()
@@ -43,6 +48,9 @@ for s, e in ev:
     e.record()
 torch.cuda.synchronize()
 ms = sorted(s.elapsed_time(e) for s, e in ev)
+if SCALAR:
+    print(f'scalar Laplace on {ne1 * copies} ragged rational elements: re-assembly kernel ms min {ms[0]:.3f} median {ms[len(ms) // 2]:.3f}; entry points {sorted(set(calls))}')
+    raise SystemExit(0)
 # parity of every diagonal block with the reference's matrix of the fixture
 v, rp, ci = device.to_host(values), device.to_host(rowptr), device.to_host(colidx)
 n1, nnz1 = 2 * nd1, len(g['K_values'])
