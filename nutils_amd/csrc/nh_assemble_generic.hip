@@ -192,50 +192,61 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
       // K[c][d] = sum_ab C[c][a][d][b] G[a][b], instead of S (S + 1) multiply-adds and 2 S + S S reads per point for EACH of the nct x ncr entries.
       const bool gram = !p.cq && form.nct * form.ncr > 1;
       if (gram) {
-        for (int k = lane; k < nbt * nbr; k += 64) {
-          const int m = k / nbr, n = k - m * nbr;
-          double G[S][S];
+        // a lane takes test function m and TWO trial functions n, n + h (h = half the trial functions): the test row of a point is read once for both
+        // (63 488 ragged elements 1.77 -> 1.67 ms; two test functions as well: 1.64 ms, not worth the code)
+        const int h = (nbr + 1) >> 1;
+        for (int k = lane; k < nbt * h; k += 64) {
+          const int m = k / h, n0 = k - m * h, n1 = n0 + h;
+          const bool two = n1 < nbr;
+          double G[2][S][S];
 #pragma unroll
-          for (int a = 0; a < S; ++a)
+          for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-            for (int b = 0; b < S; ++b) G[a][b] = 0.;
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+              for (int b = 0; b < S; ++b) G[pp][a][b] = 0.;
           for (int q = q0; q < q1; ++q) {
             const double *dt = Dt + ((q - q0) * nbt + m) * S;
-            const double *dr = Dr + ((q - q0) * nbr + n) * S;
+            const double *dr0 = Dr + ((q - q0) * nbr + n0) * S, *dr1 = Dr + ((q - q0) * nbr + (two ? n1 : n0)) * S;
             const double wq = Jw[q * JW + ND * ND];
-            double drv[S];
+            double d0[S], d1[S];
 #pragma unroll
-            for (int b = 0; b < S; ++b) drv[b] = dr[b];
+            for (int b = 0; b < S; ++b) d0[b] = dr0[b], d1[b] = dr1[b];
 #pragma unroll
             for (int a = 0; a < S; ++a) {
               const double wa = wq * dt[a];
 #pragma unroll
-              for (int b = 0; b < S; ++b) G[a][b] += wa * drv[b];
+              for (int b = 0; b < S; ++b) G[0][a][b] += wa * d0[b], G[1][a][b] += wa * d1[b];
             }
           }
           const i64 row = p.test.dofs[tdof0 + m];
           const i64 a0 = p.srowptr[row], len = p.srowptr[row + 1] - a0;
-          const i64 pos = p.emap[emap0 + m * nbr + n];
-          const int both = p.exclusive ? ft_node<ND>(p.ft, m) & ft_node<ND>(p.ft, n) : 0;
-          const bool first = p.exclusive && p.ft.on && q0 == 0 && !((both & ftlo) | ((both >> 3) & fthi));
-          for (int c = 0; c < form.nct; ++c)
-            for (int d = 0; d < form.ncr; ++d) {
-              if (!form.mask[c][d]) continue;
-              const double *Cc = form.C + ((c * S) * form.ncr + d) * S;  // C[c][a][d][b] = Cc[a * ncr * S + b]
-              double acc = 0;
 #pragma unroll
-              for (int a = 0; a < S; ++a)
+          for (int pp = 0; pp < 2; ++pp) {
+            if (pp && !two) break;
+            const int n = pp ? n1 : n0;
+            const i64 pos = p.emap[emap0 + m * nbr + n];
+            const int both = p.exclusive ? ft_node<ND>(p.ft, m) & ft_node<ND>(p.ft, n) : 0;
+            const bool first = p.exclusive && p.ft.on && q0 == 0 && !((both & ftlo) | ((both >> 3) & fthi));
+            for (int c = 0; c < form.nct; ++c)
+              for (int d = 0; d < form.ncr; ++d) {
+                if (!form.mask[c][d]) continue;
+                const double *Cc = form.C + ((c * S) * form.ncr + d) * S;  // C[c][a][d][b] = Cc[a * ncr * S + b]
+                double acc = 0;
 #pragma unroll
-                for (int b = 0; b < S; ++b) acc += Cc[a * form.ncr * S + b] * G[a][b];
-              if (p.local) {
-                double *dst = p.local + (emap0 + m * nbr + n) * (form.nct * form.ncr) + c * form.ncr + d;
-                *dst = q0 ? *dst + acc : acc;
-                continue;
+                for (int a = 0; a < S; ++a)
+#pragma unroll
+                  for (int b = 0; b < S; ++b) acc += Cc[a * form.ncr * S + b] * G[pp][a][b];
+                if (p.local) {
+                  double *dst = p.local + (emap0 + m * nbr + n) * (form.nct * form.ncr) + c * form.ncr + d;
+                  *dst = q0 ? *dst + acc : acc;
+                  continue;
+                }
+                const i64 slot = a0 * form.tot + len * form.cum[c] + pos * form.cnt[c] + form.dpos[c][d];
+                if (p.exclusive) p.values[slot] = first ? acc : p.values[slot] + acc;
+                else atomicAdd(p.values + slot, acc);
               }
-              const i64 slot = a0 * form.tot + len * form.cum[c] + pos * form.cnt[c] + form.dpos[c][d];
-              if (p.exclusive) p.values[slot] = first ? acc : p.values[slot] + acc;
-              else atomicAdd(p.values + slot, acc);
-            }
+          }
         }
       } else
       for (int k = lane; k < nentries; k += 64) {
