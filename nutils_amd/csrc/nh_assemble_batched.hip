@@ -90,6 +90,49 @@ template <int ND>
 __device__ __forceinline__ void eval_fields(const FieldK *fields, int nfields, i64 e, int q, int nq, const double (&Ji)[ND][ND], const double *ue,
                                              const double *TT, double *u) {
   constexpr int S = 1 + ND;
+  // several scalar fields on ONE basis (the phase field and the chemical potential of configs[3], ...): a table row is loaded once for all of them
+  bool shared = nfields >= 2 && nfields <= 4;
+  for (int f = 0; f < nfields && shared; ++f)
+    shared = fields[f].ncomp == 1 && fields[f].b.T == fields[0].b.T && fields[f].b.tab == fields[0].b.tab && fields[f].b.off == fields[0].b.off && fields[f].b.nb == fields[0].b.nb &&
+             fields[f].tsame == fields[0].tsame;
+  if (shared) {
+    const FieldK &F0 = fields[0];
+    const int nb = bnb(F0.b, e);
+    const double *T = (TT && F0.tsame) ? TT + (size_t)q * S : F0.b.T + (bfn(F0.b, e) * nq + q) * S;
+    double r[4][S];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int s = 0; s < S; ++s) r[f][s] = 0;
+#pragma unroll 4
+    for (int n = 0; n < nb; ++n) {
+      const double *Tn = T + (size_t)n * nq * S;
+      double tn[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) tn[s] = Tn[s];
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        if (f < nfields) {
+          const double un = ue[fields[f].ue0 + n];
+#pragma unroll
+          for (int s = 0; s < S; ++s) r[f][s] += tn[s] * un;
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+      if (f < nfields) {
+        double *o = u + fields[f].c0 * S;
+        o[0] = r[f][0];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          double sum = 0;
+#pragma unroll
+          for (int j = 0; j < ND; ++j) sum += r[f][1 + j] * Ji[j][i];
+          o[1 + i] = sum;
+        }
+      }
+    return;
+  }
   for (int f = 0; f < nfields; ++f) {
     const FieldK &F = fields[f];
     const int nb = bnb(F.b, e);
