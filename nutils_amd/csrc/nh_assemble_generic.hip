@@ -791,8 +791,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     const size_t padded = (size_t)((pat->nelems + 63) / 64 * 64) * std::max(pat->nbt * pat->nbr, 1);
     if ((rc = nh_gather_scratch(std::max((size_t)pat->emap_len, padded) * a->nct * a->ncr, &scratch)) != NH_OK) return rc;
     bool done = false;
-    int sym_nb = 0;
-    if ((rc = nh_local_scalar(a, scratch, &done, nh_stream(stream), &sym_nb)) != NH_OK) return rc;
+    if ((rc = nh_local_scalar(a, scratch, &done, nh_stream(stream))) != NH_OK) return rc;
     if (!done && (rc = nh_local_vector(a, scratch, &done, nh_stream(stream))) != NH_OK) return rc;
     if (done) {
       GSlots gs;
@@ -802,7 +801,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
         gs.cnt[c] = form.cnt[c], gs.cum[c] = form.cum[c];
         for (int d = 0; d < MAXC; ++d) gs.dpos[c][d] = form.dpos[c][d], gs.mask[c][d] = form.mask[c][d];
       }
-      return nh_gather_values(pat, scratch, a->nelems, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream), sym_nb);
+      return nh_gather_values(pat, scratch, a->nelems, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream));
     }
     p.local = scratch;
   }

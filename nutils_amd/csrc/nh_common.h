@@ -138,9 +138,8 @@ struct GSlots {
 int nh_gather_prepare(nh_pattern *p, const nh_basis &test, const int32_t *elist, hipStream_t s);  // elist: element ids of the pattern's elements, or NULL
 int nh_gather_scratch(size_t doubles, double **out);
 int nh_local_vector(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);
-// sym_nb > 0: `local` holds the upper triangles of symmetric sym_nb x sym_nb local matrices (k_local_scalar with a diagonal form on one basis)
-int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s, int sym_nb = 0);
-int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s, int *sym_nb = nullptr);
+int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s);
+int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);
 // owner-block assembly (NH_MATRIX_FUSED); *done = false: not applicable to this launch, nothing was written
 int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s);
 void nh_fused_free(nh_fused_plan *f);

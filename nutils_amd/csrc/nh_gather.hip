@@ -49,8 +49,6 @@ __global__ void k_rowof(i64 nrows, const i64 *srowptr, int32_t *grow) {
 }
 
 // pass 2: one thread per scalar entry; local: element-major [position][nct * ncr]
-// NB > 0: the local matrices are NB x NB symmetric, stored as upper triangles (k_local_scalar with SYMD); the map holds positions of the full layout
-template <int NB>
 __global__ void k_gather_values(i64 nnz, const unsigned *gptr, const int32_t *gsrc, const int32_t *grow, const i64 *srowptr, const double *local, i64 ld, int per,
                                 GSlots gs, double *values, int store) {
   const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,14 +65,6 @@ __global__ void k_gather_values(i64 nnz, const unsigned *gptr, const int32_t *gs
       double v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) idx[u] = i0 + u < e ? (unsigned)gsrc[i0 + u] : 0xffffffffu;
-      if constexpr (NB > 0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (idx[u] != 0xffffffffu) {
-            const unsigned el = idx[u] / (NB * NB), r = idx[u] - el * (NB * NB), m = r / NB, n = r - m * NB, lo = m < n ? m : n, hi = m < n ? n : m;
-            idx[u] = el * (NB * (NB + 1) / 2) + lo * NB - lo * (lo - 1) / 2 + (hi - lo);
-          }
-      }
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = idx[u] != 0xffffffffu ? local[idx[u]] : 0.;
 #pragma unroll
@@ -318,28 +308,16 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
   // neighbouring lanes are that far apart: stored straight from the registers, every instruction touches 64 lines (0.23 of the 0.61 ms of this
   // kernel on the 128^3 trilinear mesh).  The wave transposes through LDS instead, CH values per element at a time, so that 64 / CH elements' chunks of
   // CH * 8 contiguous bytes go out per instruction.
-  // SYMD: only the upper triangle is stored, row by row (entry (m, n), m <= n, at m NBT - m (m - 1) / 2 + n - m): the gather maps its positions itself
-  // (k_gather_values<NB>), the scratch traffic of both passes drops by (NBT + 1) / (2 NBT)
-  constexpr int NE = SYMD ? NBT * (NBT + 1) / 2 : NBT * NBR, CH = NE % 16 == 0 ? 16 : NE % 9 == 0 ? 9 : NE % 4 == 0 ? 4 : NE % 5 == 0 ? 5 : NE % 3 == 0 ? 3 : 1, PADW = CH | 1;
+  constexpr int NE = NBT * NBR, CH = NE % 16 == 0 ? 16 : NE % 9 == 0 ? 9 : NE % 4 == 0 ? 4 : 1, PADW = CH | 1;
   double *stg = sT + p.ldst_doubles + (threadIdx.x >> 6) * 64 * PADW;
   const int lane = threadIdx.x & 63;
   const i64 wave0 = ie0 - lane;  // first element of this wave
 #pragma unroll
   for (int c0 = 0; c0 < NE; c0 += CH) {
-    if constexpr (SYMD) {  // (the entries of this chunk by a pass over the triangle: all indices are compile-time constants after unrolling)
 #pragma unroll
-      for (int m = 0; m < NBT; ++m)
-#pragma unroll
-        for (int n = m; n < NBR; ++n) {
-          const int l = m * NBT - m * (m - 1) / 2 + (n - m);
-          if (l >= c0 && l < c0 + CH) stg[lane * PADW + (l - c0)] = A[m][n];
-        }
-    } else {
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const int l = c0 + j, m = l / NBR, n = l % NBR;
-        stg[lane * PADW + j] = A[m][n];
-      }
+    for (int j = 0; j < CH; ++j) {
+      const int l = c0 + j, m = l / NBR, n = l % NBR;
+      stg[lane * PADW + j] = (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n];
     }
     __builtin_amdgcn_wave_barrier();
     // lanes (el, idx): CH consecutive values of element el; 64 / CH elements per pass (CH = 9: 7 elements, one idle lane)
@@ -1175,22 +1153,12 @@ __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
   }
 }
 
-int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s, int sym_nb) {
+int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s) {
   if (!p->nnz) return NH_OK;
-  if (slots.nct * slots.ncr == 1) {
-    const dim3 grid((unsigned)((p->nnz + 255) / 256)), block(256);
-#define GV(NB) hipLaunchKernelGGL((k_gather_values<NB>), grid, block, 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, ld, p->nbt * p->nbr, slots, values, store)
-    switch (sym_nb) {
-      case 0: GV(0); break;
-      case 2: GV(2); break;
-      case 3: GV(3); break;
-      case 4: GV(4); break;
-      case 8: GV(8); break;
-      case 9: GV(9); break;
-      default: nh_set_error("nh_gather_values: no symmetric instantiation for %d functions", sym_nb); return NH_EINVAL;
-    }
-#undef GV
-  } else
+  if (slots.nct * slots.ncr == 1)
+    hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, ld, p->nbt * p->nbr, slots,
+                       values, store);
+  else
     hipLaunchKernelGGL(k_gather_values_v, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, slots, values, store);
   NH_LAUNCH_CHECK();
   return NH_OK;
@@ -1503,9 +1471,8 @@ int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s) {
 }
 
 // thread-per-element pass 1 for scalar forms on uniform bases of the instantiated sizes; *done = false: the caller runs the generic kernel
-int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s, int *sym_nb) {
+int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s) {
   *done = false;
-  if (sym_nb) *sym_nb = 0;
   if (a->nct != 1 || a->ncr != 1 || a->cq_dev || a->test.off_dev || a->trial.off_dev || !a->test.nb || !a->trial.nb) return NH_OK;
   const int S = 1 + a->ndims;
   LocK p;
@@ -1538,7 +1505,6 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
   const size_t ldsx = (ldst ? ldsb : rows ? ldsg : 0) + sizeof(double) * 2 * 64 * 17;  // + two waves' transposition buffers
 #define LOC(ND, NBT, NBR)                                                                                         \
   do {                                                                                                            \
-    if (NBT == NBR && symd && sym_nb) *sym_nb = NBT;                                                              \
     if (NBT == NBR && symd) {                                                                                     \
       if (ldst) hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, true, NBT == NBR>), grid, block, ldsx, s, p);    \
       else hipLaunchKernelGGL((k_local_scalar<ND, NBT, NBR, false, NBT == NBR>), grid, block, ldsx, s, p);        \
