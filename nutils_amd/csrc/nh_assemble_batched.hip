@@ -64,6 +64,7 @@ struct TermsK {
   double tabarg[TABARG];
   int rowsper;  // sum over blocks of maxnb * nct: output lanes per element
   int uesz;     // staged field coefficients per element
+  int tstage;   // all blocks and fields live on ONE uniform-size basis: the table of the batch's first element class is staged in LDS ([maxnb][nq][S] behind UE)
 };
 
 // coefficients of all fields on the elements of a batch -> LDS, ue[el][uesz]: the gathers u[dofs[...]] are two dependent global loads; here
@@ -209,13 +210,25 @@ __device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, 
   double *G = lds + p.tlen;                         // [eb * nq][ct][S]: integrand, then its reference form times w |J|
   double *U = G + (size_t)p.eb * p.nq * p.ct * S;   // [NTB][fct][S]: field values of this thread's point
   double *UE = U + (size_t)NTB * p.fct * S;         // [eb][uesz]: field coefficients of the elements of the batch
+  double *TS = UE + (size_t)p.eb * p.uesz;          // tstage: [maxnb][nq][S] table of one element class, then its tag
+  i64 *tag = reinterpret_cast<i64 *>(TS + (size_t)p.blocks[0].maxnb * p.nq * S);
   const int tid = threadIdx.x;
   for (int i = tid; i < p.tlen; i += NTB) tab[i] = p.table ? p.table[i] : p.tabarg[i];
+  if (p.tstage && tid == 0) *tag = -1;
   const int npts = p.eb * p.nq;
   for (i64 b0 = (i64)bid * p.eb; b0 < p.nelems; b0 += (i64)nbid * p.eb) {
     __syncthreads();  // table staged; G of the previous batch consumed
+    i64 cls0 = -1;
+    if (p.tstage) {  // the class of the batch's first element (it stays staged while consecutive batches keep it)
+      cls0 = bfn(p.blocks[0].test, p.elist ? p.elist[b0] : b0);
+      if (*tag != cls0) {
+        const int n = p.blocks[0].maxnb * p.nq * S;
+        for (int i = tid; i < n; i += NTB) TS[i] = p.blocks[0].test.T[cls0 * p.nq * S + i];
+      }
+    }
     stage_coeffs(p.fields, p.nfields, p.uesz, UE, p.eb, b0, p.nelems, p.elist, tid);
     __syncthreads();
+    if (p.tstage && tid == 0) *tag = cls0;
     for (int t = tid; t < npts; t += NTB) {
       const int el = t / p.nq, q = t - el * p.nq;
       const i64 ie = b0 + el;
@@ -226,7 +239,9 @@ __device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, 
       geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
       const double wdet = p.weights[q] * fabs(det);
       double *u = U + (size_t)tid * p.fct * S;
-      eval_fields<ND>(p.fields, p.nfields, e, q, p.nq, Ji, UE + (size_t)el * p.uesz, nullptr, u);
+      // (wave-uniform choice: a pointer that is LDS for some lanes and global for others would be a flat access)
+      if (p.tstage && __all(bfn(p.blocks[0].test, e) == cls0)) eval_fields<ND>(p.fields, p.nfields, e, q, p.nq, Ji, UE + (size_t)el * p.uesz, TS, u);
+      else eval_fields<ND>(p.fields, p.nfields, e, q, p.nq, Ji, UE + (size_t)el * p.uesz, nullptr, u);
       double pv[MAXP];
       eval_polys<S>(tab, p.poff, p.npolys, u, pv);
       // integrand of every block: sum of the terms
@@ -280,13 +295,16 @@ __device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, 
       const BlockK &B = p.blocks[blk];
       const int m = r / B.nct, c = r - m * B.nct;
       if (m >= bnb(B.test, e)) continue;
-      const double *T = B.test.T + (bfn(B.test, e) + m) * p.nq * S;
       const double *g = G + ((size_t)el * p.nq * p.ct + (B.c0 + c)) * S;
       double acc = 0;
-      for (int q = 0; q < p.nq; ++q) {
+      auto row = [&](const double *T) {
+        for (int q = 0; q < p.nq; ++q) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) acc += T[q * S + s] * g[(size_t)q * p.ct * S + s];
-      }
+          for (int s = 0; s < S; ++s) acc += T[q * S + s] * g[(size_t)q * p.ct * S + s];
+        }
+      };
+      if (p.tstage && bfn(B.test, e) == cls0) row(TS + (size_t)m * p.nq * S);
+      else row(B.test.T + (bfn(B.test, e) + m) * p.nq * S);
       if (B.local) B.local[(boff(B.test, e) + m) * B.nct + c] = acc;
       else atomicAdd(B.out + (i64)B.test.dofs[boff(B.test, e) + m] * B.nct + c, acc);
     }
@@ -1316,7 +1334,17 @@ int build_terms(const nh_terms_args *a, hipStream_t stream, TermsK &p, std::vect
   p.tlen = (int)tab.size();
   // elements per batch: as many as fill the workgroup in the pointwise phase
   p.eb = std::max(1, NTB / a->nq);
-  *ldsbytes = sizeof(double) * ((size_t)p.tlen + (size_t)p.eb * a->nq * p.ct * S + (size_t)NTB * p.fct * S + (size_t)p.eb * p.uesz);
+  // one basis for every block and field (uniform size, no ragged offsets): its table of the batch's element class goes to LDS (a structured mesh has one class
+  // nearly everywhere; waves with another class read global memory as before)
+  p.tstage = a->nblocks >= 1 && a->blocks[0].test.nb > 0 && !a->blocks[0].test.off_dev;
+  for (int b = 0; b < a->nblocks && p.tstage; ++b)
+    p.tstage = a->blocks[b].test.T_dev == a->blocks[0].test.T_dev && a->blocks[b].test.tab_dev == a->blocks[0].test.tab_dev && a->blocks[b].test.nb == a->blocks[0].test.nb && !a->blocks[b].test.off_dev;
+  for (int f = 0; f < a->nfields && p.tstage; ++f)
+    p.tstage = a->fields[f].basis.T_dev == a->blocks[0].test.T_dev && a->fields[f].basis.tab_dev == a->blocks[0].test.tab_dev && a->fields[f].basis.nb == a->blocks[0].test.nb && !a->fields[f].basis.off_dev;
+  const size_t tsz = p.tstage ? (size_t)a->blocks[0].test.nb * a->nq * S + 2 : 0;
+  if (tsz * sizeof(double) > 16 * 1024) p.tstage = 0;
+  for (int f = 0; f < a->nfields; ++f) p.fields[f].tsame = p.tstage;
+  *ldsbytes = sizeof(double) * ((size_t)p.tlen + (size_t)p.eb * a->nq * p.ct * S + (size_t)NTB * p.fct * S + (size_t)p.eb * p.uesz + (p.tstage ? tsz : 0));
   p.table = nullptr;
   return NH_OK;
 }
