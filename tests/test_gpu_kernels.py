@@ -1081,3 +1081,77 @@ def test_ragged_blocks_become_reproducible_from_the_second_assembly(golden):
         out.append(device.to_host(values))
         close(out[-1], g['tK_values'])
     assert numpy.array_equal(out[1], out[2]) and numpy.array_equal(out[2], out[3])
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_fused_simplex_meshes(nd):
+    '''Unstructured-type connectivity the golden fixtures do not hold: P1 triangles (quadrilaterals split in two) and P1 tetrahedra (Kuhn subdivision of hexahedra) with an
+    isoparametric simplex geometry (nd + 1 geometry functions: the general vertex loop of the geometry routines), randomly renumbered -- owner blocks against the oracle's
+    assembly and against the deterministic gather.'''
+    import itertools
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa, poly
+    n = 14 if nd == 2 else 7
+    rng = numpy.random.default_rng(21)
+    grid = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.)] * nd, indexing='ij'), -1)
+    vid = numpy.arange((n + 1) ** nd).reshape((n + 1,) * nd)
+    verts = grid.reshape(-1, nd) + rng.uniform(-.15, .15, ((n + 1) ** nd, nd))
+    cells = []
+    for c in itertools.product(range(n), repeat=nd):
+        c = numpy.array(c)
+        if nd == 2:
+            v = lambda i, j: vid[c[0] + i, c[1] + j]
+            cells += [[v(0, 0), v(1, 0), v(0, 1)], [v(1, 1), v(0, 1), v(1, 0)]]
+        else:
+            for perm in itertools.permutations(range(3)):
+                p = [c.copy()]
+                for ax in perm:
+                    q = p[-1].copy()
+                    q[ax] += 1
+                    p.append(q)
+                cells.append([vid[tuple(x)] for x in p])
+    dofs = numpy.array(cells, dtype=numpy.int64)
+    ndofs = len(verts)
+    perm = rng.permutation(ndofs)
+    dofs = perm[dofs][rng.permutation(len(dofs))]
+    v2 = numpy.empty_like(verts)
+    v2[perm] = verts
+    ne, nb = dofs.shape
+    P = poly.powers(nd, 1)  # exponent table of the degree-1 polynomials in the reference's coefficient order
+    coeffs = numpy.zeros((nb, len(P)))
+    for k, e in enumerate(P):
+        if e.sum() == 0:
+            coeffs[0, k] = 1.
+        else:
+            ax = int(numpy.argmax(e))
+            coeffs[0, k], coeffs[1 + ax, k] = -1., 1.
+    if nd == 2:
+        pts = numpy.array([[1 / 6, 1 / 6], [2 / 3, 1 / 6], [1 / 6, 2 / 3]])
+        w = numpy.full(3, 1 / 6)
+    else:
+        a, b = .5854101966249685, .1381966011250105
+        pts = numpy.array([[b, b, b], [a, b, b], [b, a, b], [b, b, a]])
+        w = numpy.full(4, 1 / 24)
+    C = oa.laplace_coefficient(nd) + .7 * oa.mass_coefficient(nd)
+    # oracle
+    N, dN = oa.tabulate(coeffs, pts)
+    x, J = oa.geometry_iso(v2, dofs, numpy.broadcast_to(N, (ne,) + N.shape), numpy.broadcast_to(dN, (ne,) + dN.shape))
+    D, det = oa.physical_tables(numpy.broadcast_to(N, (ne,) + N.shape), numpy.broadcast_to(dN, (ne,) + dN.shape), J)
+    vo, rpo, cio = oa.assemble_csr(oa.local_matrices(D, D, det * w, C), dofs, dofs, ndofs, ndofs)
+    # device
+    T = kernels.tabulate(device.to_dev(coeffs, 'float64'), nb, coeffs.shape[1], device.to_dev(pts, 'float64'), len(pts), nd)
+    d = device.to_dev(dofs.ravel(), 'int32')
+    basis = kernels.basis(T, d, nb=nb)
+    geom = kernels.geometry_iso(nb, T, d, device.to_dev(v2, 'float64'))
+    pattern = kernels.Pattern(ne, ndofs, ndofs, d, d, nbt=nb, nbr=nb)
+    rowptr, colidx = pattern.expand(1, 1, None)
+    assert numpy.array_equal(device.to_host(rowptr), rpo) and numpy.array_equal(device.to_host(colidx), cio)
+    out = {}
+    for name, kw in (('fused', dict(fused=True, store=True)), ('gather', dict(gather=True))):
+        values = device.to_dev(numpy.full(colidx.numel(), numpy.nan), 'float64') if kw.get('store') else device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=ne, ndims=nd, nq=len(pts), weights=device.to_dev(w, 'float64'), geom=geom, test=basis, trial=basis, nct=1, ncr=1, C=C, mask=None,
+                                pattern=pattern, values=values, **kw)
+        out[name] = device.to_host(values)
+        close(out[name], vo)
+    nblocks, rpb, nvisits = pattern.fused_info()
+    assert nblocks >= 1 and pattern.fused_routine == 0 and nvisits >= ne
