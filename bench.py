@@ -92,7 +92,8 @@ def timed_steps(wl, steps, world, dist, use_graph):
             with torch.cuda.graph(graph):
                 for _ in range(per_graph):
                     wl.step()
-            graph.replay()
+            for _ in range(3):  # (untimed: the first replays of a graph carry its upload to the device)
+                graph.replay()
             torch.cuda.synchronize()
         except Exception:
             graph, per_graph = None, 1
@@ -122,6 +123,8 @@ def timed_steps(wl, steps, world, dist, use_graph):
 
     elapsed, launch = run(False), 'eager'
     if graph is not None:  # both are complete executions of `steps` steps; report the faster launch mode
+        graph.replay()  # (untimed: back from the eager launch path to the graph's)
+        torch.cuda.synchronize()
         eg = run(True)
         if eg < elapsed:
             elapsed, launch = eg, f'hipGraph replay ({per_graph} steps per graph)'
