@@ -85,8 +85,8 @@ def timed_steps(wl, steps, world, dist, use_graph):
     kernel_ms = sum(s.elapsed_time(e) for s, e in kev) / steps
     graph, per_graph = None, 1
     if use_graph and world == 1:
-        # several steps per graph (a divisor of `steps`, at most 10): the replay of a one-kernel graph still costs ~8 us of launch latency per step
-        per_graph = next(g for g in (10, 8, 5, 4, 2, 1) if steps % g == 0)
+        # several steps per graph (a divisor of `steps`, at most 20): the replay of a one-kernel graph still costs ~8 us of launch latency per step
+        per_graph = next(g for g in (20, 10, 8, 5, 4, 2, 1) if steps % g == 0)
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
