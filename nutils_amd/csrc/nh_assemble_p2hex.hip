@@ -20,10 +20,11 @@
 // with 16-byte stores.  Every element is visited by 4 lines (halo recomputation of the cheap part: geometry + D table); the MFMA
 // work is 8 units of 4 rows per element instead of 6.75.
 //
-// Two kernels: k_p2hex_pipe (default) splits the workgroup into 4 MFMA waves and 4 service waves that run one element ahead -- the
-// service waves evaluate the geometry of the next slice, build the next D table and stream the planes finished in the previous
-// step while the matrix pipe works -- one barrier per element; k_p2hex (all waves in lockstep through the same phases, less LDS)
-// takes the configurations whose tables do not fit twice.
+// Three kernels.  k_p2hex_inreg (default, round 3): 4 MFMA waves form their operands in registers from one record per quadrature point (row broadcast
+// by v_fmac_f64_dpp row_newbcast), 4 service waves evaluate the geometry one slice ahead and stream the planes finished in the previous slice -- one
+// barrier per SLICE.  k_p2hex_pipe (rounds 1-2; kept for forms with a scale array and the one instantiation the in-register variant would spill):
+// the service waves also build a D table per element in LDS, one element ahead -- one barrier per element.  k_p2hex (all waves in lockstep through the
+// same phases, less LDS) takes the configurations whose tables do not fit twice (four operator slots).
 //
 // The closed-form pattern of this basis: along an axis with n elements node X couples to [X-2, X+2] (X even, clipped) or
 // [X-1, X+1] (X odd); rows are tensor products of these ranges, so row pointers and column positions are arithmetic.
