@@ -421,8 +421,13 @@ __device__ __forceinline__ void half_wait(unsigned *cnt, unsigned target) {
   asm volatile("" ::: "memory");
 }
 
+#ifdef NH_P1HEX_WPE  // experiment: tell the scheduler that two waves per SIMD is all there will ever be
+#define NH_WPE __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define NH_WPE
+#endif
 template <int TJ, int TK, bool MASS, bool COEF>
-__global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
+__global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
   constexpr bool VEC = false;
 #ifdef NH_ABLATION
   long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
 #endif
   constexpr int G = TJ * TK, NT = 2 * G, NP = 4, OJ = TJ - 1, OK = TK - 1, NS = 15, VW = 3;
   constexpr int VJ = TJ + 1, VK = TK + 1, RP = VJ * VK, PS = (RP * NS + 1) & ~1, VPG = (RP + G - 1) / G;
+  const bool getenv_stage_late = p.wbnd < 0;  // (A/B switch of the launcher: negative weight = stage behind the stores as before)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *acc = lds;                                               // [NP][RP][NS], plane stride PS
   double *vbuf = lds + NP * PS;                                    // [3][VJ][VK][VW]
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
   // its first plane and one behind its last, and the workgroups share the cost axis evenly
   // Columns on the J boundary (first and last tile row) flush through the general path (rows of different lengths, 8-byte stores) and take
   // ~1.3x as long per plane: their cost units are weighted p.wbnd / 16 so that all workgroups finish together
-  const i64 CP = NPL + 2, WI = 16, WB = p.nbj > 1 ? p.wbnd : 16;
+  const i64 CP = NPL + 2, WI = 16, WB = p.nbj > 1 ? (p.wbnd < 0 ? -p.wbnd : p.wbnd) : 16;
   const i64 rowB = p.nbk * CP * WB, rowI = p.nbk * CP * WI, nmid = max(p.nbj - 2, 0);
   const i64 ctot = (p.nbj > 1 ? 2 : 1) * rowB + nmid * rowI;
   auto unit_at = [&](i64 c) {
@@ -529,7 +535,17 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
 #pragma unroll
         for (int k = 0; k < VPG; ++k) load_vertex(needv ? s + 2 : -1, lt + k * G, J0, K0, Vn[k]);
         const int P = s - 1;
-        bool arrived = false;
+        bool arrived = false, staged = false;
+        auto stage_vertices = [&]() {
+#pragma unroll
+          for (int k = 0; k < VPG; ++k) {
+            const int r = lt + k * G;
+            if (r < RP) {
+              double *dst = vbuf + vslot_of(s + 2) + r * VW;
+              dst[0] = Vn[k][0], dst[1] = Vn[k][1], dst[2] = Vn[k][2];
+            }
+          }
+        };
         if (P >= A && !(DEBUG(p) & 2)) {
           const bool lowJ = J0 == 0, highJ = J0 + OJ >= N1;
           const int cumJ0 = J0 == 0 ? 0 : 3 * J0 - 1;
@@ -565,6 +581,13 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
             half_arrive(hcnt);
             arrived = true;
             NH_TICK(8)
+            // the vertex plane of the next layer is staged HERE, in front of the stores: its loads were issued in front of the LDS reads and have
+            // returned by now, while behind the stores the (in-order) wait for them would be a wait for the whole flush to drain
+            if (needv && !getenv_stage_late) {
+              __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+              stage_vertices();
+              staged = true;
+            }
             const i64 stride8 = 8 * (i64)(9 * (int)T2);
             char *l0 = reinterpret_cast<char *>(p.values + ((3 * (i64)P - 1) * T1 * T2 + 3 * (cumJ0 * T2) + 9 * (3 * (i64)K0 - 1)));
             char *lp = l0 + 16 * lt;
@@ -636,16 +659,7 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
           for (int t = lt; t < PS / 2; t += G) z[t] = make_double2(0., 0.);
         }
         NH_TICK(9)
-        if (needv) {
-#pragma unroll
-          for (int k = 0; k < VPG; ++k) {
-            const int r = lt + k * G;
-            if (r < RP) {
-              double *dst = vbuf + vslot_of(s + 2) + r * VW;
-              dst[0] = Vn[k][0], dst[1] = Vn[k][1], dst[2] = Vn[k][2];
-            }
-          }
-        }
+        if (needv && !staged) stage_vertices();
       }
       if (mathrole) { NH_TICK(1) } else { NH_TICK(4) }
       lds_barrier();
@@ -664,6 +678,8 @@ __global__ __launch_bounds__(2 * TJ * TK) void k_p1hex_skew(P1Args p) {
 #endif
 }
 #undef NH_TICK
+
+#include "nh_p1hex_tiles.inc"
 
 // ---- uniform geometry: all element matrices are equal (the reference hoists them out of the loop too) -------------
 // One thread evaluates the element matrix of the unit cell; the assembly is then a pure streaming kernel: every CSR entry is the
@@ -801,7 +817,7 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
 #endif
   // measured optimum at 64^3 .. 256^3 (16 = unweighted: +7 .. +18 %); the tuning override is read once per process and clamped to a sane range
   static const int wbnd_env = getenv("NH_P1HEX_WBND") ? std::min(64, std::max(8, atoi(getenv("NH_P1HEX_WBND")))) : 20;
-  p.wbnd = wbnd_env;
+  p.wbnd = getenv("NH_P1HEX_STAGE_LATE") ? -wbnd_env : wbnd_env;
   constexpr int TJ = 16, TK = 16, L = 2, NTM = L * TJ * TK, NS = VEC ? 1 : 15, VW = VEC ? 4 : 3;
   // (per-step path of a Newton loop / of a multi-GPU slab whose kernel lasts ~20 us: device queries and the LDS attribute once per process)
   static int cus = 0;
@@ -822,8 +838,8 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
 #endif
   auto kern = k_p1hex_march<TJ, TK, L, VEC, MASS, COEF>;
   if constexpr (!VEC && L == 2) {  // the matrix goes through the skewed kernel (same tile, same LDS, same launch) unless NH_P1HEX_MARCH=1
-    const char *env = getenv("NH_P1HEX_MARCH");  // (read per launch: the tests compare the two kernels within one process)
-    const bool march = env && atoi(env);
+    const char *env = getenv("NH_P1HEX_MARCH"), *kenv = getenv("NH_P1HEX_KERNEL");  // (read per launch: the tests compare the kernels within one process)
+    const bool march = (env && atoi(env)) || (kenv && !strcmp(kenv, "march"));
     if (!march) kern = k_p1hex_skew<TJ, TK, MASS, COEF>;
   }
   static const void *attr_set[2] = {nullptr, nullptr};  // (this instantiation: the marching and the skewed kernel)
@@ -855,6 +871,129 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
   }
 #endif
   return NH_OK;
+}
+
+
+// ---- launch of the exact-tile kernel (matrix) ------------------------------------------------------------------------------------
+namespace {
+struct TileScratch {
+  void *base = nullptr;  // one allocation: ctl (64 B) | flags | flags_pro | exp | exp_pro
+  size_t cap = 0;
+  unsigned *err_host = nullptr, *err_dev = nullptr;
+};
+TileScratch g_tiles[16];  // per device
+}  // namespace
+
+int nh_p1hex_tiles_release(void) {
+  for (auto &t : g_tiles) {
+    if (t.base) NH_CHECK_HIP(hipFree(t.base));
+    t.base = nullptr, t.cap = 0;
+  }
+  return NH_OK;
+}
+
+template <bool MASS, bool COEF>
+static int launch_tiles_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
+  using namespace p1t;
+  int dev = 0;
+  NH_CHECK_HIP(hipGetDevice(&dev));
+  NH_REQUIRE(dev >= 0 && dev < 16, "nh_p1hex: device index %d not supported", dev);
+  static int cus_of[16] = {0};
+  static bool attr_set[16] = {false};
+  if (!cus_of[dev]) {
+    int n = 256;
+    NH_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus_of[dev] = n;
+  }
+  auto kern = k_p1hex_tiles<MASS, COEF>;
+  if (!attr_set[dev]) {
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    attr_set[dev] = true;
+  }
+  TileScratch &ts = g_tiles[dev];
+  if (!ts.err_host) {
+    NH_CHECK_HIP(hipHostMalloc((void **)&ts.err_host, sizeof(unsigned), hipHostMallocMapped));
+    *ts.err_host = 0;
+    NH_CHECK_HIP(hipHostGetDevicePointer((void **)&ts.err_dev, ts.err_host, 0));
+  }
+  static size_t layout[16][3] = {{0}};
+  if (*ts.err_host) {  // raised by an EARLIER launch (the word is read without synchronising)
+    *ts.err_host = 0;
+    layout[dev][0] = 0;  // the flag counts of that launch are incomplete: start over on zeroed flags
+    nh_set_error("nh_p1hex_laplace: a workgroup of an earlier launch timed out waiting for the tile faces of its neighbour -- are other kernels holding CUs? "
+                 "(NH_P1HEX_KERNEL=skew selects the kernel without inter-workgroup exchange)");
+    return NH_EHIP;
+  }
+  p.nbj = (p.n1 + T - 1) / T;
+  p.nbk = (p.n2 + T - 1) / T;
+  const int ncols = p.nbj * p.nbk, NPL = p.pl1 - p.pl0;
+  NH_REQUIRE(a->max_workgroups >= 0, "nh_p1hex: negative max_workgroups");
+  const int wgmax = a->max_workgroups ? std::min(cus_of[dev], a->max_workgroups) : cus_of[dev];
+  // plane segments per column: the same in every column (producer and consumer of a tile face work on the same plane at the same time);
+  // a run of n planes costs n + 3 slots
+  int nseg = 1;
+  {
+    static const int nseg_env = getenv("NH_P1HEX_NSEG") ? atoi(getenv("NH_P1HEX_NSEG")) : 0;
+    double best = 1e300;
+    for (int c = 1; c <= NPL; ++c) {
+      const i64 rounds = ((i64)ncols * c + wgmax - 1) / wgmax;
+      const double cost = (double)rounds * ((NPL + c - 1) / c + 3);
+      if (cost < best) best = cost, nseg = c;
+    }
+    if (nseg_env > 0) nseg = std::min(nseg_env, NPL);
+  }
+  const unsigned grid = (unsigned)std::min<i64>((i64)ncols * nseg, wgmax);
+  const size_t nflags = (size_t)ncols * NPL, nfpro = (size_t)ncols * nseg;
+  const size_t off_exp = tile_exp_offset(ncols, NPL, nseg), need = off_exp + (nflags + nfpro) * NEXP * sizeof(double);
+  // the layout depends on (ncols, NPL, nseg): a change of any of them restarts the epoch on zeroed flags
+  if (need > ts.cap || layout[dev][0] != nflags || layout[dev][1] != nfpro || layout[dev][2] != (size_t)NPL) {
+    NH_CHECK_HIP(hipStreamSynchronize(nh_stream(stream)));
+    if (need > ts.cap) {
+      if (ts.base) NH_CHECK_HIP(hipFree(ts.base));
+      ts.base = nullptr, ts.cap = 0;
+      NH_CHECK_HIP(hipMalloc(&ts.base, need));
+      ts.cap = need;
+    }
+    NH_CHECK_HIP(hipMemsetAsync(ts.base, 0, off_exp, nh_stream(stream)));
+    NH_CHECK_HIP(hipMemcpyAsync((char *)ts.base + 8, &ts.err_dev, sizeof(unsigned *), hipMemcpyHostToDevice, nh_stream(stream)));
+    NH_CHECK_HIP(hipStreamSynchronize(nh_stream(stream)));
+    layout[dev][0] = nflags, layout[dev][1] = nfpro, layout[dev][2] = (size_t)NPL;
+  }
+  TileArgs ta;
+  ta.base = (char *)ts.base;
+  ta.nseg = nseg;
+  ta.xcd = grid % 8 == 0 && !a->max_workgroups;
+#ifdef NH_ABLATION
+  p.debug = getenv("NH_P1HEX_DEBUG") ? atoi(getenv("NH_P1HEX_DEBUG")) : 0;
+  if (getenv("NH_P1HEX_NOXCD")) ta.xcd = 0;
+  static long long *tdbg = nullptr;
+  if (!tdbg) NH_CHECK_HIP(hipMalloc((void **)&tdbg, 16 * sizeof(long long)));
+  NH_CHECK_HIP(hipMemsetAsync(tdbg, 0, 16 * sizeof(long long), nh_stream(stream)));
+  p.tdbg = getenv("NH_P1HEX_TIMERS") ? tdbg : nullptr;
+#endif
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, nh_stream(stream), p, ta);
+  NH_LAUNCH_CHECK();
+#ifdef NH_ABLATION
+  if (p.tdbg) {
+    long long h[16];
+    NH_CHECK_HIP(hipMemcpy(h, tdbg, sizeof h, hipMemcpyDeviceToHost));
+    const double nw = (double)grid * 4;  // waves per role
+    static int nprint = 0;
+    if (nprint++ < 3)
+      fprintf(stderr, "p1hex_tiles cycles per wave and slot (grid %u nseg %d, %.1f slots per role): MATH verts+routine %.0f | flags+imports %.0f | barrier %.0f || MEM import add+vertex loads+export+waits %.0f | "
+              "flush reads+flag+stage+stores %.0f | half wait+zero %.0f | barrier %.0f\n", grid, nseg, ((double)(p.pl1 - p.pl0) / nseg + 3) / 2,
+              h[2] / nw / (((double)(p.pl1 - p.pl0) / nseg + 3) / 2), h[3] / nw / (((double)(p.pl1 - p.pl0) / nseg + 3) / 2), h[11] / nw / (((double)(p.pl1 - p.pl0) / nseg + 3) / 2),
+              h[6] / nw / (((double)(p.pl1 - p.pl0) / nseg + 3) / 2), h[8] / nw / (((double)(p.pl1 - p.pl0) / nseg + 3) / 2), h[10] / nw / (((double)(p.pl1 - p.pl0) / nseg + 3) / 2),
+              h[12] / nw / (((double)(p.pl1 - p.pl0) / nseg + 3) / 2));
+  }
+#endif
+  return NH_OK;
+}
+
+static int launch_tiles(const nh_p1hex_args *a, P1Args &p, void *stream) {
+  const bool coef = p.qscale || p.qmass;
+  if (p.hasm) return coef ? launch_tiles_inst<true, true>(a, p, stream) : launch_tiles_inst<true, false>(a, p, stream);
+  return coef ? launch_tiles_inst<false, true>(a, p, stream) : launch_tiles_inst<false, false>(a, p, stream);
 }
 
 template <bool VEC>
@@ -951,6 +1090,11 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
     if (Ke) NH_CHECK_HIP(hipFreeAsync(Ke, nh_stream(stream)));
     return NH_OK;
   }
+  // matrix kernel (read per launch: the tests compare the kernels within one process): skew (default) | tiles | march.  The exact-tile kernel
+  // (no lateral halo, tile faces exchanged between workgroups) is correct on every mesh of the test suite but measured SLOWER at 128^3 (0.21 ms
+  // against 0.167 ms: profiles/r04_c2_exact_tiles.md) and stays opt-in.
+  const char *env = getenv("NH_P1HEX_KERNEL");
+  if (env && !strcmp(env, "tiles")) return launch_tiles(a, p, stream);
   return launch_march<false>(a, p, stream);
 }
 

@@ -143,3 +143,5 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
 // owner-block assembly (NH_MATRIX_FUSED); *done = false: not applicable to this launch, nothing was written
 int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s);
 void nh_fused_free(nh_fused_plan *f);
+// nh_assemble_p1hex.hip: exchange scratch of the exact-tile kernel
+int nh_p1hex_tiles_release(void);

@@ -696,7 +696,8 @@ extern "C" int nh_release_scratch(void) {
     NH_CHECK_HIP(hipFree(g_scratch));
     g_scratch = nullptr, g_scratch_cap = 0;
   }
-  return NH_OK;
+  NH_CHECK_HIP(hipDeviceSynchronize());
+  return nh_p1hex_tiles_release();
 }
 
 int nh_gather_prepare(nh_pattern *p, const nh_basis &test, const int32_t *elist, hipStream_t s) {

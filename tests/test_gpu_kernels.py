@@ -455,32 +455,63 @@ def test_first_touch_coloured_assembly(case, monkeypatch):
 
 
 def test_p1hex_skewed_vs_marching_kernel(monkeypatch):
-    '''The role-skewed matrix kernel (default) against the marching kernel (NH_P1HEX_MARCH=1) on random shapes, layer / plane ranges and
-    workgroup limits: the same set of entries is written (the value array is handed over full of NaN), values agree to rounding.'''
+    '''The three matrix kernels -- role-skewed halo tiles (default), exact tiles with inter-workgroup face exchange (NH_P1HEX_KERNEL=tiles),
+    marching halo tiles (march) -- on random shapes, layer / plane ranges and workgroup limits: the same set of entries is written (the
+    value array is handed over full of NaN), values agree to rounding.  Shapes reach several 16 x 16 tiles per axis, partial last tiles,
+    single-line tiles and more units than workgroups (several runs per workgroup).'''
     from nutils_amd import kernels, device, points
     x1, w1 = points.gauss1(2)
     rng = numpy.random.default_rng(11)
-    for it in range(16):
+    for it in range(20):
         shape = tuple(int(x) for x in rng.integers(2, 45, 3))
+        if it == 17:
+            shape = (5, 70, 33)
+        if it == 18:
+            shape = (40, 16, 17)
+        if it == 19:
+            shape = (3, 129, 50)
         n0 = shape[0]
         l0 = int(rng.integers(0, n0)); l1 = int(rng.integers(l0 + 1, n0 + 1))
         p0 = int(rng.integers(0, n0 + 1)); p1 = int(rng.integers(p0 + 1, n0 + 2))
-        if it % 4 == 0:
+        if it % 4 == 0 or it >= 17:
             l0, l1, p0, p1 = 0, n0, 0, n0 + 1
         nv = (shape[0] + 1) * (shape[1] + 1) * (shape[2] + 1)
         g = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3) + numpy.random.default_rng(it).uniform(-.2, .2, (nv, 3))
         verts = device.to_dev(g, 'float64')
         rowptr, colidx = kernels.p1hex_pattern(shape)
         got = []
-        for march in ('0', '1'):
-            monkeypatch.setenv('NH_P1HEX_MARCH', march)
+        for kern in ('tiles', 'skew', 'march'):
+            monkeypatch.setenv('NH_P1HEX_KERNEL', kern)
             values = device.empty(colidx.numel(), 'float64')
             values.fill_(float('nan'))
-            kernels.p1hex_laplace(shape=shape, values=values, gauss_x=x1, gauss_w=w1, verts=verts, layers=(l0, l1), planes=(p0, p1), max_workgroups=(it % 3) * 100)
+            kernels.p1hex_laplace(shape=shape, values=values, gauss_x=x1, gauss_w=w1, verts=verts, layers=(l0, l1), planes=(p0, p1), max_workgroups=(it % 3) * 100 if it != 19 else 7)
             got.append(device.to_host(values))
-        written = ~numpy.isnan(got[1])
-        assert numpy.array_equal(~numpy.isnan(got[0]), written) and written.any()
-        assert numpy.abs(got[0][written] - got[1][written]).max() <= 1e-14 * numpy.abs(got[1][written]).max()
+        written = ~numpy.isnan(got[2])
+        assert written.any()
+        for k in (0, 1):
+            assert numpy.array_equal(~numpy.isnan(got[k]), written), (shape, k)
+            assert numpy.abs(got[k][written] - got[2][written]).max() <= 1e-14 * numpy.abs(got[2][written]).max(), (shape, k)
+
+
+def test_p1hex_tiles_repeated_launches_and_layout_changes(monkeypatch):
+    '''The exact-tile kernel (NH_P1HEX_KERNEL=tiles) keeps flags across launches (epoch) and re-lays its exchange scratch when the mesh changes:
+    alternate two meshes, several launches each, every result equal to the first of its mesh and free of NaN.'''
+    from nutils_amd import kernels, device, points
+    monkeypatch.setenv('NH_P1HEX_KERNEL', 'tiles')
+    x1, w1 = points.gauss1(2)
+    first = {}
+    for it in range(8):
+        shape = (20, 40, 35) if it % 3 else (9, 33, 18)
+        nv = (shape[0] + 1) * (shape[1] + 1) * (shape[2] + 1)
+        g = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, 3) + numpy.random.default_rng(5).uniform(-.2, .2, (nv, 3))
+        rowptr, colidx = kernels.p1hex_pattern(shape)
+        values = device.empty(colidx.numel(), 'float64')
+        values.fill_(float('nan'))
+        kernels.p1hex_laplace(shape=shape, values=values, gauss_x=x1, gauss_w=w1, verts=device.to_dev(g, 'float64'))
+        v = device.to_host(values)
+        assert not numpy.isnan(v).any()
+        ref = first.setdefault(shape, v)
+        assert numpy.abs(v - ref).max() <= 1e-14 * numpy.abs(ref).max()
 
 
 # ---- fused linear forms: several elements per workgroup, all terms in one loop (nh_assemble_terms) ---------------------------------
