@@ -956,6 +956,8 @@ static int launch_tiles_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
     }
     NH_CHECK_HIP(hipMemsetAsync(ts.base, 0, off_exp, nh_stream(stream)));
     NH_CHECK_HIP(hipMemcpyAsync((char *)ts.base + 8, &ts.err_dev, sizeof(unsigned *), hipMemcpyHostToDevice, nh_stream(stream)));
+    static const unsigned always_raised = 0x7fffffffu;  // ctl[4]: the flag of a producer that does not exist
+    NH_CHECK_HIP(hipMemcpyAsync((char *)ts.base + 16, &always_raised, sizeof(unsigned), hipMemcpyHostToDevice, nh_stream(stream)));
     NH_CHECK_HIP(hipStreamSynchronize(nh_stream(stream)));
     layout[dev][0] = nflags, layout[dev][1] = nfpro, layout[dev][2] = (size_t)NPL;
   }
