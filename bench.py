@@ -44,6 +44,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--config', choices=['c2', 'c3'], default='c2', help='c2: 128^3 P1 Poisson (headline); c3: 64^3 P2 vector elasticity')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default=None, help='default: strong (one mesh split over the GPUs) when the element layers divide evenly, else weak')
+    ap.add_argument('--halo', choices=['recompute', 'reduce'], default='recompute',
+                    help='N > 1: recompute = every rank also assembles its one ghost element layer and writes only the rows it owns (no exchange; the step is one '
+                         'kernel, graph-captured); reduce = RCCL point-to-point reduce of the interface-plane rows.  The line carries the other mode as `halo_<mode>`')
     ap.add_argument('--settle', type=int, default=None, help='untimed steps before the warm-up: the first ~50 launches after idle run ~10 %% slower (clock ramp)')
     ap.add_argument('--n', '--elements-per-axis', dest='n', type=int, default=None,
                     help='elements per axis (per GPU with weak scaling; use the long form behind torch.distributed.run, whose parser claims --n)')
@@ -84,7 +87,7 @@ def timed_steps(wl, steps, world, dist, use_graph):
     torch.cuda.synchronize()
     kernel_ms = sum(s.elapsed_time(e) for s, e in kev) / steps
     graph, per_graph = None, 1
-    if use_graph and world == 1:
+    if use_graph and (world == 1 or getattr(wl, 'halo', None) is None):  # (a step without exchange is a single kernel: capturable on every rank)
         # several steps per graph (a divisor of `steps`, at most 20): the replay of a one-kernel graph still costs ~8 us of launch latency per step
         per_graph = next(g for g in (20, 10, 8, 5, 4, 2, 1) if steps % g == 0)
         try:
@@ -121,13 +124,18 @@ def timed_steps(wl, steps, world, dist, use_graph):
             el = float(t.item())
         return el
 
-    elapsed, launch = run(False), 'eager'
-    if graph is not None:  # both are complete executions of `steps` steps; report the faster launch mode
+    # Both launch modes are complete executions of exactly `steps` steps and both are reported (`ms_per_step_eager`, `ms_per_step_graph`);
+    # the headline is the graph replay whenever the step can be captured -- that is how a time loop would issue a launch-bound step -- and
+    # is NOT chosen after the fact.
+    eager = run(False)
+    modes = {'ms_per_step_eager': eager / steps * 1e3}
+    elapsed, launch = eager, 'eager'
+    if graph is not None:
         graph.replay()  # (untimed: back from the eager launch path to the graph's)
         torch.cuda.synchronize()
-        eg = run(True)
-        if eg < elapsed:
-            elapsed, launch = eg, f'hipGraph replay ({per_graph} steps per graph)'
+        elapsed, launch = run(True), f'hipGraph replay ({per_graph} steps per graph)'
+        modes['ms_per_step_graph'] = elapsed / steps * 1e3
+    timed_steps.last_modes = modes
     return elapsed, kernel_ms, launch
 
 
@@ -251,16 +259,17 @@ def fail(msg, rank, world, dist, metric):
     sys.exit(1)
 
 
-def make_workload(a, config, scaling, rank, world):
+def make_workload(a, config, scaling, rank, world, halo=None):
     from nutils_amd import workloads
+    halo = halo or a.halo
     n = a.n if config == a.config else (64 if config == 'c3' else 128)
     strong = scaling == 'strong' and world > 1
     if strong and n % world:
         raise SystemExit(f'--scaling strong: {n} element layers do not split into {world} slabs')
     layers = n // world if strong else n
     if config == 'c3':
-        return lambda r=rank, w=world: workloads.ElasticityP2(n=n, layers=layers if w > 1 else n, rank=r, world=w, variant=a.variant)
-    return lambda r=rank, w=world: workloads.PoissonSlab(n=n, layers=layers if w > 1 else n, rank=r, world=w, variant=a.variant, kernel=a.kernel)
+        return lambda r=rank, w=world: workloads.ElasticityP2(n=n, layers=layers if w > 1 else n, rank=r, world=w, variant=a.variant, halo=halo)
+    return lambda r=rank, w=world: workloads.PoissonSlab(n=n, layers=layers if w > 1 else n, rank=r, world=w, variant=a.variant, kernel=a.kernel, halo=halo)
 
 
 def settle_and_time(wl, steps, warmup, settle, world, dist, use_graph):
@@ -340,6 +349,7 @@ def main():
     torch.cuda.synchronize()
     pattern_ms = (time.perf_counter() - t0) * 1e3
     elapsed, kernel_ms, launch, settled = settle_and_time(wl, a.steps, a.warmup, a.settle, world, dist, a.graph)
+    launch_modes = dict(getattr(timed_steps, 'last_modes', {}))
 
     # size-independent check of the assembled matrix on every rank (rows it owns are complete after the interface reduce)
     wl.finish()
@@ -348,7 +358,22 @@ def main():
     if bad:
         fail(', '.join(f'{k} = {checks[k]:.3e}' for k in bad) + ': the assembled matrix is wrong', rank, world, dist, metric)
 
-    other = None
+    other = other_halo = None
+    if world > 1:
+        # the other halo mode of the same launch and scaling mode (secondary figure)
+        h2 = 'reduce' if a.halo == 'recompute' else 'recompute'
+        wh = make_workload(a, a.config, a.scaling, rank, world, halo=h2)()
+        wh.setup()
+        wh.build_pattern()
+        elh, kmsh, launchh, _ = settle_and_time(wh, a.steps, a.warmup, min(a.settle, 50), world, dist, a.graph)
+        wh.finish()
+        ch = wh.check(world, dist)
+        if not all(v < 1e-10 for v in ch.values()):
+            fail(f'halo={h2}: the assembled matrix is wrong ({ch})', rank, world, dist, metric)
+        other_halo = {'halo': h2, 'value': wh.nelems * world * a.steps / elh, 'unit': 'elements/s', 'ms_per_step': elh / a.steps * 1e3, 'kernel_ms': kmsh, 'launch': launchh,
+                      'checks': ch, **getattr(timed_steps, 'last_modes', {})}
+        del wh
+        torch.cuda.empty_cache()
     if world > 1:
         # the other scaling mode of the same launch (secondary figure; fewer settle steps -- the clocks are up)
         mode2 = 'weak' if strong else 'strong'
@@ -395,12 +420,16 @@ def main():
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': a.scaling,  # (one GPU: both modes coincide; the series N = 1, 2, 4, 8 carries one label)
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': workload, 'nelems_per_gpu': wl_nelems, 'nnz_per_gpu': nnz, 'kernel': wl.kernel_name,
-                       'parallelism': f'element slabs x{world}, halo-plane reduce' if world > 1 else 'single GPU', 'launch': launch,
+                       'parallelism': (f'element slabs x{world}, ' + ('one ghost element layer recomputed per rank, no exchange' if a.halo == 'recompute' else 'halo-plane reduce (RCCL point to point)'))
+                       if world > 1 else 'single GPU', 'halo': a.halo if world > 1 else None, 'launch': launch,
                        'settle_steps': settled, 'timed_region': 'device-resident re-assembly of the CSR values (pattern, tables, vertices in HBM)'},
             'roofline': roofline, 'pattern_ms': pattern_ms, 'setup_s': setup_s, 'checks': checks,
         }
+        out.update(launch_modes)
         if other is not None:
             out[other['scaling']] = other
+        if other_halo is not None:
+            out['halo_' + other_halo['halo']] = other_halo
         if world == 1:
             del wl
             torch.cuda.empty_cache()
@@ -414,10 +443,10 @@ def main():
             for _ in range(a.settle + a.warmup):
                 w2.step()
             torch.cuda.synchronize()
-            el2, kms, _ = timed_steps(w2, a.steps, 1, None, a.graph)
+            el2, kms, l2 = timed_steps(w2, a.steps, 1, None, a.graph)
             b2 = w2.algorithmic_bytes_per_element()
             ach = b2 * w2.nelems / (kms * 1e-3) / 1e9
-            out['variants'] = {'uniform': {'value': w2.nelems * a.steps / el2, 'unit': 'elements/s', 'ms_per_step': el2 / a.steps * 1e3, 'kernel': w2.kernel_name,
+            out['variants'] = {'uniform': {'value': w2.nelems * a.steps / el2, 'unit': 'elements/s', 'ms_per_step': el2 / a.steps * 1e3, 'kernel': w2.kernel_name, 'launch': l2,
                                            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                                                         'traffic': measured_traffic(w2.kernel_name, a.n),
                                                         'kernel_ms': kms, 'algorithmic_bytes_per_element': b2}}}
@@ -433,10 +462,10 @@ def main():
                     w3.step()
                 torch.cuda.synchronize()
                 nst = max(10, a.steps // 4)
-                el3, kms3, _ = timed_steps(w3, nst, 1, None, False)
+                el3, kms3, l3 = timed_steps(w3, nst, 1, None, a.graph)  # (same launch mode as the headline)
                 b3 = w3.algorithmic_bytes_per_element()
                 out['variants']['generic_gather'] = {'value': w3.nelems * nst / el3, 'unit': 'elements/s', 'ms_per_step': el3 / nst * 1e3, 'kernel': w3.kernel_name,
-                                                     'kernel_ms': kms3, 'hbm_frac': b3 * w3.nelems / (kms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                     'launch': l3, 'kernel_ms': kms3, 'hbm_frac': b3 * w3.nelems / (kms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                      'algorithmic_bytes_per_element': b3, 'traffic': measured_traffic(w3.kernel_name, a.n),
                                                      'note': 'nh_assemble_matrix with NH_MATRIX_GATHER | NH_MATRIX_STORE; bit-reproducible'}
                 del w3
@@ -448,9 +477,9 @@ def main():
                 for _ in range(20):
                     w5.step()
                 torch.cuda.synchronize()
-                el5, kms5, _ = timed_steps(w5, nst, 1, None, False)
+                el5, kms5, l5 = timed_steps(w5, nst, 1, None, a.graph)
                 out['variants']['generic_fused'] = {'value': w5.nelems * nst / el5, 'unit': 'elements/s', 'ms_per_step': el5 / nst * 1e3, 'kernel': w5.kernel_name,
-                                                    'kernel_ms': kms5, 'hbm_frac': b3 * w5.nelems / (kms5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                    'launch': l5, 'kernel_ms': kms5, 'hbm_frac': b3 * w5.nelems / (kms5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                     'algorithmic_bytes_per_element': b3, 'traffic': measured_traffic(w5.kernel_name, a.n),
                                                     'owner_blocks': dict(zip(('blocks', 'rows_per_block', 'element_visits'), w5.pattern.fused_info())),
                                                     'note': 'nh_assemble_matrix with NH_MATRIX_FUSED | NH_MATRIX_STORE'}
@@ -461,9 +490,9 @@ def main():
                 w4 = workloads.ElasticityP2(n=64, rank=0, world=1, variant='iso')
                 w4.setup()
                 w4.build_pattern()
-                el4, kms4, _, _ = settle_and_time(w4, 10, 3, 10, 1, None, False)
+                el4, kms4, l4, _ = settle_and_time(w4, 10, 3, 10, 1, None, a.graph)
                 c4 = w4.check(1, None)
-                v4 = {'value': w4.nelems * 10 / el4, 'unit': 'elements/s', 'steps': 10, 'ms_per_step': el4 / 10 * 1e3, 'kernel': w4.kernel_name,
+                v4 = {'value': w4.nelems * 10 / el4, 'unit': 'elements/s', 'steps': 10, 'ms_per_step': el4 / 10 * 1e3, 'kernel': w4.kernel_name, 'launch': l4,
                       'workload': '3D linear elasticity stiffness, 64^3 structured hex, p=2 vector basis, 3x3x3 Gauss, iso geometry (BASELINE.json configs[2])',
                       'roofline': c3_roofline(w4, kms4, measured_traffic(w4.kernel_name, 64)), 'checks': c4}
                 if not all(x < 1e-10 for x in c4.values()):

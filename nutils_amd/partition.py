@@ -17,6 +17,17 @@ interface plane: rank r sends the rows of its top plane (a contiguous tail of it
 values array: cols in planes I-1 and I) to rank r+1, where they are the leading 2/3
 of each owned interface row (cols sorted plane-first).  Point-to-point over
 RCCL/xGMI (torch.distributed backend nccl; gloo on CPU tensors in the tests).
+
+halo='recompute' (the default of the structured workloads since round 4): the ghost
+layer contributes VALUES as well -- rank r > 0 assembles one element layer more than
+it owns (6 % at 16 layers, 12.5 % at 8) and writes only the rows of its owned planes,
+which are then complete: no exchange, no collective, no CUs set aside, and the step is
+a single kernel that a HIP graph (or a K-steps loop) can carry.  For slabs of a
+structured mesh the interface plane is 2.4 MB (P1, 128 x 128) or ~90 MB (P2 vector,
+64 x 64) per step and neighbour, against ~20 us / 0.7 ms of kernel: recomputing is
+cheaper than any transfer at these sizes (DESIGN.md section 6 has the model).
+halo='reduce' keeps the exchange described above (unstructured partitions, where a
+ghost layer is not one layer thick, need it).
 '''
 
 import numpy
@@ -27,7 +38,10 @@ class Slab:
     `degree` dof planes per element layer, the plane on a slab boundary is shared; a row of that plane couples 2 degree + 1 planes,
     degree + 1 of them through the elements below.'''
 
-    def __init__(self, n, rank, world, shape_jk, degree=1, ncomp=1):
+    def __init__(self, n, rank, world, shape_jk, degree=1, ncomp=1, halo='reduce'):
+        if halo not in ('reduce', 'recompute'):
+            raise ValueError("halo must be 'reduce' or 'recompute'")
+        self.halo = halo
         self.n, self.rank, self.world = int(n), int(rank), int(world)
         self.nj, self.nk = (int(x) for x in shape_jk)
         self.degree, self.ncomp = int(degree), int(ncomp)
@@ -46,6 +60,18 @@ class Slab:
         self.send_plane = p * (self.ghost_layers + self.n)
         self.recv_plane = p * self.ghost_layers
         self.lower_planes, self.coupled_planes = p + 1, 2 * p + 1
+        if halo == 'recompute':
+            self.sends = self.recvs = False
+
+    @property
+    def value_layers(self):
+        '''local element layers [a, b) that contribute values: the own layers, with halo='recompute' also the ghost layer'''
+        return (0 if self.halo == 'recompute' else self.ghost_layers, self.local_layers)
+
+    @property
+    def written_planes(self):
+        '''local dof planes [a, b) whose rows the assembly writes: the owned planes, with halo='reduce' also the top plane that is sent on'''
+        return (self.own_plane_begin, self.own_plane_end if self.halo == 'recompute' else self.degree * self.local_layers + 1)
 
 
 class HaloPlan:

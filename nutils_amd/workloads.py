@@ -16,12 +16,13 @@ from . import device, function, kernels, mesh, partition
 
 class PoissonSlab:
 
-    def __init__(self, n=128, rank=0, world=1, variant='iso', kernel='auto', seed=0, layers=None):
+    def __init__(self, n=128, rank=0, world=1, variant='iso', kernel='auto', seed=0, layers=None, halo='recompute'):
         self.n, self.rank, self.world, self.variant = int(n), int(rank), int(world), variant
         self.layers = int(layers) if layers else self.n  # element layers per rank (strong scaling: n / world)
         self.kernel = kernel
         self.seed = seed
-        self.slab = partition.Slab(self.layers, self.rank, self.world, shape_jk=(self.n, self.n))
+        # halo='recompute': the ghost layer below is assembled too and only owned rows are written -- no exchange (partition.py)
+        self.slab = partition.Slab(self.layers, self.rank, self.world, shape_jk=(self.n, self.n), halo=halo)
 
     def setup(self):
         s = self.slab
@@ -67,7 +68,7 @@ class PoissonSlab:
             self.kernel_name = {'batched': 'k_mterms<3>', 'gather': 'k_local_scalar<3,8,8> + k_gather_values', 'fused': 'k_fused_p1hex<false>'}.get(self.kernel, 'k_matrix_generic<3>')
         self.values = device.zeros(self.colidx.numel(), 'float64')  # rows of a ghost plane are never written: keep them zero
         self.nnz = int(self.colidx.numel())
-        self.halo = partition.HaloPlan(self.slab, self.rowptr) if self.world > 1 else None
+        self.halo = partition.HaloPlan(self.slab, self.rowptr) if self.world > 1 and self.slab.halo == 'reduce' else None
         # with an exchange in flight next to the kernel, 8 CUs are left to the RCCL send/recv workgroups: a marching workgroup takes
         # the whole LDS of its CU, so on a fully occupied chip the transfer could only start when the assembly has finished
         self._max_wg = 0
@@ -133,7 +134,7 @@ class PoissonSlab:
 
     def _own_views(self):
         '''Structures restricted to the rank's own element layers (skip the ghost layer).'''
-        e0 = self.slab.ghost_layers * self.n * self.n
+        e0 = self.slab.value_layers[0] * self.n * self.n  # (halo='recompute': the ghost layer is assembled as well)
         if not hasattr(self, '_views'):
             t = self.tables
             test = kernels.basis(t.T, t.dofs[e0 * 8:], nb=8)
@@ -150,8 +151,8 @@ class PoissonSlab:
             s = self.slab
             if getattr(self, '_launch', None) is None:
                 self._launch = kernels.P1HexLaplace(shape=(s.local_layers, self.n, self.n), gauss_x=self._gauss_x1(), gauss_w=self._gauss_w1(), verts=self._verts_dev,
-                                                    origin=(float(s.first_global_plane), 0., 0.), layers=(s.ghost_layers, s.local_layers),
-                                                    planes=(s.ghost_layers, s.local_layers + 1), unit_matrix=self._ke, max_workgroups=self._max_wg)
+                                                    origin=(float(s.first_global_plane), 0., 0.), layers=s.value_layers,
+                                                    planes=s.written_planes, unit_matrix=self._ke, max_workgroups=self._max_wg)
             if kernel_events:
                 kernel_events[0].record()
             self._launch(self.values)
@@ -160,17 +161,18 @@ class PoissonSlab:
             self._end_step(slot, exchange)
             return
         test, g, e0 = self._own_views()
-        gather = self.kernel == 'gather' and e0 == 0 and self.nelems == self.pattern.nelems
-        fused = self.kernel == 'fused' and e0 == 0 and self.nelems == self.pattern.nelems
+        nelems = (self.slab.value_layers[1] - self.slab.value_layers[0]) * self.n * self.n  # elements assembled (self.nelems: elements owned)
+        gather = self.kernel == 'gather' and e0 == 0 and nelems == self.pattern.nelems
+        fused = self.kernel == 'fused' and e0 == 0 and nelems == self.pattern.nelems
         if not gather and not fused:
             self.values.zero_()  # (the gather and fused paths store every entry: NH_MATRIX_STORE)
         if kernel_events:
             kernel_events[0].record()
         if self.kernel == 'batched' and e0 == 0:
-            kernels.assemble_matrix_terms(nelems=self.nelems, ndims=3, nq=8, weights=self.smp._weights_dev, geom=g, test=test, trial=test, nct=1, ncr=1,
+            kernels.assemble_matrix_terms(nelems=nelems, ndims=3, nq=8, weights=self.smp._weights_dev, geom=g, test=test, trial=test, nct=1, ncr=1,
                                           mask=None, pattern=self.pattern, values=self.values, terms=[dict(C=self.C)])
         else:
-            kernels.assemble_matrix(nelems=self.nelems, ndims=3, nq=8, weights=self.smp._weights_dev, geom=g, test=test, trial=test, nct=1, ncr=1,
+            kernels.assemble_matrix(nelems=nelems, ndims=3, nq=8, weights=self.smp._weights_dev, geom=g, test=test, trial=test, nct=1, ncr=1,
                                     C=self.C, mask=None, pattern=self.pattern, values=self.values, emap_offset=e0 * 64,
                                     gather=gather, fused=fused, store=gather or fused)
         if kernel_events:
@@ -224,12 +226,12 @@ class ElasticityP2:
 
     ncomp = 3
 
-    def __init__(self, n=64, rank=0, world=1, variant='iso', seed=0, lam=1., mu=.5 / .3 - 1, layers=None):
+    def __init__(self, n=64, rank=0, world=1, variant='iso', seed=0, lam=1., mu=.5 / .3 - 1, layers=None, halo='recompute'):
         self.n, self.rank, self.world, self.variant, self.seed = int(n), int(rank), int(world), variant, seed
         self.layers = int(layers) if layers else self.n
         self.C = self.form_tensor(lam, mu)
         self.kernel_name = 'k_p2hex_inreg<3,1,1>'
-        self.slab = partition.Slab(self.layers, self.rank, self.world, shape_jk=(self.n, self.n), degree=2, ncomp=3)
+        self.slab = partition.Slab(self.layers, self.rank, self.world, shape_jk=(self.n, self.n), degree=2, ncomp=3, halo=halo)
 
     @staticmethod
     def form_tensor(lam, mu):
@@ -267,8 +269,8 @@ class ElasticityP2:
         self.nnz = int(self.colidx.numel())
         self.values = device.zeros(self.nnz, 'float64')  # write-once kernel: no zero-fill per step (rows of a ghost plane are never written)
         self._launch = kernels.P2HexMatrix(shape=self.shape, nq=self.smp.points.npoints, weights=self.smp._weights_dev, geom=self.kgeom, T=self.tables.T, ncomp=3,
-                                           C=self.C, layers=(s.ghost_layers, s.local_layers), owners=(s.ghost_layers, s.local_layers))
-        self.halo = partition.HaloPlan(s, self.rowptr) if self.world > 1 else None
+                                           C=self.C, layers=s.value_layers, owners=(s.written_planes[0] // 2, (s.written_planes[1] - 1) // 2))
+        self.halo = partition.HaloPlan(s, self.rowptr) if self.world > 1 and s.halo == 'reduce' else None
 
     def step(self, kernel_events=None, exchange=True):
         if kernel_events:

@@ -7,19 +7,25 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('halo', ['recompute', 'reduce'])
 @pytest.mark.parametrize('kernel', ['fast', 'generic'])
 @pytest.mark.parametrize('variant', ['iso', 'uniform'])
-def test_two_slabs_equal_single_mesh(kernel, variant, monkeypatch):
+def test_two_slabs_equal_single_mesh(kernel, variant, halo, monkeypatch):
+    '''halo='reduce': the interface rows travel as HaloPlan prescribes; halo='recompute': every rank assembles its ghost layer as well and writes
+    only the rows it owns -- nothing travels (the default of the workloads).  Either way the concatenated blocks are the single-mesh matrix.'''
     monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')  # the single-mesh reference goes through the generic kernel
     from nutils_amd import workloads, partition, device
     n, world = 9, 3
     blocks = []
     prev_tail = None
     for rank in range(world):
-        wl = workloads.PoissonSlab(n=n, rank=rank, world=world, variant=variant, kernel=kernel)
+        wl = workloads.PoissonSlab(n=n, rank=rank, world=world, variant=variant, kernel=kernel, halo=halo)
         wl.setup()
         wl.build_pattern()
+        if halo == 'recompute':
+            wl.values.fill_(float('nan'))  # (the owned rows are all written)
         wl.step(exchange=False)
+        assert (wl.halo is None) == (halo == 'recompute')
         if wl.slab.recvs:  # what irecv + index_add_ do in HaloPlan.exchange
             assert prev_tail.numel() == wl.halo.recv_buf.numel()
             wl.values.index_add_(0, wl.halo.recv_idx, prev_tail)
@@ -42,8 +48,9 @@ def test_two_slabs_equal_single_mesh(kernel, variant, monkeypatch):
     assert numpy.abs(v - vo).max() <= 1e-13 * numpy.abs(vo).max()
 
 
+@pytest.mark.parametrize('halo', ['recompute', 'reduce'])
 @pytest.mark.parametrize('world,layers', [(2, 3), (3, 2)])
-def test_p2_elasticity_slabs_equal_single_mesh(world, layers):
+def test_p2_elasticity_slabs_equal_single_mesh(world, layers, halo):
     '''configs[2] partitioned: every "rank" assembles its slab of the quadratic vector elasticity matrix with the HIP kernel
     (nh_p2hex_matrix with layer / owner ranges), the rows of the interface plane travel as HaloPlan prescribes, and the concatenated
     owned row blocks equal the single-mesh assembly ENTRY BY ENTRY (index arrays bit-exact).'''
@@ -51,10 +58,11 @@ def test_p2_elasticity_slabs_equal_single_mesh(world, layers):
     n = 4
     blocks, prev_tail = [], None
     for rank in range(world):
-        wl = workloads.ElasticityP2(n=n, layers=layers, rank=rank, world=world)
+        wl = workloads.ElasticityP2(n=n, layers=layers, rank=rank, world=world, halo=halo)
         wl.setup()
         wl.build_pattern()
         wl.step(exchange=False)
+        assert (wl.halo is None) == (halo == 'recompute')
         if wl.slab.recvs:  # what irecv + index_add_ do in HaloPlan.exchange
             assert prev_tail.numel() == wl.halo.recv_buf.numel()
             wl.values.index_add_(0, wl.halo.recv_idx, prev_tail)
@@ -143,6 +151,10 @@ def test_bench_multiprocess_on_one_gpu(world):
     assert rec['n_gpus'] == world and rec['steps'] == 4 and rec['scaling'] == ('strong' if strong else 'weak')
     assert rec['config']['nelems_per_gpu'] == (32 ** 3 // world if strong else 32 ** 3) and rec['value'] > 0
     assert rec['checks']['owned_row_sums_rel'] < 1e-12
+    # default halo mode: one ghost layer recomputed per rank, no exchange, the step captured in a HIP graph on every rank; the line carries the
+    # figure of the RCCL-style reduce of the interface rows as well
+    assert rec['config']['halo'] == 'recompute' and 'hipGraph' in rec['config']['launch'] and 'ms_per_step_graph' in rec and 'ms_per_step_eager' in rec
+    assert rec['halo_reduce']['value'] > 0 and rec['halo_reduce']['checks']['owned_row_sums_rel'] < 1e-12 and rec['halo_reduce']['launch'] == 'eager'
     if strong:
         assert rec['weak']['nelems_per_gpu'] == 32 ** 3 and rec['weak']['value'] > 0 and rec['weak']['checks']['owned_row_sums_rel'] < 1e-12
     assert 'WARNING' not in out.stderr

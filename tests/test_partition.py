@@ -31,18 +31,19 @@ def assemble(shape, degree, verts, zero_layers=0):
     return oa.assemble_csr(A, dofs, dofs, ndofs, ndofs)
 
 
-def local_assembly(n, nj, nk, rank, world, verts_global, degree=1):
+def local_assembly(n, nj, nk, rank, world, verts_global, degree=1, halo='reduce'):
     '''Oracle stand-in for one rank's device assembly: local mesh = own layers + ghost layer below,
-    values from the own layers only (ghost elements contribute structural zeros = pattern only).'''
+    values from the layers Slab.value_layers names (halo='reduce': the own layers only, ghost elements contribute structural zeros
+    = pattern only; halo='recompute': the ghost layer as well).'''
     from nutils_amd import partition
-    slab = partition.Slab(n, rank, world, (nj, nk), degree=degree, ncomp=form(degree)[1])
+    slab = partition.Slab(n, rank, world, (nj, nk), degree=degree, ncomp=form(degree)[1], halo=halo)
     shape = (slab.local_layers, nj, nk)
     l0 = slab.first_global_plane // degree
     verts = verts_global[l0:l0 + slab.local_layers + 1].reshape(-1, 3)
-    return slab, assemble(shape, degree, verts, zero_layers=slab.ghost_layers)
+    return slab, assemble(shape, degree, verts, zero_layers=slab.value_layers[0])
 
 
-def worker(rank, world, port, n, nj, nk, tmp, degree=1):
+def worker(rank, world, port, n, nj, nk, tmp, degree=1, halo='reduce'):
     import torch
     import torch.distributed as dist
     from nutils_amd import partition
@@ -52,18 +53,19 @@ def worker(rank, world, port, n, nj, nk, tmp, degree=1):
     NI = n * world + 1
     verts_global = numpy.stack(numpy.meshgrid(numpy.arange(NI, dtype=float), numpy.arange(nj + 1.), numpy.arange(nk + 1.), indexing='ij'), -1) \
         + rng.uniform(-.2, .2, (NI, nj + 1, nk + 1, 3))
-    slab, (values, rowptr, colidx) = local_assembly(n, nj, nk, rank, world, verts_global, degree)
+    slab, (values, rowptr, colidx) = local_assembly(n, nj, nk, rank, world, verts_global, degree, halo)
     tv, trp = torch.from_numpy(values.copy()), torch.from_numpy(rowptr.copy())
     plan = partition.HaloPlan(slab, trp)
-    plan.exchange(tv)
+    assert (slab.sends or slab.recvs) == (halo == 'reduce')
+    plan.exchange(tv)  # (halo='recompute': nothing to send or receive -- the call degenerates to a no-op)
     block = partition.owned_rows(slab, tv.numpy(), rowptr, colidx)
     numpy.savez(os.path.join(tmp, f'block{rank}.npz'), values=block[0], rowptr=block[1], colidx=block[2])
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,degree', [(2, 1), (3, 1), (2, 2), (3, 2)])
-def test_slab_partition_gloo(tmp_path, world, degree):
+@pytest.mark.parametrize('world,degree,halo', [(2, 1, 'reduce'), (3, 1, 'reduce'), (2, 2, 'reduce'), (3, 2, 'reduce'), (2, 1, 'recompute'), (3, 2, 'recompute')])
+def test_slab_partition_gloo(tmp_path, world, degree, halo):
     '''degree 1: the Poisson slabs of configs[1]; degree 2: the 3-component elasticity slabs of configs[2] (two dof planes per layer,
     interface rows couple five planes, three of them through the rank below).'''
     import torch.multiprocessing as mp
@@ -72,7 +74,7 @@ def test_slab_partition_gloo(tmp_path, world, degree):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    mp.spawn(worker, args=(world, port, n, nj, nk, str(tmp_path), degree), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, port, n, nj, nk, str(tmp_path), degree, halo), nprocs=world, join=True)
     blocks = []
     for r in range(world):
         d = numpy.load(tmp_path / f'block{r}.npz')
@@ -105,3 +107,10 @@ def test_slab_bookkeeping():
     owned = [range(s.first_global_plane + s.own_plane_begin, s.first_global_plane + s.own_plane_end) for s in (q0, q1, q2)]
     assert [(o[0], o[-1]) for o in owned] == [(0, 7), (8, 15), (16, 24)]
     assert (q1.send_plane, q1.recv_plane, q1.lower_planes, q1.coupled_planes) == (10, 2, 3, 5)
+    # which layers contribute values / which planes are written, per halo mode
+    assert (s1.value_layers, s1.written_planes) == ((1, 5), (1, 6)) and (s0.value_layers, s0.written_planes) == ((0, 4), (0, 5))
+    r0, r1, r2 = (partition.Slab(4, r, 3, (5, 6), halo='recompute') for r in range(3))
+    assert (r1.value_layers, r1.written_planes, r1.sends, r1.recvs) == ((0, 5), (1, 5), False, False)
+    assert (r0.value_layers, r0.written_planes) == ((0, 4), (0, 4)) and (r2.value_layers, r2.written_planes) == ((0, 5), (1, 6))
+    t1 = partition.Slab(4, 1, 3, (5, 6), degree=2, ncomp=3, halo='recompute')
+    assert (t1.value_layers, t1.written_planes) == ((0, 5), (2, 10))
