@@ -478,12 +478,29 @@ __global__ void k_fp_visits(i64 nelems, int nbt, int R, const int32_t *dofs, con
   if (!FILL) cnt[e] = nd;
 }
 
-__global__ void k_fp_vrow(i64 nvisits, int nbt, int R, const int32_t *dofs, const int32_t *rank, const int32_t *loff, const unsigned *vkey, const unsigned *vlist, uint16_t *vrow) {
+// (visit, local row) pairs: key = rank position of the row if it belongs to the visiting block, else ~0; value = the pair's index.  Sorted by key (stable: the
+// pairs of one row stay in visit order), the position of a pair within its key group is its TURN: the fused kernels add the contributions to a row in that order.
+__global__ void k_fp_vkeys(i64 nvisits, int nbt, int R, const int32_t *dofs, const int32_t *rank, const unsigned *vkey, const unsigned *vlist, unsigned *pkey, unsigned *pval) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nvisits * nbt) return;
   const i64 v = i / nbt;
   const int r = rank[dofs[(i64)vlist[v] * nbt + (i - v * nbt)]];
-  vrow[i] = r / R == (int)vkey[v] ? (uint16_t)loff[r] : (uint16_t)0xffff;
+  pkey[i] = r / R == (int)vkey[v] ? (unsigned)r : 0xffffffffu;
+  pval[i] = (unsigned)i;
+}
+// vrow[pair] = row index within the block | turn << 9 (0xffff: the row belongs to another block)
+__global__ void k_fp_vrow(i64 n, int R, const unsigned *pkey, const unsigned *pval, uint16_t *vrow, int *bad) {
+  const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned key = pkey[j];
+  if (key == 0xffffffffu) {
+    vrow[pval[j]] = (uint16_t)0xffff;
+    return;
+  }
+  int seq = 0;
+  while (seq < 127 && j - seq - 1 >= 0 && pkey[j - seq - 1] == key) ++seq;
+  if (seq >= 127) atomicOr(bad, 1);
+  vrow[pval[j]] = (uint16_t)((key % (unsigned)R) | (unsigned)seq << 9);
 }
 
 // the element map (position of entry (m, n) within the CSR row of its test dof) narrowed to a byte
@@ -532,7 +549,8 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_scalar(FusK p) {
   // LDS: [staged tables][row starts of the block in the value array: R x i64][accumulator offsets of its rows: R + 1 ints, padded][accumulator]
   i64 *rstartS = reinterpret_cast<i64 *>(sT + p.loc.ldst_doubles);
   int *loffS = reinterpret_cast<int *>(rstartS + p.R);
-  double *acc = reinterpret_cast<double *>(rstartS + p.R) + (p.R + 2) / 2;
+  unsigned *turn = reinterpret_cast<unsigned *>(loffS + ((p.R + 2) & ~1));  // [R] contributions a row has received so far
+  double *acc = reinterpret_cast<double *>(rstartS + p.R) + (p.R + 2) / 2 + (p.R + 1) / 2;
   const int b = blockIdx.x, NT = blockDim.x;
   const i64 r0 = (i64)b * p.R;
   const int nr = (int)min((i64)p.R, p.nrows - r0);
@@ -547,6 +565,7 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_scalar(FusK p) {
     rstartS[i] = p.rstart[r0 + i];
     loffS[i] = p.loff[r0 + i];
   }
+  for (int i = threadIdx.x; i < p.R; i += NT) turn[i] = 0;
   for (int i = threadIdx.x; i < p.max_blen; i += NT) acc[i] = 0.;
   __syncthreads();
   for (i64 i = p.vptr[b] + threadIdx.x; i < p.vptr[b + 1]; i += NT) {
@@ -570,12 +589,27 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_scalar(FusK p) {
     }
     double A[NBT][NBR];
     local_scalar_matrix<ND, NBT, NBR, LDST, SYMD>(p.loc, sT, e, e, A);
+    // The contributions to a row are added in the order of the visits (the turn of this visit within each of its rows comes with the plan): the sums do not
+    // depend on the arrival of the waves -- bit-reproducible.  A visit waits only for EARLIER visits, which are being processed or done: no deadlock; all adds of
+    // a wave reach the LDS in program order, the turn counter last.
+    unsigned pend = 0;
 #pragma unroll
-    for (int m = 0; m < NBT; ++m) {
-      const int base = vr[m];
-      if (base == 0xffff) continue;
+    for (int m = 0; m < NBT; ++m) pend |= vr[m] != 0xffff ? 1u << m : 0u;
+    while (pend) {
+      bool progress = false;
 #pragma unroll
-      for (int n = 0; n < NBR; ++n) atomicAdd(acc + base + cp[m * NBR + n], (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n]);
+      for (int m = 0; m < NBT; ++m) {
+        if (!(pend >> m & 1)) continue;
+        const int row = vr[m] & 511;
+        if (__hip_atomic_load(turn + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(vr[m] >> 9)) continue;
+        const int base = loffS[row];
+#pragma unroll
+        for (int n = 0; n < NBR; ++n) atomicAdd(acc + base + cp[m * NBR + n], (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n]);
+        atomicAdd(turn + row, 1u);
+        pend &= ~(1u << m);
+        progress = true;
+      }
+      if (pend && !progress) __builtin_amdgcn_s_sleep(1);
     }
   }
   __syncthreads();
@@ -598,7 +632,8 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_p1hex(FusK fp) {
   extern __shared__ __attribute__((aligned(16))) double sT[];
   i64 *rstartS = reinterpret_cast<i64 *>(sT);
   int *loffS = reinterpret_cast<int *>(rstartS + fp.R);
-  double *acc = reinterpret_cast<double *>(rstartS + fp.R) + (fp.R + 2) / 2;
+  unsigned *turn = reinterpret_cast<unsigned *>(loffS + ((fp.R + 2) & ~1));
+  double *acc = reinterpret_cast<double *>(rstartS + fp.R) + (fp.R + 2) / 2 + (fp.R + 1) / 2;
   const int b = blockIdx.x, NT = blockDim.x;
   const i64 r0 = (i64)b * fp.R;
   const int nr = (int)min((i64)fp.R, fp.nrows - r0);
@@ -606,6 +641,7 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_p1hex(FusK fp) {
     rstartS[i] = fp.rstart[r0 + i];
     loffS[i] = fp.loff[r0 + i];
   }
+  for (int i = threadIdx.x; i < fp.R; i += NT) turn[i] = 0;
   for (int i = threadIdx.x; i < fp.max_blen; i += NT) acc[i] = 0.;
   __syncthreads();
   const P1Tab &p = fp.tab;
@@ -653,14 +689,37 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_p1hex(FusK fp) {
       if (hasm) k += Mm[p0][p1][p2];
       return k;
     };
+    double K[36];  // upper triangle, row major
+    {
+      int q = 0;
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+      for (int a = 0; a < 8; ++a)
 #pragma unroll
-      for (int bb = a; bb < 8; ++bb) {
-        const double k = entry(a, bb);
-        if (vr[a] != 0xffff) atomicAdd(acc + vr[a] + cp[a * 8 + bb], k);
-        if (bb != a && vr[bb] != 0xffff) atomicAdd(acc + vr[bb] + cp[bb * 8 + a], k);
+        for (int bb = a; bb < 8; ++bb) K[q++] = entry(a, bb);
+    }
+    // the contributions to a row in the order of the visits (see k_fused_scalar): bit-reproducible sums
+    unsigned pend = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) pend |= vr[m] != 0xffff ? 1u << m : 0u;
+    while (pend) {
+      bool progress = false;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        if (!(pend >> m & 1)) continue;
+        const int row = vr[m] & 511;
+        if (__hip_atomic_load(turn + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(vr[m] >> 9)) continue;
+        const int base = loffS[row];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const int lo = m < n ? m : n, hi = m < n ? n : m;
+          atomicAdd(acc + base + cp[m * 8 + n], K[lo * 8 - lo * (lo - 1) / 2 + hi - lo]);
+        }
+        atomicAdd(turn + row, 1u);
+        pend &= ~(1u << m);
+        progress = true;
       }
+      if (pend && !progress) __builtin_amdgcn_s_sleep(1);
+    }
   }
   __syncthreads();
   const int hl = threadIdx.x & 31;
@@ -1268,13 +1327,45 @@ static int nh_fused_prepare(nh_pattern *p, const nh_matrix_args *a, hipStream_t 
     FP_CHECK(hipMalloc((void **)&f->vptr, (nblocks + 1) * sizeof(i64)));
     if ((rc = nh_scan_exclusive(bcount, f->vptr, nblocks, s)) != NH_OK) goto done;
     FP_CHECK(hipMalloc((void **)&f->vrow, std::max<i64>(nvisits * nbt, 1) * sizeof(uint16_t)));
-    hipLaunchKernelGGL(k_fp_vrow, dim3((unsigned)((nvisits * nbt + 255) / 256)), dim3(256), 0, s, nvisits, nbt, R, dofs, rank, f->loff, vkey2, vval2, f->vrow);
+    {
+      // the turn of every (visit, local row) within its row: stable sort of the pairs by row
+      const i64 np = nvisits * nbt;
+      if (np >= (1ll << 32)) {  // (32-bit pair indices)
+        rc = NH_ELIMIT;
+        goto done;
+      }
+      hipFree(vkey), hipFree(vval);
+      vkey = vval = nullptr;
+      unsigned *pk2 = nullptr, *pv2 = nullptr;
+      FP_CHECK(hipMalloc((void **)&vkey, np * 4));
+      FP_CHECK(hipMalloc((void **)&vval, np * 4));
+      FP_CHECK(hipMalloc((void **)&pk2, np * 4));
+      if (hipMalloc((void **)&pv2, np * 4) != hipSuccess) {
+        hipFree(pk2);
+        FP_CHECK(hipErrorOutOfMemory);
+      }
+      hipLaunchKernelGGL(k_fp_vkeys, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, nvisits, nbt, R, dofs, rank, vkey2, vval2, vkey, vval);
+      size_t tmpsz3 = 0;
+      hipError_t e3 = rocprim::radix_sort_pairs(nullptr, tmpsz3, vkey, pk2, vval, pv2, (size_t)np, 0, 32, s);
+      if (e3 == hipSuccess && tmpsz3 > std::max(tmpsz, tmpsz2)) {
+        hipFree(tmp);
+        tmp = nullptr;
+        e3 = hipMalloc(&tmp, tmpsz3);
+      }
+      if (e3 == hipSuccess) e3 = rocprim::radix_sort_pairs(tmp, tmpsz3, vkey, pk2, vval, pv2, (size_t)np, 0, 32, s);
+      if (e3 == hipSuccess) {
+        hipLaunchKernelGGL(k_fp_vrow, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, np, R, pk2, pv2, f->vrow, flags + 2);
+        e3 = hipStreamSynchronize(s);
+      }
+      hipFree(pk2), hipFree(pv2);
+      FP_CHECK(e3);
+    }
     FP_CHECK(hipMalloc((void **)&f->cpos, p->emap_len));
     hipLaunchKernelGGL(k_fp_cpos, dim3((unsigned)((p->emap_len + 255) / 256)), dim3(256), 0, s, p->emap_len, p->emap, f->cpos, flags + 2);
     FP_CHECK(hipGetLastError());
     FP_CHECK(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
     FP_CHECK(hipStreamSynchronize(s));
-    if (hflags[2] || hflags[1] > 27 * 512 || hflags[1] >= 0xffff) {
+    if (hflags[2] || hflags[1] > 27 * 512 || hflags[1] >= 0xffff || R > 512) {
       rc = NH_ELIMIT;
       goto done;
     }
@@ -1405,7 +1496,7 @@ int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s) {
   p.R = f->rows_per_block;
   p.max_blen = f->max_blen;
   p.loff = f->loff, p.blen = f->blen, p.rstart = f->rstart, p.vlist = f->vlist, p.vptr = f->vptr, p.vrow = f->vrow, p.cpos = f->cpos;
-  const size_t ldsx = (ldst ? ldsb : 0) + sizeof(double) * ((size_t)f->max_blen + f->rows_per_block + (f->rows_per_block + 2) / 2);
+  const size_t ldsx = (ldst ? ldsb : 0) + sizeof(double) * ((size_t)f->max_blen + f->rows_per_block + (f->rows_per_block + 2) / 2 + (f->rows_per_block + 1) / 2);
   int nt = FUSED_NT;
 #ifdef NH_ABLATION
   if (getenv("NH_FUSED_NT")) nt = std::min(FUSED_NT_MAX, std::max(64, atoi(getenv("NH_FUSED_NT")) & ~63));
@@ -1415,7 +1506,7 @@ int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s) {
   {
     nh_fused_plan *fw = pat->fused;
     if (fw->p1hex_key[0] != a->test.T_dev || fw->p1hex_key[1] != a->trial.T_dev || fw->p1hex_key[2] != a->geom.gT_dev || fw->p1hex_key[3] != a->weights_dev ||
-        memcmp(fw->p1hex_C, a->C_host, 16 * sizeof(double)) != 0 || fw->p1hex < 0) {
+        (a->ndims == 3 && memcmp(fw->p1hex_C, a->C_host, 16 * sizeof(double)) != 0) || fw->p1hex < 0) {  // (C_host holds (1 + ndims)^2 doubles: compared for 3-D forms only)
       bool mass = false;
       P1Tab tab;
       memset(&tab, 0, sizeof tab);
@@ -1429,7 +1520,7 @@ int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s) {
     if (fw->p1hex > 0) {
       memcpy(&p.tab, fw->p1hex_tab, sizeof p.tab);
       l.ldst_doubles = 0;
-      const size_t lds1 = sizeof(double) * ((size_t)f->max_blen + f->rows_per_block + (f->rows_per_block + 2) / 2);
+      const size_t lds1 = sizeof(double) * ((size_t)f->max_blen + f->rows_per_block + (f->rows_per_block + 2) / 2 + (f->rows_per_block + 1) / 2);
       if (fw->p1hex == 2) {
         NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_fused_p1hex<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         hipLaunchKernelGGL((k_fused_p1hex<true>), grid, block, lds1, s, p);

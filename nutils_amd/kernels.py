@@ -127,7 +127,8 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.  `first_touch=(grid_shape, nodes_per_axis)`: NH_MATRIX_FIRST_TOUCH.
     gather: NH_MATRIX_GATHER (deterministic owner-side reduction instead of atomics); None = from the second assembly on a pattern on (the gather
     map costs one device sort of the element map, which a one-off assembly does not earn back).  fused: NH_MATRIX_FUSED (owner blocks: one pass
-    without scratch or global atomics for scalar blocks on small uniform bases, not bit-reproducible; excludes gather).'''
+    without scratch or global atomics for scalar blocks on small uniform bases, contributions added in visit order: bit-reproducible; excludes gather;
+    the default for those blocks -- NUTILS_AMD_NO_FUSED=1 restores the gather / atomics choice).'''
     C = numpy.ascontiguousarray(C, dtype=float)
     if C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
         raise ValueError(f'coefficient tensor has shape {C.shape}, expected {(nct, 1 + ndims, ncr, 1 + ndims)}')
@@ -143,9 +144,11 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     if elist is None and emap_offset == 0 and not os.environ.get('NUTILS_AMD_NO_BUCKETS'):
         args.pattern = pattern._handle  # ragged bases: launches per size class of the pattern
     whole = emap_offset == 0 and not flags and not first_touch and nelems == pattern.nelems
-    if (not fused and gather is None and os.environ.get('NUTILS_AMD_FUSED') and whole and nct == ncr == 1 and cq is None and (ndims, test.nb) in FUSED_SIZES
-            and test.nb == trial.nb and test.dofs_dev == trial.dofs_dev and not test.off_dev):
-        fused = True  # (opt-in, for the blocks the owner-block kernels cover: faster than the gather from the first assembly on, but the sums are not bit-reproducible)
+    if (not fused and gather is None and not os.environ.get('NUTILS_AMD_NO_FUSED') and whole and elist is None and nct == ncr == 1 and cq is None and (ndims, test.nb) in FUSED_SIZES
+            and test.nb == trial.nb and test.dofs_dev == trial.dofs_dev and not test.off_dev and not getattr(pattern, '_fused_refused', False)):
+        # (default since round 4 for the blocks the owner-block kernels cover: one pass, 1.5 x instead of 4.6 x the algorithmic traffic, and -- with the
+        # turns of the block plan -- bit-reproducible like the gather)
+        fused = True
     if fused:
         if not whole:
             raise ValueError('fused needs all elements of the pattern in one call')

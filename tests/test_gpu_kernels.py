@@ -1044,6 +1044,8 @@ def test_fused_many_blocks_any_numbering(shuffle):
     assert ne < nvisits < 2.2 * ne, nvisits / ne  # bricks of ~8^3 nodes: (9/8)^3 = 1.42 in the interior, more at this size
     close(out[1], out[0])
     close(out[2], out[0])
+    # the contributions to a row are added in the order of the visits (turns of the block plan): two assemblies agree bit for bit
+    assert numpy.array_equal(out[1], out[2])
 
 
 def test_fused_trilinear_routine_equals_the_tabulated_one(monkeypatch):
