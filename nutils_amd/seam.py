@@ -30,6 +30,9 @@ import json
 import numpy
 
 
+PLAN_CACHE_SIZE = 128  # plans (and three times as many as_csr components) the installed hooks remember
+
+
 class Unmatched(Exception):
     '''The array is outside the class the HIP backend assembles: use the reference path.'''
 
@@ -138,6 +141,7 @@ class Built:
             else:
                 raise ValueError(f'unknown geometry kind {g["kind"]!r}')
         self.args = [function.Arg(self.bases[int(a['basis'])], int(a['ncomp']), a['name']) for a in plan['args']]
+        self.scalar_args = sorted({a['name'] for a in plan['args'] if a.get('scalar')})  # bare scalar arguments: passed as the one coefficient of a constant basis
         terms = []
         for t in plan['terms']:
             fp = None
@@ -168,12 +172,21 @@ def build(plan):
     return b
 
 
+def prepare_arguments(plan, arguments):
+    '''arguments as the built integral expects them: a bare scalar argument becomes the coefficient vector (length 1) of its constant basis'''
+    arguments = dict(arguments or {})
+    for name in build(plan).scalar_args:
+        if name in arguments:
+            arguments[name] = numpy.reshape(numpy.asarray(arguments[name], dtype=float), (1,))
+    return arguments
+
+
 def execute(plan, arguments=None):
     '''Evaluate a plan through the C ABI.  kind 'matrix': (values, rowptr, colidx) as function.as_csr of the array flattened to two axes
     (function.py:2443-2452; index arrays int64); 'vector': the array in the reference's shape; 'scalar': float.'''
     from . import function
     b = build(plan)
-    arguments = dict(arguments or {})
+    arguments = prepare_arguments(plan, arguments)
     kind = plan['kind']
     if kind == 'matrix':
         return function.eval(function.as_csr(b.integral), arguments)
@@ -211,6 +224,14 @@ def _children(node):
     if t == '_Integral':
         return [node._integrand]
     return []
+
+
+class _ScalarBasis:
+    '''stands for the "basis" of a bare scalar argument (`function.field('dt')`, shape ()): ONE function, identically one, shared by all elements --
+    emitted as a plain basis of the term's home topology, the argument's value is passed as its single coefficient'''
+
+
+_SCALAR = _ScalarBasis()
 
 
 class _Factor:
@@ -327,6 +348,10 @@ class Matcher:
             A[0, 0] = 1.
             return [_Mono(A, [('dof', 0)], [_Factor(node)])]
         if isinstance(node, rf.Argument):
+            if node.shape == () and node.dtype == float:  # a scalar parameter of the integrand (examples/cahnhilliard.py:173 `dt`): coefficient polynomial
+                A = numpy.zeros((1, self.S))
+                A[0, 0] = 1.
+                return [_Mono(A, [], [_Factor(_SCALAR, self.rename.get(node.name, node.name), 1)])]
             raise Unmatched(f'argument {node.name!r} outside function.field')
         if t == '_Jacobian':
             return [_Mono(numpy.ones(()), [], measure=(self.strip_broadcast(node._geom, 1), node._tip_dim))]
@@ -843,6 +868,16 @@ class Emitter:
         self._basis[key] = len(self.plan['bases']) - 1
         return self._basis[key]
 
+    def scalar_basis(self, transforms):
+        '''the one-function basis of a scalar argument on the topology `transforms` (see _ScalarBasis)'''
+        key = ('$scalar', id(transforms))
+        if key not in self._basis:
+            ne = len(transforms)
+            self.plan['bases'].append(dict(kind='plain', topo=self.topo(transforms), dofs=numpy.zeros(ne, dtype=numpy.int64), coeffs=numpy.ones((ne, 1)),
+                                           offsets=numpy.arange(ne + 1, dtype=numpy.int64), ndofs=1))
+            self._basis[key] = len(self.plan['bases']) - 1
+        return self._basis[key]
+
     def structured_basis(self, basis):
         '''(btype, degree) of a reference StructuredBasis whose per-axis tables equal those of nutils_amd's own structured basis of that kind'''
         from . import basis as _basis
@@ -1014,7 +1049,7 @@ def match(array, arguments=None):
     E = Emitter(M)
     nexposed = None
     # terms without any basis (constants, coefficient functions: `sigma_wall dS`) are located in the topology of the bases seen elsewhere
-    anybasis = next((f.basis for _, m, _ in terms for f in m.factors), None)
+    anybasis = next((f.basis for _, m, _ in terms for f in m.factors if f.basis is not _SCALAR), None)
     for smp, m, fac in terms:
         if m.measure is None:
             raise Unmatched('term without J(geom)')
@@ -1043,7 +1078,11 @@ def match(array, arguments=None):
         form = list(exposed)
         poly = []
         for i in bound:
-            if uses_gradient(i) or facs[i].ncomp > 1 or len(facs) <= 2:
+            if facs[i].basis is _SCALAR:
+                if uses_gradient(i):
+                    raise Unmatched('gradient of a scalar argument')
+                poly.append(i)
+            elif uses_gradient(i) or facs[i].ncomp > 1 or len([f for f in facs if f.basis is not _SCALAR]) <= 2:
                 form.append(i)
             else:
                 poly.append(i)
@@ -1116,7 +1155,11 @@ def match(array, arguments=None):
                 pargs = []
                 for i in poly:
                     f = facs[i]
-                    a = E.arg(f.name, on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None)), 1)
+                    if f.basis is _SCALAR:
+                        a = E.arg(f.name, on_home(E.scalar_basis(home)), 1)
+                        E.plan['args'][a]['scalar'] = True
+                    else:
+                        a = E.arg(f.name, on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None)), 1)
                     pargs.append(a)
                 uniq = sorted(set(pargs))
                 term['fpoly'] = dict(args=uniq, powers=numpy.array([[pargs.count(a) for a in uniq]]), coeffs=[1.])
@@ -1252,8 +1295,21 @@ def install(executor=None):
     import nutils.function as rf
     import nutils.solver as rs
     import nutils.matrix as rmatrix
+    import collections
     ex = executor or execute
-    st = dict(evaluate=rf.evaluate, as_csr=rf.as_csr, system_init=rs.System.__init__, csr={}, plans={}, matched=[], fallback=[])
+    # plans / as_csr components are remembered per array OBJECT (id + identity check) in bounded LRU maps: a time loop that builds a fresh integral
+    # every step must not grow host and device memory without bound -- an evicted plan drops its built tables ('_built') with it
+    st = dict(evaluate=rf.evaluate, as_csr=rf.as_csr, system_init=rs.System.__init__, factor_class=rf._Factor, csr=collections.OrderedDict(),
+              plans=collections.OrderedDict(), matched=[], fallback=[], max_plans=PLAN_CACHE_SIZE)
+
+    def remember(cache, key, value, limit):
+        cache[key] = value
+        cache.move_to_end(key)
+        while len(cache) > limit:
+            _, old = cache.popitem(last=False)
+            plan = old[1]
+            if isinstance(plan, dict):
+                plan.pop('_built', None)
 
     def plan_of(array):
         hit = st['plans'].get(id(array))
@@ -1266,16 +1322,41 @@ def install(executor=None):
                 plan = e
             except Exception as e:  # (an expression shape the matcher does not know must never break the user's script: reference path)
                 plan = Unmatched(f'{type(e).__name__}: {e}')
-            hit = st['plans'][id(array)] = (array, plan)
+            hit = (array, plan)
+            remember(st['plans'], id(array), hit, st['max_plans'])
+        else:
+            st['plans'].move_to_end(id(array))
         return hit[1]
+
+    def run(plan, arguments):
+        '''executor call that never breaks the user's script: a failure turns the plan into Unmatched (recorded) and the caller takes the reference path'''
+        try:
+            return ex(plan, dict(arguments))
+        except Exception as e:
+            st['fallback'].append(f'executor failed on a {plan.get("kind")} plan: {type(e).__name__}: {e}')
+            plan.pop('_built', None)
+            plan['_failed'] = True
+            return None
 
     def as_csr(array):
         out = st['as_csr'](array)  # the reference's evaluable triplet: symbolic, evaluated only if the plan is not used
         plan = plan_of(array)
         if not isinstance(plan, Unmatched):
             for i, o in enumerate(out):
-                st['csr'][id(o)] = (o, plan, i)
+                remember(st['csr'], id(o), (o, plan, i), 3 * st['max_plans'])
         return out
+
+    def factor_hook(array):
+        '''function.factor(array) (function.py:2630-2642) of an integral the matcher recognises: TRANSPARENT -- the integral itself is returned, so that
+        it is re-assembled from its plan whenever it is evaluated (per Newton step, BASELINE.json configs[3]) instead of being expanded ONCE into
+        sparse Taylor tensors by the reference's element loop (evaluable.py:5785-5874).  Anything else is factored by the reference.'''
+        try:
+            if isinstance(array, rf.Array) and not isinstance(plan_of(array), Unmatched):
+                st['matched'].append('factor')
+                return array
+        except Exception:
+            pass
+        return st['factor_class'](array)
 
     def evaluate(*arrays, arguments={}):
         results, rest = [None] * len(arrays), []
@@ -1288,14 +1369,18 @@ def install(executor=None):
                 plan, comp = plan_of(a), None
             else:
                 plan, comp = Unmatched('not an array'), None
-            if isinstance(plan, Unmatched):
+            if isinstance(plan, Unmatched) or plan.get('_failed'):
                 rest.append(i)
                 continue
             key = id(plan)
             if key not in done:
-                done[key] = ex(plan, dict(arguments))
-                st['matched'].append(plan['kind'])
+                done[key] = run(plan, arguments)
+                if done[key] is not None:
+                    st['matched'].append(plan['kind'])
             out = done[key]
+            if out is None:  # the executor failed: the reference evaluates this array
+                rest.append(i)
+                continue
             if comp is not None:
                 results[i] = out[comp]
             elif plan['kind'] == 'matrix':  # a rank-2n array asked for densely: as the reference returns it
@@ -1328,24 +1413,54 @@ def install(executor=None):
         st['matched'].append('System')
         cache = self._System__cache
         zero = lambda arguments: dict(arguments, **{t: numpy.zeros(shape) for t, shape in zip(self.trials, self.trial_shapes)})
-        cache['residual'] = sp.residual
-        if self.is_symmetric:
-            cache['value'] = lambda arguments: numpy.float64(ex(sp.value, arguments))
-        if self.is_constant_matrix:
-            # (assemble_jacobian keeps the MATRIX under this key, solver.py:321-331)
-            cache['jacobian'] = rmatrix.assemble_block_csr(sp.jacobian({}))
-        else:
-            cache['jacobian'] = sp.jacobian
-        if self.is_linear:  # the reference evaluates the residual at zeroed trial arguments and adds jac @ x (solver.py:364-378)
-            cache['jacobian_residual'] = lambda arguments: (sp.jacobian(arguments), sp.residual(zero(arguments)))
-            if self.is_symmetric:
-                cache['jacobian_residual_value'] = lambda arguments: (sp.jacobian(arguments), sp.residual(zero(arguments)), numpy.float64(ex(sp.value, zero(arguments))))
-        else:
-            cache['jacobian_residual'] = lambda arguments: (sp.jacobian(arguments), sp.residual(arguments))
-            if self.is_symmetric:
-                cache['jacobian_residual_value'] = lambda arguments: (sp.jacobian(arguments), sp.residual(arguments), numpy.float64(ex(sp.value, arguments)))
+        import nutils.evaluable as rev
+        bj, br = self._System__block_jacobian, self._System__block_residual
 
-    rf.evaluate, rf.as_csr, rs.System.__init__ = evaluate, as_csr, system_init
+        def zeroed_residual():  # what solver.py:364-366 compiles for a linear system
+            z = dict(zip(self.trials, map(rev.zeros_like, self.trial_args)))
+            return tuple(rev.replace_arguments(v, z).simplified for v in br)
+
+        # the reference's own compiled function for each cache key (solver.py:318-420), built only if a plan fails at run time
+        reference = {
+            'residual': lambda: rev.compile(br),
+            'value': lambda: rev.compile(self._System__value),
+            'jacobian': lambda: rev.compile(bj),
+            'jacobian_residual': lambda: rev.compile((bj, zeroed_residual() if self.is_linear else br)),
+            'jacobian_residual_value': lambda: rev.compile((bj, zeroed_residual(), rev.replace_arguments(self._System__value, dict(zip(self.trials, map(rev.zeros_like, self.trial_args)))))
+                                                          if self.is_linear else (bj, br, self._System__value)),
+        }
+
+        def guarded(key, ours):
+            '''our plan-based function under the reference's cache key; an executor failure is recorded, the key is handed back to the reference's own
+            compiled function and the call is answered by it: the user's script never sees the failure'''
+            def f(arguments):
+                try:
+                    return ours(arguments)
+                except Exception as e:
+                    st['fallback'].append(f'System.{key}: executor failed: {type(e).__name__}: {e}')
+                    ref = cache[key] = reference[key]()
+                    return ref(arguments)
+            return f
+
+        cache['residual'] = guarded('residual', sp.residual)
+        if self.is_symmetric:
+            cache['value'] = guarded('value', lambda arguments: numpy.float64(ex(sp.value, arguments)))
+        if not self.is_constant_matrix:
+            cache['jacobian'] = guarded('jacobian', sp.jacobian)
+        # (a constant Jacobian is kept as the assembled MATRIX under 'jacobian', solver.py:321-331: it is left to the first assemble_jacobian_residual*
+        # call, which assembles it from the blocks of OUR function below -- lazily, as the reference does, and behind the guard)
+        if self.is_linear:  # the reference evaluates the residual at zeroed trial arguments and adds jac @ x (solver.py:364-378)
+            cache['jacobian_residual'] = guarded('jacobian_residual', lambda arguments: (sp.jacobian(arguments), sp.residual(zero(arguments))))
+            if self.is_symmetric:
+                cache['jacobian_residual_value'] = guarded('jacobian_residual_value',
+                                                           lambda arguments: (sp.jacobian(arguments), sp.residual(zero(arguments)), numpy.float64(ex(sp.value, zero(arguments)))))
+        else:
+            cache['jacobian_residual'] = guarded('jacobian_residual', lambda arguments: (sp.jacobian(arguments), sp.residual(arguments)))
+            if self.is_symmetric:
+                cache['jacobian_residual_value'] = guarded('jacobian_residual_value',
+                                                           lambda arguments: (sp.jacobian(arguments), sp.residual(arguments), numpy.float64(ex(sp.value, arguments))))
+
+    rf.evaluate, rf.as_csr, rs.System.__init__, rf._Factor = evaluate, as_csr, system_init, factor_hook
     _STATE = st
     return st
 
@@ -1356,5 +1471,5 @@ def uninstall():
         return
     import nutils.function as rf
     import nutils.solver as rs
-    rf.evaluate, rf.as_csr, rs.System.__init__ = _STATE['evaluate'], _STATE['as_csr'], _STATE['system_init']
+    rf.evaluate, rf.as_csr, rs.System.__init__, rf._Factor = _STATE['evaluate'], _STATE['as_csr'], _STATE['system_init'], _STATE['factor_class']
     _STATE = None

@@ -23,6 +23,8 @@ os.environ.setdefault('NUTILS_NPROCS', '1')
 os.environ.setdefault('NUTILS_MATRIX', 'scipy')
 
 import numpy  # noqa: E402
+import nutils  # noqa: E402
+nutils.__path__.append(os.path.join(ROOT, 'oracle', 'refshim', 'nutils_ext'))  # nutils.units stand-in (re-export of the reference's nutils.SI)
 import matplotlib  # noqa: E402
 matplotlib.use('Agg')
 from nutils_amd import seam  # noqa: E402
@@ -30,7 +32,7 @@ import af_oracle  # noqa: E402
 
 
 def execute_oracle(plan, arguments):
-    out = af_oracle.evaluate(seam.build(plan).integral, arguments)
+    out = af_oracle.evaluate(seam.build(plan).integral, seam.prepare_arguments(plan, arguments))
     if plan['kind'] == 'matrix':
         return out
     return float(out) if plan['kind'] == 'scalar' else numpy.asarray(out, dtype=float).reshape(plan['shape'])
@@ -89,4 +91,4 @@ def main(modules):
 
 
 if __name__ == '__main__':
-    raise SystemExit(0 if main(sys.argv[1:] or ['laplace', 'elasticity', 'poisson', 'platewithhole', 'adaptivity']) else 1)
+    raise SystemExit(0 if main(sys.argv[1:] or ['laplace', 'elasticity', 'poisson', 'platewithhole', 'adaptivity', 'cahnhilliard']) else 1)

@@ -23,6 +23,8 @@ if not os.path.isdir(REF + '/src/nutils'):
 sys.path[:0] = [os.path.join(ROOT, 'oracle', 'refshim'), REF + '/src', REF, ROOT]
 
 import numpy  # noqa: E402
+import nutils  # noqa: E402
+nutils.__path__.append(os.path.join(ROOT, 'oracle', 'refshim', 'nutils_ext'))  # `nutils.units` (examples/cahnhilliard.py:10): re-export of the reference's nutils.SI
 from nutils import function as rf, mesh, solver as rsolver  # noqa: E402
 from nutils.expression_v2 import Namespace  # noqa: E402
 from nutils_amd import seam  # noqa: E402
@@ -158,6 +160,26 @@ def main():
         emit(f'c4_residual_{a}', ra, args)
         for b in 'φη':
             emit(f'c4_jacobian_{a}{b}', rf.derivative(ra, b), args)
+    # ---- configs[3] from the UNMODIFIED examples/cahnhilliard.py: `function.factor` made transparent by the installed seam (seam.install patches
+    # function._Factor), the functional `nrg / tol` captured at its System; residual and Jacobian blocks at the example's own initial state ----------
+    from nutils.units.typing import Length, Time, Density  # noqa: E402  (the stand-in)
+    st = seam.install(lambda plan, arguments: (_ for _ in ()).throw(RuntimeError('plans are only matched here, not executed')))
+    try:
+        captured, chargs = run_example('cahnhilliard', epsilon=Length('5cm'), mobility=(Time / Density)('1μL*s/kg'), nelems=3, degree=2, timestep=Time('1h'), endtime=Time('1h'),
+                                       circle=False)
+    finally:
+        seam.uninstall()
+    assert st['matched'].count('factor') == 4, st['matched']  # the four energy terms of examples/cahnhilliard.py:181-184 were unwrapped
+    nrgx = captured[0][0]
+    rngx = numpy.random.default_rng(7)
+    nbx = chargs['φ'].shape[0]
+    args = dict(φ=rngx.normal(0, .5, nbx), φ0=rngx.normal(0, .5, nbx), η=rngx.normal(0, .1, nbx), dt=numpy.float64(1.))
+    emit('c4x_example_energy', nrgx, args)
+    for a in 'φη':
+        ra = rf.derivative(nrgx, a)
+        emit(f'c4x_example_residual_{a}', ra, args)
+        for b in 'φη':
+            emit(f'c4x_example_jacobian_{a}{b}', rf.derivative(ra, b), args)
     # ---- configs[4]: NURBS plate with hole, hierarchical refinement towards the hole, p = 3 truncated hierarchical splines made rational -------
     levels, degree, radius, poisson = 4, 3, .5, .3
     topo, geom0 = mesh.rectilinear([1, 2])
