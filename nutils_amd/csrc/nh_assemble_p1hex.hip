@@ -680,6 +680,7 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
 #undef NH_TICK
 
 #include "nh_p1hex_tiles.inc"
+#include "nh_p1hex_tri.inc"
 
 // ---- uniform geometry: all element matrices are equal (the reference hoists them out of the loop too) -------------
 // One thread evaluates the element matrix of the unit cell; the assembly is then a pure streaming kernel: every CSR entry is the
@@ -992,6 +993,44 @@ static int launch_tiles_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
   return NH_OK;
 }
 
+// ---- launch of the three-role kernel (matrix) ---------------------------------------------------------------------------------------
+template <bool MASS, bool COEF>
+static int launch_tri_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
+  int dev = 0;
+  NH_CHECK_HIP(hipGetDevice(&dev));
+  NH_REQUIRE(dev >= 0 && dev < 16, "nh_p1hex: device index %d not supported", dev);
+  static int cus_of[16] = {0};
+  static bool attr_set[16] = {false};
+  if (!cus_of[dev]) {
+    int n = 256;
+    NH_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus_of[dev] = n;
+  }
+  auto kern = k_p1hex_tri<MASS, COEF>;
+  if (!attr_set[dev]) {
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p1r::LDS_BYTES));
+    attr_set[dev] = true;
+  }
+  p.nbj = (p.n1 + 1 + p1r::OW - 1) / p1r::OW;
+  p.nbk = (p.n2 + 1 + p1r::OW - 1) / p1r::OW;
+  NH_REQUIRE(a->max_workgroups >= 0, "nh_p1hex: negative max_workgroups");
+  const i64 units = (i64)p.nbj * p.nbk * (p.pl1 - p.pl0);
+  const unsigned grid = (unsigned)std::min<i64>(units, a->max_workgroups ? std::min(cus_of[dev], a->max_workgroups) : cus_of[dev]);
+  static const int delay = getenv("NH_P1HEX_TRI_DELAY") ? std::min(64, std::max(0, atoi(getenv("NH_P1HEX_TRI_DELAY")))) : 1;
+  p.wbnd = delay;  // (start delay of every second workgroup, in units of 4096 cycles)
+  static const int noprio = getenv("NH_P1HEX_TRI_NOPRIO") ? 1 : 0;
+  p.debug = noprio;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(768), p1r::LDS_BYTES, nh_stream(stream), p);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+static int launch_tri(const nh_p1hex_args *a, P1Args &p, void *stream) {
+  const bool coef = p.qscale || p.qmass;
+  if (p.hasm) return coef ? launch_tri_inst<true, true>(a, p, stream) : launch_tri_inst<true, false>(a, p, stream);
+  return coef ? launch_tri_inst<false, true>(a, p, stream) : launch_tri_inst<false, false>(a, p, stream);
+}
+
 static int launch_tiles(const nh_p1hex_args *a, P1Args &p, void *stream) {
   const bool coef = p.qscale || p.qmass;
   if (p.hasm) return coef ? launch_tiles_inst<true, true>(a, p, stream) : launch_tiles_inst<true, false>(a, p, stream);
@@ -1097,6 +1136,7 @@ int nh_p1hex_laplace(const nh_p1hex_args *a, void *stream) {
   // against 0.167 ms: profiles/r04_c2_exact_tiles.md) and stays opt-in.
   const char *env = getenv("NH_P1HEX_KERNEL");
   if (env && !strcmp(env, "tiles")) return launch_tiles(a, p, stream);
+  if (env && !strcmp(env, "tri")) return launch_tri(a, p, stream);
   return launch_march<false>(a, p, stream);
 }
 

@@ -455,8 +455,8 @@ def test_first_touch_coloured_assembly(case, monkeypatch):
 
 
 def test_p1hex_skewed_vs_marching_kernel(monkeypatch):
-    '''The three matrix kernels -- role-skewed halo tiles (default), exact tiles with inter-workgroup face exchange (NH_P1HEX_KERNEL=tiles),
-    marching halo tiles (march) -- on random shapes, layer / plane ranges and workgroup limits: the same set of entries is written (the
+    '''The four matrix kernels -- role-skewed halo tiles (skew), two arithmetic waves + one memory wave per SIMD (tri), exact tiles with inter-workgroup
+    face exchange (tiles), marching halo tiles (march) -- on random shapes, layer / plane ranges and workgroup limits: the same set of entries is written (the
     value array is handed over full of NaN), values agree to rounding.  Shapes reach several 16 x 16 tiles per axis, partial last tiles,
     single-line tiles and more units than workgroups (several runs per workgroup).'''
     from nutils_amd import kernels, device, points
@@ -480,17 +480,17 @@ def test_p1hex_skewed_vs_marching_kernel(monkeypatch):
         verts = device.to_dev(g, 'float64')
         rowptr, colidx = kernels.p1hex_pattern(shape)
         got = []
-        for kern in ('tiles', 'skew', 'march'):
+        for kern in ('tiles', 'tri', 'skew', 'march'):
             monkeypatch.setenv('NH_P1HEX_KERNEL', kern)
             values = device.empty(colidx.numel(), 'float64')
             values.fill_(float('nan'))
             kernels.p1hex_laplace(shape=shape, values=values, gauss_x=x1, gauss_w=w1, verts=verts, layers=(l0, l1), planes=(p0, p1), max_workgroups=(it % 3) * 100 if it != 19 else 7)
             got.append(device.to_host(values))
-        written = ~numpy.isnan(got[2])
+        written = ~numpy.isnan(got[3])
         assert written.any()
-        for k in (0, 1):
+        for k in (0, 1, 2):
             assert numpy.array_equal(~numpy.isnan(got[k]), written), (shape, k)
-            assert numpy.abs(got[k][written] - got[2][written]).max() <= 1e-14 * numpy.abs(got[2][written]).max(), (shape, k)
+            assert numpy.abs(got[k][written] - got[3][written]).max() <= 1e-14 * numpy.abs(got[3][written]).max(), (shape, k)
 
 
 def test_p1hex_tiles_repeated_launches_and_layout_changes(monkeypatch):
