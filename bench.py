@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 F64_MFMA_PEAK_TF = 78.6  # dense f64 MFMA (= f64 vector) peak, 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz
-TRAFFIC_FILE = 'profiles/r03_traffic.json'
+TRAFFIC_FILE = 'profiles/r04_traffic.json'
 
 
 def parse():
@@ -47,6 +47,9 @@ def parse():
     ap.add_argument('--halo', choices=['recompute', 'reduce'], default='recompute',
                     help='N > 1: recompute = every rank also assembles its one ghost element layer and writes only the rows it owns (no exchange; the step is one '
                          'kernel, graph-captured); reduce = RCCL point-to-point reduce of the interface-plane rows.  The line carries the other mode as `halo_<mode>`')
+    ap.add_argument('--traffic', choices=['measure', 'static'], default='measure',
+                    help='roofline.traffic: measure = two rocprofv3 --pmc passes of a short probe of the same kernel inside this run (when rocprofv3 is on PATH), '
+                         'static = the committed profile file')
     ap.add_argument('--settle', type=int, default=None, help='untimed steps before the warm-up: the first ~50 launches after idle run ~10 %% slower (clock ramp)')
     ap.add_argument('--n', '--elements-per-axis', dest='n', type=int, default=None,
                     help='elements per axis (per GPU with weak scaling; use the long form behind torch.distributed.run, whose parser claims --n)')
@@ -72,6 +75,42 @@ def measured_traffic(kernel_name, n):
     try:
         d = json.load(open(os.path.join(ROOT, TRAFFIC_FILE))).get(kernel_name)
         return d['fetch_bytes'] + d['write_bytes'] if d and d['n'] == n else None
+    except Exception:
+        return None
+
+
+def measured_traffic_inrun(kernel_substr, probe_cmd):
+    '''HBM bytes per launch of the kernel measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, and counters are
+    collected with --kernel-trace only, as the guide prescribes) of a short probe command that launches the same kernel on the same workload.  Returns
+    None when rocprofv3 is not on PATH or a pass fails (then the static profile file is used and labelled so).  Units: KB x 1024; FETCH_SIZE is
+    reported as counted AND doubled (the guide: on gfx950 a wide streaming read is tallied at half its bytes).'''
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which('rocprofv3') or os.environ.get('NUTILS_AMD_NO_INRUN_TRAFFIC'):
+        return None
+    out = {}
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = tempfile.mkdtemp(prefix='nh_pmc_', dir='/tmp')
+            env = dict(os.environ, TMPDIR='/tmp', NUTILS_AMD_NO_INRUN_TRAFFIC='1')
+            r = subprocess.run(['rocprofv3', '--kernel-trace', '--pmc', ctr, '-d', d, '-o', 'p', '-f', 'csv', '--'] + probe_cmd, cwd=ROOT, env=env,
+                               capture_output=True, text=True, timeout=240)
+            vals = []
+            for fn in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+                for row in csv.DictReader(open(fn)):
+                    if kernel_substr in row['Kernel_Name'] and row['Counter_Name'] == ctr:
+                        vals.append(float(row['Counter_Value']))
+            shutil.rmtree(d, ignore_errors=True)
+            if r.returncode != 0 or not vals:
+                return None
+            vals = vals[len(vals) // 2:]  # (the first launches of the probe run cold)
+            out[ctr] = sum(vals) / len(vals) * 1024
+        return {'fetch_bytes': out['FETCH_SIZE'], 'write_bytes': out['WRITE_SIZE'], 'bytes': out['FETCH_SIZE'] + out['WRITE_SIZE'],
+                'bytes_fetch_doubled': 2 * out['FETCH_SIZE'] + out['WRITE_SIZE'],
+                'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) of `' + ' '.join(probe_cmd) + '`, measured in this run'}
     except Exception:
         return None
 
@@ -405,15 +444,35 @@ def main():
         bytes_per_elem = wl.algorithmic_bytes_per_element()
         gbs = bytes_per_elem * wl_nelems / (kernel_ms * 1e-3) / 1e9
         traffic = measured_traffic(wl.kernel_name, a.n) if world == 1 else None
+        inrun = None
+        if world == 1 and a.traffic == 'measure':
+            probe = [sys.executable, 'tools/c3_bench.py', str(a.n), '3'] if a.config == 'c3' else [sys.executable, 'tools/c2_time.py', str(a.n), '30']
+            if a.config == 'c3' or (a.variant == 'iso' and a.kernel in ('auto', 'fast')):
+                inrun = measured_traffic_inrun(wl.kernel_name.split('<')[0], probe)
+            if inrun is not None:
+                traffic = inrun['bytes']
         if a.config == 'c3':
             roofline = c3_roofline(wl, kernel_ms, traffic)
             workload = f'3D linear elasticity stiffness, {a.n}^3 structured hex, p=2 vector basis (81 local dofs), 3x3x3 Gauss, {a.variant} geometry (BASELINE.json configs[2])'
         else:
             roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': traffic,
                         'kernel': wl.kernel_name, 'kernel_ms': kernel_ms, 'algorithmic_bytes_per_element': bytes_per_elem}
+            if a.variant == 'iso' and a.kernel in ('auto', 'fast'):
+                # second roofline of the same kernel: EXECUTED f64 arithmetic against the f64 vector peak.  Per element-thread the routine issues 1060 f64
+                # instructions = 1489 flop (ISA of nh_p1hex_math.inc + the 36 entries: 301 mul, 330 add, 429 fma; tools/isa_hist.sh) plus 8 reciprocals; the
+                # kernel computes every element of its 16 x 16 tiles incl. the one-element lateral halo and one extra layer per run of a workgroup.
+                nb = -(-(a.n + 1) // 15)
+                threads = nb * nb * 256 * (wl_layers + max(1, round(256 / (nb * nb))))
+                tf = 1489. * threads / (kernel_ms * 1e-3) / 1e12
+                roofline['f64_valu'] = {'achieved': tf, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / F64_MFMA_PEAK_TF, 'flop_per_element_thread': 1489,
+                                        'f64_instructions_per_element_thread': 1060, 'element_threads': threads,
+                                        'note': 'executed arithmetic incl. halo recompute (1.27 x the elements); counters: profiles/r04_c2_pmc.md'}
             per = f'{wl_layers} x {a.n} x {a.n} per GPU' if world > 1 else f'{a.n}^3'
             workload = f'3D Poisson stiffness, {per} structured hex, p=1, 2x2x2 Gauss, {a.variant} geometry (BASELINE.json configs[1])'
-        if traffic is not None:
+        if inrun is not None:
+            roofline['traffic_source'] = inrun['source']
+            roofline['traffic_detail'] = {k: inrun[k] for k in ('fetch_bytes', 'write_bytes', 'bytes_fetch_doubled')}
+        elif traffic is not None:
             roofline['traffic_source'] = TRAFFIC_FILE + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, separate passes; not measured in this run)'
         out = {
             'metric': metric, 'value': value, 'unit': 'elements/s', 'n_gpus': world,
