@@ -821,13 +821,17 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
   p.wbnd = getenv("NH_P1HEX_STAGE_LATE") ? -wbnd_env : wbnd_env;
   constexpr int TJ = 16, TK = 16, L = 2, NTM = L * TJ * TK, NS = VEC ? 1 : 15, VW = VEC ? 4 : 3;
   // (per-step path of a Newton loop / of a multi-GPU slab whose kernel lasts ~20 us: device queries and the LDS attribute once per process)
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 256;
-    NH_CHECK_HIP(hipGetDevice(&dev));
+  // (function attributes and the CU count belong to a DEVICE: remembered per device index; the library is driven by one host thread, include/nutils_hip.h)
+  int dev = 0;
+  NH_CHECK_HIP(hipGetDevice(&dev));
+  NH_REQUIRE(dev >= 0 && dev < 16, "nh_p1hex: device index %d not supported", dev);
+  static int cus_of[16] = {0};
+  if (!cus_of[dev]) {
+    int n = 256;
     NH_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    cus = n;
+    cus_of[dev] = n;
   }
+  const int cus = cus_of[dev];
   p.nbj = (p.n1 + 1 + TJ - 2) / (TJ - 1);
   p.nbk = (p.n2 + 1 + TK - 2) / (TK - 1);
   const size_t ldsm = sizeof(double) * ((L + 2) * (((TJ + 1) * (TK + 1) * NS + 1) & ~1) + (L + 1) * (TJ + 1) * (TK + 1) * VW + 2);
@@ -843,10 +847,10 @@ static int launch_march_inst(const nh_p1hex_args *a, P1Args &p, void *stream) {
     const bool march = (env && atoi(env)) || (kenv && !strcmp(kenv, "march"));
     if (!march) kern = k_p1hex_skew<TJ, TK, MASS, COEF>;
   }
-  static const void *attr_set[2] = {nullptr, nullptr};  // (this instantiation: the marching and the skewed kernel)
-  if (attr_set[0] != (const void *)kern && attr_set[1] != (const void *)kern) {
+  static const void *attr_set[16][2] = {{nullptr, nullptr}};  // (this instantiation: the marching and the skewed kernel, per device)
+  if (attr_set[dev][0] != (const void *)kern && attr_set[dev][1] != (const void *)kern) {
     NH_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
-    attr_set[attr_set[0] ? 1 : 0] = (const void *)kern;
+    attr_set[dev][attr_set[dev][0] ? 1 : 0] = (const void *)kern;
   }
 #ifdef NH_ABLATION
   static long long *tdbg = nullptr;

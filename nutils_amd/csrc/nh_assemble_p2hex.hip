@@ -29,6 +29,7 @@
 // The closed-form pattern of this basis: along an axis with n elements node X couples to [X-2, X+2] (X even, clipped) or
 // [X-1, X+1] (X odd); rows are tensor products of these ranges, so row pointers and column positions are arithmetic.
 #include "nh_common.h"
+#include <vector>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1495,6 +1496,22 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   bool pipe = NS == 3 && p.ks == PKS && lds_pipe <= 160 * 1024;
   p.prio = 1;
   bool inreg = pipe && !a->scale_dev;  // sqrt(w |J|) on both operands: not with a signed scale array
+  if (inreg) {
+    // ... nor with a quadrature weight <= 0 (sqrt of it: NaN in every entry of the touched elements; the table kernels carry signed weights).  The signs of a
+    // weight array are read once (the array belongs to the sample and does not change; keyed by pointer and length)
+    static const double *wkey = nullptr;
+    static int wn = 0;
+    static bool wpos = true;
+    if (wkey != a->weights_dev || wn != a->nq) {
+      std::vector<double> hw((size_t)a->nq);
+      NH_CHECK_HIP(hipMemcpyAsync(hw.data(), a->weights_dev, sizeof(double) * a->nq, hipMemcpyDeviceToHost, nh_stream(stream)));
+      NH_CHECK_HIP(hipStreamSynchronize(nh_stream(stream)));
+      wpos = true;
+      for (double w : hw) wpos = wpos && w > 0.;
+      wkey = a->weights_dev, wn = a->nq;
+    }
+    inreg = wpos;
+  }
 #ifdef NH_ABLATION  // A/B switches of the ablation build only
   if (getenv("NH_P2HEX_PIPE") && atoi(getenv("NH_P2HEX_PIPE"))) inreg = false;
   if (getenv("NH_P2HEX_LOCKSTEP") && atoi(getenv("NH_P2HEX_LOCKSTEP"))) pipe = false;

@@ -28,6 +28,7 @@ struct SPK {
   const i64 *sptr;
   i64 *skey;
   int32_t *ssrc;
+  int *bad;  // set when an element has >= 4096 functions (the sort key keeps 12 bits for the local index)
 };
 
 // phase 0: count the contributions per dof; phase 1: place (key, position) pairs through a per-dof cursor (counts, zeroed in between)
@@ -37,6 +38,7 @@ __global__ void k_sp_visit(SPK p) {
     const i64 e = p.elist ? p.elist[ie] : ie;
     const i64 o = p.nb ? e * p.nb : p.off[e];
     const int nbe = p.nb ? p.nb : (int)(p.off[e + 1] - p.off[e]);
+    if (PHASE == 0 && nbe >= 4096) atomicOr(p.bad, 1);
     for (int m = 0; m < nbe; ++m) {
       const int32_t dof = p.dofs[o + m];
       if (PHASE == 0) atomicAdd(p.counts + dof, 1);
@@ -102,17 +104,19 @@ int nh_scatter_plan_build(int64_t nelems, int64_t nrows, int nb, const int32_t *
   hipStream_t s = nh_stream(stream);
   if (!elist_dev) nlist = nelems;
   NH_REQUIRE(nlist >= 0 && nlist < ((i64)1 << 50), "nh_scatter_plan_build: list length");
-  i64 npos = 0;
+  i64 npos = 0, ntotal = nelems * (i64)nb;  // ntotal: positions of the whole basis (the plan stores 32-bit positions into its dof array)
   if (nb) npos = nlist * nb;
-  else if (!elist_dev) {
-    NH_CHECK_HIP(hipMemcpyAsync(&npos, off_dev + nelems, sizeof(i64), hipMemcpyDeviceToHost, s));
+  else {
+    NH_CHECK_HIP(hipMemcpyAsync(&ntotal, off_dev + nelems, sizeof(i64), hipMemcpyDeviceToHost, s));
     NH_CHECK_HIP(hipStreamSynchronize(s));
+    if (!elist_dev) npos = ntotal;
   }
+  NH_REQUIRE(ntotal < ((i64)1 << 31), "nh_scatter_plan_build: %lld (element, function) positions exceed the 32-bit positions of the plan", (long long)ntotal);
   nh_scatter_plan *P = new nh_scatter_plan{nrows, 0, nullptr, nullptr};
   int32_t *counts = nullptr;
   i64 *skey = nullptr;
-  int rc = NH_OK;
-  SPK k{nlist, nrows, nb, dofs_dev, elist_dev, (const i64 *)off_dev, nullptr, nullptr, nullptr, nullptr};
+  int rc = NH_OK, hbad = 0;
+  SPK k{nlist, nrows, nb, dofs_dev, elist_dev, (const i64 *)off_dev, nullptr, nullptr, nullptr, nullptr, nullptr};
   const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>((nlist + 255) / 256, 256 * 16));
   const unsigned rgrid = (unsigned)std::max<i64>(1, std::min<i64>((nrows + 255) / 256, 256 * 16));
 #define SP_HIP(expr)                                                                                              \
@@ -124,11 +128,19 @@ int nh_scatter_plan_build(int64_t nelems, int64_t nrows, int nb, const int32_t *
       goto done;                                                                                                  \
     }                                                                                                             \
   } while (0)
-  SP_HIP(hipMalloc((void **)&counts, sizeof(int32_t) * std::max<i64>(nrows, 1)));
+  SP_HIP(hipMalloc((void **)&counts, sizeof(int32_t) * (std::max<i64>(nrows, 1) + 1)));  // (+ 1: the flag of k_sp_visit)
   SP_HIP(hipMalloc((void **)&P->sptr, sizeof(i64) * (nrows + 1)));
-  SP_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * std::max<i64>(nrows, 1), s));
+  SP_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (std::max<i64>(nrows, 1) + 1), s));
   k.counts = counts;
+  k.bad = counts + std::max<i64>(nrows, 1);
   if (nlist) hipLaunchKernelGGL(k_sp_visit<0>, dim3(grid), dim3(256), 0, s, k);
+  SP_HIP(hipMemcpyAsync(&hbad, k.bad, sizeof(int), hipMemcpyDeviceToHost, s));
+  SP_HIP(hipStreamSynchronize(s));
+  if (hbad) {
+    nh_set_error("nh_scatter_plan_build: an element with 4096 or more functions (the deterministic order keeps 12 bits for the local index)");
+    rc = NH_ELIMIT;
+    goto done;
+  }
   if ((rc = nh_scan_exclusive(counts, P->sptr, nrows, s)) != NH_OK) goto done;
   if (!nb && elist_dev) {  // ragged basis on part of the topology: the total is the last scan entry
     SP_HIP(hipMemcpyAsync(&npos, P->sptr + nrows, sizeof(i64), hipMemcpyDeviceToHost, s));
