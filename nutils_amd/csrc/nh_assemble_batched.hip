@@ -647,6 +647,7 @@ struct LTermsK {
   int tlen;
   double tabarg[TABARG];
   double *local;
+  int ncls;  // k_local_terms2: element classes whose tables a workgroup stages
 };
 
 template <int ND, int NBT, int NBR, int MB, int NF>
@@ -866,6 +867,339 @@ __global__ __launch_bounds__(128) void k_local_terms(LTermsK p) {
   for (int m = 0; m < MB; ++m)
 #pragma unroll
     for (int n = 0; n < NBR; ++n) p.local[ie * (NBT * NBR) + (mb + m) * NBR + n] = A[m][n];
+}
+
+// k_local_terms re-arranged so that nothing of a point is computed twice (round 4).  The thread-per-row-block kernel above evaluates the geometry, the fields, the
+// polynomials and the term list of a point in EVERY row-block thread of the element (three times for configs[3]) and forms the pre-multiplied trial side W[n][a] for all
+// trial functions in each of them: ~14 k instructions per thread where the contraction needs ~3 k.  Here a workgroup of TPE * 64 threads owns 64 elements and walks over the
+// points in chunks of TPE:
+//   phase A: wave w takes point q0 + w of the chunk, lane l element l -- geometry, fields, polynomials, term list ONCE per (element, point); the coefficient tensor is
+//            folded with the weight and the inverse Jacobian, C'[a][b] = w sum P[a][a'] Cq[a'][b'] P[b][b'] (P = diag(1, J^-1)), so that the contraction below needs the
+//            REFERENCE tables only; C' goes to LDS (double buffered: one barrier per chunk).  The point is wave-uniform: every table read of the phase is a broadcast.
+//   phase B: thread (element, block of NBK trial functions) adds the chunk's points to its NBT x NBK entries: W[j][a] = sum_b C'[a][b] T_r[n_j][q][b] (its own trial
+//            functions only), A[m][j] += sum_a T_t[m][q][a] W[j][a]; the point is uniform over the workgroup.
+#ifndef NH_LT2_WPE
+#define NH_LT2_WPE 3
+#endif
+#ifndef NH_LT2_DB
+#define NH_LT2_DB 0  // 1: two C' buffers (one barrier per chunk, 14 kB more LDS)
+#endif
+#ifndef NH_LT2_CLS
+#define NH_LT2_CLS 6
+#endif
+#ifndef NH_LT2_GRP
+#define NH_LT2_GRP 3  // table rows read ahead of their arithmetic
+#endif
+constexpr int LT2_EPB = 64;
+constexpr int LT2_CLS = NH_LT2_CLS;  // most element classes whose tables a workgroup stages (a run of 64 consecutive elements of a wide tensor spline mesh meets two)
+template <int ND, int NBT, int NBR, int NBK, int NF, bool ISO>
+__global__ __launch_bounds__(LT2_EPB *(NBR / NBK)) __attribute__((amdgpu_waves_per_eu(NH_LT2_WPE, NH_LT2_WPE))) void k_local_terms2(LTermsK p) {
+  constexpr int S = 1 + ND, NG = 1 << ND, TPE = NBR / NBK, QC = TPE, NT = LT2_EPB * TPE, SS = S * S;
+  static_assert(NBR % NBK == 0, "trial blocks");
+  // (the term list is read from the kernel arguments with scalar loads, uniform over the launch.  Measured and not kept: the list in two registers per lane read with
+  // v_readlane -- no memory round trips, but 0.48 instead of 0.345 ms: four readlanes and a select per entry, 134 spilled scalar registers)
+  const double *tab = p.tabarg;
+  extern __shared__ __attribute__((aligned(16))) double stab[];  // tables of up to LT2_CLS element classes of the workgroup, then the C' buffers [2][QC][64][S * S]
+  __shared__ i64 clsT[LT2_CLS], clsR[LT2_CLS];
+  __shared__ int ncls, slotS[LT2_EPB];
+  const bool same_tables = p.test.T == p.trial.T && p.test.tab == p.trial.tab;
+  const int ntab = ((NBT * p.nq * S + (same_tables ? 0 : NBR * p.nq * S)) + 1) & ~1;
+  double *cbuf = stab + p.ncls * ntab;
+  constexpr int NCB = NH_LT2_DB ? 2 : 1, UES = (NF * NBT) | 1;  // C' buffers; odd pitch of an element's field coefficients
+  double *ueS = cbuf + NCB * QC * LT2_EPB * SS;                 // [64][UES]: the phase-A lane reads them per point (in registers they cost a third wave per SIMD)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const i64 ie0 = (i64)blockIdx.x * LT2_EPB;
+  // phase-A element of this lane / phase-B element of this thread
+  const i64 ieA = min(ie0 + lane, p.nelems - 1), eA = p.elist ? p.elist[ieA] : ieA;
+  const int elB = threadIdx.x / TPE, nb0 = (threadIdx.x - elB * TPE) * NBK;
+  const i64 ieB_raw = ie0 + elB, ieB = min(ieB_raw, p.nelems - 1), eB = p.elist ? p.elist[ieB] : ieB;
+  // The element classes (table pairs) of the 64 elements: on a tensor spline mesh a run of consecutive elements meets two or three (the first / last knot span of a row
+  // differs from the interior ones); with ONE staged class every fourth workgroup of a 512-element row fell back to global table reads and took ten times as long.
+  // Wave 0 numbers the distinct classes (leader election over the lanes not yet numbered); more than p.ncls (the launcher sizes the LDS for 2 on large meshes, LT2_CLS on small ones): global reads for the whole workgroup.
+  if (wave == 0) {
+    const i64 ft = bfn(p.test, eA), fr = bfn(p.trial, eA);
+    int slot = -1, k = 0;
+    unsigned long long todo = __ballot(1);
+    while (todo && k < p.ncls) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const i64 lt = __shfl(ft, leader), lr = __shfl(fr, leader);
+      if (lane == leader) clsT[k] = lt, clsR[k] = lr;
+      if (ft == lt && fr == lr) slot = k;
+      todo = __ballot(slot < 0);
+      ++k;
+    }
+    slotS[lane] = slot;
+    if (lane == 0) ncls = todo ? -1 : k;
+  }
+  __syncthreads();
+  const int staged = ncls > 0;
+  if (staged) {
+    const int nt = NBT * p.nq * S, nr = same_tables ? 0 : NBR * p.nq * S;
+    for (int c = 0; c < ncls; ++c) {
+      for (int i = threadIdx.x; i < nt; i += NT) stab[c * ntab + i] = p.test.T[clsT[c] * p.nq * S + i];
+      for (int i = threadIdx.x; i < nr; i += NT) stab[c * ntab + nt + i] = p.trial.T[clsR[c] * p.nq * S + i];
+    }
+  }
+  const int slotA = staged ? slotS[lane] : 0, slotB = staged ? slotS[elB] : 0;
+  __syncthreads();
+  constexpr bool iso = ISO;  // (p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG: the launcher's choice)
+  double X[ISO ? NG : 1][ND];
+  if (iso) {
+#pragma unroll
+    for (int a = 0; a < NG; ++a) {
+      const i64 v = p.geom.gdofs[eA * NG + a];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) X[ISO ? a : 0][i] = p.geom.verts[v * ND + i];
+    }
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int n = 0; n < NBT; ++n) ueS[lane * UES + f * NBT + n] = p.u[f][p.test.dofs[eA * (i64)NBT + n]];
+  }
+  const double *ue = ueS + lane * UES;
+  __syncthreads();
+  double A[NBT][NBK];
+#pragma unroll
+  for (int m = 0; m < NBT; ++m)
+#pragma unroll
+    for (int j = 0; j < NBK; ++j) A[m][j] = 0;
+
+  auto body = [&](const double *TtA, const double *TtB, const double *TrB) {
+    for (int q0 = 0, buf = 0; q0 < p.nq; q0 += QC, buf ^= NCB - 1) {
+      double *cq = cbuf + buf * (QC * LT2_EPB * SS);
+      if (NCB == 1 && q0) __syncthreads();  // (single buffer: phase B of the previous chunk has read it)
+      const int q = q0 + wave;
+#ifdef NH_LT2_SKIPA  // (timing experiments only)
+      if (q < p.nq && p.nq < 0) {
+#else
+      if (q < p.nq) {  // ---- phase A: (element = lane, point = q0 + wave)
+#endif
+        double Ji[ND][ND], det;
+        if (iso) {
+          double J[ND][ND];
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int j = 0; j < ND; ++j) J[i][j] = 0;
+#pragma unroll
+          for (int a = 0; a < NG; ++a) {
+            const double *tg = p.geom.gT + ((i64)a * p.nq + q) * S;
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+#pragma unroll
+              for (int j = 0; j < ND; ++j) J[i][j] += X[ISO ? a : 0][i] * tg[1 + j];
+          }
+          invert<ND>(J, Ji, det);
+          if (p.geom.bnd_axis >= 0) {
+            double s2 = 0;
+#pragma unroll
+            for (int j = 0; j < ND; ++j)
+#pragma unroll
+              for (int i = 0; i < ND; ++i)
+                if (j == p.geom.bnd_axis) s2 += Ji[j][i] * Ji[j][i];
+            det *= sqrt(s2);
+          }
+        } else
+          geometry_at<ND>(p.geom, eA, q, p.nq, nullptr, Ji, det, nullptr);
+        const double w = p.weights[q] * fabs(det);
+        const i64 ip = (p.by_elem ? eA : ieA) * p.nq + q;
+        double U[NF > 0 ? NF : 1][S];
+        {
+          double r[NF > 0 ? NF : 1][S];
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) r[f][s2] = 0;
+#pragma unroll
+          for (int n = 0; n < NBT; ++n) {  // (one pass over the table rows of the point for all fields)
+            const double *T = TtA + ((size_t)n * p.nq + q) * S;
+            double tv[S];
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) tv[s2] = T[s2];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+              for (int s2 = 0; s2 < S; ++s2) r[f][s2] += tv[s2] * ue[f * NBT + n];
+            if (n % NH_LT2_GRP == NH_LT2_GRP - 1) __builtin_amdgcn_sched_barrier(0);  // (bounds the reads in flight: hoisted all at once they cost a wave of occupancy)
+          }
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            U[f][0] = r[f][0];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+              double sum = 0;
+#pragma unroll
+              for (int j = 0; j < ND; ++j) sum += r[f][1 + j] * Ji[j][i];
+              U[f][1 + i] = sum;
+            }
+          }
+        }
+        auto field = [&](int f, int s2) { return NF > 1 && f == 1 ? U[NF > 1 ? 1 : 0][s2] : U[0][s2]; };
+        double pv[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+          pv[k] = 1.;
+          if (k < p.npolys) {
+            // (every record is read whole before it is used: one scalar round trip per record -- written entry by entry inside the loops, each power and each coefficient
+            // was a load + wait of its own and the phase was bound by them)
+            const double *P = tab + p.poff[k];
+            const double h0 = P[0], h1 = P[1], s0 = P[2], s1 = P[3], s2v = P[4], s3 = P[5];
+            const int nv = (int)h0, nt = (int)h1;
+            const int sl[4] = {(int)s0, (int)s1, (int)s2v, (int)s3};
+            double x[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) x[v] = v < nv ? field(sl[v], 0) : 1.;
+            double sum = 0;
+            for (int t2 = 0; t2 < nt; ++t2) {
+              const double *M = P + 6 + 5 * t2;
+              const double c0 = M[0], e0 = M[1], e1 = M[2], e2 = M[3], e3 = M[4];
+              const int pw[4] = {(int)e0, (int)e1, (int)e2, (int)e3};
+              double mm = c0;
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {  // x^pw by squaring, pw < 64 (branch-free over the bits that occur: pw is uniform)
+                double xp = x[v];
+                for (int e = pw[v]; e > 0; e >>= 1) {
+                  if (e & 1) mm *= xp;
+                  xp *= xp;
+                }
+              }
+              sum += mm;
+            }
+            pv[k] = sum;
+          }
+        }
+        double Cq[S][S];
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+          for (int b = 0; b < S; ++b) Cq[a][b] = 0;
+        for (int t2 = 0; t2 < p.nterms; ++t2) {
+          const double *H = tab + p.toff[t2];
+          double rec[3 + SS + S];  // [kind, field, poly, B[S][S], L[S] (kind 2)]: read whole (the tail of a shorter record is the head of the next entry of the table)
+#pragma unroll
+          for (int i2 = 0; i2 < 3 + SS + S; ++i2) rec[i2] = H[p.toff[t2] + i2 < TABARG ? i2 : 0];
+          const int kind = (int)rec[0], fld = (int)rec[1], pol = (int)rec[2];
+          double coef = p.scale[t2] ? p.scale[t2][ip] : 1.;
+          if (pol >= 0) coef *= pick(pv, pol);
+          if (p.qoff[t2]) {
+            const double *Q = tab + p.qoff[t2];
+            double qr[2 + SS];
+#pragma unroll
+            for (int i2 = 0; i2 < 2 + SS; ++i2) qr[i2] = Q[i2];
+            double sum = 0;
+            const int fa = (int)qr[0], fb = (int)qr[1];
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+              for (int b = 0; b < S; ++b) sum += qr[2 + a * S + b] * field(fa, a) * field(fb, b);
+            coef *= sum;
+          }
+          const double *B = rec + 3;
+          if (kind == 0) {
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+              for (int b = 0; b < S; ++b) Cq[a][b] += coef * B[a * S + b];
+          } else if (kind == 1) {
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+              double sum = 0;
+#pragma unroll
+              for (int b = 0; b < S; ++b) sum += B[a * S + b] * field(fld, b);
+              Cq[a][0] += coef * sum;
+            }
+          } else {
+            const double *L = B + S * S;
+#pragma unroll
+            for (int b = 0; b < S; ++b) {
+              double sum = 0;
+#pragma unroll
+              for (int x2 = 0; x2 < S; ++x2) sum += B[x2 * S + b] * field(fld, x2);
+#pragma unroll
+              for (int a = 0; a < S; ++a) Cq[a][b] += coef * L[a] * sum;
+            }
+          }
+        }
+        // fold: C'[a][b] = w sum_{a' b'} P[a][a'] Cq[a'][b'] P[b][b'], P = diag(1, J^-1) (dt[1 + i] = sum_j T[1 + j] Ji[j][i])
+        double H1[S][S];  // H1[a][b'] = sum_a' P[a][a'] Cq[a'][b']
+#pragma unroll
+        for (int b = 0; b < S; ++b) {
+          H1[0][b] = Cq[0][b];
+#pragma unroll
+          for (int j = 0; j < ND; ++j) {
+            double sum = 0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) sum += Ji[j][i] * Cq[1 + i][b];
+            H1[1 + j][b] = sum;
+          }
+        }
+        double *o = cq + ((size_t)wave * LT2_EPB + lane) * SS;
+#pragma unroll
+        for (int a = 0; a < S; ++a) {
+          o[a * S] = w * H1[a][0];
+#pragma unroll
+          for (int j = 0; j < ND; ++j) {
+            double sum = 0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) sum += H1[a][1 + i] * Ji[j][i];
+            o[a * S + 1 + j] = w * sum;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- phase B: (element, trial block) x the points of the chunk
+#ifdef NH_LT2_SKIPB
+      const int nqc = p.nq < 0 ? 1 : 0;
+#else
+      const int nqc = min(QC, p.nq - q0);
+#endif
+      for (int ql = 0; ql < nqc; ++ql) {
+        const int qb = q0 + ql;
+        const double *c = cq + ((size_t)ql * LT2_EPB + elB) * SS;
+        double Cp[S][S];
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+#pragma unroll
+          for (int b = 0; b < S; ++b) Cp[a][b] = c[a * S + b];
+        double W[NBK][S];
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) {
+          const double *T = TrB + ((size_t)(nb0 + j) * p.nq + qb) * S;
+          double tr[S];
+#pragma unroll
+          for (int b = 0; b < S; ++b) tr[b] = T[b];
+#pragma unroll
+          for (int a = 0; a < S; ++a) {
+            double sum = 0;
+#pragma unroll
+            for (int b = 0; b < S; ++b) sum += Cp[a][b] * tr[b];
+            W[j][a] = sum;
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < NBT; ++m) {
+          const double *T = TtB + ((size_t)m * p.nq + qb) * S;
+          double tt[S];
+#pragma unroll
+          for (int a = 0; a < S; ++a) tt[a] = T[a];
+#pragma unroll
+          for (int j = 0; j < NBK; ++j)
+#pragma unroll
+            for (int a = 0; a < S; ++a) A[m][j] += tt[a] * W[j][a];
+          if (m % NH_LT2_GRP == NH_LT2_GRP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+  if (staged) body(stab + slotA * ntab, stab + slotB * ntab, stab + slotB * ntab + (same_tables ? 0 : NBT * p.nq * S));
+  else body(p.test.T + bfn(p.test, eA) * p.nq * S, p.test.T + bfn(p.test, eB) * p.nq * S, p.trial.T + bfn(p.trial, eB) * p.nq * S);
+  if (ieB_raw >= p.nelems) return;
+#pragma unroll
+  for (int m = 0; m < NBT; ++m)
+#pragma unroll
+    for (int j = 0; j < NBK; ++j) p.local[ieB * (NBT * NBR) + m * NBR + nb0 + j] = A[m][j];
 }
 
 // ---- fused linear forms, scalar blocks on small uniform bases: ONE THREAD per element ------------------------------------------------------------
@@ -1185,13 +1519,47 @@ int local_terms(const nh_matrix_terms_args *a, const MTermsK &m, const std::vect
   const bool same_tables = a->test.T_dev == a->trial.T_dev && a->test.tab_dev == a->trial.tab_dev;
   const size_t ldst = sizeof(double) * (size_t)a->nq * (1 + a->ndims) * (a->test.nb + (same_tables ? 0 : a->trial.nb));  // staged tables of one element class
   if (ldst > 48 * 1024) return NH_OK;  // (tables too large to stage: the batched kernel keeps the block)
+  // the two-phase arrangement (k_local_terms2) for the blocks whose row-block threads repeat the point work; NUTILS_AMD_LOCAL_TERMS=1 keeps the kernel above
+  const bool two_phase = !(getenv("NUTILS_AMD_LOCAL_TERMS") && atoi(getenv("NUTILS_AMD_LOCAL_TERMS")) == 1);
+  bool launched2 = false;
+  if (two_phase && (key == 20909 || key == 30808)) {
+    const int S2 = 1 + a->ndims, tpe = key == 20909 ? 3 : 4;
+    p.ncls = a->nelems >= (1 << 16) ? 2 : LT2_CLS;  // (large meshes: occupancy; small ones, short rows: every class of the run staged)
+    const size_t lds2_rest = sizeof(double) * ((NH_LT2_DB ? 2 : 1) * tpe * LT2_EPB * S2 * S2 + LT2_EPB * ((a->nfields * a->test.nb) | 1));
+    while (p.ncls > 1 && p.ncls * ((ldst + 15) & ~(size_t)15) + lds2_rest > 64 * 1024) --p.ncls;
+    const size_t lds2 = p.ncls * ((ldst + 15) & ~(size_t)15) + lds2_rest;
+    dim3 grid2((unsigned)((a->nelems + LT2_EPB - 1) / LT2_EPB)), block2(LT2_EPB * tpe);
+    const bool iso2 = m.geom.kind == NH_GEOM_ISO && m.geom.ngb == (1 << a->ndims);
+#define LT2I(ND, NBT, NBR, NBK, NF, ISO)                                                                                                                  \
+  do {                                                                                                                                                   \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_local_terms2<ND, NBT, NBR, NBK, NF, ISO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));   \
+    hipLaunchKernelGGL((k_local_terms2<ND, NBT, NBR, NBK, NF, ISO>), grid2, block2, lds2, s, p);                                                          \
+  } while (0)
+#define LT2(ND, NBT, NBR, NBK, NF)             \
+  do {                                         \
+    if (iso2) LT2I(ND, NBT, NBR, NBK, NF, true); \
+    else LT2I(ND, NBT, NBR, NBK, NF, false);   \
+  } while (0)
+#define LT2F(ND, NBT, NBR, NBK)                        \
+  do {                                                 \
+    if (a->nfields == 0) LT2(ND, NBT, NBR, NBK, 0);    \
+    else if (a->nfields == 1) LT2(ND, NBT, NBR, NBK, 1); \
+    else LT2(ND, NBT, NBR, NBK, 2);                    \
+  } while (0)
+    if (key == 20909) LT2F(2, 9, 9, 3);
+    else LT2F(3, 8, 8, 2);
+#undef LT2F
+#undef LT2
+#undef LT2I
+    launched2 = true;
+  }
 #define LT(ND, NBT, NBR, MB)                                                                                  \
   do {                                                                                                        \
     if (a->nfields == 0) hipLaunchKernelGGL((k_local_terms<ND, NBT, NBR, MB, 0>), grid, block, ldst, s, p);      \
     else if (a->nfields == 1) hipLaunchKernelGGL((k_local_terms<ND, NBT, NBR, MB, 1>), grid, block, ldst, s, p); \
     else hipLaunchKernelGGL((k_local_terms<ND, NBT, NBR, MB, 2>), grid, block, ldst, s, p);                      \
   } while (0)
-  switch (key) {
+  if (!launched2) switch (key) {
     case 10202: LT(1, 2, 2, 2); break;
     case 10303: LT(1, 3, 3, 3); break;
     case 20404: LT(2, 4, 4, 4); break;

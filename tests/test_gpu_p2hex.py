@@ -173,20 +173,21 @@ def test_through_the_api_matches_generic(monkeypatch):
     assert numpy.abs(fast[0] - slow[0]).max() > 0  # (different summation orders: the two paths are really different kernels)
 
 
-def test_elasticity_20_cubed_entrywise_vs_c_port():
-    '''20^3 elements (interior lines with all four visits, 20 slices): every CSR entry against the C port of the oracle (oracle/c, port.form3d: element loop +
-    stable-sort dedup as in the reference), index arrays bit-exact -- the size between the numpy oracle's 7^3 and the 64^3 property checks.'''
+@pytest.mark.parametrize('n', [20, 32])
+def test_elasticity_entrywise_vs_c_port(n):
+    '''20^3 and 32^3 elements (interior lines with all four visits; 32^3: 823 875 dofs, 1.5e8 nonzeros, the C port on all host cores): every CSR entry against the
+    C port of the oracle (oracle/c, port.form3d: element loop + stable-sort dedup as in the reference), index arrays bit-exact -- the sizes between the numpy
+    oracle's 7^3 and the 64^3 property checks.'''
     from oracle import assemble as oa, port
     if not port.available():
         pytest.skip('oracle/c is not built')
-    n = 20
     inp = _inputs((n, n, n), True, seed=3)
     C = oa.elasticity_coefficient(3, 1., .5 / .3 - 1)
     N, dN = oa.tabulate(inp['coeffs'][0], inp['pts'])
     gN, gdN = oa.tabulate(inp['gcoeffs'][0], inp['pts'])
     T = numpy.concatenate([N.T[:, :, None], dN.transpose(1, 0, 2)], axis=2)
     gT = numpy.concatenate([gN.T[:, :, None], gdN.transpose(1, 0, 2)], axis=2)
-    vo, rpo, cio, _ = port.form3d((n, n, n), 2, C, T, gT, inp['w'], inp['verts'], threads=16)
+    vo, rpo, cio, _ = port.form3d((n, n, n), 2, C, T, gT, inp['w'], inp['verts'], threads=16 if n <= 20 else 0)
     from nutils_amd import _lib
     with _lib.trace() as calls:
         got = Dev(inp).fast(C, 3)
