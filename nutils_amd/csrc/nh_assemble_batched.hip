@@ -27,6 +27,7 @@ constexpr int NTB = 256;   // threads per workgroup
 constexpr int NBLK = 3;     // trial functions per lane in the contraction of the matrix kernel
 constexpr int MAXL = 8;    // term lists of one launch (nh_assemble_terms_multi)
 constexpr int TABARG = 256;  // doubles of the term table that fit the kernel arguments
+constexpr int TABPAD = 24;   // readable doubles behind them (records read whole, at the length of the longest kind)
 
 __device__ __forceinline__ i64 boff(const BasisK &b, i64 e) { return b.off ? b.off[e] : e * (i64)b.nb; }
 __device__ __forceinline__ int bnb(const BasisK &b, i64 e) { return b.off ? (int)(b.off[e + 1] - b.off[e]) : b.nb; }
@@ -645,7 +646,7 @@ struct LTermsK {
   const double *scale[MAXT];
   int toff[MAXT], poff[MAXP], qoff[MAXT];
   int tlen;
-  double tabarg[TABARG];
+  double tabarg[TABARG + TABPAD];  // (+ pad: the two-phase kernel reads every record at its full length)
   double *local;
   int ncls;  // k_local_terms2: element classes whose tables a workgroup stages
 };
@@ -1079,7 +1080,7 @@ __global__ __launch_bounds__(LT2_EPB *(NBR / NBK)) __attribute__((amdgpu_waves_p
           const double *H = tab + p.toff[t2];
           double rec[3 + SS + S];  // [kind, field, poly, B[S][S], L[S] (kind 2)]: read whole (the tail of a shorter record is the head of the next entry of the table)
 #pragma unroll
-          for (int i2 = 0; i2 < 3 + SS + S; ++i2) rec[i2] = H[p.toff[t2] + i2 < TABARG ? i2 : 0];
+          for (int i2 = 0; i2 < 3 + SS + S; ++i2) rec[i2] = H[i2];
           const int kind = (int)rec[0], fld = (int)rec[1], pol = (int)rec[2];
           double coef = p.scale[t2] ? p.scale[t2][ip] : 1.;
           if (pol >= 0) coef *= pick(pv, pol);
@@ -1220,7 +1221,8 @@ struct VTermsK {
   const double *scale[MAXT];
   int toff[MAXT], poff[MAXP], qoff[MAXT];
   int tlen;
-  double tabarg[TABARG];
+  double tabarg[TABARG + TABPAD];
+  int ncls;  // k_local_vterms2: element classes whose tables a workgroup stages
 };
 
 template <int ND, int NB, int NF>
@@ -1391,6 +1393,236 @@ __global__ __launch_bounds__(128) void k_local_vterms(VTermsK p) {
     for (int m = 0; m < NB; ++m) {
       if (p.local[b]) p.local[b][e * NB + m] = r[b][m];
       else atomicAdd(p.out[b] + dofs[m], r[b][m]);
+    }
+  }
+}
+
+// k_local_vterms for meshes of 2^14 elements and more, with the parallelism of the batched kernel and none of its run-time loops (round 4): a workgroup of LV2_NW waves
+// owns 64 elements -- lane l of every wave is element l, wave w takes the points w, w + LV2_NW, ... -- so that the point is uniform over a wave (every table read a broadcast
+// from the staged tables of the element's class), each thread keeps partial sums r[block][m] of ITS points, and the waves' partial sums are added in wave order through
+// LDS at the end (deterministic).  configs[3] residual (262 144 elements, 25 points, 3 fields, 2 blocks): k_terms_multi 0.56 ms with 257 M wave instructions, 38 % of them
+// scalar bookkeeping of its generic loops over blocks / components / slots.
+constexpr int LV2_NW = 4;
+constexpr i64 LV2_MIN_ELEMS = 1 << 14;  // lists of this size get a launch of their own (nh_assemble_terms_multi)
+#ifndef NH_LV2_WPE
+#define NH_LV2_WPE 2
+#endif
+template <int ND, int NB, int NF>
+__global__ __launch_bounds__(64 * LV2_NW) __attribute__((amdgpu_waves_per_eu(NH_LV2_WPE, NH_LV2_WPE))) void k_local_vterms2(VTermsK p) {
+  constexpr int S = 1 + ND, NG = 1 << ND, NT = 64 * LV2_NW, UES = (NF * NB) | 1, RS = (2 * NB) | 1;
+  const double *tab = p.tabarg;
+  extern __shared__ __attribute__((aligned(16))) double stab[];  // [ncls][NB][nq][S] tables | ue [64][UES], later the partial sums [LV2_NW - 1][64][RS]
+  __shared__ i64 clsT[LT2_CLS];
+  __shared__ int ncls, slotS[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntab = (NB * p.nq * S + 1) & ~1;
+  double *ueS = stab + p.ncls * ntab;
+  const i64 ie_raw = (i64)blockIdx.x * 64 + lane, ie = min(ie_raw, p.nelems - 1), e = p.elist ? p.elist[ie] : ie;
+  if (wave == 0) {  // element classes of the 64 elements (k_local_terms2)
+    const i64 ft = bfn(p.test, e);
+    int slot = -1, k = 0;
+    unsigned long long todo = __ballot(1);
+    while (todo && k < p.ncls) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const i64 lt = __shfl(ft, leader);
+      if (lane == leader) clsT[k] = lt;
+      if (ft == lt) slot = k;
+      todo = __ballot(slot < 0);
+      ++k;
+    }
+    slotS[lane] = slot;
+    if (lane == 0) ncls = todo ? -1 : k;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) ueS[lane * UES + f * NB + n] = p.u[f][p.test.dofs[e * (i64)NB + n]];
+  }
+  __syncthreads();
+  const int staged = ncls > 0;
+  if (staged)
+    for (int c = 0; c < ncls; ++c)
+      for (int i = threadIdx.x; i < NB * p.nq * S; i += NT) stab[c * ntab + i] = p.test.T[clsT[c] * p.nq * S + i];
+  const int slot = staged ? slotS[lane] : 0;
+  __syncthreads();
+  const bool iso = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG;
+  const bool perpoint = iso || p.geom.kind == NH_GEOM_TAB;
+  double Jc[ND][ND], detc = 0;  // geometry that does not depend on the point (boxes): once
+  if (!perpoint) geometry_at<ND>(p.geom, e, 0, p.nq, nullptr, Jc, detc, nullptr);
+  const double *ue = ueS + lane * UES;
+  double r[2][NB];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int m = 0; m < NB; ++m) r[b][m] = 0;
+  auto body = [&](const double *Tt) {
+    for (int q = wave; q < p.nq; q += LV2_NW) {
+      double Ji[ND][ND], det;
+      if (perpoint) geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
+      else {
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) Ji[i][j] = Jc[i][j];
+        det = detc;
+      }
+      const double w = p.weights[q] * fabs(det);
+      const i64 ip = ie * p.nq + q;
+      const double *Tq = Tt + (size_t)q * S;  // row n of the point: Tq[n * nq * S + s] (read for the fields and again for the test side: broadcasts, not registers)
+      double U[NF > 0 ? NF : 1][S];
+      {
+        double rr[NF > 0 ? NF : 1][S];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) rr[f][s2] = 0;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          double tn[S];
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) tn[s2] = Tq[(size_t)n * p.nq * S + s2];
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            const double un = ue[f * NB + n];
+#pragma unroll
+            for (int s2 = 0; s2 < S; ++s2) rr[f][s2] += tn[s2] * un;
+          }
+          if (n % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          U[f][0] = rr[f][0];
+#pragma unroll
+          for (int i = 0; i < ND; ++i) {
+            double sum = 0;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) sum += rr[f][1 + j] * Ji[j][i];
+            U[f][1 + i] = sum;
+          }
+        }
+      }
+      // (a select of VALUES: written as a select of array elements it becomes one load through a selected address, and U lives in scratch memory)
+      auto field = [&](int f, int s2) {
+        const double u0 = U[0][s2], u1 = U[NF > 1 ? 1 : 0][s2], u2 = U[NF > 2 ? 2 : 0][s2];
+        double v = u0;
+        if (NF > 1) v = f == 1 ? u1 : v;
+        if (NF > 2) v = f == 2 ? u2 : v;
+        return v;
+      };
+      double pv[MAXP];
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        pv[k] = 1.;
+        if (k < p.npolys) {  // (records read whole before use: one scalar round trip each)
+          const double *P = tab + p.poff[k];
+          const double h0 = P[0], h1 = P[1], s0 = P[2], s1 = P[3], s2v = P[4], s3 = P[5];
+          const int nv = (int)h0, nt = (int)h1;
+          const int sl[4] = {(int)s0, (int)s1, (int)s2v, (int)s3};
+          double x[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) x[v] = v < nv ? field(sl[v], 0) : 1.;
+          double sum = 0;
+          for (int t2 = 0; t2 < nt; ++t2) {
+            const double *M = P + 6 + 5 * t2;
+            const double c0 = M[0], e0 = M[1], e1 = M[2], e2 = M[3], e3 = M[4];
+            const int pw[4] = {(int)e0, (int)e1, (int)e2, (int)e3};
+            double mm = c0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              double xp = x[v];
+              for (int ex = pw[v]; ex > 0; ex >>= 1) {
+                if (ex & 1) mm *= xp;
+                xp *= xp;
+              }
+            }
+            sum += mm;
+          }
+          pv[k] = sum;
+        }
+      }
+      double G[2][S];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < S; ++a) G[b][a] = 0;
+      for (int t2 = 0; t2 < p.nterms; ++t2) {
+        const double *H = tab + p.toff[t2];
+        double rec[5 + S + S * S];  // [block, field, poly, hasC, hasf, f[S], C[S][S]]
+#pragma unroll
+        for (int i2 = 0; i2 < 5 + S + S * S; ++i2) rec[i2] = H[i2];
+        const int blk = (int)rec[0], fld = (int)rec[1], pol = (int)rec[2], hasC = (int)rec[3], hasf = (int)rec[4];
+        double coef = p.scale[t2] ? p.scale[t2][ip] : 1.;
+        if (pol >= 0) coef *= pick(pv, pol);
+        if (p.qoff[t2]) {
+          const double *Q = tab + p.qoff[t2];
+          double qr[2 + S * S];
+#pragma unroll
+          for (int i2 = 0; i2 < 2 + S * S; ++i2) qr[i2] = Q[i2];
+          const int fa = (int)qr[0], fb = (int)qr[1];
+          double sum = 0;
+#pragma unroll
+          for (int a = 0; a < S; ++a)
+#pragma unroll
+            for (int b = 0; b < S; ++b) sum += qr[2 + a * S + b] * field(fa, a) * field(fb, b);
+          coef *= sum;
+        }
+        const double *fv = rec + 5, *C = fv + S;
+#pragma unroll
+        for (int a = 0; a < S; ++a) {
+          double sum = hasf ? fv[a] : 0.;
+          if (hasC) {
+#pragma unroll
+            for (int b = 0; b < S; ++b) sum += C[a * S + b] * field(fld, b);
+          }
+          if (blk == 0) G[0][a] += coef * sum;
+          else G[1][a] += coef * sum;
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (b >= p.nblocks) break;
+        double g[S];
+        g[0] = w * G[b][0];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+          double sum = 0;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) sum += Ji[j][i] * G[b][1 + i];
+          g[1 + j] = w * sum;
+        }
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) r[b][m] += Tq[(size_t)m * p.nq * S + s2] * g[s2];
+          if (m % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+  if (staged) body(stab + slot * ntab);
+  else body(p.test.T + bfn(p.test, e) * p.nq * S);
+  // partial sums of waves 1 .. LV2_NW - 1 -> LDS (over the field coefficients, which nobody reads any more), added by wave 0 in wave order
+  __syncthreads();
+  double *part = ueS;
+  if (wave > 0) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int m = 0; m < NB; ++m) part[((wave - 1) * 64 + lane) * RS + b * NB + m] = r[b][m];
+  }
+  __syncthreads();
+  if (wave > 0 || ie_raw >= p.nelems) return;
+  for (int w2 = 0; w2 < LV2_NW - 1; ++w2)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int m = 0; m < NB; ++m) r[b][m] += part[(w2 * 64 + lane) * RS + b * NB + m];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    if (b >= p.nblocks) break;
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      if (p.local[b]) p.local[b][e * NB + m] = r[b][m];
+      else atomicAdd(p.out[b] + p.test.dofs[e * (i64)NB + m], r[b][m]);
     }
   }
 }
@@ -1583,7 +1815,7 @@ int local_vterms(const nh_terms_args *a, const TermsK &m, const std::vector<doub
   const nh_basis &tb = a->blocks[0].test;
   // (one thread per element pays when there are enough elements to hide its serial pass over the points: 2 M trilinear elements 0.82 ms against
   // 1.16 ms of the batched kernel, but 262 144 elements of 25 points 0.78 against 0.45 ms -- there the lanes-over-points batches win)
-  if (a->nelems < (1 << 20) || a->nfields > 3 || tab.size() > (size_t)TABARG || tb.off_dev || !tb.nb) return NH_OK;
+  if (a->nelems < LV2_MIN_ELEMS || a->nfields > 3 || tab.size() > (size_t)TABARG || tb.off_dev || !tb.nb) return NH_OK;
   auto same = [&](const nh_basis &b) { return b.T_dev == tb.T_dev && b.dofs_dev == tb.dofs_dev && b.tab_dev == tb.tab_dev && b.off_dev == tb.off_dev && b.nb == tb.nb; };
   for (int b = 0; b < a->nblocks; ++b)
     if (a->blocks[b].nct != 1 || !same(a->blocks[b].test)) return NH_OK;
@@ -1600,6 +1832,48 @@ int local_vterms(const nh_terms_args *a, const TermsK &m, const std::vector<doub
   for (int k = 0; k < MAXP; ++k) p.poff[k] = m.poff[k];
   p.tlen = (int)tab.size();
   std::copy(tab.begin(), tab.end(), p.tabarg);
+  // the waves-over-points arrangement (k_local_vterms2); NUTILS_AMD_LOCAL_VTERMS=1 keeps one thread per element (from 2^20 elements on, as before round 4)
+  const bool waves_over_points = !(getenv("NUTILS_AMD_LOCAL_VTERMS") && atoi(getenv("NUTILS_AMD_LOCAL_VTERMS")) == 1);
+  if (waves_over_points) {
+    const int S2 = 1 + a->ndims, nb = tb.nb;
+    const size_t tabb = sizeof(double) * (((size_t)nb * a->nq * S2 + 1) & ~(size_t)1);
+    const size_t rest = sizeof(double) * std::max<size_t>((size_t)64 * ((a->nfields * nb) | 1), (size_t)(LV2_NW - 1) * 64 * ((2 * nb) | 1));
+    p.ncls = a->nelems >= (1 << 16) ? 2 : LT2_CLS;
+    while (p.ncls > 1 && p.ncls * tabb + rest > 64 * 1024) --p.ncls;
+    const size_t lds2 = p.ncls * tabb + rest;
+    if (lds2 <= 96 * 1024) {
+      dim3 grid2((unsigned)((a->nelems + 63) / 64)), block2(64 * LV2_NW);
+#define LV2I(ND, NB, NF)                                                                                                                  \
+  do {                                                                                                                                   \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_local_vterms2<ND, NB, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));  \
+    hipLaunchKernelGGL((k_local_vterms2<ND, NB, NF>), grid2, block2, lds2, s, p);                                                         \
+  } while (0)
+#define LV2(ND, NB)                             \
+  do {                                          \
+    if (a->nfields == 0) LV2I(ND, NB, 0);       \
+    else if (a->nfields == 1) LV2I(ND, NB, 1);  \
+    else if (a->nfields == 2) LV2I(ND, NB, 2);  \
+    else LV2I(ND, NB, 3);                       \
+  } while (0)
+      bool ok = true;
+      switch (a->ndims * 100 + tb.nb) {
+        case 102: LV2(1, 2); break;
+        case 103: LV2(1, 3); break;
+        case 204: LV2(2, 4); break;
+        case 209: LV2(2, 9); break;
+        case 308: LV2(3, 8); break;
+        default: ok = false;
+      }
+#undef LV2
+#undef LV2I
+      if (ok) {
+        NH_LAUNCH_CHECK();
+        *done = true;
+        return NH_OK;
+      }
+    }
+  }
+  if (a->nelems < (1 << 20)) return NH_OK;
   dim3 grid((unsigned)((a->nelems + 127) / 128)), block(128);
 #define LV(ND, NB)                                                                                     \
   do {                                                                                                 \
@@ -1802,7 +2076,7 @@ extern "C" int nh_assemble_terms_multi(int count, const nh_terms_args *const *li
   for (int i = 0; i < count; ++i) {
     const nh_terms_args *a = lists[i];
     // lists that get their own kind of kernel (thread per element on large meshes), other dimensions or more lists than a launch takes: on their own
-    if (a && (a->nelems >= (1 << 20) || (ndims && a->ndims != ndims) || (int)ps.size() == MAXL)) {
+    if (a && (a->nelems >= LV2_MIN_ELEMS || (ndims && a->ndims != ndims) || (int)ps.size() == MAXL)) {
       if ((rc = nh_assemble_terms(a, stream)) != NH_OK) return rc;
       continue;
     }
