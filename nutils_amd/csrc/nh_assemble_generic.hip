@@ -35,7 +35,7 @@ struct FormK {
 
 __device__ __forceinline__ const FormK &stage_form(double *lds, const FormK &arg, int lane) {
   const double *src = reinterpret_cast<const double *>(&arg);
-  for (int i = lane; i < arg.formd; i += 64) lds[i] = src[i];
+  for (int i = lane; i < arg.formd; i += (int)blockDim.x) lds[i] = src[i];
   __syncthreads();
   return *reinterpret_cast<const FormK *>(lds);
 }
@@ -52,7 +52,7 @@ __device__ __forceinline__ void fill_D(double *D, const BasisK &b, i64 e, int nb
   constexpr int S = 1 + ND, JW = ND * ND + 1;
   const i64 fn0 = bfn(b, e);
   const int n = (q1 - q0) * nb;
-  for (int t = lane; t < n; t += 64) {
+  for (int t = lane; t < n; t += (int)blockDim.x) {
     const int ql = t / nb, m = t % nb, q = q0 + ql;
     const double *T = b.T + ((fn0 + m) * nq + q) * S;
     const double *Ji = Jw + q * JW;
@@ -126,7 +126,7 @@ struct MatK {
 };
 
 template <int ND>
-__global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
+__global__ __launch_bounds__(256) void k_matrix_generic(MatK p, FormK formarg) {  // one, two or four waves per element (the launcher: two when an element has work for them)
   constexpr int S = 1 + ND, JW = ND * ND + 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FormK &form = stage_form(lds, formarg, threadIdx.x);
@@ -134,13 +134,13 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
   double *Dt = Jw + p.nq * JW;                        // [qchunk][maxnbt][S]
   double *Dr = p.same ? Dt : Dt + p.qchunk * p.maxnbt * S;
   double *W = Dr + p.qchunk * p.maxnbr * S;            // [qchunk][maxnbr][ncr][nct][S]
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, NTG = (int)blockDim.x;
   for (i64 ie = blockIdx.x; ie < p.nelems; ie += gridDim.x) {
     const i64 e = p.elist ? p.elist[ie] : ie;
     const int nbt = bnb(p.test, e), nbr = bnb(p.trial, e);
     int ftlo = 0, fthi = 0;
     if (p.ft.on) ft_element<ND>(p.ft, e, ftlo, fthi);
-    for (int q = lane; q < p.nq; q += 64) {
+    for (int q = lane; q < p.nq; q += NTG) {
       double Ji[ND][ND], det;
       geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
 #pragma unroll
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
       // so that an entry costs S multiply-adds per point instead of S*S
       if (p.use_w) {  // (never set for the blocks that take the Gram path below)
         const int ncd = form.ncr * form.nct;
-        for (int t = lane; t < (q1 - q0) * nbr * ncd; t += 64) {
+        for (int t = lane; t < (q1 - q0) * nbr * ncd; t += NTG) {
           int r = t;
           const int c = r % form.nct; r /= form.nct;
           const int d = r % form.ncr; r /= form.ncr;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
         // a lane takes test function m and TWO trial functions n, n + h (h = half the trial functions): the test row of a point is read once for both
         // (63 488 ragged elements 1.77 -> 1.67 ms; two test functions as well: 1.64 ms, not worth the code)
         const int h = (nbr + 1) >> 1;
-        for (int k = lane; k < nbt * h; k += 64) {
+        for (int k = lane; k < nbt * h; k += NTG) {
           const int m = k / h, n0 = k - m * h, n1 = n0 + h;
           const bool two = n1 < nbr;
           double G[2][S][S];
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void k_matrix_generic(MatK p, FormK formarg) {
           }
         }
       } else
-      for (int k = lane; k < nentries; k += 64) {
+      for (int k = lane; k < nentries; k += NTG) {
         int r = k;
         const int d = r % form.ncr; r /= form.ncr;
         const int n = r % nbr; r /= nbr;
@@ -351,7 +351,7 @@ template <int ND, int MT>
 __global__ __launch_bounds__(256) void k_matrix_mfma(MatK p, FormK formarg, MfmaX x) {
   constexpr int S = 1 + ND, JW = ND * ND + 1;
   extern __shared__ __attribute__((aligned(32))) double lds[];
-  const FormK &form = stage_form(lds, formarg, threadIdx.x & 63);
+  const FormK &form = stage_form(lds, formarg, threadIdx.x);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nb = p.test.nb;  // test and trial share tables on this path (p.same)
   const int nqp = (p.nq + 3) & ~3;                 // q padded to the MFMA k-step: K index k = a * nqp + q (slot-major)
@@ -867,7 +867,12 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     q.qchunk = std::max(1, std::min(a->nq, LDS_BUDGET / std::max(per_q, 1)));
     const size_t lds = fixed + (size_t)q.qchunk * per_q;
     NH_REQUIRE(lds <= 160 * 1024, "element too large for LDS (%zu bytes)", lds);
-    dim3 grid(grid_for(q.nelems)), block(64);
+    // two waves per element when its (node pairs of the Gram path | entries) keep both busy: the one-wave workgroups of the ragged rational workload ran at 1.9 waves
+    // per SIMD (LDS bound) and waited 61 % of their cycles
+    const i64 work = (!a->cq_dev && a->nct * a->ncr > 1) ? (i64)q.maxnbt * ((q.maxnbr + 1) / 2) : (i64)q.maxnbt * a->nct * q.maxnbr * a->ncr;
+    int nw = work > 96 ? 2 : 1;
+    if (getenv("NUTILS_AMD_GENERIC_WAVES")) nw = std::max(1, std::min(4, atoi(getenv("NUTILS_AMD_GENERIC_WAVES"))));
+    dim3 grid(grid_for(q.nelems)), block(64 * nw);
 #define LAUNCH(ND)                                                                                                          \
   do {                                                                                                                      \
     NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_matrix_generic<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
