@@ -120,6 +120,9 @@ def basis(T, dofs, nb=0, off=None, tab=None):
 
 
 FUSED_SIZES = {(1, 2), (1, 3), (2, 3), (2, 4), (2, 9), (3, 4), (3, 8)}  # (dimension, functions per element) of the owner-block kernels (NH_MATRIX_FUSED)
+# ... and those for which they are the DEFAULT: measured faster than the gather with the ordered sums (tools/generic_probe.py, round 4: 128^3 trilinear 0.94 against
+# 1.20 ms through the API; 2048^2 bilinear 0.87 against 0.59 and 1024^2 biquadratic 1.47 against 0.96 ms are NOT -- their rows are short, the turn protocol is not)
+FUSED_DEFAULT = {(3, 8)}
 
 
 def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0,
@@ -144,7 +147,7 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     if elist is None and emap_offset == 0 and not os.environ.get('NUTILS_AMD_NO_BUCKETS'):
         args.pattern = pattern._handle  # ragged bases: launches per size class of the pattern
     whole = emap_offset == 0 and not flags and not first_touch and nelems == pattern.nelems
-    if (not fused and gather is None and not os.environ.get('NUTILS_AMD_NO_FUSED') and whole and elist is None and nct == ncr == 1 and cq is None and (ndims, test.nb) in FUSED_SIZES
+    if (not fused and gather is None and not os.environ.get('NUTILS_AMD_NO_FUSED') and whole and elist is None and nct == ncr == 1 and cq is None and ((ndims, test.nb) in FUSED_DEFAULT or os.environ.get('NUTILS_AMD_FUSED') and (ndims, test.nb) in FUSED_SIZES)
             and test.nb == trial.nb and test.dofs_dev == trial.dofs_dev and not test.off_dev and not getattr(pattern, '_fused_refused', False)):
         # (default since round 4 for the blocks the owner-block kernels cover: one pass, 1.5 x instead of 4.6 x the algorithmic traffic, and -- with the
         # turns of the block plan -- bit-reproducible like the gather)
