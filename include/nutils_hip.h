@@ -482,6 +482,26 @@ int nh_monomial_csr(int64_t nrows, const int64_t *rowptr_dev, const int64_t *col
 int nh_monomial(int64_t n, const double *values_dev, int nargs, const double *const *args_dev, const int64_t *const *indices_dev,
                 const int64_t *out_index_dev, double alpha, double *out_dev, void *stream);
 
+/* ---- building the Taylor coefficient tensors of rank 3 and 4 ---------------------------------
+ * replaces the one-time element loop + sparse dedup of evaluable.factor (evaluable.py:5785-5874: `zeroed.assparse`, zeros pruned) for value
+ * polynomials of ONE scalar field, c int s(x) u^k dV -> C_k[i1..ik] = coeff int s N_i1 .. N_ik dV: every permutation stored, entries sorted by
+ * (i1, .., ik) lexicographically, exact zeros dropped -- the arrays evaluable.Monomial holds (evaluable.py:5693-5751) and nh_monomial consumes.
+ * nh_factor_tensor builds the tensor and reports its length; nh_factor_fetch copies it into caller-owned buffers (values[nnz], indices[rank][nnz])
+ * and releases the library's copy.  One build at a time (the single-stream contract of the scratch buffers). */
+typedef struct {
+  int64_t nelems;
+  const int32_t *elist_dev;  /* optional element subset; scale_dev is indexed by list position */
+  int ndims, nq, rank;       /* rank 3 or 4 */
+  const double *weights_dev; /* [nq] */
+  nh_geometry geom;
+  nh_basis basis;            /* uniform nb */
+  const double *scale_dev;   /* [nelems][nq] coefficient function at the points, or NULL */
+  double coeff;              /* constant factor */
+  int64_t ndofs;             /* length of the field's coefficient vector; ndofs^rank must fit 63 bits */
+} nh_factor_args;
+int nh_factor_tensor(const nh_factor_args *args, int64_t *nnz, void *stream);
+int nh_factor_fetch(double *values_dev, int64_t *indices_dev, void *stream);
+
 /* ---- block merge / submatrix: indexed copy of CSR values -----------------------------------
  * dst[dst_index[i]] = src[src_index[i]] (an index array may be NULL: i), plain stores, no accumulation.  The value half of
  * matrix.assemble_block_csr (matrix/__init__.py:103-151: the positions of every block entry in the merged matrix are fixed once

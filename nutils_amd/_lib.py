@@ -46,6 +46,11 @@ class MatrixArgs(ctypes.Structure):
                 ('grid_shape', ctypes.c_int * 3), ('nodes_per_axis', ctypes.c_int), ('pattern', vp)]
 
 
+class FactorArgs(ctypes.Structure):
+    _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('rank', ctypes.c_int), ('weights_dev', vp),
+                ('geom', Geometry), ('basis', Basis), ('scale_dev', vp), ('coeff', ctypes.c_double), ('ndofs', c_i64)]
+
+
 class VectorArgs(ctypes.Structure):
     _fields_ = [('nelems', c_i64), ('elist_dev', vp), ('ndims', ctypes.c_int), ('nq', ctypes.c_int), ('weights_dev', vp),
                 ('geom', Geometry), ('test', Basis), ('trial', Basis), ('nct', ctypes.c_int), ('ncr', ctypes.c_int),
@@ -140,6 +145,8 @@ SIGNATURES = {
     'nh_assemble_matrix_terms': (ctypes.c_int, [ctypes.POINTER(MatrixTermsArgs), vp]),
     'nh_sample_eval': (ctypes.c_int, [ctypes.POINTER(EvalArgs), vp]),
     'nh_monomial_csr': (ctypes.c_int, [c_i64, vp, vp, vp, vp, ctypes.c_double, vp, vp]),
+    'nh_factor_tensor': (ctypes.c_int, [ctypes.POINTER(FactorArgs), ctypes.POINTER(c_i64), vp]),
+    'nh_factor_fetch': (ctypes.c_int, [vp, vp, vp]),
     'nh_monomial': (ctypes.c_int, [c_i64, vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, ctypes.c_double, vp, vp]),
     'nh_index_copy': (ctypes.c_int, [c_i64, vp, vp, vp, vp, vp]),
     'nh_pointwise_poly': (ctypes.c_int, [c_i64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_double),

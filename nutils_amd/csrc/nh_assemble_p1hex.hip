@@ -535,7 +535,7 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
 #pragma unroll
         for (int k = 0; k < VPG; ++k) load_vertex(needv ? s + 2 : -1, lt + k * G, J0, K0, Vn[k]);
         const int P = s - 1;
-        bool arrived = false, staged = false;
+        bool arrived = false, staged = false, recycled = false;
         auto stage_vertices = [&]() {
 #pragma unroll
           for (int k = 0; k < VPG; ++k) {
@@ -591,6 +591,26 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
             const i64 stride8 = 8 * (i64)(9 * (int)T2);
             char *l0 = reinterpret_cast<char *>(p.values + ((3 * (i64)P - 1) * T1 * T2 + 3 * (cumJ0 * T2) + 9 * (3 * (i64)K0 - 1)));
             char *lp = l0 + 16 * lt;
+#ifdef NH_P1HEX_INTERLEAVE
+            // the recycling of the slot of plane s-2 BETWEEN the stores: a store that finds the queue of the memory pipeline full stalls the wave, and the
+            // LDS writes placed behind all of them waited for the whole flush; one write behind each store goes out while the queue drains
+            half_wait(hcnt, htarget);
+            recycled = true;
+            {
+              double2 *z = reinterpret_cast<double2 *>(acc + slot_of(s - 2));
+              constexpr int NZ = (PS / 2 + G - 1) / G;
+              static_assert(NZ <= OJ, "one zeroing write per store");
+#pragma unroll
+              for (int i = 0; i < OJ; ++i) {
+                if (lt < 202) {
+                  const double2 v = make_double2(a0[i], a1[i]);
+                  __builtin_memcpy(lp + i * stride8, &v, 16);
+                }
+                if (i < NZ && lt + i * G < PS / 2) z[lt + i * G] = make_double2(0., 0.);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#else
             if (lt < 202) {
 #pragma unroll
               for (int i = 0; i < OJ; ++i) {
@@ -598,6 +618,7 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
                 __builtin_memcpy(lp + i * stride8, &v, 16);  // 8-byte aligned 16-byte store
               }
             }
+#endif
             if (lone) *reinterpret_cast<double *>(l0 + li * stride8 + 8 * 404) = aL;
           } else {
             // 32 lanes per row (27 slots), 8 rows per pass, two passes per K line
@@ -652,9 +673,9 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
         }
         NH_TICK(6)
         if (!arrived) half_arrive(hcnt);
-        half_wait(hcnt, htarget);  // every wave of this half has read what it needs of plane s-2: recycle its slot
+        if (!recycled) half_wait(hcnt, htarget);  // every wave of this half has read what it needs of plane s-2: recycle its slot
         NH_TICK(7)
-        {
+        if (!recycled) {
           double2 *z = reinterpret_cast<double2 *>(acc + slot_of(s - 2));
           for (int t = lt; t < PS / 2; t += G) z[t] = make_double2(0., 0.);
         }

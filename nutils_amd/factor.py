@@ -4,10 +4,14 @@ the Monomial kernels (gather-multiply-scatter over nnz) instead of re-running th
 
 Reference: function.factor (/root/reference/src/nutils/function.py:2630-2642) ->
 evaluable.factor (evaluable.py:5785-5874) + Monomial (evaluable.py:5693-5751).  The reference
-expands to arbitrary polynomial degree; the accelerated class of integrands (function.py here)
-is at most quadratic in a field, so the expansion is  c + f.u + 1/2 u.K.u  with K kept as
-device-resident CSR tensors (one per sample: volume and boundary terms have different
-patterns, exactly as the reference keeps a sum of Monomials).'''
+expands to arbitrary polynomial degree.  Here: c + f.u + 1/2 u.K.u with K kept as device-resident
+CSR tensors (one per sample: volume and boundary terms have different patterns, exactly as the
+reference keeps a sum of Monomials), plus -- round 4 -- the rank-3 and rank-4 tensors of value
+polynomials  c int s(x) u^k dV  (the double-well potential of examples/cahnhilliard.py:175, a cubic
+functional), BUILT on the device (nh_factor_tensor: element moments, radix sort of the flat keys,
+run sums, zeros pruned -- evaluable.py:5846-5856) in the reference's own layout and evaluated per
+step by nh_monomial.  Terms of degree >= 3 that carry gradient slots (kappa(u) |grad u|^2) are
+refused, not truncated.'''
 
 import numpy
 
@@ -44,8 +48,35 @@ class Factored:
         for term in hess.terms:
             by_sample.setdefault(id(term[0]), []).append(term)
         for terms in by_sample.values():
-            values, rowptr, colidx, ncols = _sample._MatrixPlan(terms).run()
+            values, rowptr, colidx, ncols = _sample._MatrixPlan(terms).run(zero)  # (terms whose coefficient is a polynomial of the field: evaluated at u = 0)
             self.K.append((values, rowptr, colidx))
+        # tensors of rank >= 3: value polynomials of the field in scalar terms (nothing of them survives in c, f, K: their derivatives vanish at u = 0)
+        self.T = []  # (rank, values[nnz], indices[rank][nnz]) on the device
+        for smp, itg, fac in integral.terms:
+            fp = itg.fscale
+            if fp is None or not fp.depends_on(name):
+                continue
+            i = next(j for j, a in enumerate(fp.args) if a.name == name)
+            bound = sum(a is not None and a.name == name for a in (itg.test, itg.trial))
+            for key, coef in fp.terms.items():
+                k = key[i] + bound
+                if k <= 2:
+                    continue
+                if bound or itg.qform is not None or itg.qscalar is not None:
+                    raise NotImplementedError(f'factor: a term of degree {k} in {name!r} with gradient slots (rank-{k} tensor of a quasi-linear form)')
+                if sum(key) != key[i] or arg.ncomp != 1:
+                    raise NotImplementedError('factor: polynomial of several fields / a vector field in a term of degree >= 3')
+                if k > 4:
+                    raise NotImplementedError(f'factor: degree {k} (tensors up to rank 4 are built)')
+                pt = smp.tables(arg.basis)
+                if not pt.nb:
+                    raise NotImplementedError('factor: rank >= 3 tensors on a ragged basis')
+                geom = itg.measure if itg.measure is not None else _sample._default_geometry(smp.topo)
+                values, indices = kernels.factor_tensor(nelems=smp.nlist, ndims=smp.ndims, nq=smp.points.npoints, rank=k, weights=smp._weights_dev, geom=smp.geometry(geom),
+                                                        basis=pt.struct, ndofs=arg.basis.ndofs, coeff=float(coef) * float(numpy.asarray(itg.f0)) * float(fac),
+                                                        scale=smp.scale(itg.scale), elist=smp._elist_dev)
+                if values.numel():
+                    self.T.append((k, values, indices))
 
     def _u(self, arguments):
         if self.name not in arguments:
@@ -60,6 +91,8 @@ class Factored:
         g = self.f.clone() if self.f is not None else device.zeros(self.size, 'float64')
         for values, rowptr, colidx in self.K:
             kernels.monomial_csr(rowptr, colidx, values, u, g)
+        for k, values, indices in self.T:  # d/du_m of T[u, .., u] = k T[m, u, .., u] (all permutations are stored: evaluable.py:5727-5735, powers[0])
+            kernels.monomial(values, [u] * (k - 1), [indices[a] for a in range(1, k)], g, out_index=indices[0], alpha=float(k))
         return g
 
     def eval(self, **arguments):
@@ -72,6 +105,8 @@ class Factored:
             ku = device.zeros(self.size, 'float64')
             kernels.monomial_csr(rowptr, colidx, values, u, ku)
             kernels.monomial(ku, [u], [idx], out, alpha=.5)
+        for k, values, indices in self.T:
+            kernels.monomial(values, [u] * k, [indices[a] for a in range(k)], out)
         return self.c + float(device.to_host(out)[0])
 
     def derivative(self, name):
@@ -103,6 +138,8 @@ class FactoredMatrix:
         self.parent = parent
 
     def as_csr(self):
+        if self.parent.T:
+            raise NotImplementedError('Hessian of a factored functional of degree >= 3 (depends on the argument): integrate the second derivative instead')
         if len(self.parent.K) != 1:
             raise NotImplementedError('sum of tensors with different patterns: assemble per sample and add')
         values, rowptr, colidx = self.parent.K[0]

@@ -107,6 +107,18 @@ def geometry_tab(jac, x=None, bnd_axis=-1):
     return g
 
 
+def factor_tensor(*, nelems, ndims, nq, rank, weights, geom, basis, ndofs, coeff=1., scale=None, elist=None):
+    '''Taylor coefficient tensor of rank 3 or 4 of  coeff int scale u^rank dV  built on the device (nh_factor_tensor / nh_factor_fetch): (values[nnz],
+    indices[rank][nnz]) as the reference's Monomial holds them (evaluable.py:5693-5751, 5785-5874).'''
+    args = _lib.FactorArgs(nelems, device.ptr(elist), ndims, nq, rank, device.ptr(weights), geom, basis, device.ptr(scale), float(coeff), int(ndofs))
+    nnz = ctypes.c_int64(0)
+    _lib.call('nh_factor_tensor', ctypes.byref(args), ctypes.byref(nnz), device.stream())
+    values = device.empty(nnz.value, 'float64')
+    indices = device.empty(rank * nnz.value, 'int64')
+    _lib.call('nh_factor_fetch', device.ptr(values), device.ptr(indices), device.stream())
+    return values, indices.reshape(rank, nnz.value)
+
+
 def rationalize(T, nelems, nb, dofs, weights, nq, ndims, W=None, dW=None, off=None):
     '''N_i = w_i B_i / W in place on per-element tables (nh_rationalize).'''
     _lib.call('nh_rationalize', device.ptr(T), nelems, nb, device.ptr(off), device.ptr(dofs), device.ptr(weights), device.ptr(W), device.ptr(dW), nq, ndims,
