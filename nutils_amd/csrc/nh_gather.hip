@@ -1016,9 +1016,12 @@ struct LocVK {
   unsigned char mask[3][3];
   double *local;
   int ldst_doubles;
+  double lam, mu, mu2;  // ISOF instantiations: C[c][1+a][d][1+b] = lam d_ca d_db + mu d_cd d_ab + mu2 d_cb d_ad, nothing on the value slots
 };
 
-template <int ND, int NB, int NC, bool LDST>
+// ISOF: the isotropic three-parameter family (linear elasticity: lam div div + 2 mu sym grad : sym grad) applied in closed form -- per (c, d) two or three multiply-adds
+// from registers instead of S * S reads of the form tensor from LDS and as many multiply-adds: the kernel was bound by those (uniform) LDS reads, 240 per point and thread.
+template <int ND, int NB, int NC, bool LDST, bool ISOF>
 __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
   constexpr int S = 1 + ND, NG = 1 << ND, NCD = NC * NC;
   // the form tensor goes to LDS: its NC * S * NC * S doubles do not fit the scalar registers (read from the kernel arguments they were spilled to
@@ -1150,12 +1153,32 @@ __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
         dt[1 + i] = sum;
       }
     }
+    double gJ[ND];  // ISOF: J^-1 applied to the physical gradient of the test function once per point
+    if constexpr (ISOF) {
+#pragma unroll
+      for (int j = 0; j < ND; ++j) {
+        double sum = 0;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) sum += Ji[j][i] * dt[1 + i];
+        gJ[j] = p.mu * sum;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       double tw[NC][S];
 #pragma unroll
       for (int d = 0; d < NC; ++d) {
-        if (p.mask[c][d]) {  // (uniform)
+        if constexpr (ISOF) {
+          static_assert(!ISOF || NC == ND, "isotropic form: one component per axis");
+          tw[d][0] = 0.;
+          const double lc = p.lam * dt[1 + c], md = p.mu2 * dt[1 + d];
+#pragma unroll
+          for (int j = 0; j < ND; ++j) {
+            double t = lc * Ji[j][d < ND ? d : 0] + md * Ji[j][c < ND ? c : 0];
+            if (c == d) t += gJ[j];
+            tw[d][1 + j] = w * t;
+          }
+        } else if (p.mask[c][d]) {  // (uniform)
           double cd[S];
 #pragma unroll
           for (int b = 0; b < S; ++b) {
@@ -1186,7 +1209,7 @@ __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
 #pragma unroll
         for (int d = 0; d < NC; ++d)
 #pragma unroll
-          for (int s2 = 0; s2 < S; ++s2) A[n][c][d] += tw[d][s2] * tn[s2];
+          for (int s2 = ISOF ? 1 : 0; s2 < S; ++s2) A[n][c][d] += tw[d][s2] * tn[s2];
       }
     }
   }
@@ -1660,10 +1683,28 @@ int nh_local_vector(const nh_matrix_args *a, double *local, bool *done, hipStrea
   p.ldst_doubles = ldst ? (int)(ldsb / sizeof(double)) : 0;
   const size_t ldsx = sizeof(double) * 144 + (ldst ? ldsb : 0) + sizeof(double) * 2 * 64 * 17 + sizeof(double) * 128 * 3 +  // + vertices of the elements of the workgroup
                       sizeof(double) * (128 / a->test.nb + 1) * a->nq * (a->ndims * a->ndims + 1);                      // + inverse Jacobians and weights of their points
+  // the isotropic three-parameter family on the gradient slots (all blocks coupled, one component per axis)?
+  bool isof = nc == a->ndims && !getenv("NUTILS_AMD_NO_ISOFORM");
+  {
+    const double *C = a->C_host;
+    auto at = [&](int c, int sa, int d, int sb) { return C[((c * S + sa) * nc + d) * S + sb]; };
+    const double lam = nc > 1 ? at(0, 1, 1, 2) : 0., mu2 = nc > 1 ? at(0, 2, 1, 1) : 0., mu = nc > 1 ? at(0, 2, 0, 2) : 0.;
+    for (int c = 0; c < nc && isof; ++c)
+      for (int sa = 0; sa < S && isof; ++sa)
+        for (int d = 0; d < nc && isof; ++d)
+          for (int sb = 0; sb < S && isof; ++sb) {
+            const double expect = (sa && sb) ? lam * (c == sa - 1 && d == sb - 1) + mu * (c == d && sa == sb) + mu2 * (c == sb - 1 && sa - 1 == d) : 0.;
+            if (at(c, sa, d, sb) != expect || !p.mask[c][d]) isof = false;
+          }
+    p.lam = lam, p.mu = mu, p.mu2 = mu2;
+  }
 #define ROWSV(ND, NB, NC)                                                                                       \
   do {                                                                                                          \
-    if (ldst) hipLaunchKernelGGL((k_local_rows_v<ND, NB, NC, true>), grid, block, ldsx, s, p);                  \
-    else hipLaunchKernelGGL((k_local_rows_v<ND, NB, NC, false>), grid, block, ldsx, s, p);                      \
+    if (isof) {                                                                                                 \
+      if (ldst) hipLaunchKernelGGL((k_local_rows_v<ND, NB, NC, true, true>), grid, block, ldsx, s, p);          \
+      else hipLaunchKernelGGL((k_local_rows_v<ND, NB, NC, false, true>), grid, block, ldsx, s, p);              \
+    } else if (ldst) hipLaunchKernelGGL((k_local_rows_v<ND, NB, NC, true, false>), grid, block, ldsx, s, p);    \
+    else hipLaunchKernelGGL((k_local_rows_v<ND, NB, NC, false, false>), grid, block, ldsx, s, p);               \
   } while (0)
   switch (a->ndims * 1000 + a->test.nb * 10 + nc) {
     case 3083: ROWSV(3, 8, 3); break;  // trilinear hexahedra, 3 components

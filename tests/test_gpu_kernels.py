@@ -853,6 +853,40 @@ def test_gather_with_a_full_coefficient_tensor(golden, name):
     assert numpy.array_equal(out[1], out[2])
 
 
+@pytest.mark.parametrize('name', ['lap3d_p1_543_iso', 'lap2d_p1_4x3_iso', 'lap2d_spline2_5x4_iso'])
+def test_vector_thread_pass_isotropic_form_in_closed_form(golden, name, monkeypatch):
+    '''Vector-valued blocks on the small uniform bases of the thread pass (k_local_rows_v): the isotropic three-parameter family lam d_ca d_db + mu d_cd d_ab +
+    mu2 d_cb d_ad is recognised on the host and applied in closed form (no form tensor in LDS); against the same kernel with the tensor read from LDS
+    (NUTILS_AMD_NO_ISOFORM=1), against the one-wave-per-element kernel with atomics, and -- with three different parameters and a scale array -- a family member that
+    is NOT symmetric.'''
+    from nutils_amd import device, kernels
+    g = golden(name)
+    c = Case(g)
+    nd, S = c.nd, 1 + c.nd
+    rng = numpy.random.default_rng(23)
+    lam, mu, mu2 = 1.3, .7, -.4
+    C = numpy.zeros((nd, S, nd, S))
+    for cc in range(nd):
+        for a in range(nd):
+            for d in range(nd):
+                for b in range(nd):
+                    C[cc, 1 + a, d, 1 + b] = lam * (cc == a and d == b) + mu * (cc == d and a == b) + mu2 * (cc == b and a == d)
+    scale = device.to_dev(rng.uniform(.5, 1.5, c.nelems * c.nq), 'float64')
+    rowptr, colidx = c.pattern.expand(nd, nd, None)
+
+    def run(gather):
+        values = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=c.nelems, ndims=nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=nd, ncr=nd, C=C, mask=None,
+                                pattern=c.pattern, values=values, gather=gather, scale=scale)
+        return device.to_host(values)
+    atomics, closed = run(False), run(True)
+    monkeypatch.setenv('NUTILS_AMD_NO_ISOFORM', '1')
+    table = run(True)
+    close(closed, atomics)
+    close(closed, table)
+    assert numpy.abs(closed - table).max() > 0  # (two different instruction sequences)
+
+
 def test_gather_ragged_and_structured_large(golden):
     '''Ragged bases (size classes + gather) and a structured trilinear mesh of 24^3 elements against the atomic scatter.'''
     from nutils_amd import device, kernels, mesh, sample, points
