@@ -13,7 +13,10 @@ CASES = [('3D P1 128^3', [128] * 3, 'std', 1, 1), ('3D P2 scalar 64^3', [64] * 3
          ('3D P1 elasticity 96^3', [96] * 3, 'std', 1, 3), ('2D P1 elasticity 1024^2', [1024] * 2, 'std', 1, 2), ('2D P2 elasticity 512^2', [512] * 2, 'std', 2, 2),
          ('3D P2 elasticity 32^3', [32] * 3, 'std', 2, 3)]
 only = sys.argv[1:] 
+ONLY = os.environ.get("GENERIC_PROBE_ONLY")
 for name, shape, btype, degree, nc in CASES:
+    if ONLY and ONLY not in name:
+        continue
     if only and not any(o in name for o in only):
         continue
     nd = len(shape)
