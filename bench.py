@@ -17,9 +17,10 @@ and `reassembly_host_ready_ms` (values only); the CPU leg times pattern + values
 With --gpus N (default `--scaling strong`, SURVEY.md 8e / BASELINE.json north_star: "elements are partitioned across the
 GPUs of one node"): the ONE n^3 mesh is split into N slabs of n/N element layers; the line also carries the weak-scaling
 figure of the same launch (`weak`: every rank assembles its own n^3-element slab of an (n N) x n x n mesh).  `--scaling weak`
-makes the weak figure the headline instead.  The shared dof plane between neighbouring slabs is reduced over RCCL (point to
-point, interface rows only).  At N = 1 the default line also carries `variants.c3` (BASELINE.json configs[2], measured in the
-same run: kernel time by HIP events, HBM fraction, CPU port).
+makes the weak figure the headline instead.  With the default `--halo recompute` no data moves between the ranks (each assembles its ghost element layer and
+writes the rows it owns); `--halo reduce` reduces the shared dof plane over RCCL (point to point, interface rows only).  At N = 1 the default line also carries `variants.c3` (BASELINE.json configs[2], measured in the
+same run: kernel time by HIP events, HBM fraction, CPU port), `variants.c4` (configs[3]: one Newton step of the 512^2 Cahn-Hilliard system, tools/c4_step.py) and
+`variants.c5` (the configs[4] class: 63 488 ragged rational hierarchical elements, parity-checked against the reference fixture, tools/ragged_probe.py).
 
 Prints ONE JSON line on rank 0.
 '''
@@ -28,6 +29,7 @@ import json
 import os
 import sys
 import time
+import subprocess
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -564,6 +566,14 @@ def main():
                         v4['cpu_baseline'] = cb3
                         v4['speedup_vs_cpu_port'] = v4['value'] / cb3['value']
                 out['variants']['c3'] = v4
+                # BASELINE.json configs[3] and the configs[4] class: the probes of tools/ in their own processes (their parity checks run there); a failure drops the entry
+                for key, cmd in (('c4', [sys.executable, 'tools/c4_step.py', '512']), ('c5', [sys.executable, 'tools/ragged_probe.py', '256', '10'])):
+                    try:
+                        r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd=os.path.dirname(os.path.abspath(__file__)))
+                        line = next(l for l in r.stdout.splitlines() if l.startswith('RESULT '))
+                        out['variants'][key] = json.loads(line[7:])
+                    except Exception as e:  # noqa: BLE001 (secondary figures)
+                        out['variants'][key] = {'error': f'{type(e).__name__}: {e}'[:200]}
         if not a.no_cpu and world == 1:
             cb = cpu_baseline_c3(make(0, 1)) if a.config == 'c3' else cpu_baseline_c2(a.variant)
             if cb:

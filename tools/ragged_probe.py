@@ -68,3 +68,8 @@ print(f'{copies} plates: {nel} elements ({int(nb.min())}-{int(nb.max())} functio
 print(f'first assembly (pattern + tables + values) {first * 1e3:.1f} ms; re-assembly kernel ms: min {ms[0]:.3f} median {med:.3f} max {ms[-1]:.3f} -> {nel / med * 1e3:.3e} elements/s, '
       f'{bytes_ / med / 1e6:.0f} GB/s of {bytes_ / 1e6:.0f} MB algorithmic = {bytes_ / med / 1e6 / 8000:.3f} of the HBM peak')
 print('entry points of a re-assembly:', sorted(set(calls)))
+import json
+print('RESULT ' + json.dumps({'workload': f'{nel} ragged rational hierarchical elements (tests/golden/iga_plate_p3_l10.npz tiled {copies} x: p = 3 th-splines over 10 levels, {int(nb.min())}-{int(nb.max())} functions per '
+                                          f'element, {nq} points, 2 components, tabulated NURBS geometry; BASELINE.json configs[4] class)', 'value': nel / med * 1e3, 'unit': 'elements/s',
+                              'ms_per_step': med, 'steps': steps, 'launch': 'eager (HIP events around one assembly)', 'nnz': int(len(v)), 'max_rel_err_vs_reference': float(err),
+                              'algorithmic_bytes': int(bytes_), 'hbm_frac': bytes_ / med / 1e6 / 8000, 'entry_points': sorted(set(calls))}))
