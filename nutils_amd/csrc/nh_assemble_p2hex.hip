@@ -1036,7 +1036,7 @@ struct LaneK {   // per-lane constants of the operand fetch
 };
 
 // all units of one element for one column tile: 7 k-steps, then form tensor + LDS reduction of every unit
-template <int NC, int S0, int MODE, int NU>
+template <int NC, int S0, int MODE, int NU, int KS0 = 0, int KS1 = PKS>
 __device__ __forceinline__ void element_task(const P2K &p, double *lds, const double *jv, const double (&TB)[PKS][4], const LaneK &lc, const int (&taoff)[NU],
                                              const TaskD (&d)[NU], int cK0, int cK2, int dK0, int m0s) {
   int2 m[NU];  // where the rows live: read ahead of the MFMA chain
@@ -1068,12 +1068,13 @@ __device__ __forceinline__ void element_task(const P2K &p, double *lds, const do
     }
   };
   if (!DBG(p, 4)) {
+    constexpr bool PREF = KS1 - KS0 == PKS;  // (the split variant: the other matrix wave of the SIMD covers the operand latency, and the second operand set does not fit its registers)
     Ops cur, nxt;
-    fetch(0, cur);
+    fetch(KS0, cur);
     asm volatile("s_nop 4");  // (exec written by the branch above -> first DPP read)
 #pragma unroll
-    for (int ks = 0; ks < PKS; ++ks) {
-      if (ks + 1 < PKS) fetch(ks + 1, nxt);  // operands of the next k-step are in flight while the matrix pipe works
+    for (int ks = KS0; ks < KS1; ++ks) {
+      if (PREF && ks + 1 < KS1) fetch(ks + 1, nxt);  // operands of the next k-step are in flight while the matrix pipe works
       double B[3], A[NU];
       form_B<S0>(cur.xr, TB[ks], B);
 #pragma unroll
@@ -1085,7 +1086,10 @@ __device__ __forceinline__ void element_task(const P2K &p, double *lds, const do
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[u][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[u], B[b], acc[u][b], 0, 0, 0);
-      if (ks + 1 < PKS) cur = nxt;
+      if (ks + 1 < KS1) {
+        if constexpr (PREF) cur = nxt;
+        else fetch(ks + 1, cur);
+      }
     }
   }
 #pragma unroll
@@ -1102,7 +1106,7 @@ __device__ __forceinline__ int ta_offset(int u, int lane) {
   return (node * PNQ + lk) * 4;
 }
 
-template <int NC, int S0, int MODE, int VA, int NUA, int VB, int NUB>
+template <int NC, int S0, int MODE, int VA, int NUA, int VB, int NUB, int KS0 = 0, int KS1 = PKS>
 __device__ __forceinline__ void inreg_mfma_lines(const P2K &p, double *lds, const double (&TB)[PKS][4], const LaneK &lc, int nt, int lane) {
   const int lk = lane >> 4;
 #ifdef NH_ABLATION
@@ -1129,8 +1133,8 @@ __device__ __forceinline__ void inreg_mfma_lines(const P2K &p, double *lds, cons
     for (int k = 0; k < p.n2; ++k) {
       const int cK0 = ax_cnt(2 * k, p.n2), cK2 = ax_cnt(2 * k + 2, p.n2), dK0 = k > 0 ? 2 : 0, m0s = (2 * k) & 7;
       const double *jvs = lds + PR<NC>::JV + (k & 1) * RJSZ + lk * RJ;
-      if (hasA) element_task<NC, S0, MODE, NUA>(p, lds, jvs + VA * PNQ * RJ, TB, lc, taA, dA, cK0, cK2, dK0, m0s);
-      if (hasB) element_task<NC, S0, MODE, NUB>(p, lds, jvs + VB * PNQ * RJ, TB, lc, taB, dB, cK0, cK2, dK0, m0s);
+      if (hasA) element_task<NC, S0, MODE, NUA, KS0, KS1>(p, lds, jvs + VA * PNQ * RJ, TB, lc, taA, dA, cK0, cK2, dK0, m0s);
+      if (hasB) element_task<NC, S0, MODE, NUB, KS0, KS1>(p, lds, jvs + VB * PNQ * RJ, TB, lc, taB, dB, cK0, cK2, dK0, m0s);
       TICK(0);
       lds_barrier();
       TICK(1);
@@ -1143,7 +1147,7 @@ __device__ __forceinline__ void inreg_mfma_lines(const P2K &p, double *lds, cons
 #endif
 }
 
-template <int NC, int S0, int MODE>
+template <int NC, int S0, int MODE, int KS0 = 0, int KS1 = PKS>
 __device__ __forceinline__ void inreg_mfma_role(const P2K &p, double *lds, int wave, int lane) {
   const int lk = lane >> 4, li = lane & 15, nt = wave >> 1;
   double TB[PKS][4];  // reference values of this lane's column node at its point of every k-step
@@ -1152,13 +1156,13 @@ __device__ __forceinline__ void inreg_mfma_role(const P2K &p, double *lds, int w
 #pragma unroll
     for (int ks = 0; ks < PKS; ++ks) {
       const int q = 4 * ks + lk;
-      const bool ok = n < NB && q < p.nq;
+      const bool ok = n < NB && q < p.nq && ks >= KS0 && ks < KS1;  // (a wave of the split variant keeps the k-steps of its half only)
 #pragma unroll
       for (int i = 0; i < 4; ++i) TB[ks][i] = ok ? p.T[((i64)n * p.nq + q) * 4 + i] : 0.;
     }
     // (pinned: loads without a use stay pending for the wait-count bookkeeping)
 #pragma unroll
-    for (int ks = 0; ks < PKS; ++ks)
+    for (int ks = KS0; ks < KS1; ++ks)
 #pragma unroll
       for (int i = (S0 == 1 ? 1 : 0); i < 4; ++i) asm volatile("" : "+v"(TB[ks][i]));
   }
@@ -1179,8 +1183,8 @@ __device__ __forceinline__ void inreg_mfma_role(const P2K &p, double *lds, int w
       lc.awoff = val ? 9 : 10;
     }
   }
-  if (wave & 1) inreg_mfma_lines<NC, S0, MODE, 1, 2, 2, 2>(p, lds, TB, lc, nt, lane);
-  else inreg_mfma_lines<NC, S0, MODE, 0, 3, 3, 1>(p, lds, TB, lc, nt, lane);
+  if (wave & 1) inreg_mfma_lines<NC, S0, MODE, 1, 2, 2, 2, KS0, KS1>(p, lds, TB, lc, nt, lane);
+  else inreg_mfma_lines<NC, S0, MODE, 0, 3, 3, 1, KS0, KS1>(p, lds, TB, lc, nt, lane);
 }
 
 // pair slots per thread (256 threads) of node block b of a pair of planes: blocks 0..3 the even plane, 4..7 the odd one; interior row lengths are the maxima
@@ -1191,7 +1195,7 @@ __host__ __device__ constexpr int inreg_ub(int b, int nc) {
 
 // stream the finished rows of node blocks 0 .. NBLK - 1 of planes K0 (blocks 0..3) and K0 + 1 (4..7) to the value array and zero them in the buffers; thread t of 256.
 // As flush_blocks, with the slot count of every block fitted to its size.
-template <int NC, int NBLK>
+template <int NC, int NBLK, int B0 = 0>
 __device__ __forceinline__ void inreg_flush(const P2K &p, double *lds, int K0, int t) {
   if (DBG(p, 128)) return;
   const int *meta = reinterpret_cast<const int *>(lds + PL<NC>::META);
@@ -1199,17 +1203,17 @@ __device__ __forceinline__ void inreg_flush(const P2K &p, double *lds, int K0, i
   int2 f[NBLK];
   i64 g[NBLK];
 #pragma unroll
-  for (int b = 0; b < NBLK; ++b) {
+  for (int b = B0; b < NBLK; ++b) {
     const int s = ((K0 + (b >> 2)) & 7) * 4 + (b & 3);
     f[b] = *reinterpret_cast<const int2 *>(meta + 64 + s * 2);
     g[b] = gm[s];
   }
-  constexpr int UBM = inreg_ub(0, NC);
+  constexpr int UBM = inreg_ub(B0, NC);
   v2d v[NBLK][UBM];
   double hv[NBLK], tv[NBLK];
   auto grab = [](double *q) { return __hip_atomic_exchange(q, 0., __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 #pragma unroll
-  for (int b = 0; b < NBLK; ++b) {
+  for (int b = B0; b < NBLK; ++b) {
     const int first = __builtin_amdgcn_readfirstlane(f[b].x), w = __builtin_amdgcn_readfirstlane(f[b].y);
     const int np = w & 0x3fffffff;
     double *lp = lds + first;
@@ -1221,7 +1225,7 @@ __device__ __forceinline__ void inreg_flush(const P2K &p, double *lds, int K0, i
   }
   if (DBG(p, 1)) return;
 #pragma unroll
-  for (int b = 0; b < NBLK; ++b) {
+  for (int b = B0; b < NBLK; ++b) {
     const int w = __builtin_amdgcn_readfirstlane(f[b].y);
     const int np = w & 0x3fffffff, head = (w >> 30) & 1;
     const i64 goff = ((i64)__builtin_amdgcn_readfirstlane((int)(g[b] >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g[b]);
@@ -1236,7 +1240,7 @@ __device__ __forceinline__ void inreg_flush(const P2K &p, double *lds, int K0, i
 }
 
 // waves 4..7: wave 4 + V evaluates the geometry of visit V one slice ahead; all stream the planes finished in the previous slice
-template <int NC>
+template <int NC, bool SPLIT = false>
 __device__ __forceinline__ void inreg_service_role(const P2K &p, double *lds, int V, int lane) {
   const int st = V * 64 + lane, nq = p.nq;
   const bool fast = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == 8 && !p.geom.nograd && p.geom.bnd_axis < 0;
@@ -1333,12 +1337,22 @@ __device__ __forceinline__ void inreg_service_role(const P2K &p, double *lds, in
         if (V == 0 && lane < 8 && !DBG(p, 64)) pipe_meta_node<NC>(p, LM, lds, 2 * k + 3 + (lane >> 2), lane & 3);
       }
       TICK(3);
-      if (k > 0) inreg_flush<NC, 8>(p, lds, 2 * k - 2, st);
+      if (k > 0) {
+        if constexpr (SPLIT) {  // (the twelve-wave variant: the even and the odd plane one after the other -- half the registers)
+          inreg_flush<NC, 4>(p, lds, 2 * k - 2, st);
+          inreg_flush<NC, 8, 4>(p, lds, 2 * k - 2, st);
+        } else
+          inreg_flush<NC, 8>(p, lds, 2 * k - 2, st);
+      }
       TICK(4);
       lds_barrier();
       TICK(5);
     }
-    inreg_flush<NC, 8>(p, lds, 2 * p.n2 - 2, st);
+    if constexpr (SPLIT) {
+      inreg_flush<NC, 4>(p, lds, 2 * p.n2 - 2, st);
+      inreg_flush<NC, 8, 4>(p, lds, 2 * p.n2 - 2, st);
+    } else
+      inreg_flush<NC, 8>(p, lds, 2 * p.n2 - 2, st);
     inreg_flush<NC, 4>(p, lds, 2 * p.n2, st);
     TICK(2);
   }
@@ -1348,13 +1362,17 @@ __device__ __forceinline__ void inreg_service_role(const P2K &p, double *lds, in
 #endif
 }
 
-template <int NC, int S0, int MODE>
-__global__ __launch_bounds__(NTP4) void k_p2hex_inreg(P2K p) {
+// SPLIT: twelve waves -- the k-steps of every (unit, column tile) product are shared by TWO matrix waves per SIMD (waves w and 8 + w: k-steps [0, 4) and [4, 7)), each of
+// which adds its partial Gram matrices to the row buffers: the stalls of one wave (operand reads, the LDS reduction) are covered by the other.
+constexpr int KSPLIT = 4;
+template <int NC, int S0, int MODE, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? NTP4 + 256 : NTP4) void k_p2hex_inreg(P2K p) {
+  constexpr int NTK = SPLIT ? NTP4 + 256 : NTP4;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // row buffers are re-zeroed by the flush; the records of the pad points stay zero
-  for (int i = tid; i < PR<NC>::TT; i += NTP4) lds[i] = 0.;
-  for (int i = tid; i < 28 * PNQ; i += NTP4) {
+  for (int i = tid; i < PR<NC>::TT; i += NTK) lds[i] = 0.;
+  for (int i = tid; i < 28 * PNQ; i += NTK) {
     const int node = i / PNQ, q = i - node * PNQ;
     const bool ok = node < NB && q < p.nq;
     const double *Tp = p.T + ((i64)(ok ? node : 0) * p.nq + (ok ? q : 0)) * 4;
@@ -1362,13 +1380,22 @@ __global__ __launch_bounds__(NTP4) void k_p2hex_inreg(P2K p) {
     *reinterpret_cast<v2d *>(o) = ok ? v2d{Tp[1], Tp[2]} : v2d{0., 0.};
     *reinterpret_cast<v2d *>(o + 2) = ok ? v2d{Tp[3], Tp[0]} : v2d{0., 0.};
   }
-  for (int i = PL<NC>::META + tid; i < PL<NC>::END; i += NTP4) lds[i] = 0.;
-  if (wave < 4) {
+  for (int i = PL<NC>::META + tid; i < PL<NC>::END; i += NTK) lds[i] = 0.;
+  if constexpr (SPLIT) {
+    if (wave < 4) {
+      inreg_mfma_role<NC, S0, MODE, 0, KSPLIT>(p, lds, wave, lane);
+      return;
+    }
+    if (wave >= 8) {
+      inreg_mfma_role<NC, S0, MODE, KSPLIT, PKS>(p, lds, wave - 8, lane);
+      return;
+    }
+  } else if (wave < 4) {
     inreg_mfma_role<NC, S0, MODE>(p, lds, wave, lane);
     return;
   }
   if (p.prio) __builtin_amdgcn_s_setprio(3);
-  inreg_service_role<NC>(p, lds, wave - 4, lane);
+  inreg_service_role<NC, SPLIT>(p, lds, wave - 4, lane);
 }
 
 // closed-form CSR index arrays: one wave per node, rows (node, c) of length len * NC, columns (colnode, d) lexicographic
@@ -1397,11 +1424,16 @@ template <int NC, int S0, int MODE>
 hipError_t launch_pipe(unsigned grid, size_t ldsb, hipStream_t s, const P2K &p, bool inreg) {
   auto kern = k_p2hex_pipe<NC, S0, MODE>;
   // (three components with the value slot and a dense form tensor: the in-register variant spills, the table kernel keeps it)
+  int nthreads = NTP4;
   if constexpr (!(NC == 3 && S0 == 0))
-    if (inreg) kern = k_p2hex_inreg<NC, S0, MODE>;
+    if (inreg) {
+      static const bool split = getenv("NH_P2HEX_SPLIT") && atoi(getenv("NH_P2HEX_SPLIT"));
+      kern = k_p2hex_inreg<NC, S0, MODE>;
+      if (split) kern = k_p2hex_inreg<NC, S0, MODE, true>, nthreads = NTP4 + 256;
+    }
   hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTP4), ldsb, s, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, s, p);
   return hipSuccess;
 }
 
