@@ -133,7 +133,8 @@ def timed_steps(wl, steps, world, dist, use_graph):
         per_graph = next(g for g in (20, 10, 8, 5, 4, 2, 1) if steps % g == 0)
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (thread-local capture mode: with N > 1 the RCCL watchdog thread of torch.distributed issues event queries of its own while this thread captures)
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 for _ in range(per_graph):
                     wl.step()
             for _ in range(3):  # (untimed: the first replays of a graph carry its upload to the device)
@@ -142,6 +143,11 @@ def timed_steps(wl, steps, world, dist, use_graph):
         except Exception:
             graph, per_graph = None, 1
             torch.cuda.synchronize()
+        if world > 1:  # (every rank times the same launch modes -- the timed regions are bracketed by collectives: one rank without a graph means no rank replays)
+            ok = torch.tensor([1 if graph is not None else 0], device='cuda', dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                graph, per_graph = None, 1
 
     def run(replay):
         if world > 1:
