@@ -48,7 +48,9 @@ def parse():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default=None, help='default: strong (one mesh split over the GPUs) when the element layers divide evenly, else weak')
     ap.add_argument('--halo', choices=['recompute', 'reduce'], default='recompute',
                     help='N > 1: recompute = every rank also assembles its one ghost element layer and writes only the rows it owns (no exchange; the step is one '
-                         'kernel, graph-captured); reduce = RCCL point-to-point reduce of the interface-plane rows.  The line carries the other mode as `halo_<mode>`')
+                         'kernel, graph-captured); reduce = RCCL point-to-point reduce of the interface-plane rows.  With --compare-halo the line carries the other mode as `halo_<mode>`')
+    ap.add_argument('--compare-halo', action='store_true', help='N > 1: also time the other halo mode (secondary figure).  Off by default: the reduce mode is the only part of the '
+                    'bench that moves data between ranks, and it has never run on multi-GPU hardware -- a stall there would take the headline line with it')
     ap.add_argument('--traffic', choices=['measure', 'static'], default='measure',
                     help='roofline.traffic: measure = two rocprofv3 --pmc passes of a short probe of the same kernel inside this run (when rocprofv3 is on PATH), '
                          'static = the committed profile file')
@@ -406,7 +408,7 @@ def main():
         fail(', '.join(f'{k} = {checks[k]:.3e}' for k in bad) + ': the assembled matrix is wrong', rank, world, dist, metric)
 
     other = other_halo = None
-    if world > 1:
+    if world > 1 and a.compare_halo:
         # the other halo mode of the same launch and scaling mode (secondary figure)
         h2 = 'reduce' if a.halo == 'recompute' else 'recompute'
         wh = make_workload(a, a.config, a.scaling, rank, world, halo=h2)()

@@ -140,7 +140,7 @@ def test_bench_multiprocess_on_one_gpu(world):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NUTILS_AMD_BENCH_ONE_GPU='1', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1', '--master-port', str(29500 + world),
-           'bench.py', '--gpus', str(world), '--steps', '4', '--warmup', '2', '--elements-per-axis', '32', '--no-cpu']
+           'bench.py', '--gpus', str(world), '--steps', '4', '--warmup', '2', '--elements-per-axis', '32', '--no-cpu', '--compare-halo']
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
