@@ -123,6 +123,7 @@ struct MatK {
   int use_w;      // pre-multiplied trial table W in LDS (pays when it does not cost occupancy)
   int exclusive;  // NH_MATRIX_EXCLUSIVE: no two elements of this launch share a matrix entry -> plain read-modify-write (deterministic)
   double *local;  // NH_MATRIX_GATHER: element-major local matrices [emap position][nct * ncr] instead of the scatter
+  int sym;        // Gram path: test == trial (tables AND dofs) and C[c][a][d][b] == C[d][b][c][a]: the node pairs m >= n only, each written to both of its places
 };
 
 template <int ND>
@@ -155,8 +156,10 @@ __global__ __launch_bounds__(256) void k_matrix_generic(MatK p, FormK formarg) {
     const int nentries = nbt * form.nct * nbr * form.ncr;
     for (int q0 = 0; q0 < p.nq; q0 += p.qchunk) {
       const int q1 = min(p.nq, q0 + p.qchunk);
+#ifndef NH_GEN_SKIPFILL
       fill_D<ND>(Dt, p.test, e, nbt, p.nq, q0, q1, Jw, lane);
       if (!p.same) fill_D<ND>(Dr, p.trial, e, nbr, p.nq, q0, q1, Jw, lane);
+#endif
       __syncthreads();
       // trial side pre-multiplied by the form and the quadrature weight, once per (q, n, d, c):
       //   W[q][n][d][c][a] = w_q |J_q| sum_b C[c][a][d][b] Dr[q][n][b]
@@ -191,7 +194,86 @@ __global__ __launch_bounds__(256) void k_matrix_generic(MatK p, FormK formarg) {
       // (S x S accumulators per lane, 2 S + 1 LDS reads and S (S + 1) multiply-adds per point) and the form tensor is applied once per pair,
       // K[c][d] = sum_ab C[c][a][d][b] G[a][b], instead of S (S + 1) multiply-adds and 2 S + S S reads per point for EACH of the nct x ncr entries.
       const bool gram = !p.cq && form.nct * form.ncr > 1;
-      if (gram) {
+      if (gram && p.sym) {
+        // symmetric blocks (test == trial, C[c][a][d][b] == C[d][b][c][a]): G_nm[a][b] = G_mn[b][a] and K_nm = K_mn^T -- the node pairs m >= n only (nb (nb + 1) / 2 of
+        // nb^2), two of them per lane, each written to its place and (m != n) transposed to the mirrored one: half the quadrature sums of the kernel's longest phase
+        const int np = nbt * (nbt + 1) / 2, hp = (np + 1) >> 1;
+        for (int k = lane; k < hp; k += NTG) {
+          int mm[2], nn[2];
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            const int kk = min(k + pp * hp, np - 1);
+            int m = (int)((sqrt(8. * kk + 1.) - 1.) * .5);  // kk = m (m + 1) / 2 + n, 0 <= n <= m
+            m += (m + 1) * (m + 2) / 2 <= kk;
+            m -= m * (m + 1) / 2 > kk;
+            mm[pp] = m, nn[pp] = kk - m * (m + 1) / 2;
+          }
+          const bool two = k + hp < np;
+          double G[2][S][S];
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int a = 0; a < S; ++a)
+#pragma unroll
+              for (int b = 0; b < S; ++b) G[pp][a][b] = 0.;
+#ifdef NH_GEN_SKIPQ  // (timing experiments)
+          for (int q = q0; q < min(q1, q0 + 1); ++q) {
+#else
+          for (int q = q0; q < q1; ++q) {
+#endif
+            const double *Dq = Dt + (q - q0) * nbt * S;
+            const double wq = Jw[q * JW + ND * ND];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+              const double *dt = Dq + mm[pp] * S, *dr = Dq + nn[pp] * S;
+              double d0[S];
+#pragma unroll
+              for (int b = 0; b < S; ++b) d0[b] = dr[b];
+#pragma unroll
+              for (int a = 0; a < S; ++a) {
+                const double wa = wq * dt[a];
+#pragma unroll
+                for (int b = 0; b < S; ++b) G[pp][a][b] += wa * d0[b];
+              }
+            }
+          }
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            if (pp && !two) break;
+            const int m = mm[pp], n = nn[pp];
+            i64 rowm = 0, a0m = 0, lenm = 0, posm = 0, rown = 0, a0n = 0, lenn = 0, posn = 0;
+            if (!p.local) {
+              rowm = p.test.dofs[tdof0 + m], a0m = p.srowptr[rowm], lenm = p.srowptr[rowm + 1] - a0m, posm = p.emap[emap0 + m * nbr + n];
+              rown = p.test.dofs[tdof0 + n], a0n = p.srowptr[rown], lenn = p.srowptr[rown + 1] - a0n, posn = p.emap[emap0 + n * nbr + m];
+            }
+            for (int c = 0; c < form.nct; ++c)
+              for (int d = 0; d < form.ncr; ++d) {
+                if (!form.mask[c][d]) continue;
+                const double *Cc = form.C + ((c * S) * form.ncr + d) * S;
+                double acc = 0;
+#pragma unroll
+                for (int a = 0; a < S; ++a)
+#pragma unroll
+                  for (int b = 0; b < S; ++b) acc += Cc[a * form.ncr * S + b] * G[pp][a][b];
+#ifdef NH_GEN_SKIPST
+                if (acc == 1.2345e300) p.local[0] = acc;
+                continue;
+#endif
+                if (p.local) {
+                  double *dst = p.local + (emap0 + m * nbr + n) * (form.nct * form.ncr) + c * form.ncr + d;
+                  *dst = q0 ? *dst + acc : acc;
+                  if (m != n) {
+                    double *dst2 = p.local + (emap0 + n * nbr + m) * (form.nct * form.ncr) + d * form.ncr + c;
+                    *dst2 = q0 ? *dst2 + acc : acc;
+                  }
+                  continue;
+                }
+                atomicAdd(p.values + a0m * form.tot + lenm * form.cum[c] + posm * form.cnt[c] + form.dpos[c][d], acc);
+                if (m != n) atomicAdd(p.values + a0n * form.tot + lenn * form.cum[d] + posn * form.cnt[d] + form.dpos[d][c], acc);
+              }
+          }
+        }
+      } else if (gram) {
         // a lane takes test function m and TWO trial functions n, n + h (h = half the trial functions): the test row of a point is read once for both
         // (63 488 ragged elements 1.77 -> 1.67 ms; two test functions as well: 1.64 ms, not worth the code)
         const int h = (nbr + 1) >> 1;
@@ -730,6 +812,20 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   p.trial = to_k(a->trial);
   p.same = (a->test.T_dev == a->trial.T_dev && a->test.off_dev == a->trial.off_dev && a->test.tab_dev == a->trial.tab_dev &&
             a->test.nb == a->trial.nb);
+  p.sym = 0;
+  if (p.same && a->test.dofs_dev == a->trial.dofs_dev && a->nct == a->ncr && !a->cq_dev && !(a->flags & (NH_MATRIX_EXCLUSIVE | NH_MATRIX_FIRST_TOUCH)) && !getenv("NUTILS_AMD_NO_SYM_GRAM")) {
+    const int S2 = 1 + a->ndims, nc2 = a->nct;
+    p.sym = 1;
+    for (int c = 0; c < nc2 && p.sym; ++c)
+      for (int sa = 0; sa < S2 && p.sym; ++sa)
+        for (int d = 0; d < nc2 && p.sym; ++d)
+          for (int sb = 0; sb < S2; ++sb)
+            if (a->C_host[((c * S2 + sa) * nc2 + d) * S2 + sb] != a->C_host[((d * S2 + sb) * nc2 + c) * S2 + sa] ||
+                (a->mask_host && a->mask_host[c * nc2 + d] != a->mask_host[d * nc2 + c])) {
+              p.sym = 0;
+              break;
+            }
+  }
   p.srowptr = (const i64 *)a->srowptr_dev;
   p.emap = a->emap_dev;
   p.eoff = (const i64 *)a->eoff_dev;
@@ -869,7 +965,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     NH_REQUIRE(lds <= 160 * 1024, "element too large for LDS (%zu bytes)", lds);
     // two waves per element when its (node pairs of the Gram path | entries) keep both busy: the one-wave workgroups of the ragged rational workload ran at 1.9 waves
     // per SIMD (LDS bound) and waited 61 % of their cycles
-    const i64 work = (!a->cq_dev && a->nct * a->ncr > 1) ? (i64)q.maxnbt * ((q.maxnbr + 1) / 2) : (i64)q.maxnbt * a->nct * q.maxnbr * a->ncr;
+    const i64 work = (!a->cq_dev && a->nct * a->ncr > 1) ? (q.sym ? (i64)q.maxnbt * (q.maxnbt + 1) / 4 : (i64)q.maxnbt * ((q.maxnbr + 1) / 2)) : (i64)q.maxnbt * a->nct * q.maxnbr * a->ncr;
     int nw = work > 96 ? 2 : 1;
     if (getenv("NUTILS_AMD_GENERIC_WAVES")) nw = std::max(1, std::min(4, atoi(getenv("NUTILS_AMD_GENERIC_WAVES"))));
     dim3 grid(grid_for(q.nelems)), block(64 * nw);
