@@ -94,7 +94,8 @@ struct nh_fused_plan {
   int32_t *blen;      // [nblocks]: doubles of the block's accumulator
   i64 *vptr;          // [nblocks + 1]: visits of block b
   int32_t *vlist;     // [nvisits]: element
-  uint16_t *vrow;     // [nvisits][nbt]: accumulator offset of the row of local function m, 0xffff: the row belongs to another block
+  uint16_t *vrow;     // [nvisits][nbt]: row of local function m within the block | (colour or turn) << 9, 0xffff: the row belongs to another block
+  int ncol;           // > 0: sums ordered by colours (this many), 0: by turns
   uint8_t *cpos;      // [nelems][nbt * nbr]: position of entry (m, n) within its CSR row
   // trilinear hexahedra at the 2 x 2 x 2 Gauss points (recognised from the tables of a launch): -1 not looked at, 0 no, 1 yes, 2 yes with a mass term
   int p1hex;

@@ -503,6 +503,41 @@ __global__ void k_fp_vrow(i64 n, int R, const unsigned *pkey, const unsigned *pv
   vrow[pval[j]] = (uint16_t)((key % (unsigned)R) | (unsigned)seq << 9);
 }
 
+// ORDER BY COLOURS (round 4; NH_FUSED_ORDER=colours -- measured: 0.80 ms against 0.57 ms with the turns on the 128^3 trilinear mesh, the adds of a colour phase are a
+// serial chain of LDS atomics with most threads idle): the visits of a block are coloured so that two visits of one colour share no row of the block (greedy, in visit order: one thread per
+// block, the colours a row has seen in a 64-bit mask); the fused kernels add colour by colour with a workgroup barrier in between -- every CSR entry is the sum of its
+// contributions in (round, colour) order whatever the wave scheduling, and no visit waits for another.  vrow[pair] = row index within the block | colour << 9.
+__global__ void k_fp_color(int nblocks, int nbt, int R, const i64 *vptr, const int32_t *vlist, const int32_t *dofs, const int32_t *rank, uint16_t *vrow, int *flags) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  unsigned long long mask[512];
+  for (int r = 0; r < R; ++r) mask[r] = 0ull;
+  int maxc = 0;
+  for (i64 i = vptr[b]; i < vptr[b + 1]; ++i) {
+    const i64 e = vlist[i];
+    unsigned long long used = 0ull;
+    for (int m = 0; m < nbt; ++m) {
+      const int r = rank[dofs[e * nbt + m]];
+      if (r / R == b) used |= mask[r % R];
+    }
+    int c = __ffsll((long long)~used) - 1;
+    if (c < 0 || c > 126) {
+      atomicOr(flags + 2, 1);
+      c = 0;
+    }
+    for (int m = 0; m < nbt; ++m) {
+      const int r = rank[dofs[e * nbt + m]];
+      if (r / R == b) {
+        mask[r % R] |= 1ull << c;
+        vrow[i * nbt + m] = (uint16_t)((unsigned)(r % R) | (unsigned)c << 9);
+      } else
+        vrow[i * nbt + m] = (uint16_t)0xffff;
+    }
+    maxc = max(maxc, c + 1);
+  }
+  atomicMax(flags + 3, maxc);
+}
+
 // the element map (position of entry (m, n) within the CSR row of its test dof) narrowed to a byte
 __global__ void k_fp_cpos(i64 n, const int32_t *emap, uint8_t *cpos, int *bad) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -540,6 +575,7 @@ struct FusK {
   const i64 *vptr, *rstart;
   const uint16_t *vrow;
   const uint8_t *cpos;
+  int ncol;  // > 0: the plan orders the sums by colours (k_fp_color), 0: by turns (k_fp_vrow)
 };
 
 template <int ND, int NBT, int NBR, bool LDST, bool SYMD>
@@ -568,17 +604,20 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_scalar(FusK p) {
   for (int i = threadIdx.x; i < p.R; i += NT) turn[i] = 0;
   for (int i = threadIdx.x; i < p.max_blen; i += NT) acc[i] = 0.;
   __syncthreads();
-  for (i64 i = p.vptr[b] + threadIdx.x; i < p.vptr[b + 1]; i += NT) {
-    const i64 e = p.vlist[i];
+  const i64 v0 = p.vptr[b], v1 = p.vptr[b + 1];
+  for (i64 base = v0; base < v1; base += NT) {  // (the same number of rounds for every thread: the colour phases end in workgroup barriers)
+    const i64 i = base + threadIdx.x;
+    const bool act = i < v1;
+    const i64 e = p.vlist[act ? i : v0];
     // accumulator offsets of the element's rows and the positions of its entries within them: whole words where the sizes allow
     uint16_t vr[NBT];
     uint8_t cp[NE];
     if constexpr (NBT % 8 == 0) {
 #pragma unroll
-      for (int k = 0; k < NBT / 8; ++k) *reinterpret_cast<uint4 *>(vr + 8 * k) = reinterpret_cast<const uint4 *>(p.vrow + i * NBT)[k];
+      for (int k = 0; k < NBT / 8; ++k) *reinterpret_cast<uint4 *>(vr + 8 * k) = reinterpret_cast<const uint4 *>(p.vrow + (act ? i : v0) * NBT)[k];
     } else {
 #pragma unroll
-      for (int m = 0; m < NBT; ++m) vr[m] = p.vrow[i * NBT + m];
+      for (int m = 0; m < NBT; ++m) vr[m] = p.vrow[(act ? i : v0) * NBT + m];
     }
     if constexpr (NE % 16 == 0) {
 #pragma unroll
@@ -588,13 +627,30 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_scalar(FusK p) {
       for (int l = 0; l < NE; ++l) cp[l] = p.cpos[e * NE + l];
     }
     double A[NBT][NBR];
-    local_scalar_matrix<ND, NBT, NBR, LDST, SYMD>(p.loc, sT, e, e, A);
-    // The contributions to a row are added in the order of the visits (the turn of this visit within each of its rows comes with the plan): the sums do not
-    // depend on the arrival of the waves -- bit-reproducible.  A visit waits only for EARLIER visits, which are being processed or done: no deadlock; all adds of
-    // a wave reach the LDS in program order, the turn counter last.
+    if (act) local_scalar_matrix<ND, NBT, NBR, LDST, SYMD>(p.loc, sT, e, e, A);
     unsigned pend = 0;
+    int mycol = -1;
 #pragma unroll
-    for (int m = 0; m < NBT; ++m) pend |= vr[m] != 0xffff ? 1u << m : 0u;
+    for (int m = 0; m < NBT; ++m)
+      if (act && vr[m] != 0xffff) pend |= 1u << m, mycol = vr[m] >> 9;
+    if (p.ncol) {
+      // colour by colour: the visits of a colour share no row, the barrier orders the colours -- bit-reproducible sums without a visit waiting for another
+      for (int c = 0; c < p.ncol; ++c) {
+        if (mycol == c) {
+#pragma unroll
+          for (int m = 0; m < NBT; ++m) {
+            if (!(pend >> m & 1)) continue;
+            const int base2 = loffS[vr[m] & 511];
+#pragma unroll
+            for (int n = 0; n < NBR; ++n) atomicAdd(acc + base2 + cp[m * NBR + n], (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n]);
+          }
+        }
+        __syncthreads();
+      }
+      continue;
+    }
+    // by turns: the contributions to a row are added in the order of the visits (the turn of this visit within each of its rows comes with the plan).  A visit waits
+    // only for EARLIER visits, which are being processed or done: no deadlock; all adds of a wave reach the LDS in program order, the turn counter last.
     while (pend) {
       bool progress = false;
 #pragma unroll
@@ -602,9 +658,9 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_scalar(FusK p) {
         if (!(pend >> m & 1)) continue;
         const int row = vr[m] & 511;
         if (__hip_atomic_load(turn + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(vr[m] >> 9)) continue;
-        const int base = loffS[row];
+        const int base2 = loffS[row];
 #pragma unroll
-        for (int n = 0; n < NBR; ++n) atomicAdd(acc + base + cp[m * NBR + n], (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n]);
+        for (int n = 0; n < NBR; ++n) atomicAdd(acc + base2 + cp[m * NBR + n], (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n]);
         atomicAdd(turn + row, 1u);
         pend &= ~(1u << m);
         progress = true;
@@ -645,7 +701,10 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_p1hex(FusK fp) {
   for (int i = threadIdx.x; i < fp.max_blen; i += NT) acc[i] = 0.;
   __syncthreads();
   const P1Tab &p = fp.tab;
-  for (i64 i = fp.vptr[b] + threadIdx.x; i < fp.vptr[b + 1]; i += NT) {
+  const i64 v0 = fp.vptr[b], v1 = fp.vptr[b + 1];
+  for (i64 base = v0; base < v1; base += NT) {  // (uniform number of rounds: the colour phases end in workgroup barriers)
+    const i64 i = min(base + (i64)threadIdx.x, v1 - 1);  // (threads behind the last visit shadow it and add nothing)
+    const bool act = base + threadIdx.x < v1;
     const i64 e = fp.vlist[i];
     uint16_t vr[NBT];
     uint8_t cp[NE];
@@ -697,10 +756,30 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_p1hex(FusK fp) {
 #pragma unroll
         for (int bb = a; bb < 8; ++bb) K[q++] = entry(a, bb);
     }
-    // the contributions to a row in the order of the visits (see k_fused_scalar): bit-reproducible sums
+    // the contributions to a row colour by colour or in the order of the visits (see k_fused_scalar): bit-reproducible sums
     unsigned pend = 0;
+    int mycol = -1;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) pend |= vr[m] != 0xffff ? 1u << m : 0u;
+    for (int m = 0; m < 8; ++m)
+      if (act && vr[m] != 0xffff) pend |= 1u << m, mycol = vr[m] >> 9;
+    if (fp.ncol) {
+      for (int c = 0; c < fp.ncol; ++c) {
+        if (mycol == c) {
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            if (!(pend >> m & 1)) continue;
+            const int base2 = loffS[vr[m] & 511];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+              const int lo = m < n ? m : n, hi = m < n ? n : m;
+              atomicAdd(acc + base2 + cp[m * 8 + n], K[lo * 8 - lo * (lo - 1) / 2 + hi - lo]);
+            }
+          }
+        }
+        __syncthreads();
+      }
+      continue;
+    }
     while (pend) {
       bool progress = false;
 #pragma unroll
@@ -1266,7 +1345,7 @@ static int nh_fused_prepare(nh_pattern *p, const nh_matrix_args *a, hipStream_t 
   unsigned long long *mm = nullptr;
   unsigned *ekey = nullptr, *nkey = nullptr, *iota = nullptr, *nkey2 = nullptr, *order = nullptr, *vkey = nullptr, *vval = nullptr, *vkey2 = nullptr, *vval2 = nullptr;
   int32_t *rank = nullptr, *cnt = nullptr, *bcount = nullptr;
-  int *flags = nullptr;  // [0] longest row, [1] largest block accumulator, [2] bad column position
+  int *flags = nullptr;  // [0] longest row, [1] largest block accumulator, [2] bad column position / colour, [3] colours
   i64 *voff = nullptr;
   void *tmp = nullptr;
   int rc = NH_OK, hflags[3] = {0, 0, 0};
@@ -1285,8 +1364,8 @@ static int nh_fused_prepare(nh_pattern *p, const nh_matrix_args *a, hipStream_t 
     FP_CHECK(hipMalloc((void **)&cent, ne * 3 * sizeof(double)));
     FP_CHECK(hipMalloc((void **)&mm, sizeof mm0));
     FP_CHECK(hipMemcpyAsync(mm, mm0, sizeof mm0, hipMemcpyHostToDevice, s));
-    FP_CHECK(hipMalloc((void **)&flags, 3 * sizeof(int)));
-    FP_CHECK(hipMemsetAsync(flags, 0, 3 * sizeof(int), s));
+    FP_CHECK(hipMalloc((void **)&flags, 4 * sizeof(int)));
+    FP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
     hipLaunchKernelGGL(k_fp_centroid, dim3(ge), dim3(256), 0, s, ne, to_k(a->geom), a->ndims, a->nq, cent, mm);
     FP_CHECK(hipMalloc((void **)&ekey, ne * 4));
     hipLaunchKernelGGL(k_fp_ekey, dim3(ge), dim3(256), 0, s, ne, cent, mm, ekey);
@@ -1350,7 +1429,17 @@ static int nh_fused_prepare(nh_pattern *p, const nh_matrix_args *a, hipStream_t 
     FP_CHECK(hipMalloc((void **)&f->vptr, (nblocks + 1) * sizeof(i64)));
     if ((rc = nh_scan_exclusive(bcount, f->vptr, nblocks, s)) != NH_OK) goto done;
     FP_CHECK(hipMalloc((void **)&f->vrow, std::max<i64>(nvisits * nbt, 1) * sizeof(uint16_t)));
-    {
+    f->ncol = 0;
+    if (getenv("NH_FUSED_ORDER") && !strcmp(getenv("NH_FUSED_ORDER"), "colours")) {
+      // colours (measured slower than the turns, not the default): greedy colouring of the visits of every block, one thread per block
+      FP_CHECK(hipMemsetAsync(flags + 3, 0, sizeof(int), s));
+      hipLaunchKernelGGL(k_fp_color, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nblocks, nbt, R, f->vptr, reinterpret_cast<const int32_t *>(vval2), dofs, rank, f->vrow, flags);
+      FP_CHECK(hipGetLastError());
+      int ncol = 0;
+      FP_CHECK(hipMemcpyAsync(&ncol, flags + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+      FP_CHECK(hipStreamSynchronize(s));
+      f->ncol = ncol;
+    } else {
       // the turn of every (visit, local row) within its row: stable sort of the pairs by row
       const i64 np = nvisits * nbt;
       if (np >= (1ll << 32)) {  // (32-bit pair indices)
@@ -1519,6 +1608,7 @@ int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s) {
   p.R = f->rows_per_block;
   p.max_blen = f->max_blen;
   p.loff = f->loff, p.blen = f->blen, p.rstart = f->rstart, p.vlist = f->vlist, p.vptr = f->vptr, p.vrow = f->vrow, p.cpos = f->cpos;
+  p.ncol = f->ncol;
   const size_t ldsx = (ldst ? ldsb : 0) + sizeof(double) * ((size_t)f->max_blen + f->rows_per_block + (f->rows_per_block + 2) / 2 + (f->rows_per_block + 1) / 2);
   int nt = FUSED_NT;
 #ifdef NH_ABLATION
