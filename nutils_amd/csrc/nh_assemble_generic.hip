@@ -124,6 +124,7 @@ struct MatK {
   int exclusive;  // NH_MATRIX_EXCLUSIVE: no two elements of this launch share a matrix entry -> plain read-modify-write (deterministic)
   double *local;  // NH_MATRIX_GATHER: element-major local matrices [emap position][nct * ncr] instead of the scatter
   int sym;        // Gram path: test == trial (tables AND dofs) and C[c][a][d][b] == C[d][b][c][a]: the node pairs m >= n only, each written to both of its places
+                  // (2 with NH_MATRIX_GATHER: to its own place only -- the gather map for symmetric producers mirrors it)
 };
 
 template <int ND>
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void k_matrix_generic(MatK p, FormK formarg) {
                 if (p.local) {
                   double *dst = p.local + (emap0 + m * nbr + n) * (form.nct * form.ncr) + c * form.ncr + d;
                   *dst = q0 ? *dst + acc : acc;
-                  if (m != n) {
+                  if (m != n && p.sym != 2) {  // (sym == 2: the gather reads the (n, m) entries from this block, transposed)
                     double *dst2 = p.local + (emap0 + n * nbr + m) * (form.nct * form.ncr) + d * form.ncr + c;
                     *dst2 = q0 ? *dst2 + acc : acc;
                   }
@@ -900,6 +901,12 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
       return nh_gather_values(pat, scratch, a->nelems, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream));
     }
     p.local = scratch;
+    // NUTILS_AMD_SYM_SCRATCH=1 (measured, NOT the default): symmetric Gram blocks of 2 or 3 components send the node pairs m >= n only to the scratch and the gather mirrors
+    // them -- half the scratch bytes, but the mirrored sources of a CSR row lie nb blocks apart: the gather of the ragged rational workload 0.39 -> ~1.0 ms (1.27 -> 1.88 ms in all)
+    if (p.sym && a->nct * a->ncr > 1 && (a->nct == 2 || a->nct == 3) && getenv("NUTILS_AMD_SYM_SCRATCH") && atoi(getenv("NUTILS_AMD_SYM_SCRATCH"))) {
+      if ((rc = nh_gather_prepare_sym(pat, a->test, a->elist_dev, nh_stream(stream))) != NH_OK) return rc;
+      p.sym = 2;
+    }
   }
   // MFMA path: uniform shared tables, >= 16 local rows and columns, tile counts we instantiate
   const int Nloc = a->trial.nb * a->ncr;
@@ -1004,7 +1011,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
       gs.cnt[c] = form.cnt[c], gs.cum[c] = form.cum[c];
       for (int d = 0; d < MAXC; ++d) gs.dpos[c][d] = form.dpos[c][d], gs.mask[c][d] = form.mask[c][d];
     }
-    return nh_gather_values(a->pattern, p.local, local_ld, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream));
+    return nh_gather_values(a->pattern, p.local, local_ld, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream), p.sym == 2);
   }
   return NH_OK;
 }

@@ -121,6 +121,7 @@ struct nh_pattern {
   // gather map (nh_gather.hip; built on the first NH_MATRIX_GATHER assembly): for scalar entry k the local-matrix positions
   // gsrc[gptr[k] .. gptr[k+1]) in ascending order (element, m, n) -- the order numpy.add.at accumulates them in -- and the row of k
   int32_t *gsrc;
+  int32_t *gsrc_sym;  // the same map for producers that write the node pairs m >= n only: sources of (m < n) entries point to the (n, m) block, bit 31 set = transpose it
   unsigned *gptr;
   int32_t *grow;
   nh_fused_plan *fused;  // NH_MATRIX_FUSED: built on the first such assembly
@@ -139,7 +140,8 @@ struct GSlots {
 int nh_gather_prepare(nh_pattern *p, const nh_basis &test, const int32_t *elist, hipStream_t s);  // elist: element ids of the pattern's elements, or NULL
 int nh_gather_scratch(size_t doubles, double **out);
 int nh_local_vector(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);
-int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s);
+int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s, bool sym_sources = false);
+int nh_gather_prepare_sym(nh_pattern *p, const nh_basis &test, const int32_t *elist, hipStream_t s);
 int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);
 // owner-block assembly (NH_MATRIX_FUSED); *done = false: not applicable to this launch, nothing was written
 int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s);

@@ -43,6 +43,25 @@ __global__ void k_narrow(i64 n, const i64 *in, unsigned *out) {
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) out[i] = (unsigned)in[i];
 }
 
+// symmetric producers (the node pairs m >= n only): canonical source of every local position -- (m, n) itself, or the (n, m) block with bit 31 = transpose
+__global__ void k_gather_canon(i64 nelems, const int32_t *elist, BasisK test, int nbr_uniform, const i64 *eoff, unsigned *canon) {
+  for (i64 e = blockIdx.x; e < nelems; e += gridDim.x) {
+    const i64 eid = elist ? elist[e] : e;
+    const int nbt = bnb(test, eid);
+    if (!nbt) continue;
+    const i64 e0 = eoff ? eoff[e] : e * (i64)nbt * nbr_uniform;
+    const i64 cnt = (eoff ? eoff[e + 1] : e0 + (i64)nbt * nbr_uniform) - e0;
+    const int nbr = (int)(cnt / nbt);
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+      const int m = i / nbr, n = i - m * nbr;
+      canon[e0 + i] = m >= n ? (unsigned)(e0 + i) : ((unsigned)(e0 + (i64)n * nbr + m) | 0x80000000u);
+    }
+  }
+}
+__global__ void k_gather_remap(i64 n, const int32_t *gsrc, const unsigned *canon, int32_t *out) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) out[i] = (int32_t)canon[(unsigned)gsrc[i]];
+}
+
 __global__ void k_rowof(i64 nrows, const i64 *srowptr, int32_t *grow) {
   for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (i64)gridDim.x * blockDim.x)
     for (i64 k = srowptr[r]; k < srowptr[r + 1]; ++k) grow[k] = (int32_t)r;
@@ -75,6 +94,7 @@ __global__ void k_gather_values(i64 nnz, const unsigned *gptr, const int32_t *gs
   }
 }
 
+template <bool SYMSRC>  // sources with bit 31 set are the mirrored block: read transposed (nct == ncr)
 __global__ void k_gather_values_v(i64 nnz, const unsigned *gptr, const int32_t *gsrc, const int32_t *grow, const i64 *srowptr, const double *local, GSlots gs,
                                   double *values, int store) {
   const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,7 +108,9 @@ __global__ void k_gather_values_v(i64 nnz, const unsigned *gptr, const int32_t *
 #pragma unroll
   for (int j = 0; j < 16; ++j) sum[j] = 0;
   for (unsigned i0 = b; i0 < e; i0 += 2) {
-    const i64 i1 = (i64)(unsigned)gsrc[i0], i2 = i0 + 1 < e ? (i64)(unsigned)gsrc[i0 + 1] : -1;
+    const unsigned r1 = (unsigned)gsrc[i0], r2 = i0 + 1 < e ? (unsigned)gsrc[i0 + 1] : 0u;
+    const bool t1 = SYMSRC && (r1 >> 31), t2 = SYMSRC && (r2 >> 31);
+    const i64 i1 = (i64)(SYMSRC ? r1 & 0x7fffffffu : r1), i2 = i0 + 1 < e ? (i64)(SYMSRC ? r2 & 0x7fffffffu : r2) : -1;
     const double *s1 = local + i1 * ncd, *s2 = local + (i2 >= 0 ? i2 : i1) * ncd;
     double v1[16], v2[16];
     if (ncd == 9) {  // 3 x 3 blocks (72 bytes, 8-byte aligned): four 16-byte loads + one instead of nine 8-byte loads per lane
@@ -122,6 +144,21 @@ __global__ void k_gather_values_v(i64 nnz, const unsigned *gptr, const int32_t *
         v1[j] = j < ncd ? s1[j] : 0.;
         v2[j] = j < ncd && i2 >= 0 ? s2[j] : 0.;
       }
+    }
+    if constexpr (SYMSRC) {  // (3 x 3 and 2 x 2 blocks: the transposition is a fixed permutation of the registers)
+      auto transpose = [&](double (&v)[16]) {
+        if (ncd == 9) {
+          double t;
+          t = v[1], v[1] = v[3], v[3] = t;
+          t = v[2], v[2] = v[6], v[6] = t;
+          t = v[5], v[5] = v[7], v[7] = t;
+        } else if (ncd == 4) {
+          const double t = v[1];
+          v[1] = v[2], v[2] = t;
+        }
+      };
+      if (t1) transpose(v1);
+      if (t2) transpose(v2);
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) sum[j] += v1[j];
@@ -1315,14 +1352,41 @@ __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
   }
 }
 
-int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s) {
+int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s, bool sym_sources) {
   if (!p->nnz) return NH_OK;
-  if (slots.nct * slots.ncr == 1)
+  if (sym_sources) {
+    NH_REQUIRE(p->gsrc_sym && slots.nct == slots.ncr && (slots.nct == 2 || slots.nct == 3), "gather: symmetric sources need their map and 2 x 2 / 3 x 3 blocks");
+    hipLaunchKernelGGL(k_gather_values_v<true>, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc_sym, p->grow, p->srowptr, local, slots, values, store);
+  } else if (slots.nct * slots.ncr == 1)
     hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, ld, p->nbt * p->nbr, slots,
                        values, store);
   else
-    hipLaunchKernelGGL(k_gather_values_v, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, slots, values, store);
+    hipLaunchKernelGGL(k_gather_values_v<false>, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, slots, values, store);
   NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+// the map for symmetric producers, derived from the gather map (once per pattern)
+int nh_gather_prepare_sym(nh_pattern *p, const nh_basis &test, const int32_t *elist, hipStream_t s) {
+  if (p->gsrc_sym) return NH_OK;
+  NH_REQUIRE(p->gsrc, "nh_gather_prepare_sym: the gather map comes first");
+  NH_REQUIRE(p->emap_len < (1ll << 31), "NH_MATRIX_GATHER: pattern too large for flagged 31-bit gather indices");
+  unsigned *canon = nullptr;
+  NH_CHECK_HIP(hipMalloc((void **)&canon, std::max<i64>(p->emap_len, 1) * 4));
+  hipError_t e = hipMalloc((void **)&p->gsrc_sym, std::max<i64>(p->emap_len, 1) * 4);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_gather_canon, dim3((unsigned)std::min<i64>(p->nelems, 1 << 20)), dim3(64), 0, s, p->nelems, elist, to_k(test), p->nbr, p->eoff, canon);
+    hipLaunchKernelGGL(k_gather_remap, dim3((unsigned)std::min<i64>((p->emap_len + 255) / 256, 1 << 16)), dim3(256), 0, s, p->emap_len, p->gsrc, canon, p->gsrc_sym);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
+  hipFree(canon);
+  if (e != hipSuccess) {
+    hipFree(p->gsrc_sym);
+    p->gsrc_sym = nullptr;
+    nh_set_error("nh_gather_prepare_sym failed: %s", hipGetErrorString(e));
+    return NH_EHIP;
+  }
   return NH_OK;
 }
 

@@ -394,6 +394,7 @@ int nh_pattern_free(nh_pattern *p) {
   hipFree(p->eoff);
   hipFree(p->bucket_store);
   hipFree(p->gsrc);
+  hipFree(p->gsrc_sym);
   hipFree(p->gptr);
   hipFree(p->grow);
   nh_fused_free(p->fused);

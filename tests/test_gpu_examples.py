@@ -393,9 +393,9 @@ def test_ragged_rational_workload_tiled():
     to 1e-13; the tool asserts it and prints the throughput -- 256 plates = 63 488 elements: profiles/r03_ragged_c4.md)'''
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # three arrangements of the element kernel, each against the reference's matrix: the default (two waves per element, symmetric node pairs m >= n mirrored on the
-    # way out), all node pairs (NUTILS_AMD_NO_SYM_GRAM), one wave per element (NUTILS_AMD_GENERIC_WAVES=1)
-    for extra in ({}, {'NUTILS_AMD_NO_SYM_GRAM': '1'}, {'NUTILS_AMD_GENERIC_WAVES': '1'}):
+    # four arrangements of the element kernel, each against the reference's matrix: the default (two waves per element, symmetric node pairs m >= n mirrored on the
+    # way out), all node pairs (NUTILS_AMD_NO_SYM_GRAM), one wave per element (NUTILS_AMD_GENERIC_WAVES=1), mirrored by the gather instead (NUTILS_AMD_SYM_SCRATCH=1)
+    for extra in ({}, {'NUTILS_AMD_NO_SYM_GRAM': '1'}, {'NUTILS_AMD_GENERIC_WAVES': '1'}, {'NUTILS_AMD_SYM_SCRATCH': '1'}):
         out = subprocess.run([sys.executable, 'tools/ragged_probe.py', '12', '2'], cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
         assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
         assert '2976 elements' in out.stdout and 'nh_assemble_matrix' in out.stdout
