@@ -168,11 +168,12 @@ __global__ __launch_bounds__(256) void k_matrix_generic(MatK p, FormK formarg) {
       if (p.use_w) {  // (never set for the blocks that take the Gram path below)
         const int ncd = form.ncr * form.nct;
         for (int t = lane; t < (q1 - q0) * nbr * ncd; t += NTG) {
-          int r = t;
-          const int c = r % form.nct; r /= form.nct;
-          const int d = r % form.ncr; r /= form.ncr;
-          const int n = r % nbr;
-          const int ql = r / nbr;
+          int r = t, c = 0, d = 0;
+          if (ncd > 1) {  // (scalar blocks: one division per item instead of three)
+            c = r % form.nct; r /= form.nct;
+            d = r % form.ncr; r /= form.ncr;
+          }
+          const int ql = r / nbr, n = r - ql * nbr;
           const double *dr = Dr + (ql * nbr + n) * S;
           const double wq = Jw[(q0 + ql) * JW + ND * ND];
           double *w = W + (size_t)t * S;
@@ -330,6 +331,45 @@ __global__ __launch_bounds__(256) void k_matrix_generic(MatK p, FormK formarg) {
                 else atomicAdd(p.values + slot, acc);
               }
           }
+        }
+      } else if (form.nct * form.ncr == 1 && !p.cq && p.sym && !p.exclusive) {
+        // scalar symmetric blocks (test == trial, C[a][b] == C[b][a]): the entries m >= n only, mirrored on the way out
+        const int np = nbt * (nbt + 1) / 2;
+        for (int k = lane; k < np; k += NTG) {
+          int m = (int)((sqrt(8. * k + 1.) - 1.) * .5);  // k = m (m + 1) / 2 + n, 0 <= n <= m
+          m += (m + 1) * (m + 2) / 2 <= k;
+          m -= m * (m + 1) / 2 > k;
+          const int n = k - m * (m + 1) / 2;
+          double acc = 0;
+          if (p.use_w) {
+            for (int q = q0; q < q1; ++q) {
+              const double *dt = Dt + ((q - q0) * nbt + m) * S, *w = W + ((size_t)(q - q0) * nbr + n) * S;
+#pragma unroll
+              for (int a = 0; a < S; ++a) acc += dt[a] * w[a];
+            }
+          } else {
+            for (int q = q0; q < q1; ++q) {
+              const double *dt = Dt + ((q - q0) * nbt + m) * S, *dr = Dr + ((q - q0) * nbr + n) * S;
+              double sq = 0;
+#pragma unroll
+              for (int a = 0; a < S; ++a) {
+                double t = 0;
+#pragma unroll
+                for (int b = 0; b < S; ++b) t += form.C[a * S + b] * dr[b];
+                sq += dt[a] * t;
+              }
+              acc += Jw[q * JW + ND * ND] * sq;
+            }
+          }
+          if (p.local) {
+            double *dst = p.local + (emap0 + m * nbr + n), *dst2 = p.local + (emap0 + n * nbr + m);
+            *dst = q0 ? *dst + acc : acc;
+            if (m != n) *dst2 = q0 ? *dst2 + acc : acc;
+            continue;
+          }
+          const i64 rowm = p.test.dofs[tdof0 + m], rown = p.test.dofs[tdof0 + n];
+          atomicAdd(p.values + p.srowptr[rowm] + p.emap[emap0 + m * nbr + n], acc);
+          if (m != n) atomicAdd(p.values + p.srowptr[rown] + p.emap[emap0 + n * nbr + m], acc);
         }
       } else
       for (int k = lane; k < nentries; k += NTG) {
