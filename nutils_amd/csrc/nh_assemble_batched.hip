@@ -1751,6 +1751,12 @@ int local_terms(const nh_matrix_terms_args *a, const MTermsK &m, const std::vect
   const bool same_tables = a->test.T_dev == a->trial.T_dev && a->test.tab_dev == a->trial.tab_dev;
   const size_t ldst = sizeof(double) * (size_t)a->nq * (1 + a->ndims) * (a->test.nb + (same_tables ? 0 : a->trial.nb));  // staged tables of one element class
   if (ldst > 48 * 1024) return NH_OK;  // (tables too large to stage: the batched kernel keeps the block)
+  if (getenv("NH_DEBUG_TERMS")) {
+    fprintf(stderr, "local_terms: key %d nterms %d npolys %d nfields %d tlen %zu:", key, m.nterms, m.npolys, a->nfields, tab.size());
+    for (int t = 0; t < m.nterms; ++t) fprintf(stderr, " [kind %d fld %d pol %d scale %d q %d]", (int)tab[m.toff[t]], (int)tab[m.toff[t] + 1], (int)tab[m.toff[t] + 2], m.scale[t] != nullptr, m.qoff[t] != 0);
+    for (int k = 0; k < m.npolys; ++k) fprintf(stderr, " {poly nv %d nt %d}", (int)tab[m.poff[k]], (int)tab[m.poff[k] + 1]);
+    fprintf(stderr, "\n");
+  }
   // the two-phase arrangement (k_local_terms2) for the blocks whose row-block threads repeat the point work; NUTILS_AMD_LOCAL_TERMS=1 keeps the kernel above
   const bool two_phase = !(getenv("NUTILS_AMD_LOCAL_TERMS") && atoi(getenv("NUTILS_AMD_LOCAL_TERMS")) == 1);
   bool launched2 = false;
@@ -1821,6 +1827,12 @@ int local_vterms(const nh_terms_args *a, const TermsK &m, const std::vector<doub
     if (a->blocks[b].nct != 1 || !same(a->blocks[b].test)) return NH_OK;
   for (int f = 0; f < a->nfields; ++f)
     if (a->fields[f].ncomp != 1 || !same(a->fields[f].basis)) return NH_OK;
+  if (getenv("NH_DEBUG_TERMS")) {
+    fprintf(stderr, "local_vterms: nelems %lld nterms %d npolys %d nfields %d nblocks %d tlen %zu:", (long long)a->nelems, m.nterms, m.npolys, a->nfields, a->nblocks, tab.size());
+    for (int t = 0; t < m.nterms; ++t) fprintf(stderr, " [blk %d fld %d pol %d C %d f %d scale %d q %d]", (int)tab[m.toff[t]], (int)tab[m.toff[t] + 1], (int)tab[m.toff[t] + 2], (int)tab[m.toff[t] + 3], (int)tab[m.toff[t] + 4], m.scale[t] != nullptr, m.qoff[t] != 0);
+    for (int k = 0; k < m.npolys; ++k) fprintf(stderr, " {poly nv %d nt %d}", (int)tab[m.poff[k]], (int)tab[m.poff[k] + 1]);
+    fprintf(stderr, "\n");
+  }
   VTermsK p;
   p.nelems = a->nelems, p.elist = a->elist_dev, p.nq = a->nq, p.weights = a->weights_dev;
   p.geom = m.geom, p.test = to_k(tb);
