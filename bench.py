@@ -476,7 +476,7 @@ def main():
                 tf = 1489. * threads / (kernel_ms * 1e-3) / 1e12
                 roofline['f64_valu'] = {'achieved': tf, 'peak': F64_MFMA_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / F64_MFMA_PEAK_TF, 'flop_per_element_thread': 1489,
                                         'f64_instructions_per_element_thread': 1060, 'element_threads': threads,
-                                        'note': 'executed arithmetic incl. halo recompute (1.27 x the elements); counters: profiles/r04_c2_pmc.md'}
+                                        'note': 'executed arithmetic incl. halo recompute (1.27 x the elements); counters: profiles/r04_c2_kernels.md section 2'}
             per = f'{wl_layers} x {a.n} x {a.n} per GPU' if world > 1 else f'{a.n}^3'
             workload = f'3D Poisson stiffness, {per} structured hex, p=1, 2x2x2 Gauss, {a.variant} geometry (BASELINE.json configs[1])'
         if inrun is not None:

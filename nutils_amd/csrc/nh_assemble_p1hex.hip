@@ -46,7 +46,7 @@ struct P1Args {
   int nbj, nbk;            // column tiles per axis (j, k)
   long long *tdbg;         // phase timers (ablation builds)
   int wbnd;                // cost weight (x16) of a plane of a J-boundary column in the work split of the skewed kernel
-  int debug;               // ablation switches (NH_P1HEX_DEBUG env): 1 = no LDS reduction, 2 = no HBM stores, 4 = no element math
+  int debug;               // ablation switches (NH_P1HEX_DEBUG env): 1 = no LDS reduction, 2 = no HBM stores, 4 = no element math; skewed kernel: 8 = no vertex loads / staging, 16 = every second line stored only
 };
 
 __device__ __forceinline__ int len_of(int X, int N) { return (X > 0) + 1 + (X < N - 1); }       // columns coupled along one axis
@@ -518,6 +518,9 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
       htarget += G / 64;
       NH_TICK(0)
       const bool mathrole = ((s - (A - 1)) & 1) == grp;
+#ifdef NH_P1HEX_PRIO  // experiment: issue priority by role (1 = arithmetic wave first, 2 = memory wave first)
+      if (mathrole == (NH_P1HEX_PRIO == 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
       if (mathrole) {
         // ---- arithmetic role: element layer s -------------------------------------------------------------------------------
         const int ej = lt / TK, ek = lt % TK;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
         NH_TICK(3)
       } else {
         // ---- memory role: vertex plane s+2 (for layer s+1, next slot), flush of plane s-1, recycling of the slot of plane s-2 ------
-        const bool needv = s + 1 < B;  // vertex plane s+2 for layer s+1 (next slot): loaded in front of the stores, staged behind them
+        const bool needv = s + 1 < B && !(DEBUG(p) & 8);  // vertex plane s+2 for layer s+1 (next slot): loaded in front of the stores, staged behind them
         double Vn[VPG][3];
 #pragma unroll
         for (int k = 0; k < VPG; ++k) load_vertex(needv ? s + 2 : -1, lt + k * G, J0, K0, Vn[k]);
@@ -562,6 +565,47 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
               below = sl_ < 9;
               return (VK + ok_ + 1) * NS + (sl_ >= 13 ? sl_ - 13 : (dJ_ * VK + dK_) * NS + 13 - sl_);
             };
+#ifdef NH_P1HEX_PIPEFLUSH
+            // Per-LINE software pipeline: the LDS reads of line i + D are in flight while line i is stored, so the first store leaves ~1.5 k cycles
+            // earlier and the reads of the plane hide behind the (throughput-bound) stores instead of preceding them.  No exec region around the
+            // stores: the lanes beyond the 202 pairs of a line repeat lane 201 (same address, same data) -- a branch here would make the
+            // compiler's wait for the vertex loads BEHIND the stores a vmcnt(0), i.e. a wait for the whole flush to drain (the join of the skipped
+            // path has the loads as its youngest operations); straight-line, it is vmcnt(stores issued since), which only needs the loads.
+            constexpr int D = NH_P1HEX_PIPEFLUSH;
+            const int ec = 2 * min(lt, 201);
+            bool belowA, belowB;
+            const int offA = source(ec, belowA), offB = source(ec + 1, belowB);
+            const double *sA = acc + (belowA ? slot_of(P - 1) : slot_of(P)) + offA;
+            const double *sB = acc + (belowB ? slot_of(P - 1) : slot_of(P)) + offB;
+            const int li = lt - 202;
+            const bool lone = li >= 0 && li < OJ;
+            bool belowL;
+            const int offL = source(404, belowL);
+            const double aL = acc[(belowL ? slot_of(P - 1) : slot_of(P)) + offL + (lone ? li : 0) * (VK * NS)];
+            const i64 stride8 = 8 * (i64)(9 * (int)T2);
+            char *l0 = reinterpret_cast<char *>(p.values + ((3 * (i64)P - 1) * T1 * T2 + 3 * (cumJ0 * T2) + 9 * (3 * (i64)K0 - 1)));
+            char *lp = l0 + 8 * ec;
+            double a0[OJ], a1[OJ];
+#pragma unroll
+            for (int i = 0; i < D && i < OJ; ++i) a0[i] = sA[i * (VK * NS)], a1[i] = sB[i * (VK * NS)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < OJ; ++i) {
+              if (i + D < OJ) a0[i + D] = sA[(i + D) * (VK * NS)], a1[i + D] = sB[(i + D) * (VK * NS)];
+              __builtin_amdgcn_sched_barrier(0);
+              const double2 v = make_double2(a0[i], a1[i]);
+              __builtin_memcpy(lp + i * stride8, &v, 16);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            half_arrive(hcnt);
+            arrived = true;
+            if (needv) {
+              stage_vertices();
+              staged = true;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (lone) *reinterpret_cast<double *>(l0 + li * stride8 + 8 * 404) = aL;
+#else
             bool belowA, belowB;
             const int offA = source(e < 405 ? e : 404, belowA), offB = source(e + 1 < 405 ? e + 1 : 404, belowB);
             const double *sA = acc + (belowA ? slot_of(P - 1) : slot_of(P)) + offA;
@@ -614,12 +658,14 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
             if (lt < 202) {
 #pragma unroll
               for (int i = 0; i < OJ; ++i) {
+                if ((DEBUG(p) & 16) && (i & 1)) continue;  // (ablation: half of the store bytes)
                 const double2 v = make_double2(a0[i], a1[i]);
                 __builtin_memcpy(lp + i * stride8, &v, 16);  // 8-byte aligned 16-byte store
               }
             }
 #endif
             if (lone) *reinterpret_cast<double *>(l0 + li * stride8 + 8 * 404) = aL;
+#endif
           } else {
             // 32 lanes per row (27 slots), 8 rows per pass, two passes per K line
             constexpr int RPP = G / 32, KP = (OK + RPP - 1) / RPP;
@@ -653,7 +699,7 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
                   char *lp = reinterpret_cast<char *>(line);
 #pragma unroll
                   for (int oj = 0; oj < OJ; ++oj) {
-                    *reinterpret_cast<double *>(lp + voff8) = v[kp][oj];
+                    if (!((DEBUG(p) & 16) && (oj & 1))) *reinterpret_cast<double *>(lp + voff8) = v[kp][oj];
                     lp += stride8;
                   }
                 }
@@ -664,7 +710,7 @@ __global__ __launch_bounds__(2 * TJ * TK) NH_WPE void k_p1hex_skew(P1Args p) {
                   const int loJ = J > 0, hiJ = J < N1 - 1, lenJ = loJ + 1 + hiJ;
                   const int flag = loI | loJ << 1 | loK << 2 | hiI << 3 | hiJ << 4 | hiK << 5;
                   const unsigned voff = (unsigned)(lenI * lenJ * cumK + ((dI + loI) * lenJ + (dJ + loJ)) * lenK + (dK + loK));
-                  if (kact && J < N1 && (flag & need) == need) line[voff] = v[kp][oj];
+                  if (kact && J < N1 && (flag & need) == need && !((DEBUG(p) & 16) && (oj & 1))) line[voff] = v[kp][oj];
                   line += lenI * lenJ * (int)T2;
                 }
               }
