@@ -62,6 +62,9 @@ def main(modules):
         matched = Counter(st['matched'])
         print(f'{name}: {res.testsRun} reference tests, {len(res.failures)} failures, {len(res.errors)} errors; systems assembled from plans: {matched["System"]}; '
               f'unmatched systems: {sum(1 for f in st["fallback"] if isinstance(f, str))}')
+        reasons = Counter(f for f in st['fallback'] if isinstance(f, str))
+        if reasons:
+            print('    declined: ' + '; '.join(f'{n} x {r}' for r, n in reasons.most_common()))
         ok = ok and res.wasSuccessful() and res.testsRun > 0 and matched['System'] > 0
     # the basis used as an array, through function.as_csr / function.eval
     from nutils import mesh, function
