@@ -390,16 +390,28 @@ class _MatrixPlan:
 
     def __init__(self, terms):
         smp0, itg0, _ = terms[0]
-        for smp, itg, fac in terms:
+        by_sample = {}
+        for term in terms:
+            smp, itg, fac = term
             if itg.B is None or not (itg.rows and itg.cols):
                 raise ValueError('as_csr needs a matrix-valued integral (both dof axes exposed)')
-            if smp is not smp0:
-                raise NotImplementedError('matrix terms on different samples in one as_csr: evaluate them separately and add the matrices')
             if not (itg.test.basis is itg0.test.basis and itg.trial.basis is itg0.trial.basis and itg.test.ncomp == itg0.test.ncomp
                     and itg.trial.ncomp == itg0.trial.ncomp):
                 raise NotImplementedError('matrix terms with different bases')
+            by_sample.setdefault(id(smp), []).append(term)
         self.terms = terms
         self.test, self.trial = itg0.test, itg0.trial
+        self.parts = None
+        if len(by_sample) > 1:
+            # Terms on several samples (a volume integral + boundary terms in one form: evaluable.py:6841-6895 runs one loop per sample and the
+            # dedup of evaluable.py:588-616 sees the triplets of all of them): one plan per sample, the CSR of the sum is the UNION of their
+            # patterns.  Largest sample first -- its pattern usually contains the others (a boundary term couples dofs of one parent element).
+            groups = sorted(by_sample.values(), key=lambda ts: -ts[0][0].nlist)
+            self.parts = [_MatrixPlan(ts) for ts in groups]
+            self.mask = numpy.logical_or.reduce([p.mask for p in self.parts])
+            self.smp0 = self.parts[0].smp0
+            self._merge = None
+            return
         self.mask = numpy.zeros((self.test.ncomp, self.trial.ncomp), dtype=bool)
         for smp, itg, fac in terms:
             if itg.qform is not None:  # scalar fields: one block
@@ -637,7 +649,45 @@ class _MatrixPlan:
                                           values=values, terms=tl, fields=fields, polys=polys)
         return rest
 
+    def _run_parts(self, arguments):
+        '''Sum of the per-sample matrices.  The symbolic part (union of the sorted-unique patterns, position of every entry of a part in it) is
+        computed once per set of index arrays (they are cached by the patterns, so re-assemblies find the same tensors); the values of a
+        re-assembly are added at the precomputed positions by nh_monomial (unique positions per part: no atomics, fixed order).'''
+        import torch
+        results = [p.run(arguments) for p in self.parts]
+        ncols = results[0][3]
+        key = tuple((r[1].data_ptr(), r[2].data_ptr(), r[2].numel()) for r in results)
+        if self._merge is None or self._merge['key'] != key:
+            keys = []
+            for values, rowptr, colidx, nc in results:
+                if nc != ncols or rowptr.numel() != results[0][1].numel():
+                    raise ValueError('matrix terms of different shape in one integral')
+                rows = torch.repeat_interleave(torch.arange(rowptr.numel() - 1, device=rowptr.device, dtype=torch.int64), rowptr[1:] - rowptr[:-1])
+                keys.append(rows * ncols + colidx)
+            ukeys = torch.unique(torch.cat(keys))  # sorted
+            if ukeys.numel() == keys[0].numel():  # the first pattern contains the others: its arrays ARE the union
+                rowptr_u, colidx_u, contained = results[0][1], results[0][2], True
+            else:
+                nrows = results[0][1].numel() - 1
+                rows_u = torch.div(ukeys, ncols, rounding_mode='floor')
+                colidx_u = (ukeys - rows_u * ncols).contiguous()
+                rowptr_u = torch.searchsorted(rows_u, torch.arange(nrows + 1, device=ukeys.device, dtype=torch.int64)).to(torch.int64).contiguous()
+                contained = False
+            pos = [None if contained and i == 0 else torch.searchsorted(ukeys, k).to(torch.int64).contiguous() for i, k in enumerate(keys)]
+            self._merge = dict(key=key, keep=[(r[1], r[2]) for r in results], rowptr=rowptr_u, colidx=colidx_u, pos=pos, n=ukeys.numel())
+        m = self._merge
+        if m['pos'][0] is None:
+            out = results[0][0]  # (a fresh array of this assembly)
+        else:
+            out = device.zeros(m['n'], 'float64')
+        for (values, _, _, _), pos in zip(results, m['pos']):
+            if pos is not None:
+                kernels.monomial(values, [], [], out, out_index=pos)
+        return out, m['rowptr'], m['colidx'], ncols
+
     def run(self, arguments=None):
+        if self.parts is not None:
+            return self._run_parts(arguments)
         fast = self._p1hex_laplace(arguments)
         if fast is not None and not fast[4]:
             return fast[:4]

@@ -32,12 +32,13 @@ from nutils_amd import seam  # noqa: E402
 OUT = os.environ.get('NUTILS_AMD_PLAN_OUT') or os.path.join(ROOT, 'tests', 'golden', 'plans')
 
 
-def emit(name, array, arguments):
-    '''match `array`, store the plan with the arguments and the reference's result (CSR of the array flattened to two axes for matrices)'''
+def emit(name, array, arguments, row_axes=None):
+    '''match `array`, store the plan with the arguments and the reference's result (CSR of the array flattened to two axes for matrices: the first
+    `row_axes` axes are the rows -- half of the axes unless given, which is wrong for blocks of a vector against a scalar field)'''
     plan = seam.match(array)
     expect = {}
     if plan['kind'] == 'matrix':
-        flat = rf.Array.cast(numpy.reshape(rf.Array.cast(array), (int(numpy.prod(array.shape[:array.ndim // 2])), -1)))
+        flat = rf.Array.cast(numpy.reshape(rf.Array.cast(array), (int(numpy.prod(array.shape[:array.ndim // 2 if row_axes is None else row_axes])), -1)))
         expect['values'], expect['rowptr'], expect['colidx'] = rf.eval(rf.as_csr(flat), arguments)
     elif plan['kind'] == 'vector':
         expect['vector'] = numpy.asarray(rf.eval(array, arguments))
@@ -180,6 +181,19 @@ def main():
         emit(f'c4x_example_residual_{a}', ra, args)
         for b in 'φη':
             emit(f'c4x_example_jacobian_{a}{b}', rf.derivative(ra, b), args)
+    # ---- examples/drivencavity.py, unmodified (Taylor-Hood: velocity degree 2, pressure degree 1 in ONE functional; weak tangential conditions): the
+    # Stokes residual captured at its System -- volume terms + the Nitsche boundary terms with n, uwall; rectangular blocks of mixed degree -------------
+    captured, _ = run_example('drivencavity', nelems=3, etype='square', degree=2, reynolds=100., compatible=False, strongbc=False)
+    stokes = next(res for res, trial, test in captured if trial == 'u,p')
+    rngs = numpy.random.default_rng(11)
+    shapes = {k: v.shape for k, v in rf.arguments_for(stokes).items()}
+    args = {k: rngs.normal(size=shp) for k, shp in shapes.items()}
+    for t in 'vq':
+        rt = rf.derivative(stokes, t)
+        emit(f'stokes_th_residual_{t}', rt, args)
+        for a in 'up':
+            if (t, a) != ('q', 'p'):  # (no pressure-pressure block)
+                emit(f'stokes_th_jacobian_{t}{a}', rf.derivative(rt, a), args, row_axes=len(shapes[t]))
     # ---- configs[4]: NURBS plate with hole, hierarchical refinement towards the hole, p = 3 truncated hierarchical splines made rational -------
     levels, degree, radius, poisson = 4, 3, .5, .3
     topo, geom0 = mesh.rectilinear([1, 2])
