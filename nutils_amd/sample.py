@@ -52,9 +52,12 @@ class _BasisTables:
             w = device.to_dev(basis.weights, 'float64')
             W = dW = None
             if basis.W is not None:
-                if basis.W.shape != (ne, nq) or basis.dW.shape != (ne, nq, nd):
+                Wt, dWt = smp._per_element(basis.W, 'weight function table', by_list=False), smp._per_element(basis.dW, 'weight function table', by_list=False)
+                if Wt.shape != (ne, nq) or dWt.shape != (ne, nq, nd):
                     raise ValueError('weight function tables do not match this sample')
-                W, dW = device.to_dev(basis.W, 'float64'), device.to_dev(basis.dW, 'float64')
+                if smp.elist is not None:
+                    Wt = numpy.where(Wt == 0, 1., Wt)  # (rows of unlisted elements: never read)
+                W, dW = device.to_dev(Wt, 'float64'), device.to_dev(dWt, 'float64')
             if pt.off is None:  # uniform nb: expand the class tables to per-element tables, then transform in place
                 S = 1 + nd
                 cls = pt.tab.long() if pt.tab is not None else device.torch().zeros(ne, dtype=device.torch().long, device='cuda')
@@ -145,20 +148,40 @@ class Sample:
             t = self._tables[id(basis)] = _BasisTables(self, basis)
         return t
 
+    def _per_element(self, table, what, by_list=True):
+        '''A table [elements][points]... as the kernels index it: by ELEMENT of the topology.  Producers that know a sample of an element subset
+        only (a boundary side, the cells of one hierarchical level) hand it over by position in the sample's element list (`by_list`: what the
+        producer means when both readings fit): spread to element rows.'''
+        table = numpy.asarray(table)
+        fits_elements = table.shape[:2] == (self.nelems, self.points.npoints)
+        fits_list = self.elist is not None and table.shape[:2] == (self.nlist, self.points.npoints)
+        if fits_list and (by_list or not fits_elements) and not (fits_elements and numpy.array_equal(self.elist, numpy.arange(self.nelems))):
+            if len(numpy.unique(self.elist)) != self.nlist:
+                raise NotImplementedError(f'{what} per list position on a sample that lists an element twice')
+            full = numpy.zeros((self.nelems,) + table.shape[1:], dtype=table.dtype)
+            if full.ndim == 4:  # (Jacobians of unlisted elements: identity, never read, but never singular either)
+                full[:] = numpy.eye(table.shape[2], table.shape[3])
+            full[numpy.asarray(self.elist)] = table
+            return full
+        if fits_elements:
+            return table
+        raise ValueError(f'{what} does not match this sample')
+
     def geometry(self, geom):
         def make():
             if isinstance(geom, function.IsoGeometry):
                 t = self.tables(geom.basis)
-                return kernels.geometry_iso(geom.basis.nb, t.T, t.dofs, device.to_dev(geom.verts, 'float64'), self.bnd_axis)
+                if not t.nb:
+                    raise NotImplementedError('isoparametric geometry on a basis with a varying number of functions per element')
+                return kernels.geometry_iso(t.nb, t.T, t.dofs, device.to_dev(geom.verts, 'float64'), self.bnd_axis)
             if isinstance(geom, (function.RectilinearGeometry, function.BoxGeometry)):
                 origin, size = geom.element_boxes()
                 if len(origin) != self.nelems:
                     raise ValueError('geometry does not match the sample')
                 return kernels.geometry_box(device.to_dev(origin, 'float64'), device.to_dev(size, 'float64'), self.bnd_axis)
             if isinstance(geom, function.TabulatedGeometry):
-                if geom.x.shape[:2] != (self.nelems, self.points.npoints):
-                    raise ValueError('tabulated geometry does not match this sample')
-                return kernels.geometry_tab(device.to_dev(geom.jac, 'float64'), device.to_dev(geom.x, 'float64'), self.bnd_axis)
+                x, jac = self._per_element(geom.x, 'tabulated geometry'), self._per_element(geom.jac, 'tabulated geometry')
+                return kernels.geometry_tab(device.to_dev(jac, 'float64'), device.to_dev(x, 'float64'), self.bnd_axis)
             raise TypeError(f'unsupported geometry {type(geom).__name__}')
         return _cached(self._geoms, geom, make)
 
@@ -395,10 +418,14 @@ class _MatrixPlan:
             smp, itg, fac = term
             if itg.B is None or not (itg.rows and itg.cols):
                 raise ValueError('as_csr needs a matrix-valued integral (both dof axes exposed)')
-            if not (itg.test.basis is itg0.test.basis and itg.trial.basis is itg0.trial.basis and itg.test.ncomp == itg0.test.ncomp
-                    and itg.trial.ncomp == itg0.trial.ncomp):
+            group = by_sample.setdefault(id(smp), [])
+            group.append(term)
+            first = group[0][1]
+            # one pair of basis objects per sample; across samples the same dof spaces (a rational basis comes with the weight function tabulated per
+            # sample: one object each)
+            if not (itg.test.basis is first.test.basis and itg.trial.basis is first.trial.basis and itg.test.ncomp == itg0.test.ncomp
+                    and itg.trial.ncomp == itg0.trial.ncomp and itg.test.basis.ndofs == itg0.test.basis.ndofs and itg.trial.basis.ndofs == itg0.trial.basis.ndofs):
                 raise NotImplementedError('matrix terms with different bases')
-            by_sample.setdefault(id(smp), []).append(term)
         self.terms = terms
         self.test, self.trial = itg0.test, itg0.trial
         self.parts = None
@@ -1102,8 +1129,18 @@ def evaluate(f, arguments):
     out = None
     if exposed:
         a0 = exposed[0].test
-        if len(exposed) != len(f.terms) or not all(itg.test.basis is a0.basis and itg.test.ncomp == a0.ncomp for itg in exposed):
+        if len(exposed) != len(f.terms) or not all(itg.test.basis.ndofs == a0.basis.ndofs and itg.test.ncomp == a0.ncomp for itg in exposed):
             raise NotImplementedError('vector terms with different test spaces')
+        if not all(itg.test.basis is a0.basis for itg in exposed):
+            # the same dof space through several basis objects (a rational basis tabulated per sample): one pass per object, summed in term order
+            groups = {}
+            for term in f.terms:
+                groups.setdefault(id(term[1].test.basis), []).append(term)
+            total = None
+            for terms in groups.values():
+                part = evaluate(function.Integral(terms), arguments)
+                total = part if total is None else total + part
+            return total
         out = device.zeros(a0.basis.ndofs * a0.ncomp, 'float64')
     scalar = [device.zeros(1, 'float64'), 0.]  # device accumulator, host-side addend
     if out is not None:

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+'''TEST INFRASTRUCTURE (build container only).  Sweep for the composition that cannot run in one process (the reference exists only in the
+build container, the GPU only on the box): the UNMODIFIED examples run with the seam installed and the CPU evaluator tests/af_oracle.py as executor; every
+distinct plan the hooks hand to the executor is written -- with the arguments of its first evaluation and the evaluator's result, which the example's own unit
+tests check against the reference's embedded vectors -- to a directory that tools/hip_plan_sweep.py replays through seam.execute (the C ABI) on the GPU box.
+
+  python tools/hip_plan_capture.py OUTDIR [example ...]'''
+import os
+import sys
+import tempfile
+import unittest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = '/root/reference'
+sys.path[:0] = [os.path.join(ROOT, 'oracle', 'refshim'), REF + '/src', REF, ROOT, os.path.join(ROOT, 'tests')]
+os.environ.setdefault('NUTILS_NPROCS', '1')
+os.environ.setdefault('NUTILS_MATRIX', 'scipy')
+import numpy  # noqa: E402
+import nutils  # noqa: E402
+nutils.__path__.append(os.path.join(ROOT, 'oracle', 'refshim', 'nutils_ext'))
+import matplotlib  # noqa: E402
+matplotlib.use('Agg')
+from nutils_amd import seam  # noqa: E402
+import af_oracle  # noqa: E402
+import nutils.testing  # noqa: E402
+
+
+def main(out, modules):
+    import importlib
+    out = os.path.abspath(out)
+    os.makedirs(out, exist_ok=True)
+    orig = nutils.testing.TestCase.assertAlmostEqual64
+
+    def snapped(self, actual, desired, **kwargs):  # (as tests/seam_hook_run.py)
+        actual = numpy.asarray(actual, dtype=float)
+        return orig(self, numpy.where(numpy.abs(actual) < 1e-12, 0., actual), desired, **kwargs)
+    nutils.testing.TestCase.assertAlmostEqual64 = snapped
+    os.chdir(tempfile.mkdtemp())
+    for name in modules:
+        seen, count = {}, [0]
+
+        def executor(plan, arguments):
+            res = af_oracle.evaluate(seam.build(plan).integral, seam.prepare_arguments(plan, arguments))
+            if plan['kind'] == 'matrix':
+                expect = dict(values=res[0], rowptr=res[1], colidx=res[2])
+                ret = res
+            elif plan['kind'] == 'scalar':
+                ret = float(res)
+                expect = dict(scalar=numpy.asarray(ret))
+            else:
+                ret = numpy.asarray(res, dtype=float).reshape(plan['shape'])
+                expect = dict(vector=ret)
+            if id(plan) not in seen:
+                seen[id(plan)] = plan  # (kept alive: ids are not recycled)
+                for k, v in (arguments or {}).items():
+                    if numpy.asarray(v).dtype.kind in 'fiub':
+                        expect['arg_' + k] = numpy.asarray(v, dtype=float)
+                clean = {k: v for k, v in plan.items() if not k.startswith('_')}
+                seam.save(os.path.join(out, f'{name}_{count[0]:03d}.npz'), clean, expect)
+                count[0] += 1
+            return ret
+        mod = importlib.import_module('examples.' + name)
+        st = seam.install(executor)
+        try:
+            res = unittest.TextTestRunner(verbosity=0, stream=open(os.devnull, 'w')).run(unittest.defaultTestLoader.loadTestsFromTestCase(mod.test))
+        finally:
+            seam.uninstall()
+        print(f'{name}: {res.testsRun} reference tests, {len(res.failures)} failures, {len(res.errors)} errors; {count[0]} distinct plans written')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2:] or ['laplace', 'elasticity', 'poisson', 'platewithhole', 'adaptivity', 'cahnhilliard', 'drivencavity', 'burgers', 'finitestrain'])
