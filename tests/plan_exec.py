@@ -56,3 +56,37 @@ def compare(out, expect, rtol=1e-13):
         err = abs(float(out['scalar']) - float(expect['scalar'])) / abs(float(expect['scalar']))
     assert err < rtol, err
     return err
+
+
+# ---- plans captured from the unmodified examples (tools/hip_plan_capture.py): every distinct plan the installed seam handed to its executor while the
+# examples' own unit tests ran, with the arguments of its first evaluation and the result of the CPU evaluator tests/af_oracle.py (checked against the
+# reference's embedded vectors by those unit tests in the same run) -----------------------------------------------------------------------------------
+EXAMPLE_PLANS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'plans_examples')
+
+
+def example_names():
+    return sorted(f[:-4] for f in os.listdir(EXAMPLE_PLANS) if f.endswith('.npz'))
+
+
+def load_example(name):
+    from nutils_amd import seam
+    plan, expect = seam.load(os.path.join(EXAMPLE_PLANS, name + '.npz'))
+    args = {k[4:]: v for k, v in expect.items() if k.startswith('arg_')}
+    return plan, args, {k: v for k, v in expect.items() if not k.startswith('arg_')}
+
+
+def compare_example(plan, out, expect, args, rtol=1e-12):
+    '''index arrays exact; values relative to the largest entry.  Vectors / scalars that are rounding residue in the reference (a residual at its own
+    solution, a squared distance at the projection) have no relative accuracy: their scale is at least (largest term coefficient) x (argument scale).'''
+    if plan['kind'] == 'matrix':
+        assert numpy.array_equal(out[1], expect['rowptr']) and numpy.array_equal(out[2], expect['colidx'])
+        err = numpy.abs(out[0] - expect['values']).max() / max(numpy.abs(expect['values']).max(), 1e-300)
+    else:
+        ref = numpy.asarray(expect['vector'] if plan['kind'] == 'vector' else expect['scalar'], dtype=float)
+        mine = numpy.asarray(out, dtype=float).reshape(ref.shape)
+        coef = max([1.] + [abs(float(t['fac'])) * max([float(numpy.abs(numpy.asarray(t[k], dtype=float)).max()) for k in ('B', 'L', 'f0') if t.get(k) is not None] + [0.])
+                           for t in plan['terms']])
+        scale = max(numpy.abs(ref).max(), coef * max([0.] + [float(numpy.abs(v).max()) ** (2 if plan['kind'] == 'scalar' else 1) for v in args.values() if numpy.size(v)]))
+        err = numpy.abs(mine - ref).max() / max(scale, 1e-300)
+    assert err < rtol, err
+    return err

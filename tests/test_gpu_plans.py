@@ -31,3 +31,15 @@ def test_reexecution_reuses_the_built_plan():
     b = seam.execute(plan, {k: 2. * v for k, v in args.items()})
     assert plan['_built'] is built
     assert numpy.abs(a - expect['vector']).max() < 1e-13 * numpy.abs(expect['vector']).max() and numpy.abs(a - b).max() > 1e-3
+
+
+@pytest.mark.parametrize('name', plan_exec.example_names())
+def test_example_plan_through_the_c_abi(name):
+    '''Every distinct plan the installed seam emitted while the unit tests of nine UNMODIFIED reference examples ran (laplace, elasticity, poisson,
+    platewithhole, adaptivity, cahnhilliard, drivencavity, burgers, finitestrain; tools/hip_plan_capture.py in the build container), replayed through
+    seam.execute = the C ABI: the half of "seam + HIP + reference in one process" that can run on the GPU box.  Boundary sides as element subsets with
+    tabulated NURBS geometries, hierarchical (ragged) bases, rational bases tabulated per sample, Taylor-Hood blocks, DG projections.'''
+    from nutils_amd import seam
+    plan, args, expect = plan_exec.load_example(name)
+    out = seam.execute(plan, args)
+    plan_exec.compare_example(plan, out, expect, args)

@@ -57,3 +57,17 @@ def test_plan_files_round_trip(tmp_path):
             assert numpy.array_equal(numpy.asarray(a[k], dtype=object if a[k] is None or isinstance(a[k], dict) else None), numpy.asarray(b[k], dtype=object if b[k] is None or isinstance(b[k], dict) else None)) \
                 if not isinstance(b[k], dict) else set(a[k]) == set(b[k])
     assert numpy.array_equal(expect2['values'], expect['values'])
+
+
+@pytest.mark.parametrize('example', sorted({n.rsplit('_', 1)[0] for n in plan_exec.example_names()}))
+def test_example_plans_on_the_cpu_evaluator(example):
+    '''the plans captured from the unmodified examples (tools/hip_plan_capture.py; replayed through the C ABI by tests/test_gpu_plans.py) load, build and
+    give the stored results on the CPU evaluator -- the fixtures are what the current matcher / plan format produce'''
+    from nutils_amd import seam
+    import af_oracle
+    names = [n for n in plan_exec.example_names() if n.rsplit('_', 1)[0] == example]
+    assert names
+    for name in names:
+        plan, args, expect = plan_exec.load_example(name)
+        out = af_oracle.evaluate(seam.build(plan).integral, seam.prepare_arguments(plan, args))
+        plan_exec.compare_example(plan, out, expect, args, rtol=1e-10)
