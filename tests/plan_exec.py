@@ -69,10 +69,14 @@ def example_names():
 
 
 def load_example(name):
+    '''-> plan, arguments, expected result, (arguments, expected result) of a later evaluation of the same plan or None'''
     from nutils_amd import seam
     plan, expect = seam.load(os.path.join(EXAMPLE_PLANS, name + '.npz'))
     args = {k[4:]: v for k, v in expect.items() if k.startswith('arg_')}
-    return plan, args, {k: v for k, v in expect.items() if not k.startswith('arg_')}
+    args2 = {k[5:]: v for k, v in expect.items() if k.startswith('arg2_')}
+    later = {k[:-1]: v for k, v in expect.items() if k in ('values2', 'rowptr2', 'colidx2', 'vector2', 'scalar2')}
+    first = {k: v for k, v in expect.items() if k in ('values', 'rowptr', 'colidx', 'vector', 'scalar')}
+    return plan, args, first, (args2, later) if later else None
 
 
 def compare_example(plan, out, expect, args, rtol=1e-12):

@@ -40,6 +40,9 @@ def test_example_plan_through_the_c_abi(name):
     seam.execute = the C ABI: the half of "seam + HIP + reference in one process" that can run on the GPU box.  Boundary sides as element subsets with
     tabulated NURBS geometries, hierarchical (ragged) bases, rational bases tabulated per sample, Taylor-Hood blocks, DG projections.'''
     from nutils_amd import seam
-    plan, args, expect = plan_exec.load_example(name)
+    plan, args, expect, later = plan_exec.load_example(name)
     out = seam.execute(plan, args)
     plan_exec.compare_example(plan, out, expect, args)
+    if later is not None:  # the same built plan with the arguments of a later Newton iteration / time step
+        out = seam.execute(plan, later[0])
+        plan_exec.compare_example(plan, out, later[1], later[0])

@@ -68,6 +68,7 @@ def test_example_plans_on_the_cpu_evaluator(example):
     names = [n for n in plan_exec.example_names() if n.rsplit('_', 1)[0] == example]
     assert names
     for name in names:
-        plan, args, expect = plan_exec.load_example(name)
-        out = af_oracle.evaluate(seam.build(plan).integral, seam.prepare_arguments(plan, args))
-        plan_exec.compare_example(plan, out, expect, args, rtol=1e-10)
+        plan, args, expect, later = plan_exec.load_example(name)
+        for a, e in [(args, expect)] + ([later] if later else []):
+            out = af_oracle.evaluate(seam.build(plan).integral, seam.prepare_arguments(plan, a))
+            plan_exec.compare_example(plan, out, e, a, rtol=1e-10)

@@ -62,14 +62,26 @@ def main(out, modules):
             else:
                 ret = numpy.asarray(res, dtype=float).reshape(plan['shape'])
                 expect = dict(vector=ret)
+            numeric = {k: numpy.asarray(v, dtype=float) for k, v in (arguments or {}).items() if numpy.asarray(v).dtype.kind in 'fiub'}
             if id(plan) not in seen:
-                seen[id(plan)] = plan  # (kept alive: ids are not recycled)
-                for k, v in (arguments or {}).items():
-                    if numpy.asarray(v).dtype.kind in 'fiub':
-                        expect['arg_' + k] = numpy.asarray(v, dtype=float)
-                clean = {k: v for k, v in plan.items() if not k.startswith('_')}
-                seam.save(os.path.join(out, f'{name}_{count[0]:03d}.npz'), clean, expect)
+                for k, v in numeric.items():
+                    expect['arg_' + k] = v
+                seen[id(plan)] = dict(plan=plan, path=os.path.join(out, f'{name}_{count[0]:03d}.npz'), first=expect, args=numeric, later=False)  # (plan kept alive: ids are not recycled)
+                seam.save(seen[id(plan)]['path'], {k: v for k, v in plan.items() if not k.startswith('_')}, expect)
                 count[0] += 1
+            else:
+                # a LATER evaluation of the same plan with other arguments (a Newton iteration, the next time step): stored once, as `*2` / `arg2_*`,
+                # so that the replay re-executes the built plan with new arguments
+                rec = seen[id(plan)]
+                same = set(numeric) == set(rec['args']) and all(numpy.array_equal(numeric[k], rec['args'][k]) for k in numeric)
+                if not rec['later'] and not same and plan['kind'] != 'matrix' or not rec['later'] and not same and any(t.get('fpoly') is not None for t in plan['terms']):
+                    rec['later'] = True
+                    both = dict(rec['first'])
+                    for k, v in expect.items():
+                        both[k + '2'] = v
+                    for k, v in numeric.items():
+                        both['arg2_' + k] = v
+                    seam.save(rec['path'], {k: v for k, v in plan.items() if not k.startswith('_')}, both)
             return ret
         if isinstance(name, tuple):  # a run of main(**kwargs) at a larger size: no embedded vectors to check, the evaluator's results are the expectation
             module, tag, kwargs = name
