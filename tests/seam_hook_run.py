@@ -53,10 +53,12 @@ def main(modules):
     os.chdir(tempfile.mkdtemp())
     ok = True
     for name in modules:
+        name, _, only = name.partition(':')  # `module:test_a,test_b` runs the named tests of the example only
         mod = importlib.import_module('examples.' + name)
         st = seam.install(execute_oracle)
         try:
-            res = unittest.TextTestRunner(verbosity=0, stream=open(os.devnull, 'w')).run(unittest.defaultTestLoader.loadTestsFromTestCase(mod.test))
+            suite = unittest.defaultTestLoader.loadTestsFromNames(only.split(','), mod.test) if only else unittest.defaultTestLoader.loadTestsFromTestCase(mod.test)
+            res = unittest.TextTestRunner(verbosity=0, stream=open(os.devnull, 'w')).run(suite)
         finally:
             seam.uninstall()
         matched = Counter(st['matched'])
