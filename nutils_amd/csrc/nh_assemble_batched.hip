@@ -1998,6 +1998,13 @@ int build_terms(const nh_terms_args *a, hipStream_t stream, TermsK &p, std::vect
   const size_t tsz = p.tstage ? (size_t)a->blocks[0].test.nb * a->nq * S + 2 : 0;
   if (tsz * sizeof(double) > 16 * 1024) p.tstage = 0;
   for (int f = 0; f < a->nfields; ++f) p.fields[f].tsame = p.tstage;
+  {
+    // ... within an LDS budget: with few points per element (one-point rules, boundary sides) NTB / nq elements of a wide vector-valued basis do not fit
+    // (27 nodes x 3 components x 256 elements: 217 kB); half of the LDS keeps two workgroups per CU, one element per batch is the floor
+    const size_t fixed = (size_t)p.tlen + (size_t)NTB * p.fct * S + (p.tstage ? tsz : 0), per_elem = (size_t)a->nq * p.ct * S + (size_t)p.uesz;
+    const size_t limit = 160 * 1024 / sizeof(double), budget = limit / 2;
+    if (per_elem && fixed + (size_t)p.eb * per_elem > limit) p.eb = (int)std::max<size_t>(1, budget > fixed ? (budget - fixed) / per_elem : 1);
+  }
   *ldsbytes = sizeof(double) * ((size_t)p.tlen + (size_t)p.eb * a->nq * p.ct * S + (size_t)NTB * p.fct * S + (size_t)p.eb * p.uesz + (p.tstage ? tsz : 0));
   p.table = nullptr;
   return NH_OK;

@@ -81,13 +81,17 @@ def evaluate(integral, arguments=None):
     rows, cols = kinds.pop()
     geos = {}
     scalar, vec, coo = 0., None, []
-    mask = None
+    masks = {}
     if rows and cols:
+        # component blocks that a sample's terms couple: the reference runs one loop per sample and concatenates the triplets (evaluable.py:6841-6895,
+        # :588-616), so a block that only the boundary terms couple is structurally absent from the rows of interior elements (checked against the
+        # reference: tools/hip_plan.py `mixed_blocks_*`)
         t0, r0 = integral.terms[0][1].test, integral.terms[0][1].trial
-        mask = numpy.zeros((t0.ncomp, r0.ncomp), dtype=bool)
-        for _, itg, _ in integral.terms:
-            mask |= True if itg.qform is not None else (numpy.abs(itg.B).sum(axis=(1, 3)) != 0)
+        for smp, itg, _ in integral.terms:
+            m = masks.setdefault(id(smp), numpy.zeros((t0.ncomp, r0.ncomp), dtype=bool))
+            m |= True if itg.qform is not None else (numpy.abs(itg.B).sum(axis=(1, 3)) != 0)
     for smp, itg, fac in integral.terms:
+        mask = masks.get(id(smp))
         gkey = (id(smp), id(itg.measure))
         if gkey not in geos:
             geos[gkey] = _Geo(smp, itg.measure)

@@ -194,6 +194,19 @@ def main():
         for a in 'up':
             if (t, a) != ('q', 'p'):  # (no pressure-pressure block)
                 emit(f'stokes_th_jacobian_{t}{a}', rf.derivative(rt, a), args, row_axes=len(shapes[t]))
+    # ---- component blocks per sample: a block-diagonal volume form + a boundary form that couples all components.  The reference runs one loop per
+    # sample and concatenates the triplets, so the off-diagonal blocks exist in the rows of the boundary elements only (nnz 364, not 520) --------------
+    domain, geom = mesh.rectilinear([3, 4])
+    ns = Namespace()
+    ns.x = geom
+    ns.Σ = rf.ones([2])
+    ns.define_for('x', gradient='∇', normal='n', jacobians=('dV', 'dS'))
+    ns.u = domain.field('u', btype='std', degree=1, shape=[2])
+    ns.v = rf.replace_arguments(ns.u, 'u:v')
+    mixed = domain.integral('∇_j(v_i) ∇_j(u_i) dV' @ ns, degree=2) + domain.boundary['right'].integral('v_i Σ_i u_j Σ_j dS' @ ns, degree=2)
+    argsm = dict(u=numpy.random.default_rng(5).normal(size=(20, 2)), v=numpy.zeros((20, 2)))
+    emit('mixed_blocks_matrix', rf.derivative(rf.derivative(mixed, 'v'), 'u'), argsm, row_axes=2)
+    emit('mixed_blocks_residual', rf.derivative(mixed, 'v'), argsm)
     # ---- configs[4]: NURBS plate with hole, hierarchical refinement towards the hole, p = 3 truncated hierarchical splines made rational -------
     levels, degree, radius, poisson = 4, 3, .5, .3
     topo, geom0 = mesh.rectilinear([1, 2])
