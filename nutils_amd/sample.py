@@ -1093,9 +1093,116 @@ def start_blocks(fs, arguments, flat=False):
     return finish
 
 
+def _is_ragged(basis):
+    b = basis.parent if isinstance(basis, RationalBasis) else basis
+    return isinstance(b, PlainBasis) and len(set(numpy.diff(b.offsets).tolist())) > 1
+
+
+class _SubsetView:
+    '''A sample of an element SUBSET as a full sample of its own little topology: the listed elements, in list order (an element listed twice is two
+    elements), with bases (same dof numbers), weight tables and geometries restricted to them.  The kernels take element lists with uniform bases only;
+    bases with a varying number of functions per element (hierarchical refinements) reach them this way.  The dof spaces are unchanged, so the terms
+    add into the same vectors / matrices (one basis object per sample: _MatrixPlan, evaluate).'''
+
+    def __init__(self, smp):
+        from . import topology
+        self.el = numpy.asarray(smp.elist)
+        box = getattr(smp.topo, 'geom', None)
+        if isinstance(box, function.BoxGeometry):
+            origin, size = numpy.asarray(box.origin)[self.el], numpy.asarray(box.size)[self.el]
+        else:
+            origin, size = numpy.zeros((len(self.el), smp.ndims)), numpy.ones((len(self.el), smp.ndims))
+        self.topo = topology.ElementList(origin, size)
+        self.smp = Sample(self.topo, smp.points, elist=None, bnd_axis=smp.bnd_axis)
+        self.parent = smp
+        self.objs = {}
+
+    def basis(self, b):
+        if id(b) not in self.objs:
+            if isinstance(b, RationalBasis):
+                W = None if b.W is None else self.parent._per_element(b.W, 'weight function table', by_list=False)[self.el]
+                dW = None if b.W is None else self.parent._per_element(b.dW, 'weight function table', by_list=False)[self.el]
+                r = RationalBasis(self.basis(b.parent), b.weights, W=W, dW=dW)
+            else:
+                r = PlainBasis([b.get_coefficients(int(e)) for e in self.el], [b.get_dofs(int(e)) for e in self.el], b.ndofs, b.ndims)
+            self.objs[id(b)] = (b, r)
+        return self.objs[id(b)][1]
+
+    def arg(self, a):
+        if a is None:
+            return None
+        if id(a) not in self.objs:
+            self.objs[id(a)] = (a, function.Arg(self.basis(a.basis), a.ncomp, a.name))
+        return self.objs[id(a)][1]
+
+    def geom(self, g):
+        if g is None:
+            return None
+        if id(g) not in self.objs:
+            if isinstance(g, function.TabulatedGeometry):
+                per_list = g.x.shape[0] == len(self.el) and not (g.x.shape[0] == self.parent.nelems and numpy.array_equal(self.el, numpy.arange(self.parent.nelems)))
+                r = g if per_list else function.TabulatedGeometry(g.x[self.el], g.jac[self.el])
+            elif isinstance(g, function.IsoGeometry):
+                r = function.IsoGeometry(self.basis(g.basis), g.verts)
+            elif hasattr(g, 'element_boxes'):
+                origin, size = g.element_boxes()
+                r = function.BoxGeometry(numpy.asarray(origin)[self.el], numpy.asarray(size)[self.el])
+            else:
+                raise NotImplementedError(f'element subset with a {type(g).__name__}')
+            self.objs[id(g)] = (g, r)
+        return self.objs[id(g)][1]
+
+    def integrand(self, itg):
+        kw = dict(test=self.arg(itg.test), trial=self.arg(itg.trial), geom=self.geom(itg.geom), measure=self.geom(itg.measure))
+        if itg.fscale is not None:
+            kw['fscale'] = function.FieldPoly([self.arg(a) for a in itg.fscale.args], dict(itg.fscale.terms))
+        if itg.qform is not None:
+            kw['qform'] = (itg.qform[0], self.arg(itg.qform[1])) + tuple(itg.qform[2:])
+        if itg.qscalar is not None:
+            kw['qscalar'] = (itg.qscalar[0], self.arg(itg.qscalar[1]), self.arg(itg.qscalar[2]))
+        return itg._copy(**kw)
+
+
+def _restrict_ragged_subsets(terms):
+    '''terms with samples of element subsets on ragged bases rewritten through _SubsetView (cached on the sample); the list itself if there are none'''
+    out, changed = [], False
+    for smp, itg, fac in terms:
+        args = [a for a in (itg.test, itg.trial) if a is not None] + (list(itg.fscale.args) if itg.fscale is not None else [])
+        args += [itg.qform[1]] if itg.qform is not None else []
+        args += [itg.qscalar[1], itg.qscalar[2]] if itg.qscalar is not None else []
+        bases = [a.basis for a in args] + [g.basis for g in (itg.geom, itg.measure) if isinstance(g, function.IsoGeometry)]
+        if smp.elist is None or not any(_is_ragged(b) for b in bases) or isinstance(itg.scale, function.PointFunc) and not isinstance(itg.scale, function.PointTable):
+            out.append((smp, itg, fac))
+            continue
+        view = smp.__dict__.get('_subset_view')
+        if view is None:
+            view = smp.__dict__['_subset_view'] = _SubsetView(smp)
+        key = 'itg', id(itg)
+        if key not in view.objs:
+            view.objs[key] = (itg, view.integrand(itg))
+        out.append((view.smp, view.objs[key][1], fac))
+        changed = True
+    return out if changed else terms
+
+
+def _restricted(f):
+    '''the Integral with its terms through _restrict_ragged_subsets, cached on the object (the term plans are keyed by the identity of the term lists)'''
+    r = f.__dict__.get('_restricted')
+    if r is None:
+        terms = _restrict_ragged_subsets(f.terms)
+        r = f.__dict__['_restricted'] = f if terms is f.terms else function.Integral(terms)
+    return r
+
+
 def evaluate(f, arguments):
     '''Evaluate one Integral / as_csr / as_coo wrapper.'''
     from . import factor as _factor0
+    if isinstance(f, function.Integral) and type(f) is function.Integral:
+        f = _restricted(f)
+    elif isinstance(f, (function._AsCSR, function._AsCOO)) and type(getattr(f, 'integral', None)) is function.Integral:
+        g = _restricted(f.integral)
+        if g is not f.integral:
+            f = type(f)(g)
     if isinstance(f, _Bound):
         return f.eval(arguments)
     if isinstance(f, function._AsCSR) and isinstance(f.integral, _factor0.FactoredMatrix):

@@ -143,65 +143,9 @@ class Built:
         self.args = [function.Arg(self.bases[int(a['basis'])], int(a['ncomp']), a['name']) for a in plan['args']]
         self.scalar_args = sorted({a['name'] for a in plan['args'] if a.get('scalar')})  # bare scalar arguments: passed as the one coefficient of a constant basis
 
-        # A sample of an element SUBSET (a boundary side, one level of a hierarchy) on a basis with a varying number of functions per element: the
-        # kernels take element lists with uniform bases only.  Such a sample is rebuilt as a full sample of its own little topology -- the listed
-        # elements, in list order -- with the bases (same dof numbers), weight tables and geometries restricted to them.  The dof spaces are
-        # unchanged, so the terms add into the same vectors / matrices (one basis object per sample: sample._MatrixPlan, evaluate).
-        views = {}
-
-        def view(si):
-            if si in views:
-                return views[si]
-            smp = self.samples[si]
-            ragged = [b for b in self.bases if isinstance(b, _basis.PlainBasis) and b.nelems == smp.nelems and len(set(numpy.diff(b.offsets).tolist())) > 1]
-            v = None
-            if smp.elist is not None and isinstance(smp.topo, topology.ElementList) and ragged and len(numpy.unique(smp.elist)) == smp.nlist:
-                el = numpy.asarray(smp.elist)
-                box = smp.topo.geom
-                topo = topology.ElementList(numpy.asarray(box.origin)[el], numpy.asarray(box.size)[el])
-                v = dict(el=el, topo=topo, smp=_sample.Sample(topo, smp.points, elist=None, bnd_axis=smp.bnd_axis), bases={}, args={}, geoms={})
-            views[si] = v
-            return v
-
-        def basis_in(v, b):
-            if id(b) not in v['bases']:
-                el = v['el']
-                if isinstance(b, _basis.PlainBasis):
-                    r = _basis.PlainBasis([b.get_coefficients(int(e)) for e in el], [b.get_dofs(int(e)) for e in el], b.ndofs, b.ndims)
-                elif isinstance(b, _basis.RationalBasis):
-                    r = _basis.RationalBasis(basis_in(v, b.parent), b.weights, W=None if b.W is None else numpy.asarray(b.W)[el],
-                                             dW=None if b.W is None else numpy.asarray(b.dW)[el])
-                else:
-                    raise NotImplementedError('element subset of a structured basis on an element list')
-                v['bases'][id(b)] = r
-            return v['bases'][id(b)]
-
-        def arg_in(v, a):
-            if a is None or v is None:
-                return a
-            if id(a) not in v['args']:
-                v['args'][id(a)] = function.Arg(basis_in(v, a.basis), a.ncomp, a.name)
-            return v['args'][id(a)]
-
-        def geom_in(v, g):
-            if g is None or v is None:
-                return g
-            if id(g) not in v['geoms']:
-                if isinstance(g, function.TabulatedGeometry):
-                    nl = len(v['el'])
-                    r = g if g.x.shape[0] == nl else function.TabulatedGeometry(g.x[v['el']], g.jac[v['el']])  # (per list position already, or per element)
-                elif isinstance(g, function.IsoGeometry):
-                    r = function.IsoGeometry(basis_in(v, g.basis), g.verts)
-                elif isinstance(g, function.BoxGeometry):
-                    r = v['topo'].geom
-                else:
-                    raise NotImplementedError(f'element subset with a {type(g).__name__}')
-                v['geoms'][id(g)] = r
-            return v['geoms'][id(g)]
-
+        # (samples of element subsets on ragged bases: the front end rewrites them as samples of their own element list, sample._SubsetView)
         terms = []
         for t in plan['terms']:
-            v = view(int(t['sample']))
             fp = None
             if t.get('fpoly') is not None:
                 p = t['fpoly']
@@ -209,13 +153,13 @@ class Built:
                 for pw, c in zip(numpy.asarray(p['powers']).reshape(len(p['coeffs']), -1), p['coeffs']):
                     k = tuple(int(x) for x in pw)
                     mono[k] = mono.get(k, 0.) + float(c)
-                fp = function.FieldPoly([arg_in(v, self.args[int(i)]) for i in p['args']], mono)
+                fp = function.FieldPoly([self.args[int(i)] for i in p['args']], mono)
             sc = None if t.get('scale') is None else function.PointTable(numpy.asarray(t['scale'], dtype=float))
             arr = lambda k: None if t.get(k) is None else numpy.asarray(t[k], dtype=float)
-            itg = function.Integrand(test=None if int(t['test']) < 0 else arg_in(v, self.args[int(t['test'])]), trial=None if int(t['trial']) < 0 else arg_in(v, self.args[int(t['trial'])]),
-                                     B=arr('B'), L=arr('L'), f0=arr('f0'), geom=None if int(t['geom']) < 0 else geom_in(v, self.geoms[int(t['geom'])]),
-                                     measure=geom_in(v, self.geoms[int(t['measure'])]), rows=bool(t['rows']), cols=bool(t['cols']), scale=sc, fscale=fp)
-            terms.append((self.samples[int(t['sample'])] if v is None else v['smp'], itg, float(t['fac'])))
+            itg = function.Integrand(test=None if int(t['test']) < 0 else self.args[int(t['test'])], trial=None if int(t['trial']) < 0 else self.args[int(t['trial'])],
+                                     B=arr('B'), L=arr('L'), f0=arr('f0'), geom=None if int(t['geom']) < 0 else self.geoms[int(t['geom'])],
+                                     measure=self.geoms[int(t['measure'])], rows=bool(t['rows']), cols=bool(t['cols']), scale=sc, fscale=fp)
+            terms.append((self.samples[int(t['sample'])], itg, float(t['fac'])))
         integral = function.Integral(terms)
         for name in plan.get('derivs', []):
             integral = function.derivative(integral, name)

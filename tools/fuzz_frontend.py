@@ -35,17 +35,64 @@ def random_case(rng):
         grid = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.) for n in shape], indexing='ij'), -1).reshape(-1, nd)
         geom = gb @ (grid + rng.uniform(-.2, .2, grid.shape))
     basis = domain.basis(btype, degree=degree)
+    wbasis = basis
+    unstructured = None
+    if not periodic and gkind in ('unit', 'scaled', 'graded') and rng.random() < .3:
+        # the same functions as a PLAIN basis on an element list (the form in which hierarchical / imported bases arrive): uniform, or RAGGED -- some
+        # elements carry extra functions (copies of their own with new dof numbers) --, optionally made rational
+        from nutils_amd import topology, basis as _basis, sample as _sample
+        origin, size = geom.element_boxes()
+        topo = topology.ElementList(origin, size)
+        ne = len(origin)
+        coeffs = [numpy.array(basis.get_coefficients(e)) for e in range(ne)]
+        dofs = [numpy.array(basis.get_dofs(e)) for e in range(ne)]
+        ndofs = len(basis)
+        if rng.random() < .6:
+            for e in range(ne):
+                for _ in range(int(rng.integers(0, 3))):
+                    k = int(rng.integers(len(dofs[e])))
+                    coeffs[e] = numpy.concatenate([coeffs[e], coeffs[e][k:k + 1] * rng.normal()])
+                    dofs[e] = numpy.concatenate([dofs[e], [ndofs]])
+                    ndofs += 1
+        pb = _basis.PlainBasis(coeffs, dofs, ndofs, nd)
+        if rng.random() < .3:
+            pb = _basis.RationalBasis(pb, .5 + rng.random(ndofs))
+        unstructured = dict(topo=topo, Sample=_sample.Sample)
+        basis = wbasis = pb
+        geom = topo.geom
+        domain = None
     ncomp = int(rng.choice([1, 1, nd, 2]))
     kind = str(rng.choice(['matrix', 'matrix', 'vector', 'scalar']))
     S = 1 + nd
     test, trial = function.Arg(basis, ncomp, 'v'), function.Arg(basis, ncomp, 'u')
     sides = ['left', 'right', 'bottom', 'top', 'front', 'back'][:2 * nd]
-    samples = [domain.sample('gauss', int(rng.integers(1, 2 * degree + 3)))]
-    if nd > 1 and rng.random() < .4 and not periodic:
+    from nutils_amd import points as _points
+    if unstructured is not None:
+        topo = unstructured['topo']
+        samples = [unstructured['Sample'](topo, _points.gauss(int(rng.integers(1, 2 * degree + 3)), nd))]
+        if rng.random() < .4 and topo.nelems > 1:  # a subset of the elements (in list order), also as a boundary side
+            el = numpy.sort(rng.choice(topo.nelems, size=int(rng.integers(1, topo.nelems)), replace=False))
+            bnd = int(rng.integers(-1, nd)) if nd > 1 else -1
+            pts = _points.gauss(int(rng.integers(1, 2 * degree + 2)), nd)
+            if bnd >= 0:  # points on the face xi_bnd = 0 or 1
+                face = _points.gauss(int(rng.integers(1, 2 * degree + 2)), nd - 1)
+                coords = numpy.insert(face.coords, bnd, float(rng.integers(0, 2)), axis=1)
+                pts = _points.Points(coords, face.weights)
+            samples.append(unstructured['Sample'](topo, pts, elist=el, bnd_axis=bnd))
+            if rng.random() < .3:
+                samples = samples[1:]
+    else:
+        samples = [domain.sample('gauss', int(rng.integers(1, 2 * degree + 3)))]
+        if rng.random() < .2 and len(domain) > 1:  # element subset of a structured topology
+            from nutils_amd import sample as _sample
+            el = numpy.sort(rng.choice(len(domain), size=int(rng.integers(1, len(domain))), replace=False))
+            samples.append(_sample.Sample(domain, _points.gauss(int(rng.integers(1, 2 * degree + 2)), nd), elist=el))
+    if unstructured is None and nd > 1 and rng.random() < .4 and not periodic:
         for side in rng.choice(sides, size=int(rng.integers(1, 3)), replace=False):
             samples.append(domain.boundary[str(side)].sample('gauss', int(rng.integers(1, 2 * degree + 2))))
         if rng.random() < .3:
             samples = samples[1:]  # boundary terms only
+    warg = function.Arg(wbasis, 1, 'w')
     terms = []
     for smp in samples:
         for _ in range(int(rng.integers(1, 3))):
@@ -75,11 +122,31 @@ def random_case(rng):
                     itg = function.Integrand(test=test, L=B[:, :, 0, 0].copy(), geom=geom, measure=geom, rows=True, cols=False)
             else:
                 itg = function.Integrand(test=test, trial=trial, B=B, geom=geom, measure=geom, rows=False, cols=False)
+            extra = {}
+            if rng.random() < .25:  # coefficient given by its values at the points of the sample
+                extra['scale'] = function.PointTable(.5 + rng.random((smp.nlist, smp.points.npoints)))
+            if rng.random() < .25:  # polynomial of the values of a scalar field
+                mono = {(int(rng.integers(1, 4)),): float(rng.normal())}
+                if rng.random() < .5:
+                    mono[(0,)] = float(rng.normal())
+                extra['fscale'] = function.FieldPoly([warg], mono)
+            if extra:
+                itg = itg._copy(**extra)
             terms.append((smp, itg, fac))
-    nd_ = len(basis)
-    args = dict(u=rng.normal(size=(nd_, ncomp) if ncomp > 1 else nd_), v=rng.normal(size=(nd_, ncomp) if ncomp > 1 else nd_))
+    nd_ = basis.ndofs if hasattr(basis, 'ndofs') else len(basis)
+    args = dict(u=rng.normal(size=(nd_, ncomp) if ncomp > 1 else nd_), v=rng.normal(size=(nd_, ncomp) if ncomp > 1 else nd_), w=rng.normal(size=nd_))
     desc = f'nd={nd} shape={shape} {btype}{degree} periodic={periodic} geom={gkind} ncomp={ncomp} {kind} samples={[(s.nlist, s.points.npoints, s.bnd_axis) for s in samples]} terms={len(terms)}'
-    return function.Integral(terms), args, kind, desc
+    integral = function.Integral(terms)
+    if kind == 'vector' and ncomp == 1 and rng.random() < .3 and all(itg.fscale is not None for _, itg, _ in terms):
+        # Jacobian of a residual whose coefficient depends on a field: the product-rule terms of function.derivative
+        try:
+            integral = function.derivative(integral, 'w')
+            kind = 'matrix'
+            desc += ' d/dw'
+        except NotImplementedError:
+            pass
+    desc += f' unstructured={None if unstructured is None else type(basis).__name__} extras={sum(itg.scale is not None for _, itg, _ in terms)}+{sum(itg.fscale is not None for _, itg, _ in terms)}'
+    return integral, args, kind, desc
 
 
 def main(ncases, seed):
@@ -109,7 +176,8 @@ def main(ncases, seed):
                 else:
                     r = numpy.asarray(ref, dtype=float)
                     err = numpy.abs(numpy.asarray(out, dtype=float).reshape(r.shape) - r).max() / max(numpy.abs(r).max(), 1e-300)
-                if not err < 1e-11:
+                # (a scalar is a sum of terms of either sign: relative to the result there is no accuracy to speak of when they cancel)
+                if not err < (1e-9 if kind == 'scalar' else 1e-11):
                     status = f'MISMATCH {err:.3e} (execution {rep})'
                     break
         except Exception as e:
