@@ -19,6 +19,8 @@ def random_case(rng):
     big = rng.random() < .15
     hi = {1: 300, 2: 40, 3: 11}[nd] if big else {1: 9, 2: 7, 3: 5}[nd]
     shape = [int(rng.integers(1, hi + 1)) for _ in range(nd)]
+    if os.environ.get('FUZZ_HUGE') and rng.random() < float(os.environ['FUZZ_HUGE']):  # past the size thresholds of the executor (coloured launches, owner-side reduction)
+        shape = [int(rng.integers(lo, hi + 1)) for lo, hi in {1: [(5000, 9000)], 2: [(64, 90)] * 2, 3: [(16, 21)] * 3}[nd]]
     btype = str(rng.choice(['std', 'spline']))
     degree = int(rng.integers(1, 4 if btype == 'std' or nd == 3 else 5))
     periodic = tuple(i for i in range(nd) if rng.random() < .15 and shape[i] > degree + 1)
