@@ -98,8 +98,16 @@ def random_case(rng):
     terms = []
     for smp in samples:
         for _ in range(int(rng.integers(1, 3))):
-            pat = str(rng.choice(['full', 'mass', 'stiff', 'block', 'sparse']))
+            pat = str(rng.choice(['full', 'mass', 'stiff', 'block', 'sparse', 'laplace', 'laplace', 'elastic']))
             B = rng.normal(size=(ncomp, S, ncomp, S))
+            if pat == 'laplace':  # kappa grad . grad + mu value value per component: the forms the structured / closed-form kernels recognise
+                m, k = (float(rng.normal()) if rng.random() < .5 else 0.), float(rng.normal())
+                B = numpy.einsum('cd,ab->cadb', numpy.eye(ncomp), numpy.diag([m] + [k] * nd))
+            elif pat == 'elastic' and ncomp == nd:  # lambda div div + 2 mu eps : eps
+                lam, mu = rng.random(2) + .1
+                B = numpy.zeros((ncomp, S, ncomp, S))
+                G = lam * numpy.einsum('ca,db->cadb', numpy.eye(nd), numpy.eye(nd)) + mu * (numpy.einsum('cd,ab->cadb', numpy.eye(nd), numpy.eye(nd)) + numpy.einsum('cb,ad->cadb', numpy.eye(nd), numpy.eye(nd)))
+                B[:, 1:, :, 1:] = G
             if pat == 'mass':
                 B[:, 1:] = 0
                 B[:, :, :, 1:] = 0
