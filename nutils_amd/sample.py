@@ -158,6 +158,8 @@ class Sample:
         if fits_list and (by_list or not fits_elements) and not (fits_elements and numpy.array_equal(self.elist, numpy.arange(self.nelems))):
             if len(numpy.unique(self.elist)) != self.nlist:
                 raise NotImplementedError(f'{what} per list position on a sample that lists an element twice')
+            if self.nelems * int(numpy.prod(table.shape[1:])) * 8 > 1 << 28:
+                raise NotImplementedError(f'{what} per list position of a small subset of a large topology')
             full = numpy.zeros((self.nelems,) + table.shape[1:], dtype=table.dtype)
             if full.ndim == 4:  # (Jacobians of unlisted elements: identity, never read, but never singular either)
                 full[:] = numpy.eye(table.shape[2], table.shape[3])
@@ -1115,7 +1117,8 @@ class _SubsetView:
         self.topo = topology.ElementList(origin, size)
         self.smp = Sample(self.topo, smp.points, elist=None, bnd_axis=smp.bnd_axis)
         self.parent = smp
-        self.objs = {}
+        self.objs = {}         # id(basis / argument / geometry) -> (object, its restriction)
+        self.integrands = {}   # id(integrand) -> (integrand, its restriction): bounded
 
     def basis(self, b):
         if id(b) not in self.objs:
@@ -1171,16 +1174,22 @@ def _restrict_ragged_subsets(terms):
         args += [itg.qform[1]] if itg.qform is not None else []
         args += [itg.qscalar[1], itg.qscalar[2]] if itg.qscalar is not None else []
         bases = [a.basis for a in args] + [g.basis for g in (itg.geom, itg.measure) if isinstance(g, function.IsoGeometry)]
-        if smp.elist is None or not any(_is_ragged(b) for b in bases) or isinstance(itg.scale, function.PointFunc) and not isinstance(itg.scale, function.PointTable):
+        # also: a geometry tabulated per LIST position (a side of a NURBS patch) -- spreading it to element rows (Sample._per_element) costs the memory of
+        # the whole topology for the sake of a side
+        per_list = any(isinstance(g, function.TabulatedGeometry) and smp.elist is not None and g.x.shape[0] == smp.nlist != smp.nelems for g in (itg.geom, itg.measure))
+        if (smp.elist is None or not (per_list or any(_is_ragged(b) for b in bases))
+                or isinstance(itg.scale, function.PointFunc) and not isinstance(itg.scale, function.PointTable)):
             out.append((smp, itg, fac))
             continue
         view = smp.__dict__.get('_subset_view')
         if view is None:
             view = smp.__dict__['_subset_view'] = _SubsetView(smp)
-        key = 'itg', id(itg)
-        if key not in view.objs:
-            view.objs[key] = (itg, view.integrand(itg))
-        out.append((view.smp, view.objs[key][1], fac))
+        key = id(itg)
+        if key not in view.integrands:
+            while len(view.integrands) >= 256:  # (a script that builds new integrands every step must not pile them up on a long-lived sample)
+                view.integrands.pop(next(iter(view.integrands)))
+            view.integrands[key] = (itg, view.integrand(itg))
+        out.append((view.smp, view.integrands[key][1], fac))
         changed = True
     return out if changed else terms
 
