@@ -115,6 +115,9 @@ int nh_pattern_info(const nh_pattern *p, int64_t *nnz_scalar, const int64_t **sr
  * launch: -1 none yet, 0 the tabulated any-element routine, 1 / 2 the sum-factorised routine for trilinear hexahedra at the 2 x 2 x 2 Gauss
  * points (recognised from the tables of the launch; 2: with a mass term) */
 int nh_pattern_fused_info(const nh_pattern *p, int *nblocks, int *rows_per_block, int64_t *nvisits, int *routine);
+/* row tasks of NH_MATRIX_FUSED for vector-valued blocks built for this pattern so far (nh_owner.hip): row blocks (0: none yet, or the plan does not
+ * apply), node rows per block, element visits of all blocks, chunks of 64 contributions */
+int nh_pattern_owner_info(const nh_pattern *p, int *nblocks, int *rows_per_block, int64_t *nvisits, int64_t *nchunks);
 int nh_pattern_expanded_nnz(const nh_pattern *p, int nct, int ncr, const unsigned char *mask, int64_t *nnz);
 int nh_pattern_expand(const nh_pattern *p, int nct, int ncr, const unsigned char *mask, int64_t *rowptr_dev,
                       int64_t *colidx_dev, void *stream);
@@ -208,19 +211,22 @@ typedef struct {
 #define NH_MATRIX_STORE 128          /* with NH_MATRIX_GATHER or NH_MATRIX_FUSED: the sums are STORED, values_dev is not read (first term on a
                                         fresh array: no zero fill, no read-modify-write) */
 
-#define NH_MATRIX_FUSED 256          /* owner blocks: ONE pass without scratch array or global atomics, for scalar blocks on small uniform bases
-                                        (2 .. 9 functions per element, test and trial on one dof array; needs `pattern`, all of its elements in
-                                        one call, no elist).  The dofs are clustered by the Morton code of the centroid of the first element
-                                        that contains them; a block of rows that fits the LDS of a workgroup recomputes every element touching
-                                        one of its rows (1.7 x the element arithmetic for blocks of 288 rows), reduces the entries of its
-                                        rows in LDS and writes each CSR row once: 1.5 x the algorithmic bytes instead of 4.6 x with
-                                        NH_MATRIX_GATHER.  Trilinear hexahedra at the 2 x 2 x 2 Gauss points with a form kappa grad.grad +
-                                        mass phi phi (recognised from the tables passed) take the sum-factorised element routine of
-                                        nh_p1hex_laplace (an exactly singular element then gives inf / NaN instead of numeric.inv's all-NaN
-                                        inverse).  The order of the floating-point sums follows the arrival of the waves: NOT
-                                        bit-reproducible (NH_MATRIX_GATHER is).  The block plan is built on the first such call and cached in the
-                                        pattern handle.  Launches the flag does not apply to take the default path (atomics; with
-                                        NH_MATRIX_STORE after a zero fill of a scalar block's values). */
+#define NH_MATRIX_FUSED 256          /* owner blocks: ONE pass without scratch array or global atomics (needs `pattern`, all of its elements in
+                                        one call, no elist, test and trial on one dof array).  The dofs are clustered by the Morton code of the
+                                        centroid of the first element that contains them; runs of R consecutive dofs form a block, and a block
+                                        recomputes what it needs of every element touching one of its rows and writes each of its CSR rows once.
+                                        SCALAR blocks on small uniform bases (2 .. 9 functions per element): the visiting elements' local
+                                        matrices are reduced in LDS (1.7 x the element arithmetic for blocks of 288 rows, 1.5 x the algorithmic
+                                        bytes instead of 4.6 x with NH_MATRIX_GATHER); trilinear hexahedra at the 2 x 2 x 2 Gauss points with a
+                                        form kappa grad.grad + mass phi phi (recognised from the tables passed) take the sum-factorised element
+                                        routine of nh_p1hex_laplace (an exactly singular element then gives inf / NaN instead of numeric.inv's
+                                        all-NaN inverse).  VECTOR-VALUED blocks (nct = ncr = 2 or 3 on trilinear hexahedra, bilinear or
+                                        biquadratic quadrilaterals, one table set for test and trial): LDS holds the physical gradients of the
+                                        visiting elements, a lane sums the Gram matrix of one contribution (element, m, n), a segmented sum over
+                                        the lanes of a scalar entry forms it once and the form tensor is applied per entry (nh_owner.hip).
+                                        Every sum is formed in an order fixed by the plan: repeated assemblies are bit-identical.  The plan is
+                                        built on the first such call and cached in the pattern handle.  Launches the flag does not apply to take
+                                        the default path (atomics; with NH_MATRIX_STORE after a zero fill of the block's values). */
 
 int nh_assemble_matrix(const nh_matrix_args *args, void *stream);
 

@@ -136,6 +136,7 @@ SIGNATURES = {
     'nh_pattern_free': (ctypes.c_int, [vp]),
     'nh_pattern_info': (ctypes.c_int, [vp, c_i64p, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), c_i64p, ctypes.POINTER(vp)]),
     'nh_pattern_fused_info': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), c_i64p, ctypes.POINTER(ctypes.c_int)]),
+    'nh_pattern_owner_info': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), c_i64p, c_i64p]),
     'nh_pattern_expanded_nnz': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, c_i64p]),
     'nh_pattern_expand': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
     'nh_assemble_matrix': (ctypes.c_int, [ctypes.POINTER(MatrixArgs), vp]),

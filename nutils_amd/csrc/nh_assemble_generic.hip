@@ -825,6 +825,18 @@ int max_nb(const nh_basis &b, i64 nelems, int *out, hipStream_t s) {
 
 static int grid_for(i64 nelems) { return (int)std::min<i64>(nelems, 256 * 32); }
 
+// component-block layout of the expanded pattern for the kernels of nh_gather.hip / nh_owner.hip
+static GSlots slots_of(const FormK &form) {
+  GSlots gs;
+  memset(&gs, 0, sizeof gs);
+  gs.nct = form.nct, gs.ncr = form.ncr, gs.tot = form.tot;
+  for (int c = 0; c < MAXC; ++c) {
+    gs.cnt[c] = form.cnt[c], gs.cum[c] = form.cum[c];
+    for (int d = 0; d < MAXC; ++d) gs.dpos[c][d] = form.dpos[c][d], gs.mask[c][d] = form.mask[c][d];
+  }
+  return gs;
+}
+
 extern "C" {
 
 int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
@@ -913,9 +925,11 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     bool done = false;
     if ((rc = nh_fused_scalar(a, &done, nh_stream(stream))) != NH_OK) return rc;
     if (done) return NH_OK;
+    if ((rc = nh_owner_vector(a, slots_of(form), &done, nh_stream(stream))) != NH_OK) return rc;  // vector-valued blocks: row tasks (nh_owner.hip)
+    if (done) return NH_OK;
     if (a->flags & NH_MATRIX_STORE) {  // not applicable to this launch: the default path adds, so the block starts from zero
-      NH_REQUIRE(a->pattern && a->nct == 1 && a->ncr == 1, "NH_MATRIX_FUSED | NH_MATRIX_STORE: scalar blocks with a pattern handle only");
-      NH_CHECK_HIP(hipMemsetAsync(a->values_dev, 0, sizeof(double) * (size_t)a->pattern->nnz, nh_stream(stream)));
+      NH_REQUIRE(a->pattern, "NH_MATRIX_FUSED | NH_MATRIX_STORE needs the pattern handle");
+      NH_CHECK_HIP(hipMemsetAsync(a->values_dev, 0, sizeof(double) * (size_t)a->pattern->nnz * form.tot, nh_stream(stream)));
     }
   }
   if (gather) {
@@ -931,14 +945,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     if ((rc = nh_local_scalar(a, scratch, &done, nh_stream(stream))) != NH_OK) return rc;
     if (!done && (rc = nh_local_vector(a, scratch, &done, nh_stream(stream))) != NH_OK) return rc;
     if (done) {
-      GSlots gs;
-      memset(&gs, 0, sizeof gs);
-      gs.nct = form.nct, gs.ncr = form.ncr, gs.tot = form.tot;
-      for (int c = 0; c < MAXC; ++c) {
-        gs.cnt[c] = form.cnt[c], gs.cum[c] = form.cum[c];
-        for (int d = 0; d < MAXC; ++d) gs.dpos[c][d] = form.dpos[c][d], gs.mask[c][d] = form.mask[c][d];
-      }
-      return nh_gather_values(pat, scratch, a->nelems, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream));
+      return nh_gather_values(pat, scratch, a->nelems, slots_of(form), a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream));
     }
     p.local = scratch;
     // NUTILS_AMD_SYM_SCRATCH=1 (measured, NOT the default): symmetric Gram blocks of 2 or 3 components send the node pairs m >= n only to the scratch and the gather mirrors
@@ -1044,14 +1051,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   } else if ((rc = launch_generic(p)) != NH_OK)
     return rc;
   if (gather) {
-    GSlots gs;
-    memset(&gs, 0, sizeof gs);
-    gs.nct = form.nct, gs.ncr = form.ncr, gs.tot = form.tot;
-    for (int c = 0; c < MAXC; ++c) {
-      gs.cnt[c] = form.cnt[c], gs.cum[c] = form.cum[c];
-      for (int d = 0; d < MAXC; ++d) gs.dpos[c][d] = form.dpos[c][d], gs.mask[c][d] = form.mask[c][d];
-    }
-    return nh_gather_values(a->pattern, p.local, local_ld, gs, a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream), p.sym == 2);
+    return nh_gather_values(a->pattern, p.local, local_ld, slots_of(form), a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream), p.sym == 2);
   }
   return NH_OK;
 }

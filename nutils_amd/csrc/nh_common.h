@@ -104,6 +104,21 @@ struct nh_fused_plan {
   double p1hex_tab[32];      // tables of the sum-factorised routine (P1Tab of nh_gather.hip)
 };
 
+// row tasks of the owner kernel for vector-valued blocks (nh_owner.hip): the contributions (visit, m, n) to the scalar entries of a block's rows as lane items, sorted by
+// (row, position in the row, element) and packed into chunks of 64 lanes such that the items of one entry never straddle a chunk
+struct nh_owner_plan {
+  int nblocks, rows_per_block, max_visits, nsteps;  // rows_per_block: at most; nsteps: doubling steps of the segmented sum (2^nsteps >= contributions of the fullest entry)
+  i64 nvisits, nchunks;
+  int32_t *order;   // [nrows]: dof at rank position i
+  i64 *bptr;        // [nblocks + 1]: first rank position of block b (Morton boxes of at most rows_per_block rows)
+  i64 *vptr;        // [nblocks + 1]
+  int32_t *vlist;   // [nvisits]: element, ascending within a block
+  i64 *cptr;        // [nblocks + 1]: chunks of block b
+  uint32_t *isrc;   // [nchunks * 64]: bit 31 valid, bit 30 first item of its entry, bits 10-21 visit within the block, 5-9 m, 0-4 n
+  uint32_t *idst;   // [nchunks * 64]: row within the block << 16 | position of the entry in its scalar row
+};
+void nh_owner_free(nh_owner_plan *o);
+
 struct nh_pattern {
   i64 nelems, nrows, ncols, nnz;
   int nbt, nbr;
@@ -126,6 +141,8 @@ struct nh_pattern {
   int32_t *grow;
   nh_fused_plan *fused;  // NH_MATRIX_FUSED: built on the first such assembly
   int fused_failed;      // the plan cannot be built for this pattern: do not try again
+  nh_owner_plan *owner;  // NH_MATRIX_FUSED, vector-valued blocks: built on the first such assembly
+  int owner_failed;
 };
 
 // component-block layout of an expanded pattern (mirrors FormK of nh_assemble_generic.hip)
@@ -146,5 +163,7 @@ int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStrea
 // owner-block assembly (NH_MATRIX_FUSED); *done = false: not applicable to this launch, nothing was written
 int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s);
 void nh_fused_free(nh_fused_plan *f);
+// nh_owner.hip: the same for vector-valued blocks on small uniform bases (row tasks: Gram sums per scalar entry from D tables in LDS)
+int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hipStream_t s);
 // nh_assemble_p1hex.hip: exchange scratch of the exact-tile kernel
 int nh_p1hex_tiles_release(void);

@@ -9,6 +9,7 @@
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -385,135 +386,7 @@ constexpr int FUSED_CAP = 27 * 288;  // doubles of a block accumulator (62 kB: w
 constexpr int FUSED_NT = 256;        // threads of a block (~470 visits of a 288-row block: two rounds)
 constexpr int FUSED_NT_MAX = 384;    // launch bound (ablation builds may launch more threads)
 
-__device__ __forceinline__ unsigned long long ord64(double x) {  // order-preserving map to unsigned
-  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double unord64(unsigned long long u) {
-  return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
-}
-
-// centroid of every element (a point inside it, for clustering only) + bounding box
-__global__ void k_fp_centroid(i64 nelems, GeomK g, int nd, int nq, double *cent, unsigned long long *mm) {
-  const i64 e0 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  const i64 e = min(e0, nelems - 1);
-  double c[3] = {0., 0., 0.};
-  if (g.kind == NH_GEOM_ISO) {
-    for (int a = 0; a < g.ngb; ++a) {
-      const i64 v = g.gdofs[e * g.ngb + a];
-      for (int i = 0; i < nd; ++i) c[i] += g.verts[v * nd + i];
-    }
-    for (int i = 0; i < nd; ++i) c[i] /= g.ngb;
-  } else if (g.kind == NH_GEOM_TAB) {
-    if (g.x)
-      for (int i = 0; i < nd; ++i) c[i] = g.x[(e * nq) * nd + i];
-    else
-      c[0] = (double)e;  // (no positions: the element order is all there is)
-  } else {
-    for (int i = 0; i < nd; ++i) c[i] = g.origin[e * nd + i] + .5 * g.size[e * nd + i];
-  }
-  if (e0 < nelems)
-    for (int i = 0; i < 3; ++i) cent[e * 3 + i] = c[i];
-  __shared__ unsigned long long red[4][6];  // (256 threads: wave results, then six atomics per workgroup -- one per wave were 2 ms of contention at 2 M elements)
-  for (int i = 0; i < 3; ++i) {
-    unsigned long long lo = ord64(c[i]), hi = lo;
-    for (int d = 32; d; d >>= 1) {
-      const unsigned long long ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
-      lo = ol < lo ? ol : lo;
-      hi = oh > hi ? oh : hi;
-    }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = lo, red[threadIdx.x >> 6][3 + i] = hi;
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    unsigned long long v = red[0][threadIdx.x];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = threadIdx.x < 3 ? (red[w][threadIdx.x] < v ? red[w][threadIdx.x] : v) : (red[w][threadIdx.x] > v ? red[w][threadIdx.x] : v);
-    if (threadIdx.x < 3) atomicMin(mm + threadIdx.x, v);
-    else atomicMax(mm + threadIdx.x, v);
-  }
-}
-
-__device__ __forceinline__ unsigned spread10(unsigned x) {  // 10 bits -> every third bit
-  x &= 1023;
-  x = (x | (x << 16)) & 0x030000ff;
-  x = (x | (x << 8)) & 0x0300f00f;
-  x = (x | (x << 4)) & 0x030c30c3;
-  x = (x | (x << 2)) & 0x09249249;
-  return x;
-}
-
-__global__ void k_fp_ekey(i64 nelems, const double *cent, const unsigned long long *mm, unsigned *ekey) {
-  const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nelems) return;
-  unsigned k = 0;
-  for (int i = 0; i < 3; ++i) {
-    const double lo = unord64(mm[i]), hi = unord64(mm[3 + i]);
-    const double t = hi > lo ? (cent[e * 3 + i] - lo) / (hi - lo) : 0.;
-    k |= spread10((unsigned)min(1023., max(0., t * 1024.))) << i;
-  }
-  ekey[e] = k;
-}
-
-__global__ void k_fp_fill(i64 n, unsigned *keys, unsigned v, unsigned *iota) {
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
-    if (keys) keys[i] = v;
-    if (iota) iota[i] = (unsigned)i;
-  }
-}
-
-__global__ void k_fp_nodekey(i64 nelems, int nbt, const int32_t *dofs, const unsigned *ekey, unsigned *nkey) {
-  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nelems * nbt) return;
-  atomicMin(nkey + dofs[i], ekey[i / nbt]);
-}
-
-// rank of every dof; length of the longest row
-__global__ void k_fp_rank(i64 nrows, const unsigned *order, const i64 *srowptr, int32_t *rank, int *maxlen) {
-  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  int len = 0;
-  if (i < nrows) {
-    rank[order[i]] = (int32_t)i;
-    len = (int)(srowptr[i + 1] - srowptr[i]);
-  }
-  for (int d = 32; d; d >>= 1) len = max(len, __shfl_xor(len, d));
-  if ((threadIdx.x & 63) == 0 && len) atomicMax(maxlen, len);
-}
-
-// offsets of the rows in the accumulator of their block (one thread per block)
-__global__ void k_fp_loff(i64 nrows, int R, int nblocks, const unsigned *order, const i64 *srowptr, int32_t *loff, i64 *rstart, int32_t *blen, int *max_blen) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nblocks) return;
-  int cur = 0;
-  for (i64 i = (i64)b * R; i < min((i64)(b + 1) * R, nrows); ++i) {
-    const i64 r = order[i];
-    loff[i] = cur;
-    rstart[i] = srowptr[r];
-    cur += (int)(srowptr[r + 1] - srowptr[r]);
-  }
-  blen[b] = cur;
-  atomicMax(max_blen, cur);
-}
-
-// distinct blocks among the rows of an element -> visits; FILL: write them
-template <bool FILL>
-__global__ void k_fp_visits(i64 nelems, int nbt, int R, const int32_t *dofs, const int32_t *rank, int32_t *cnt, const i64 *voff, unsigned *vkey, unsigned *vval, int32_t *bcount) {
-  const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nelems) return;
-  int nd = 0;
-  for (int m = 0; m < nbt; ++m) {
-    const int b = rank[dofs[e * nbt + m]] / R;
-    bool seen = false;
-    for (int k = 0; k < m; ++k) seen |= rank[dofs[e * nbt + k]] / R == b;
-    if (seen) continue;
-    if (FILL) {
-      vkey[voff[e] + nd] = (unsigned)b;
-      vval[voff[e] + nd] = (unsigned)e;
-      atomicAdd(bcount + b, 1);
-    }
-    ++nd;
-  }
-  if (!FILL) cnt[e] = nd;
-}
+#include "nh_blockplan.inc"
 
 // (visit, local row) pairs: key = rank position of the row if it belongs to the visiting block, else ~0; value = the pair's index.  Sorted by key (stable: the
 // pairs of one row stay in visit order), the position of a pair within its key group is its TURN: the fused kernels add the contributions to a row in that order.
@@ -1432,7 +1305,10 @@ static int nh_fused_prepare(nh_pattern *p, const nh_matrix_args *a, hipStream_t 
     FP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
     hipLaunchKernelGGL(k_fp_centroid, dim3(ge), dim3(256), 0, s, ne, to_k(a->geom), a->ndims, a->nq, cent, mm);
     FP_CHECK(hipMalloc((void **)&ekey, ne * 4));
-    hipLaunchKernelGGL(k_fp_ekey, dim3(ge), dim3(256), 0, s, ne, cent, mm, ekey);
+    unsigned long long mmh[6];
+    FP_CHECK(hipMemcpyAsync(mmh, mm, sizeof mmh, hipMemcpyDeviceToHost, s));
+    FP_CHECK(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_fp_ekey, dim3(ge), dim3(256), 0, s, ne, cent, mm, bp_cell_size(mmh, ne), ekey);
     FP_CHECK(hipMalloc((void **)&nkey, nrows * 4));
     FP_CHECK(hipMalloc((void **)&iota, nrows * 4));
     FP_CHECK(hipMalloc((void **)&nkey2, nrows * 4));

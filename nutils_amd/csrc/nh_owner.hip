@@ -1,0 +1,589 @@
+// Owner blocks for VECTOR-VALUED matrix blocks on small uniform bases (NH_MATRIX_FUSED, include/nutils_hip.h): one pass, no scratch array, no atomics, sums in a
+// fixed order.  Replaces the scatter of numeric.accumulate / numpy.add.at (numeric.py:434-460, evaluable.py:3405-3411) and the einsum that feeds it
+// (evaluable.py:1885-1886) for blocks with nct = ncr = 2 or 3 components per node.
+//
+// The scalar owner blocks of nh_gather.hip keep every CSR entry of a block's rows in LDS and let the visiting elements add to it; with NC x NC values per node pair
+// 62 kB hold 32 node rows of trilinear elasticity, which 75 elements visit.  Here the roles are swapped: LDS holds what the ELEMENTS know -- the physical
+// gradients D[visit][point][node][axis] and the weights w|J| of every element that touches a row of the block, computed once per visit -- and the ENTRIES are
+// formed in registers.  With G_mn[a][b] = sum_q w|J| D_m[q][a] D_n[q][b] (the Gram matrix of a node pair, independent of the form and of the number of components)
+//   A[(m,c),(n,d)] = sum_ab C[c,a,d,b] G_mn[a][b]:
+// a lane takes one CONTRIBUTION (visit, m, n) to a scalar entry of one of the block's rows and sums its Gram matrix over the points; the contributions to an entry sit
+// in adjacent lanes (the plan sorts them by (row, position in the row, element) and never lets an entry straddle a wave), a segmented sum over the lanes of the entry
+// leaves the total in its first lane, which applies the form tensor ONCE per entry and stores the NC x NC values in their places of the CSR array -- neighbouring
+// lanes write neighbouring positions of one row.  The order of every sum is fixed by the plan: repeated assemblies are bit-identical.
+//
+// Per contribution and point: 2 * ND + 1 LDS reads (the lanes of a row read a dense set of tables: no bank conflicts beyond the bandwidth) and ND + ND * ND
+// multiply-adds instead of the 3 * ND * ND per (pair, component pair) of the thread pass.  Read from HBM per assembly: 8 bytes per contribution (the item words),
+// the vertices of the visiting elements (L2 hits beyond the first), nothing else; written: every CSR value once.
+#include "nh_common.h"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+#include "nh_geom.inc"
+#include "nh_blockplan.inc"
+
+typedef unsigned long long u64;
+
+// ---- plan ---------------------------------------------------------------------------------------------------------------------------------------------
+// one item per local entry (e, m, n): key = rank position of the row << 16 | position of the entry in its scalar row, value = visit within the block | m | n
+__global__ void k_op_items(i64 n, int nbt, int nbr, const int32_t *blk, const int32_t *dofs, const int32_t *rank, const int32_t *emap, const i64 *vptr, const unsigned *vlist,
+                           u64 *key, unsigned *val, int *bad) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const i64 e = i / (nbt * nbr);
+  const int l = (int)(i - e * nbt * nbr), m = l / nbr, nn = l - m * nbr;
+  const int rp = rank[dofs[e * nbt + m]];
+  const int b = blk[rp];
+  i64 lo = vptr[b], hi = vptr[b + 1];
+  const i64 v0 = lo;
+  while (lo < hi) {  // the visits of a block are sorted by element
+    const i64 mid = (lo + hi) >> 1;
+    if ((i64)vlist[mid] < e) lo = mid + 1;
+    else hi = mid;
+  }
+  const int pos = emap[i];
+  if (lo - v0 >= 4096 || pos < 0 || pos > 0xffff || (i64)vlist[lo] != e) atomicOr(bad, 1);
+  key[i] = (u64)(unsigned)rp << 16 | (u64)(unsigned)(pos & 0xffff);
+  val[i] = (unsigned)(lo - v0) << 10 | (unsigned)m << 5 | (unsigned)nn;
+}
+
+// first sorted item of every block (binary search: a block without items gets an empty range)
+__global__ void k_op_bstart(int nblocks, const i64 *bptr, i64 n, const u64 *key, i64 *bstart) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nblocks) return;
+  const u64 k = (u64)bptr[b] << 16;
+  i64 lo = 0, hi = n;
+  while (lo < hi) {
+    const i64 mid = (lo + hi) >> 1;
+    if (key[mid] < k) lo = mid + 1;
+    else hi = mid;
+  }
+  bstart[b] = lo;
+}
+
+// the items of a block packed into chunks of 64 lanes, entries (runs of equal keys) never straddling a chunk; FILL = false: count the chunks
+template <bool FILL>
+__global__ void k_op_pack(int nblocks, const i64 *bptr, const i64 *bstart, const u64 *key, const unsigned *val, int32_t *nch, const i64 *cptr, uint32_t *isrc, uint32_t *idst,
+                          int *maxseg) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  const i64 i1 = bstart[b + 1];
+  i64 cur = 0;
+  int longest = 0;
+  for (i64 i = bstart[b]; i < i1;) {
+    const u64 k = key[i];
+    i64 j = i + 1;
+    while (j < i1 && key[j] == k) ++j;
+    const int len = (int)(j - i);
+    longest = max(longest, len);
+    if ((cur & 63) + len > 64) cur = (cur + 63) & ~(i64)63;
+    if (FILL && len <= 64) {
+      const i64 base = cptr[b] * 64 + cur;
+      const unsigned dst = (unsigned)((k >> 16) - (u64)bptr[b]) << 16 | (unsigned)(k & 0xffff);
+      for (int t = 0; t < len; ++t) {
+        isrc[base + t] = 0x80000000u | (t == 0 ? 0x40000000u : 0u) | val[i + t];
+        idst[base + t] = dst;
+      }
+    }
+    cur += len;
+    i = j;
+  }
+  if (!FILL) {
+    nch[b] = (int32_t)((cur + 63) >> 6);
+    atomicMax(maxseg, longest);
+  }
+}
+
+__global__ void k_op_maxvisits(int nblocks, const i64 *vptr, int *out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nblocks) atomicMax(out, (int)(vptr[b + 1] - vptr[b]));
+}
+
+// ---- kernel -------------------------------------------------------------------------------------------------------------------------------------------
+struct OwnK {
+  int nq;
+  const double *weights;
+  GeomK geom;
+  BasisK test;
+  const double *scale;
+  double C[144];  // [c][a][d][b], NC <= 3, S <= 4
+  GSlots gs;
+  double lam, mu, mu2;  // ISOF: C[c][1+a][d][1+b] = lam d_ca d_db + mu d_cd d_ab + mu2 d_cb d_ad
+  const i64 *srowptr;
+  double *values;
+  int store;
+  i64 nrows;
+  int R, nsteps, vmax, ldst;
+  const int32_t *order, *vlist;
+  const i64 *vptr, *cptr, *bptr;
+  const uint32_t *isrc, *idst;
+  int debug;  // ablation builds: 1 = no geometry / D tables, 2 = no Gram sums, 4 = no segmented sum, 8 = no stores
+  unsigned long long *tdbg;  // ablation builds: cycles of wave 0 per phase, summed over the blocks
+};
+#ifdef NH_ABLATION
+#define ODBG(p) ((p).debug)
+#define OTICK(i) do { if (p.tdbg && tid == 0) { const long long t_ = __builtin_readcyclecounter(); atomicAdd(p.tdbg + i, (unsigned long long)(t_ - tlast)); tlast = t_; } } while (0)
+#else
+#define ODBG(p) 0
+#define OTICK(i)
+#endif
+
+__device__ __forceinline__ i64 bfn(const BasisK &b, i64 e) { return b.tab ? (i64)b.tab[e] * b.nb : 0; }
+
+constexpr int OWN_NT_MAX = 1024;  // (launch bound; the host picks 256 .. 1024 threads by the LDS a block takes)
+
+// ISOF: the isotropic three-parameter family on the gradient slots, applied in closed form; USE0: the form reads the value slot (then D holds S slots per node)
+// XLDS: the vertices of the visiting elements are staged in LDS; else every (visit, point) lane keeps them in registers (at most 512 threads then)
+template <int ND, int NB, int NC, bool ISOF, bool USE0, bool XLDS>
+__global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_rows_v(OwnK p) {
+  constexpr int S = 1 + ND, NG = 1 << ND, SD = USE0 ? S : ND, O = USE0 ? 0 : 1;  // D slot a is operator slot O + a
+  static_assert(!(ISOF && USE0), "the isotropic family has no value slot");
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int nq = p.nq, b = blockIdx.x, tid = threadIdx.x, OWN_NT = blockDim.x;
+  // strides of the D table, in doubles: odd per point and per visit, so that the lanes of phase 1 (consecutive points of consecutive visits) and of phase 2 (the nodes
+  // of arbitrary visits at one point) spread over the banks -- with 24 / 192 doubles they all met in two bank pairs
+  const int QS = (NB * SD) | 1, VS = (nq * QS) | 1, XS = (NG * ND) | 1;
+  const bool iso = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG;
+  // LDS: [row starts R x i64][row lengths R x int, padded][form 144][test table][geometry table][vertices vmax x NG x ND][weights vmax x nq][D vmax x nq x NB x SD]
+  i64 *rs = reinterpret_cast<i64 *>(sm);
+  int *rl = reinterpret_cast<int *>(rs + p.R);
+  double *sC = sm + p.R + (p.R + 1) / 2;
+  double *sT = sC + (ISOF ? 0 : 144);
+  double *sgT = sT + (p.ldst ? NB * nq * S : 0);
+  double *sX = sgT + (p.ldst && iso ? NG * nq * S : 0);
+  double *sW = sX + (iso && XLDS ? p.vmax * XS : 0);
+  double *sD = sW + p.vmax * nq;
+#ifdef NH_ABLATION
+  long long tlast = __builtin_readcyclecounter();
+#endif
+  const i64 v0 = p.vptr[b];
+  const int nv = (int)(p.vptr[b + 1] - v0);
+  constexpr int PRE = 4;
+  const int lane = tid & 63, wave = tid >> 6, nw = OWN_NT >> 6;
+  const i64 c0 = p.cptr[b], c1 = p.cptr[b + 1];
+  uint32_t pit[PRE], pds[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+    const i64 c = c0 + wave + (i64)k * nw;
+    pit[k] = c < c1 ? p.isrc[c * 64 + lane] : 0u;
+    pds[k] = c < c1 ? p.idst[c * 64 + lane] : 0u;
+  }
+  const i64 r0 = p.bptr[b];
+  const int nr = (int)(p.bptr[b + 1] - r0);
+  for (int i = tid; i < nr; i += OWN_NT) {
+    const i64 r = p.order[r0 + i];
+    const i64 a0 = p.srowptr[r];
+    rs[i] = a0;
+    rl[i] = (int)(p.srowptr[r + 1] - a0);
+  }
+  if (!ISOF)
+    for (int i = tid; i < 144; i += OWN_NT) sC[i] = p.C[i];
+  if (p.ldst) {
+    for (int i = tid; i < NB * nq * S; i += OWN_NT) sT[i] = p.test.T[i];
+    if (iso)
+      for (int i = tid; i < NG * nq * S; i += OWN_NT) sgT[i] = p.geom.gT[i];
+  }
+  if (iso && XLDS)
+    for (int i = tid; i < nv * NG; i += OWN_NT) {
+      const int v = i / NG, a = i - v * NG;
+      const i64 e = p.vlist[v0 + v];
+      const i64 vert = p.geom.gdofs[e * NG + a];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) sX[v * XS + a * ND + d] = p.geom.verts[vert * ND + d];
+    }
+  __syncthreads();
+  OTICK(0);
+  // phase 1: lanes over (visit, point) -- inverse Jacobian, weight, physical gradients of the NB functions
+  for (int i = tid; i < nv * nq && !(ODBG(p) & 1); i += OWN_NT) {
+    const int v = i / nq, q = i - v * nq;
+    const i64 e = p.vlist[v0 + v];
+    double Ji[ND][ND], det;
+    if (iso) {
+      double Xr[XLDS ? 1 : NG][ND];
+      if constexpr (!XLDS) {
+        int idx[NG];
+#pragma unroll
+        for (int a = 0; a < NG; ++a) idx[a] = p.geom.gdofs[e * NG + a];
+#pragma unroll
+        for (int a = 0; a < NG; ++a)
+#pragma unroll
+          for (int r = 0; r < ND; ++r) Xr[XLDS ? 0 : a][r] = p.geom.verts[(i64)idx[a] * ND + r];
+      }
+      double J[ND][ND];
+#pragma unroll
+      for (int r = 0; r < ND; ++r)
+#pragma unroll
+        for (int c = 0; c < ND; ++c) J[r][c] = 0;
+      const double *gT = p.ldst ? sgT : p.geom.gT;
+#pragma unroll
+      for (int a = 0; a < NG; ++a) {
+        const double *t = gT + (a * nq + q) * S;
+#pragma unroll
+        for (int r = 0; r < ND; ++r)
+#pragma unroll
+          for (int c = 0; c < ND; ++c) J[r][c] += (XLDS ? sX[v * XS + a * ND + r] : Xr[XLDS ? 0 : a][r]) * t[1 + c];
+      }
+      invert<ND>(J, Ji, det);
+      if (p.geom.bnd_axis >= 0) {
+        double s2 = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int c = 0; c < ND; ++c)
+            if (j == p.geom.bnd_axis) s2 += Ji[j][c] * Ji[j][c];
+        det *= sqrt(s2);
+      }
+      if (p.geom.nograd) {
+#pragma unroll
+        for (int r = 0; r < ND; ++r)
+#pragma unroll
+          for (int c = 0; c < ND; ++c) Ji[r][c] = 0.;
+      }
+    } else
+      geometry_at<ND>(p.geom, e, q, nq, nullptr, Ji, det, nullptr);
+    sW[i] = p.weights[q] * fabs(det) * (p.scale ? p.scale[e * nq + q] : 1.);
+    const double *T = p.ldst ? sT : p.test.T + bfn(p.test, e) * nq * S;
+    double *D = sD + v * VS + q * QS;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const double *t = T + (n * nq + q) * S;
+      if (USE0) D[n * SD] = t[0];
+#pragma unroll
+      for (int c = 0; c < ND; ++c) {
+        double sum = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) sum += t[1 + j] * Ji[j][c];
+        D[n * SD + (USE0 ? 1 : 0) + c] = sum;
+      }
+    }
+  }
+  OTICK(1);
+  __syncthreads();
+  OTICK(2);
+  // phase 2: a wave per chunk of 64 contributions (the item words of the wave's first chunks were requested before phase 0: their latency is behind the element phase)
+  auto process = [&](const uint32_t item, const uint32_t dst) {
+    const bool valid = item >> 31, head = (item >> 30) & 1;
+    const int v = (item >> 10) & 0xfff, m = (item >> 5) & 31, n = item & 31;
+    double G[SD][SD];
+#pragma unroll
+    for (int a = 0; a < SD; ++a)
+#pragma unroll
+      for (int bb = 0; bb < SD; ++bb) G[a][bb] = 0;
+    if (valid && !(ODBG(p) & 2)) {
+      const double *Dv = sD + v * VS, *Wv = sW + v * nq;
+      for (int q = 0; q < nq; ++q) {
+        const double w = Wv[q];
+        const double *dm = Dv + q * QS + m * SD, *dn = Dv + q * QS + n * SD;
+        double wm[SD], tn[SD];
+#pragma unroll
+        for (int a = 0; a < SD; ++a) wm[a] = w * dm[a], tn[a] = dn[a];
+#pragma unroll
+        for (int a = 0; a < SD; ++a)
+#pragma unroll
+          for (int bb = 0; bb < SD; ++bb) G[a][bb] += wm[a] * tn[bb];
+      }
+    }
+    // segmented sum over the lanes of an entry (ascending elements), total in the first lane: rem = lanes of my entry behind me
+    const u64 hm = __ballot(head || !valid);
+    const u64 behind = lane < 63 ? hm >> (lane + 1) : 0ull;
+    const int rem = behind ? __builtin_ctzll(behind) : 63 - lane;
+    for (int s = 0, d = 1; s < p.nsteps && !(ODBG(p) & 4); ++s, d <<= 1) {
+#pragma unroll
+      for (int a = 0; a < SD; ++a)
+#pragma unroll
+        for (int bb = 0; bb < SD; ++bb) {
+          const double o = __shfl_down(G[a][bb], d);
+          if (d <= rem) G[a][bb] += o;
+        }
+    }
+    if (valid && head && !(ODBG(p) & 8)) {
+      const int rowl = dst >> 16, pos = dst & 0xffff;
+      const i64 a0 = rs[rowl];
+      const int len = rl[rowl];
+      double *base = p.values + a0 * p.gs.tot;
+      double tr = 0;
+      if (ISOF) {
+#pragma unroll
+        for (int a = 0; a < ND; ++a) tr += G[a][a];
+      }
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+        for (int dd = 0; dd < NC; ++dd) {
+          if (!p.gs.mask[cc][dd]) continue;  // (uniform)
+          double val;
+          if constexpr (ISOF) {
+            val = p.lam * G[cc < SD ? cc : 0][dd < SD ? dd : 0] + p.mu2 * G[dd < SD ? dd : 0][cc < SD ? cc : 0];
+            if (cc == dd) val += p.mu * tr;
+          } else {
+            val = 0;
+#pragma unroll
+            for (int a = 0; a < SD; ++a)
+#pragma unroll
+              for (int bb = 0; bb < SD; ++bb) val += sC[((cc * S + O + a) * NC + dd) * S + O + bb] * G[a][bb];
+          }
+          double *ptr = base + (i64)len * p.gs.cum[cc] + (i64)pos * p.gs.cnt[cc] + p.gs.dpos[cc][dd];
+          *ptr = p.store ? val : *ptr + val;
+        }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < PRE; ++k)
+    if (c0 + wave + (i64)k * nw < c1) process(pit[k], pds[k]);
+  for (i64 c = c0 + wave + (i64)PRE * nw; c < c1; c += nw) process(p.isrc[c * 64 + lane], p.idst[c * 64 + lane]);
+  OTICK(3);
+}
+
+}  // namespace
+
+void nh_owner_free(nh_owner_plan *o) {
+  if (!o) return;
+  hipFree(o->order), hipFree(o->bptr), hipFree(o->vptr), hipFree(o->vlist), hipFree(o->cptr), hipFree(o->isrc), hipFree(o->idst);
+  delete o;
+}
+
+// LDS bytes of a block with `vmax` visits
+static size_t owner_lds(int R, int vmax, int nq, int nb, int nd, int sd, bool isof, bool ldst, bool iso, bool xlds = true) {
+  const int S = 1 + nd, NG = 1 << nd;
+  const size_t QS = (size_t)(nb * sd) | 1, VS = (nq * QS) | 1, XS = (size_t)(NG * nd) | 1;  // (the odd strides of the kernel)
+  size_t d = (size_t)R + (R + 1) / 2 + (isof ? 0 : 144) + (ldst ? (size_t)nb * nq * S : 0) + (ldst && iso ? (size_t)NG * nq * S : 0) + (iso && xlds ? (size_t)vmax * XS : 0) +
+             (size_t)vmax * nq + (size_t)vmax * VS;
+  return d * sizeof(double);
+}
+
+static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool isof, bool ldst, bool iso, hipStream_t s) {
+  const i64 ne = p->nelems, nrows = p->nrows;
+  const int nbt = p->nbt, nbr = p->nbr;
+  if (!(ne < (1ll << 31) && nrows < (1ll << 31) && p->emap_len == ne * nbt * nbr && p->emap_len < (1ll << 32) && nbt <= 32 && nbr <= 32)) return NH_ELIMIT;
+  const int32_t *dofs = a->test.dofs_dev;
+  BpTmp t;
+  t.n = 0;
+  unsigned *order = nullptr, *vlist = nullptr, *val = nullptr, *val2 = nullptr;
+  int32_t *rank = nullptr, *nch = nullptr;
+  i64 *vptr = nullptr, *bstart = nullptr, *cptr = nullptr, *bptr = nullptr;
+  int32_t *blk = nullptr;
+  u64 *key = nullptr, *key2 = nullptr;
+  uint32_t *isrc = nullptr, *idst = nullptr;
+  int *flags = nullptr;  // [0] bad item, [1] longest entry, [2] most visits of a block
+  int maxlen = 0, rc = NH_OK, hflags[3] = {0, 0, 0};
+  nh_owner_plan *o = nullptr;
+#define OP_CHECK(expr)                                                                          \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      nh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+      rc = NH_EHIP;                                                                             \
+      goto done;                                                                                \
+    }                                                                                           \
+  } while (0)
+  {
+    unsigned *skeys = nullptr;
+    if ((rc = bp_cluster(t, p, a, &order, &rank, &maxlen, s, &skeys)) != NH_OK) goto done;
+    if (maxlen > 0xffff) {
+      rc = NH_ELIMIT;
+      goto done;
+    }
+    OP_CHECK(bp_alloc(t, &flags, 3));
+    // rows per block: the largest candidate whose fullest block fits the LDS budget (two workgroups per CU)
+    size_t budget = 80 * 1024;
+    if (getenv("NH_OWNER_LDS")) budget = (size_t)std::max(16, std::min(160, atoi(getenv("NH_OWNER_LDS")))) * 1024;
+    int R = 0, vmax = 0, nblocks = 0;
+    i64 nvisits = 0;
+    const int cand[] = {64, 32, 16, 8, 4, 2, 1};
+    int forced = getenv("NH_OWNER_ROWS") ? std::max(1, std::min(256, atoi(getenv("NH_OWNER_ROWS")))) : 0;
+    for (int ci = 0; ci < 7; ++ci) {
+      const int Rc = forced ? forced : cand[ci];
+      const int tn = t.n;
+      OP_CHECK(hipMemsetAsync(flags, 0, 3 * sizeof(int), s));
+      if ((rc = bp_blocks(t, skeys, nrows, Rc, &nblocks, &bptr, &blk, s)) != NH_OK) goto done;
+      if ((rc = bp_visits(t, p, dofs, rank, blk, nblocks, &nvisits, &vptr, &vlist, s)) != NH_OK) goto done;
+      hipLaunchKernelGGL(k_op_maxvisits, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s, nblocks, vptr, flags + 2);
+      OP_CHECK(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+      OP_CHECK(hipStreamSynchronize(s));
+      if (hflags[2] < 4096 && owner_lds(Rc, hflags[2], a->nq, nbt, a->ndims, sd, isof, ldst, iso, false) <= budget) {  // (without the staged vertices if need be)
+        R = Rc, vmax = hflags[2];
+        break;
+      }
+      if (getenv("NH_OWNER_VERBOSE")) fprintf(stderr, "nh_owner plan: %d rows per block -> at most %d visits, %zu B of LDS: over the budget\n", Rc, hflags[2], owner_lds(Rc, hflags[2], a->nq, nbt, a->ndims, sd, isof, ldst, iso));
+      if (forced) break;
+      for (int i = tn; i < t.n; ++i) hipFree(t.ptr[i]);  // (this candidate's arrays)
+      t.n = tn;
+    }
+    if (!R) {
+      rc = NH_ELIMIT;
+      goto done;
+    }
+    const i64 ni = p->emap_len;
+    OP_CHECK(bp_alloc(t, &key, (size_t)ni));
+    OP_CHECK(bp_alloc(t, &val, (size_t)ni));
+    hipLaunchKernelGGL(k_op_items, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, s, ni, nbt, nbr, blk, dofs, rank, p->emap, vptr, vlist, key, val, flags);
+    OP_CHECK(hipGetLastError());
+    int bits = 17;
+    while ((1ll << (bits - 16)) < nrows) ++bits;
+    if ((rc = bp_sort_pairs(t, key, val, (size_t)ni, bits, &key2, &val2, s)) != NH_OK) goto done;  // stable: the items of an entry in (element, m, n) order
+    OP_CHECK(bp_alloc(t, &bstart, (size_t)nblocks + 1));
+    OP_CHECK(bp_alloc(t, &nch, (size_t)nblocks + 1));
+    OP_CHECK(bp_alloc(t, &cptr, (size_t)nblocks + 1));
+    hipLaunchKernelGGL(k_op_bstart, dim3((unsigned)((nblocks + 256) / 256)), dim3(256), 0, s, nblocks, bptr, ni, key2, bstart);
+    hipLaunchKernelGGL((k_op_pack<false>), dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nblocks, bptr, bstart, key2, val2, nch, (const i64 *)nullptr, (uint32_t *)nullptr,
+                       (uint32_t *)nullptr, flags + 1);
+    OP_CHECK(hipGetLastError());
+    if ((rc = nh_scan_exclusive(nch, cptr, nblocks, s)) != NH_OK) goto done;
+    i64 nchunks = 0;
+    OP_CHECK(hipMemcpyAsync(&nchunks, cptr + nblocks, sizeof(i64), hipMemcpyDeviceToHost, s));
+    OP_CHECK(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+    OP_CHECK(hipStreamSynchronize(s));
+    if (hflags[0] || hflags[1] > 64 || nchunks * 64 >= (1ll << 32)) {
+      rc = NH_ELIMIT;
+      goto done;
+    }
+    OP_CHECK(bp_alloc(t, &isrc, (size_t)nchunks * 64));
+    OP_CHECK(bp_alloc(t, &idst, (size_t)nchunks * 64));
+    OP_CHECK(hipMemsetAsync(isrc, 0, (size_t)nchunks * 64 * 4, s));
+    OP_CHECK(hipMemsetAsync(idst, 0, (size_t)nchunks * 64 * 4, s));
+    hipLaunchKernelGGL((k_op_pack<true>), dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nblocks, bptr, bstart, key2, val2, (int32_t *)nullptr, cptr, isrc, idst, (int *)nullptr);
+    OP_CHECK(hipGetLastError());
+    OP_CHECK(hipStreamSynchronize(s));
+    o = new nh_owner_plan();
+    memset(o, 0, sizeof *o);
+    o->nblocks = nblocks, o->rows_per_block = R, o->max_visits = vmax, o->nvisits = nvisits, o->nchunks = nchunks;
+    o->nsteps = 0;
+    while ((1 << o->nsteps) < hflags[1]) ++o->nsteps;
+    o->order = reinterpret_cast<int32_t *>(bp_keep(t, order));
+    o->bptr = bp_keep(t, bptr);
+    o->vptr = bp_keep(t, vptr);
+    o->vlist = reinterpret_cast<int32_t *>(bp_keep(t, vlist));
+    o->cptr = bp_keep(t, cptr);
+    o->isrc = bp_keep(t, isrc);
+    o->idst = bp_keep(t, idst);
+    if (getenv("NH_OWNER_VERBOSE"))
+      fprintf(stderr, "nh_owner plan: %d blocks of %d rows, %lld visits (%.2f per element, at most %d per block), %lld chunks for %lld items (%.2f lanes used), entries of up to %d items, %zu B of LDS\n",
+              nblocks, R, (long long)nvisits, (double)nvisits / (double)ne, vmax, (long long)nchunks, (long long)ni, (double)ni / (64. * (double)nchunks), hflags[1],
+              owner_lds(R, vmax, a->nq, nbt, a->ndims, sd, isof, ldst, iso));
+  }
+done:
+#undef OP_CHECK
+  bp_free(t);
+  if (rc == NH_OK) p->owner = o;
+  return rc;
+}
+
+int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hipStream_t s) {
+  *done = false;
+  const int nc = a->nct;
+  if (nc < 2 || nc > 3 || a->ncr != nc || a->cq_dev || a->test.off_dev || a->trial.off_dev || !a->test.nb || a->test.nb != a->trial.nb || a->elist_dev) return NH_OK;
+  if (a->test.T_dev != a->trial.T_dev || a->test.tab_dev != a->trial.tab_dev || a->test.dofs_dev != a->trial.dofs_dev) return NH_OK;
+  nh_pattern *pat = const_cast<nh_pattern *>(a->pattern);
+  if (!pat || pat->nelems != a->nelems || pat->eoff || pat->owner_failed || pat->nbt != a->test.nb || pat->nbr != a->trial.nb) return NH_OK;
+  const int key = a->ndims * 1000 + a->test.nb * 10 + nc;
+  switch (key) {
+    case 3083: case 2042: case 2092: break;
+    default: return NH_OK;
+  }
+  const int S = 1 + a->ndims;
+  OwnK p;
+  memset(&p, 0, sizeof p);
+  for (int i = 0; i < 144; ++i) p.C[i] = i < nc * S * nc * S ? a->C_host[i] : 0.;
+  p.gs = slots;
+  // the isotropic three-parameter family on the gradient slots (all blocks coupled, one component per axis)?  does the form read the value slot?
+  bool isof = nc == a->ndims && !getenv("NUTILS_AMD_NO_ISOFORM"), use0 = false;
+  {
+    const double *C = a->C_host;
+    auto at = [&](int c, int sa, int d, int sb) { return C[((c * S + sa) * nc + d) * S + sb]; };
+    const double lam = at(0, 1, 1, 2), mu2 = at(0, 2, 1, 1), mu = at(0, 2, 0, 2);
+    for (int c = 0; c < nc; ++c)
+      for (int sa = 0; sa < S; ++sa)
+        for (int d = 0; d < nc; ++d)
+          for (int sb = 0; sb < S; ++sb) {
+            const double expect = (sa && sb) ? lam * (c == sa - 1 && d == sb - 1) + mu * (c == d && sa == sb) + mu2 * (c == sb - 1 && sa - 1 == d) : 0.;
+            if (at(c, sa, d, sb) != expect || !slots.mask[c][d]) isof = false;
+            if ((!sa || !sb) && at(c, sa, d, sb) != 0.) use0 = true;
+          }
+    p.lam = lam, p.mu = mu, p.mu2 = mu2;
+  }
+  const bool iso = a->geom.kind == NH_GEOM_ISO && a->geom.ngb == (1 << a->ndims);
+  const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + (iso ? (1 << a->ndims) : 0));
+  const bool ldst = !a->test.tab_dev && ldsb <= 24 * 1024;
+  const int sd = use0 ? S : a->ndims;
+  if (!pat->owner) {
+    const int rc = nh_owner_prepare(pat, a, sd, isof, ldst, iso, s);
+    if (rc == NH_ELIMIT) {
+      pat->owner_failed = 1;
+      return NH_OK;
+    }
+    if (rc != NH_OK) return rc;
+  }
+  const nh_owner_plan *o = pat->owner;
+  size_t lds = owner_lds(o->rows_per_block, o->max_visits, a->nq, a->test.nb, a->ndims, sd, isof, ldst, iso);
+  // the staged vertices are given up where they cost a workgroup per CU (two of 80 kB fit, three of 53 kB)
+  const size_t lds0 = owner_lds(o->rows_per_block, o->max_visits, a->nq, a->test.nb, a->ndims, sd, isof, ldst, iso, false);
+  bool xlds = iso && (160 * 1024 / lds0 == 160 * 1024 / std::max<size_t>(lds, 1)) && lds <= 160 * 1024;
+  if (getenv("NH_OWNER_XLDS")) xlds = iso && atoi(getenv("NH_OWNER_XLDS")) != 0;
+  if (!xlds) lds = lds0;
+  if (lds > 160 * 1024) return NH_OK;  // (a plan built for other tables / forms: the caller keeps its other paths)
+  p.nq = a->nq;
+  p.weights = a->weights_dev;
+  p.geom = to_k(a->geom);
+  p.geom.nograd = !uses_gradients(a->C_host, nc, S, nc);
+  p.test = to_k(a->test);
+  p.scale = a->scale_dev;
+  p.srowptr = pat->srowptr;
+  p.values = a->values_dev;
+  p.store = (a->flags & NH_MATRIX_STORE) != 0;
+  p.nrows = pat->nrows;
+  p.R = o->rows_per_block, p.nsteps = o->nsteps, p.vmax = o->max_visits, p.ldst = ldst;
+  p.order = o->order, p.vlist = o->vlist, p.vptr = o->vptr, p.cptr = o->cptr, p.bptr = o->bptr, p.isrc = o->isrc, p.idst = o->idst;
+  // threads: enough waves for the chunks of a block, and for the latencies of phase 1 when one block takes most of a CU's LDS
+  int nt = lds > 80 * 1024 ? 1024 : lds > 52 * 1024 ? 512 : 256;
+  if (getenv("NH_OWNER_NT")) nt = std::max(64, std::min(OWN_NT_MAX, atoi(getenv("NH_OWNER_NT")) & ~63));
+  if (!xlds) nt = std::min(nt, OWN_NT_MAX / 2);
+#ifdef NH_ABLATION
+  if (getenv("NH_OWNER_DEBUG")) p.debug = atoi(getenv("NH_OWNER_DEBUG"));
+  if (getenv("NH_OWNER_TICKS")) {
+    NH_CHECK_HIP(hipMalloc((void **)&p.tdbg, 4 * sizeof(unsigned long long)));
+    NH_CHECK_HIP(hipMemsetAsync(p.tdbg, 0, 4 * sizeof(unsigned long long), s));
+  }
+#endif
+  dim3 grid((unsigned)o->nblocks), block(nt);
+#define OWN3(ND, NB, NC, IS, U0, XL)                                                                                                          \
+  do {                                                                                                                                        \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_owner_rows_v<ND, NB, NC, IS, U0, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_owner_rows_v<ND, NB, NC, IS, U0, XL>), grid, block, lds, s, p);                                                      \
+  } while (0)
+#define OWN2(ND, NB, NC, IS, U0)             \
+  do {                                       \
+    if (xlds) OWN3(ND, NB, NC, IS, U0, true); \
+    else OWN3(ND, NB, NC, IS, U0, false);    \
+  } while (0)
+#define OWN(ND, NB, NC)                              \
+  do {                                               \
+    if (isof && ND == NC) OWN2(ND, NB, NC, (ND == NC), false); \
+    else if (use0) OWN2(ND, NB, NC, false, true);    \
+    else OWN2(ND, NB, NC, false, false);             \
+  } while (0)
+  switch (key) {
+    case 3083: OWN(3, 8, 3); break;  // trilinear hexahedra, 3 components
+    case 2042: OWN(2, 4, 2); break;  // bilinear quadrilaterals, 2 components
+    case 2092: OWN(2, 9, 2); break;  // biquadratic quadrilaterals / quadratic splines, 2 components
+  }
+#undef OWN
+#undef OWN2
+#undef OWN3
+  NH_LAUNCH_CHECK();
+#ifdef NH_ABLATION
+  if (p.tdbg) {
+    unsigned long long h[4];
+    NH_CHECK_HIP(hipStreamSynchronize(s));
+    NH_CHECK_HIP(hipMemcpy(h, p.tdbg, sizeof h, hipMemcpyDeviceToHost));
+    hipFree(p.tdbg);
+    fprintf(stderr, "nh_owner ticks per block (wave 0): staging %.0f, element phase %.0f, barrier %.0f, entries %.0f\n", (double)h[0] / o->nblocks, (double)h[1] / o->nblocks,
+            (double)h[2] / o->nblocks, (double)h[3] / o->nblocks);
+  }
+#endif
+  *done = true;
+  return NH_OK;
+}

@@ -398,6 +398,7 @@ int nh_pattern_free(nh_pattern *p) {
   hipFree(p->gptr);
   hipFree(p->grow);
   nh_fused_free(p->fused);
+  nh_owner_free(p->owner);
   delete p;
   return NH_OK;
 }
@@ -408,6 +409,15 @@ int nh_pattern_fused_info(const nh_pattern *p, int *nblocks, int *rows_per_block
   if (nblocks) *nblocks = p->fused ? p->fused->nblocks : 0;
   if (rows_per_block) *rows_per_block = p->fused ? p->fused->rows_per_block : 0;
   if (nvisits) *nvisits = p->fused ? p->fused->nvisits : 0;
+  return NH_OK;
+}
+
+int nh_pattern_owner_info(const nh_pattern *p, int *nblocks, int *rows_per_block, int64_t *nvisits, int64_t *nchunks) {
+  NH_REQUIRE(p, "nh_pattern_owner_info: NULL pattern");
+  if (nblocks) *nblocks = p->owner ? p->owner->nblocks : 0;
+  if (rows_per_block) *rows_per_block = p->owner ? p->owner->rows_per_block : 0;
+  if (nvisits) *nvisits = p->owner ? p->owner->nvisits : 0;
+  if (nchunks) *nchunks = p->owner ? p->owner->nchunks : 0;
   return NH_OK;
 }
 

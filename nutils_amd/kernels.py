@@ -56,6 +56,12 @@ class Pattern:
         self.fused_routine = rt.value  # -1 none yet, 0 tabulated any-element routine, 1 / 2 sum-factorised trilinear routine (2: with a mass term)
         return nb.value, rpb.value, nv.value
 
+    def owner_info(self):
+        '''(row blocks, node rows per block, element visits, chunks of 64 contributions) of the row tasks built for vector-valued NH_MATRIX_FUSED so far; zeros: none'''
+        nb, rpb, nv, nc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.call('nh_pattern_owner_info', self._handle, ctypes.byref(nb), ctypes.byref(rpb), ctypes.byref(nv), ctypes.byref(nc))
+        return nb.value, rpb.value, nv.value, nc.value
+
     def expanded_nnz(self, nct, ncr, mask=None):
         nnz = ctypes.c_int64()
         m = None if mask is None else numpy.ascontiguousarray(mask, dtype=numpy.uint8)
@@ -135,15 +141,18 @@ FUSED_SIZES = {(1, 2), (1, 3), (2, 3), (2, 4), (2, 9), (3, 4), (3, 8)}  # (dimen
 # ... and those for which they are the DEFAULT: measured faster than the gather with the ordered sums (tools/generic_probe.py, round 4: 128^3 trilinear 0.94 against
 # 1.20 ms through the API; 2048^2 bilinear 0.87 against 0.59 and 1024^2 biquadratic 1.47 against 0.96 ms are NOT -- their rows are short, the turn protocol is not)
 FUSED_DEFAULT = {(3, 8)}
+# (dimension, functions per element, components) of the owner kernel for vector-valued blocks (nh_owner.hip: Gram sums per scalar entry from D tables in LDS, one pass)
+OWNER_VECTOR = {(3, 8, 3), (2, 4, 2), (2, 9, 2)}
 
 
 def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0,
-                    cq=None, first_touch=None, gather=None, store=False, fused=False):
+                    cq=None, first_touch=None, gather=None, store=False, fused=False, fresh=False):
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.  `first_touch=(grid_shape, nodes_per_axis)`: NH_MATRIX_FIRST_TOUCH.
     gather: NH_MATRIX_GATHER (deterministic owner-side reduction instead of atomics); None = from the second assembly on a pattern on (the gather
     map costs one device sort of the element map, which a one-off assembly does not earn back).  fused: NH_MATRIX_FUSED (owner blocks: one pass
     without scratch or global atomics for scalar blocks on small uniform bases, contributions added in visit order: bit-reproducible; excludes gather;
-    the default for those blocks -- NUTILS_AMD_NO_FUSED=1 restores the gather / atomics choice).'''
+    the default for those blocks -- NUTILS_AMD_NO_FUSED=1 restores the gather / atomics choice).  fresh: `values` is uninitialised -- the gather and
+    owner-block paths STORE their sums (no zero fill, no read of the old values), every other path gets the array zero-filled first.'''
     C = numpy.ascontiguousarray(C, dtype=float)
     if C.shape != (nct, 1 + ndims, ncr, 1 + ndims):
         raise ValueError(f'coefficient tensor has shape {C.shape}, expected {(nct, 1 + ndims, ncr, 1 + ndims)}')
@@ -164,6 +173,9 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
         # (default since round 4 for the blocks the owner-block kernels cover: one pass, 1.5 x instead of 4.6 x the algorithmic traffic, and -- with the
         # turns of the block plan -- bit-reproducible like the gather)
         fused = True
+    if (not fused and gather is None and not os.environ.get('NUTILS_AMD_NO_FUSED') and whole and elist is None and nct == ncr and cq is None and (ndims, test.nb, nct) in OWNER_VECTOR
+            and test.nb == trial.nb and test.T_dev == trial.T_dev and test.dofs_dev == trial.dofs_dev and test.tab_dev == trial.tab_dev and not test.off_dev):
+        fused = True  # (vector-valued blocks on small uniform bases: one pass instead of the thread pass + gather, 2.3 x the algorithmic bytes)
     if fused:
         if not whole:
             raise ValueError('fused needs all elements of the pattern in one call')
@@ -185,6 +197,11 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
                   and 8 * pattern.emap_len * nct * ncr <= GATHER_SCRATCH_LIMIT and pattern.emap_len < 2 ** 32 and pattern.nnz_scalar < 2 ** 32)
     if whole:
         pattern._assemblies = getattr(pattern, '_assemblies', 0) + 1
+    if fresh:
+        if gather or fused:
+            store = True
+        else:
+            values.zero_()
     if gather:
         if not whole:
             raise ValueError('gather needs all elements of the pattern in one call')

@@ -596,7 +596,7 @@ class _MatrixPlan:
         pat = smp.pattern(itg.test.basis, itg.trial.basis)
         return getattr(pat, '_assemblies', 0) >= 1 and 8 * pat.emap_len <= kernels.GATHER_SCRATCH_LIMIT
 
-    def _batched(self, terms, values, mask, arguments):
+    def _batched(self, terms, values, mask, arguments, fresh=None):
         '''Bases with few functions per element: ALL terms of the block that share a measure go through one nh_assemble_matrix_terms launch
         (several elements per workgroup; coefficient functions, polynomial factors of field values and the point-dependent product-rule
         tensors are evaluated inside the kernel).  Returns the terms that remain for the per-term kernels.'''
@@ -673,6 +673,9 @@ class _MatrixPlan:
                 keys = list(fp.terms)
                 polys.append(([(fidx(a), 0) for a in fp.args], [fp.terms[k] for k in keys], keys))
             fields = [(smp.tables(a.basis).struct, _argument_dev(arguments, a), a.ncomp) for a in fkeys]
+            if fresh is not None and fresh[0]:  # (this entry accumulates)
+                values.zero_()
+                fresh[0] = False
             kernels.assemble_matrix_terms(nelems=smp.nlist, elist=smp._elist_dev, ndims=nd, nq=nq, weights=smp._weights_dev, geom=smp.geometry(items[0][1].measure),
                                           test=tt.struct, trial=tr.struct, nct=nct, ncr=ncr, mask=mask, pattern=smp.pattern(self.test.basis, self.trial.basis),
                                           values=values, terms=tl, fields=fields, polys=polys)
@@ -724,7 +727,7 @@ class _MatrixPlan:
         nct, ncr = self.test.ncomp, self.trial.ncomp
         mask = None if self.mask.all() else self.mask
         rowptr, colidx = pat.expand(nct, ncr, mask)
-        first_touch = None
+        first_touch, fresh = None, [False]
         if fast is None:
             values = self._p2hex(rowptr, colidx)
             if values is not None:
@@ -735,9 +738,12 @@ class _MatrixPlan:
             # the first term of a coloured assembly on a C0 basis STORES the entries no earlier colour has touched (NH_MATRIX_FIRST_TOUCH):
             # no zero-fill, no read of the entries that receive a single contribution
             first_touch = self._first_touch(self.terms[0])
-            values, terms = (device.empty if first_touch else device.zeros)(colidx.numel(), 'float64'), self.terms
+            # (a FRESH array: the first kernel that can STORES its sums -- gather / owner blocks: no zero fill, no read-modify-write of 8 bytes per entry --
+            # every other path zero-fills it first)
+            values, terms = device.empty(colidx.numel(), 'float64'), self.terms
+            fresh = [not first_touch]
         if first_touch is None and not os.environ.get('NUTILS_AMD_NO_BATCHED'):
-            terms = self._batched(terms, values, mask, arguments)
+            terms = self._batched(terms, values, mask, arguments, fresh)
         for iterm, (smp, itg, fac) in enumerate(terms):
             if itg.measure is None:
                 raise NotImplementedError('integrand without J(geom): reference-space integrals are outside the accelerated path')
@@ -758,18 +764,25 @@ class _MatrixPlan:
                 else:                         # 'test': C_q[a][b] = L[a] sum_x B[x][b] U[x]
                     cq = kernels.point_forms(2, U, Bq, L=itg.qform[2][0], scale=sq)
                 common_q = dict(common, C=numpy.ones((nct, S, ncr, S)))
-                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, cq=cq, **common_q)
+                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, cq=cq, fresh=fresh[0], **common_q)
+                fresh[0] = False
                 continue
             if (itg.test.basis is itg.trial.basis and smp.nlist >= COLOR_THRESHOLD and tt.nb >= 16 and not self._rows_pass(smp, itg)
                     and not os.environ.get('NUTILS_AMD_NO_COLORS')):  # (small local matrices: 8 coloured launches measured slower than atomics, 4.7 vs 4.0 ms)
                 colors = _colors(smp, itg.test.basis)
             if colors:
+                if fresh[0]:
+                    values.zero_()
+                    fresh[0] = False
                 ft = first_touch if iterm == 0 and terms is self.terms else None
                 for el in colors:
                     kernels.assemble_matrix(nelems=el.numel(), elist=el, flags=1 | 2, scale=scale, first_touch=ft, **common)
                 common['pattern']._assemblies = getattr(common['pattern'], '_assemblies', 0) + 1  # (a re-assembly may take the gather path: _rows_pass)
             else:
-                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, scale=scale, **common)
+                kernels.assemble_matrix(nelems=smp.nlist, elist=smp._elist_dev, scale=scale, fresh=fresh[0], **common)
+                fresh[0] = False
+        if fresh[0]:  # (no term at all)
+            values.zero_()
         return values, rowptr, colidx, self.trial.basis.ndofs * ncr
 
 
