@@ -110,7 +110,7 @@ int nh_pattern_info(const nh_pattern *p, int64_t *nnz_scalar, const int64_t **sr
  * int64[nnz]; nnz returned by nh_pattern_expanded_nnz.  Hand-back format of
  * matrix/__init__.py:30-70 (assemble_csr) -- indices int64, rows sorted, cols strictly
  * increasing within a row. */
-/* owner blocks of NH_MATRIX_FUSED built for this pattern so far: number of row blocks (0: none yet, or the plan does not apply), rows per
+/* owner blocks of NH_MATRIX_FUSED built for this pattern so far: number of row blocks (0: none yet, or the plan does not apply), rows of the largest
  * block, element visits over all blocks (>= nelems: elements on block borders are recomputed), and the element routine of the last fused
  * launch: -1 none yet, 0 the tabulated any-element routine, 1 / 2 the sum-factorised routine for trilinear hexahedra at the 2 x 2 x 2 Gauss
  * points (recognised from the tables of the launch; 2: with a mass term) */
@@ -213,20 +213,23 @@ typedef struct {
 
 #define NH_MATRIX_FUSED 256          /* owner blocks: ONE pass without scratch array or global atomics (needs `pattern`, all of its elements in
                                         one call, no elist, test and trial on one dof array).  The dofs are clustered by the Morton code of the
-                                        centroid of the first element that contains them; runs of R consecutive dofs form a block, and a block
-                                        recomputes what it needs of every element touching one of its rows and writes each of its CSR rows once.
-                                        SCALAR blocks on small uniform bases (2 .. 9 functions per element): the visiting elements' local
-                                        matrices are reduced in LDS (1.7 x the element arithmetic for blocks of 288 rows, 1.5 x the algorithmic
-                                        bytes instead of 4.6 x with NH_MATRIX_GATHER); trilinear hexahedra at the 2 x 2 x 2 Gauss points with a
-                                        form kappa grad.grad + mass phi phi (recognised from the tables passed) take the sum-factorised element
-                                        routine of nh_p1hex_laplace (an exactly singular element then gives inf / NaN instead of numeric.inv's
-                                        all-NaN inverse).  VECTOR-VALUED blocks (nct = ncr = 2 or 3 on trilinear hexahedra, bilinear or
-                                        biquadratic quadrilaterals, one table set for test and trial): LDS holds the physical gradients of the
-                                        visiting elements, a lane sums the Gram matrix of one contribution (element, m, n), a segmented sum over
-                                        the lanes of a scalar entry forms it once and the form tensor is applied per entry (nh_owner.hip).
-                                        Every sum is formed in an order fixed by the plan: repeated assemblies are bit-identical.  The plan is
-                                        built on the first such call and cached in the pattern handle.  Launches the flag does not apply to take
-                                        the default path (atomics; with NH_MATRIX_STORE after a zero fill of the block's values). */
+                                        centroid of the first element that contains them; Morton boxes of at most R rows form a block, and a
+                                        block recomputes what it needs of every element touching one of its rows and writes each of its CSR rows
+                                        once.  SCALAR blocks on small uniform bases (2 .. 9 functions per element): every contribution (element,
+                                        m, n) to a row of the block has its own LDS slot, the slots of a CSR entry adjacent and in ascending
+                                        (element, m, n) order; the visiting elements STORE their local matrices there and every entry is summed
+                                        over its slots front to back -- the order of NH_MATRIX_GATHER, i.e. of the reference's numpy.add.at:
+                                        bit-identical to the gather path, 1.5 x the algorithmic bytes instead of 4.6 x.  Trilinear hexahedra at
+                                        the 2 x 2 x 2 Gauss points with a form kappa grad.grad + mass phi phi (recognised from the tables passed)
+                                        take the sum-factorised element routine of nh_p1hex_laplace (an exactly singular element then gives inf /
+                                        NaN instead of numeric.inv's all-NaN inverse).  VECTOR-VALUED blocks (nct = ncr = 2 or 3 on trilinear
+                                        hexahedra, bilinear or biquadratic quadrilaterals, one table set for test and trial): LDS holds the
+                                        physical gradients of the visiting elements, a lane sums the Gram matrix of one contribution (element,
+                                        m, n), a segmented sum over the lanes of a scalar entry forms it once and the form tensor is applied per
+                                        entry (nh_owner.hip).  Every sum is formed in an order fixed by the plan: repeated assemblies are
+                                        bit-identical.  The plan is built on the first such call and cached in the pattern handle.  Launches the
+                                        flag does not apply to take the default path (atomics; with NH_MATRIX_STORE after a zero fill of the
+                                        block's values). */
 
 int nh_assemble_matrix(const nh_matrix_args *args, void *stream);
 

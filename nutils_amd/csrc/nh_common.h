@@ -85,17 +85,17 @@ constexpr int NH_MAX_BUCKETS = 9;
 // owner blocks of NH_MATRIX_FUSED (nh_gather.hip): rows clustered into blocks whose CSR rows fit the LDS of a workgroup; a block recomputes every element
 // that touches one of its rows and writes its rows once
 struct nh_fused_plan {
-  int nblocks, rows_per_block;
-  int max_blen;       // doubles of the largest block accumulator
+  int nblocks, rows_per_block;  // rows_per_block: of the largest block (Morton boxes of at most that many rows)
+  int max_ents;       // doubles of the fullest block's accumulator (= CSR entries of its rows)
+  int nturns;         // visitors of the busiest row: rounds of the ordered adds
   i64 nvisits;
-  int32_t *order;     // [nrows]: dof at rank position i (block b = positions b * rows_per_block ...)
-  int32_t *loff;      // [nrows], by rank position: offset of the row in the accumulator of its block
+  int32_t *order;     // [nrows]: dof at rank position i
+  i64 *bptr;          // [nblocks + 1]: first rank position of block b
   i64 *rstart;        // [nrows], by rank position: first entry of the row in the value array
-  int32_t *blen;      // [nblocks]: doubles of the block's accumulator
+  i64 *epos;          // [nrows + 1], by rank position: CSR entries of the rows in front (offset of the row in its block's accumulator: epos[i] - epos[bptr[b]])
   i64 *vptr;          // [nblocks + 1]: visits of block b
   int32_t *vlist;     // [nvisits]: element
-  uint16_t *vrow;     // [nvisits][nbt]: row of local function m within the block | (colour or turn) << 9, 0xffff: the row belongs to another block
-  int ncol;           // > 0: sums ordered by colours (this many), 0: by turns
+  uint16_t *vrow;     // [nvisits][nbt]: row of local function m within the block | turn << 9, 0xffff: the row belongs to another block
   uint8_t *cpos;      // [nelems][nbt * nbr]: position of entry (m, n) within its CSR row
   // trilinear hexahedra at the 2 x 2 x 2 Gauss points (recognised from the tables of a launch): -1 not looked at, 0 no, 1 yes, 2 yes with a mass term
   int p1hex;

@@ -375,31 +375,48 @@ __global__ __launch_bounds__(128) void k_local_scalar(LocK p) {
 
 // ---- owner blocks (NH_MATRIX_FUSED): one pass, no scratch, no global atomics ------------------------------------------------------------------
 // The two-pass reduction above moves every local matrix through HBM twice and reads a 4-byte source index per contribution: 4.6 x the algorithmic bytes
-// on the 128^3 trilinear mesh.  Here the ROWS are clustered: dofs are sorted by the Morton code of the centroid of the first element that contains them, runs
-// of R consecutive dofs form a block whose CSR rows fit the LDS of a workgroup, and a block recomputes every element that touches one of its rows (8 x 8 x 8
-// node bricks on a structured mesh: 1.42 x the element arithmetic), adds the entries of ITS rows in LDS (ds_add_f64) and writes each row once.  Read per visit:
-// element id, 2 bytes per local row (accumulator offset or "not mine"), 1 byte per local entry (position within its CSR row), the geometry.  The sums are formed in
-// the order the waves arrive: NOT bit-reproducible (NH_MATRIX_GATHER is), same 1e-13 parity.
-// Block size (128^3 trilinear mesh, rows x threads -> ms, tools/fused_probe.py): 512 x 384 0.91 | 384 x 384 0.86 | 320 x 320 0.96 | 288 x 256 0.72 | 256 x 256 0.75 | 192 x 192 0.86 |
-// 128 x 128 0.77: two workgroups per CU (one streams its rows while the other computes) beat the smaller halo of one large block.
-constexpr int FUSED_CAP = 27 * 288;  // doubles of a block accumulator (62 kB: with staged tables and row tables two workgroups fit the 160 kB of a CU)
-constexpr int FUSED_NT = 256;        // threads of a block (~470 visits of a 288-row block: two rounds)
+// on the 128^3 trilinear mesh.  Here the ROWS are clustered (nh_blockplan.inc): dofs sorted by the Morton code of the centroid of the first element that contains
+// them, Morton boxes of at most R rows form a block whose CSR rows fit the LDS of a workgroup (8 x 8 x 4 node boxes on a structured mesh: 1.6 x the element
+// arithmetic), and a block recomputes every element that touches one of its rows, adds the entries of ITS rows in LDS (ds_add_f64) and writes each row once.
+// Read per visit: element id, 2 bytes per local row (row within the block and turn, or "not mine"), 1 byte per local entry (position within its CSR row), the geometry.
+// The sums are ORDERED: the block plan carries, for every (visit, local row), the TURN of that visit within its row (visits ascending = elements ascending: the order
+// of the reference's numpy.add.at, numeric.py:434-460); the visits of a round add in rounds -- in round t every row receives the contribution of its t-th visitor and
+// no other, a workgroup barrier separates the rounds -- so every CSR entry is the sum of its contributions in visit order whatever the wave scheduling: bit-reproducible.
+// (Round 4 let a visit spin on a per-row LDS turn counter instead: 23 % of the kernel in waits and retries.  Measured and dropped in round 5: one LDS slot per
+// CONTRIBUTION, stored without atomics and summed at the flush -- 64 slots for the 27 entries of a trilinear row shrink the blocks to 128 rows, and their fixed
+// chain of dependent loads per block made the kernel slower, 0.88-1.0 against 0.55 ms.)
+constexpr size_t FUSED_LDS = 66 * 1024;  // accumulator + row tables of a block (with staged element tables two workgroups fit the 160 kB of a CU)
+constexpr int FUSED_NT = 256;        // threads of a block (~405 visits of a 256-row block: two rounds)
 constexpr int FUSED_NT_MAX = 384;    // launch bound (ablation builds may launch more threads)
 
 #include "nh_blockplan.inc"
 
+// per rank position: first entry of the row in the value array, its length
+__global__ void k_fs_rowinfo(i64 nrows, const unsigned *order, const i64 *srowptr, i64 *rstart, int32_t *rlen) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  const i64 r = order[i];
+  rstart[i] = srowptr[r];
+  rlen[i] = (int32_t)(srowptr[r + 1] - srowptr[r]);
+}
+// entries of the fullest block
+__global__ void k_fs_maxents(int nblocks, const i64 *bptr, const i64 *epos, int *max_ents) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nblocks) atomicMax(max_ents, (int)(epos[bptr[b + 1]] - epos[bptr[b]]));
+}
 // (visit, local row) pairs: key = rank position of the row if it belongs to the visiting block, else ~0; value = the pair's index.  Sorted by key (stable: the
-// pairs of one row stay in visit order), the position of a pair within its key group is its TURN: the fused kernels add the contributions to a row in that order.
-__global__ void k_fp_vkeys(i64 nvisits, int nbt, int R, const int32_t *dofs, const int32_t *rank, const unsigned *vkey, const unsigned *vlist, unsigned *pkey, unsigned *pval) {
+// pairs of one row stay in visit order), the position of a pair within its key group is its TURN.
+__global__ void k_fs_vkeys(i64 nvisits, int nbt, const int32_t *blk, const int32_t *dofs, const int32_t *rank, const i64 *vptr, const unsigned *vlist, unsigned *pkey, unsigned *pval) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nvisits * nbt) return;
   const i64 v = i / nbt;
-  const int r = rank[dofs[(i64)vlist[v] * nbt + (i - v * nbt)]];
-  pkey[i] = r / R == (int)vkey[v] ? (unsigned)r : 0xffffffffu;
+  const int rp = rank[dofs[(i64)vlist[v] * nbt + (i - v * nbt)]];
+  const int b = blk[rp];
+  pkey[i] = (v >= vptr[b] && v < vptr[b + 1]) ? (unsigned)rp : 0xffffffffu;  // (visit v belongs to the block of this row?)
   pval[i] = (unsigned)i;
 }
-// vrow[pair] = row index within the block | turn << 9 (0xffff: the row belongs to another block)
-__global__ void k_fp_vrow(i64 n, int R, const unsigned *pkey, const unsigned *pval, uint16_t *vrow, int *bad) {
+// vrow[pair] = row within the block | turn << 9 (0xffff: the row belongs to another block); flags[0]: a turn does not fit, flags[1]: turns of the busiest row
+__global__ void k_fs_vrow(i64 n, const i64 *bptr, const int32_t *blk, const unsigned *pkey, const unsigned *pval, uint16_t *vrow, int *flags) {
   const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const unsigned key = pkey[j];
@@ -408,48 +425,13 @@ __global__ void k_fp_vrow(i64 n, int R, const unsigned *pkey, const unsigned *pv
     return;
   }
   int seq = 0;
-  while (seq < 127 && j - seq - 1 >= 0 && pkey[j - seq - 1] == key) ++seq;
-  if (seq >= 127) atomicOr(bad, 1);
-  vrow[pval[j]] = (uint16_t)((key % (unsigned)R) | (unsigned)seq << 9);
+  while (seq < 126 && j - seq - 1 >= 0 && pkey[j - seq - 1] == key) ++seq;
+  if (seq >= 126) atomicOr(flags, 1);
+  atomicMax(flags + 1, seq + 1);
+  vrow[pval[j]] = (uint16_t)((unsigned)(key - (unsigned)bptr[blk[key]]) | (unsigned)seq << 9);
 }
-
-// ORDER BY COLOURS (round 4; NH_FUSED_ORDER=colours -- measured: 0.80 ms against 0.57 ms with the turns on the 128^3 trilinear mesh, the adds of a colour phase are a
-// serial chain of LDS atomics with most threads idle): the visits of a block are coloured so that two visits of one colour share no row of the block (greedy, in visit order: one thread per
-// block, the colours a row has seen in a 64-bit mask); the fused kernels add colour by colour with a workgroup barrier in between -- every CSR entry is the sum of its
-// contributions in (round, colour) order whatever the wave scheduling, and no visit waits for another.  vrow[pair] = row index within the block | colour << 9.
-__global__ void k_fp_color(int nblocks, int nbt, int R, const i64 *vptr, const int32_t *vlist, const int32_t *dofs, const int32_t *rank, uint16_t *vrow, int *flags) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nblocks) return;
-  unsigned long long mask[512];
-  for (int r = 0; r < R; ++r) mask[r] = 0ull;
-  int maxc = 0;
-  for (i64 i = vptr[b]; i < vptr[b + 1]; ++i) {
-    const i64 e = vlist[i];
-    unsigned long long used = 0ull;
-    for (int m = 0; m < nbt; ++m) {
-      const int r = rank[dofs[e * nbt + m]];
-      if (r / R == b) used |= mask[r % R];
-    }
-    int c = __ffsll((long long)~used) - 1;
-    if (c < 0 || c > 126) {
-      atomicOr(flags + 2, 1);
-      c = 0;
-    }
-    for (int m = 0; m < nbt; ++m) {
-      const int r = rank[dofs[e * nbt + m]];
-      if (r / R == b) {
-        mask[r % R] |= 1ull << c;
-        vrow[i * nbt + m] = (uint16_t)((unsigned)(r % R) | (unsigned)c << 9);
-      } else
-        vrow[i * nbt + m] = (uint16_t)0xffff;
-    }
-    maxc = max(maxc, c + 1);
-  }
-  atomicMax(flags + 3, maxc);
-}
-
 // the element map (position of entry (m, n) within the CSR row of its test dof) narrowed to a byte
-__global__ void k_fp_cpos(i64 n, const int32_t *emap, uint8_t *cpos, int *bad) {
+__global__ void k_fs_cpos(i64 n, const int32_t *emap, uint8_t *cpos, int *bad) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int d = emap[i];
@@ -476,30 +458,59 @@ __device__ __forceinline__ double fast_rcp(double d) {
 struct FusK {
   LocK loc;
   P1Tab tab;
-  const i64 *srowptr;
   double *values;
   int store;
-  i64 nrows;
-  int R, max_blen;
-  const int32_t *loff, *blen, *vlist;
-  const i64 *vptr, *rstart;
+  int R, max_ents, nturns;  // rows of the largest block, entries of the fullest, visitors of the busiest row
+  const i64 *bptr, *vptr, *rstart, *epos;
+  const int32_t *vlist;
   const uint16_t *vrow;
   const uint8_t *cpos;
-  int ncol;  // > 0: the plan orders the sums by colours (k_fp_color), 0: by turns (k_fp_vrow)
 };
+
+// LDS of an owner block behind the staged element tables: [row starts R x i64][accumulator offsets R + 1 ints, padded][accumulator: the rows of the block, entry by entry]
+struct FusLds {
+  i64 *rstart;
+  int *eoff;
+  double *acc;
+};
+__device__ __forceinline__ FusLds fused_lds(double *base, int R) {
+  FusLds l;
+  l.rstart = reinterpret_cast<i64 *>(base);
+  l.eoff = reinterpret_cast<int *>(l.rstart + R);
+  l.acc = base + R + (R + 2) / 2;
+  return l;
+}
+static size_t fused_lds_bytes(int R, int max_ents) { return sizeof(double) * ((size_t)max_ents + (size_t)R + ((size_t)R + 2) / 2); }
+
+// row tables of block b, accumulator zeroed
+__device__ __forceinline__ int fused_stage_rows(const FusK &p, int b, const FusLds &l) {
+  const i64 r0 = p.bptr[b];
+  const int nr = (int)(p.bptr[b + 1] - r0);
+  const i64 e0 = p.epos[r0];
+  for (int i = threadIdx.x; i <= nr; i += blockDim.x) {
+    if (i < nr) l.rstart[i] = p.rstart[r0 + i];
+    l.eoff[i] = (int)(p.epos[r0 + i] - e0);
+  }
+  const int nent = (int)(p.epos[r0 + nr] - e0);
+  for (int i = threadIdx.x; i < nent; i += blockDim.x) l.acc[i] = 0.;
+  return nr;
+}
+// the rows of the block, half a wave per row (row starts and offsets are staged: no chain of dependent global loads); a row is one contiguous piece of the value array
+__device__ __forceinline__ void fused_flush_rows(const FusK &p, const FusLds &l, int nr) {
+  const int hl = threadIdx.x & 31, NT = blockDim.x;
+  for (int i = threadIdx.x >> 5; i < nr; i += NT >> 5) {
+    const int lo = l.eoff[i], len = l.eoff[i + 1] - lo;
+    double *dst = p.values + l.rstart[i];
+    for (int j = hl; j < len; j += 32) dst[j] = p.store ? l.acc[lo + j] : dst[j] + l.acc[lo + j];
+  }
+}
 
 template <int ND, int NBT, int NBR, bool LDST, bool SYMD>
 __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_scalar(FusK p) {
   constexpr int S = 1 + ND, NG = 1 << ND, NE = NBT * NBR;
   extern __shared__ __attribute__((aligned(16))) double sT[];
-  // LDS: [staged tables][row starts of the block in the value array: R x i64][accumulator offsets of its rows: R + 1 ints, padded][accumulator]
-  i64 *rstartS = reinterpret_cast<i64 *>(sT + p.loc.ldst_doubles);
-  int *loffS = reinterpret_cast<int *>(rstartS + p.R);
-  unsigned *turn = reinterpret_cast<unsigned *>(loffS + ((p.R + 2) & ~1));  // [R] contributions a row has received so far
-  double *acc = reinterpret_cast<double *>(rstartS + p.R) + (p.R + 2) / 2 + (p.R + 1) / 2;
+  const FusLds l = fused_lds(sT + p.loc.ldst_doubles, p.R);
   const int b = blockIdx.x, NT = blockDim.x;
-  const i64 r0 = (i64)b * p.R;
-  const int nr = (int)min((i64)p.R, p.nrows - r0);
   if (LDST) {
     const int nt = NBT * p.loc.nq * S, ntr = NBR * p.loc.nq * S, ng = NG * p.loc.nq * S;
     for (int i = threadIdx.x; i < nt; i += NT) sT[i] = p.loc.test.T[i];
@@ -507,86 +518,45 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_scalar(FusK p) {
     if (p.loc.geom.kind == NH_GEOM_ISO && p.loc.geom.ngb == NG)
       for (int i = threadIdx.x; i < ng; i += NT) sT[nt + ntr + i] = p.loc.geom.gT[i];
   }
-  for (int i = threadIdx.x; i < nr; i += NT) {
-    rstartS[i] = p.rstart[r0 + i];
-    loffS[i] = p.loff[r0 + i];
-  }
-  for (int i = threadIdx.x; i < p.R; i += NT) turn[i] = 0;
-  for (int i = threadIdx.x; i < p.max_blen; i += NT) acc[i] = 0.;
+  const int nr = fused_stage_rows(p, b, l);
   __syncthreads();
   const i64 v0 = p.vptr[b], v1 = p.vptr[b + 1];
-  for (i64 base = v0; base < v1; base += NT) {  // (the same number of rounds for every thread: the colour phases end in workgroup barriers)
-    const i64 i = base + threadIdx.x;
-    const bool act = i < v1;
-    const i64 e = p.vlist[act ? i : v0];
-    // accumulator offsets of the element's rows and the positions of its entries within them: whole words where the sizes allow
+  for (i64 base = v0; base < v1; base += NT) {  // (the same number of rounds for every thread: the turns end in workgroup barriers)
+    const bool act = base + threadIdx.x < v1;
+    const i64 i = act ? base + threadIdx.x : v1 - 1;  // (threads behind the last visit shadow it and add nothing)
+    const i64 e = p.vlist[i];
+    // rows of the element within the block with their turns, and the positions of its entries within the rows: whole words where the sizes allow
     uint16_t vr[NBT];
     uint8_t cp[NE];
     if constexpr (NBT % 8 == 0) {
 #pragma unroll
-      for (int k = 0; k < NBT / 8; ++k) *reinterpret_cast<uint4 *>(vr + 8 * k) = reinterpret_cast<const uint4 *>(p.vrow + (act ? i : v0) * NBT)[k];
+      for (int k = 0; k < NBT / 8; ++k) *reinterpret_cast<uint4 *>(vr + 8 * k) = reinterpret_cast<const uint4 *>(p.vrow + i * NBT)[k];
     } else {
 #pragma unroll
-      for (int m = 0; m < NBT; ++m) vr[m] = p.vrow[(act ? i : v0) * NBT + m];
+      for (int m = 0; m < NBT; ++m) vr[m] = p.vrow[i * NBT + m];
     }
     if constexpr (NE % 16 == 0) {
 #pragma unroll
       for (int k = 0; k < NE / 16; ++k) *reinterpret_cast<uint4 *>(cp + 16 * k) = reinterpret_cast<const uint4 *>(p.cpos + e * NE)[k];
     } else {
 #pragma unroll
-      for (int l = 0; l < NE; ++l) cp[l] = p.cpos[e * NE + l];
+      for (int k = 0; k < NE; ++k) cp[k] = p.cpos[e * NE + k];
     }
     double A[NBT][NBR];
-    if (act) local_scalar_matrix<ND, NBT, NBR, LDST, SYMD>(p.loc, sT, e, e, A);
-    unsigned pend = 0;
-    int mycol = -1;
-#pragma unroll
-    for (int m = 0; m < NBT; ++m)
-      if (act && vr[m] != 0xffff) pend |= 1u << m, mycol = vr[m] >> 9;
-    if (p.ncol) {
-      // colour by colour: the visits of a colour share no row, the barrier orders the colours -- bit-reproducible sums without a visit waiting for another
-      for (int c = 0; c < p.ncol; ++c) {
-        if (mycol == c) {
-#pragma unroll
-          for (int m = 0; m < NBT; ++m) {
-            if (!(pend >> m & 1)) continue;
-            const int base2 = loffS[vr[m] & 511];
-#pragma unroll
-            for (int n = 0; n < NBR; ++n) atomicAdd(acc + base2 + cp[m * NBR + n], (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n]);
-          }
-        }
-        __syncthreads();
-      }
-      continue;
-    }
-    // by turns: the contributions to a row are added in the order of the visits (the turn of this visit within each of its rows comes with the plan).  A visit waits
-    // only for EARLIER visits, which are being processed or done: no deadlock; all adds of a wave reach the LDS in program order, the turn counter last.
-    while (pend) {
-      bool progress = false;
+    local_scalar_matrix<ND, NBT, NBR, LDST, SYMD>(p.loc, sT, e, e, A);
+    // turn t: every row of the block receives the contribution of its t-th visitor -- no two threads meet in a row, the barrier orders the turns
+    for (int t = 0; t < p.nturns; ++t) {
 #pragma unroll
       for (int m = 0; m < NBT; ++m) {
-        if (!(pend >> m & 1)) continue;
-        const int row = vr[m] & 511;
-        if (__hip_atomic_load(turn + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(vr[m] >> 9)) continue;
-        const int base2 = loffS[row];
+        if (!act || vr[m] == 0xffff || (vr[m] >> 9) != t) continue;
+        double *row = l.acc + l.eoff[vr[m] & 511];
 #pragma unroll
-        for (int n = 0; n < NBR; ++n) atomicAdd(acc + base2 + cp[m * NBR + n], (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n]);
-        atomicAdd(turn + row, 1u);
-        pend &= ~(1u << m);
-        progress = true;
+        for (int n = 0; n < NBR; ++n) atomicAdd(row + cp[m * NBR + n], (SYMD && n < m) ? A[n < NBT ? n : 0][m < NBR ? m : 0] : A[m][n]);
       }
-      if (pend && !progress) __builtin_amdgcn_s_sleep(1);
+      __syncthreads();
     }
   }
-  __syncthreads();
-  // the rows of the block, half a wave per row (row starts and offsets are staged: no chain of dependent global loads); a row is one contiguous piece of the
-  // value array
-  const int hl = threadIdx.x & 31;
-  for (int i = threadIdx.x >> 5; i < nr; i += NT >> 5) {
-    const int lo = loffS[i], len = (i + 1 < nr ? loffS[i + 1] : p.blen[b]) - lo;
-    double *dst = p.values + rstartS[i];
-    for (int l = hl; l < len; l += 32) dst[l] = p.store ? acc[lo + l] : dst[l] + acc[lo + l];
-  }
+  fused_flush_rows(p, l, nr);
 }
 
 // the same owner blocks for TRILINEAR HEXAHEDRA with the 2 x 2 x 2 Gauss scheme (recognised from the tables the caller passes: nh_fused_scalar) and forms
@@ -596,25 +566,15 @@ template <bool MASS>
 __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_p1hex(FusK fp) {
   constexpr int NBT = 8, NE = 64;
   extern __shared__ __attribute__((aligned(16))) double sT[];
-  i64 *rstartS = reinterpret_cast<i64 *>(sT);
-  int *loffS = reinterpret_cast<int *>(rstartS + fp.R);
-  unsigned *turn = reinterpret_cast<unsigned *>(loffS + ((fp.R + 2) & ~1));
-  double *acc = reinterpret_cast<double *>(rstartS + fp.R) + (fp.R + 2) / 2 + (fp.R + 1) / 2;
+  const FusLds l = fused_lds(sT, fp.R);
   const int b = blockIdx.x, NT = blockDim.x;
-  const i64 r0 = (i64)b * fp.R;
-  const int nr = (int)min((i64)fp.R, fp.nrows - r0);
-  for (int i = threadIdx.x; i < nr; i += NT) {
-    rstartS[i] = fp.rstart[r0 + i];
-    loffS[i] = fp.loff[r0 + i];
-  }
-  for (int i = threadIdx.x; i < fp.R; i += NT) turn[i] = 0;
-  for (int i = threadIdx.x; i < fp.max_blen; i += NT) acc[i] = 0.;
+  const int nr = fused_stage_rows(fp, b, l);
   __syncthreads();
   const P1Tab &p = fp.tab;
   const i64 v0 = fp.vptr[b], v1 = fp.vptr[b + 1];
-  for (i64 base = v0; base < v1; base += NT) {  // (uniform number of rounds: the colour phases end in workgroup barriers)
-    const i64 i = min(base + (i64)threadIdx.x, v1 - 1);  // (threads behind the last visit shadow it and add nothing)
+  for (i64 base = v0; base < v1; base += NT) {
     const bool act = base + threadIdx.x < v1;
+    const i64 i = act ? base + threadIdx.x : v1 - 1;
     const i64 e = fp.vlist[i];
     uint16_t vr[NBT];
     uint8_t cp[NE];
@@ -666,57 +626,21 @@ __global__ __launch_bounds__(FUSED_NT_MAX) void k_fused_p1hex(FusK fp) {
 #pragma unroll
         for (int bb = a; bb < 8; ++bb) K[q++] = entry(a, bb);
     }
-    // the contributions to a row colour by colour or in the order of the visits (see k_fused_scalar): bit-reproducible sums
-    unsigned pend = 0;
-    int mycol = -1;
-#pragma unroll
-    for (int m = 0; m < 8; ++m)
-      if (act && vr[m] != 0xffff) pend |= 1u << m, mycol = vr[m] >> 9;
-    if (fp.ncol) {
-      for (int c = 0; c < fp.ncol; ++c) {
-        if (mycol == c) {
-#pragma unroll
-          for (int m = 0; m < 8; ++m) {
-            if (!(pend >> m & 1)) continue;
-            const int base2 = loffS[vr[m] & 511];
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-              const int lo = m < n ? m : n, hi = m < n ? n : m;
-              atomicAdd(acc + base2 + cp[m * 8 + n], K[lo * 8 - lo * (lo - 1) / 2 + hi - lo]);
-            }
-          }
-        }
-        __syncthreads();
-      }
-      continue;
-    }
-    while (pend) {
-      bool progress = false;
+    for (int t = 0; t < fp.nturns; ++t) {
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        if (!(pend >> m & 1)) continue;
-        const int row = vr[m] & 511;
-        if (__hip_atomic_load(turn + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)(vr[m] >> 9)) continue;
-        const int base = loffS[row];
+        if (!act || vr[m] == 0xffff || (vr[m] >> 9) != t) continue;
+        double *row = l.acc + l.eoff[vr[m] & 511];
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
           const int lo = m < n ? m : n, hi = m < n ? n : m;
-          atomicAdd(acc + base + cp[m * 8 + n], K[lo * 8 - lo * (lo - 1) / 2 + hi - lo]);
+          atomicAdd(row + cp[m * 8 + n], K[lo * 8 - lo * (lo - 1) / 2 + hi - lo]);
         }
-        atomicAdd(turn + row, 1u);
-        pend &= ~(1u << m);
-        progress = true;
       }
-      if (pend && !progress) __builtin_amdgcn_s_sleep(1);
+      __syncthreads();
     }
   }
-  __syncthreads();
-  const int hl = threadIdx.x & 31;
-  for (int i = threadIdx.x >> 5; i < nr; i += NT >> 5) {
-    const int lo = loffS[i], len = (i + 1 < nr ? loffS[i + 1] : fp.blen[b]) - lo;
-    double *dst = fp.values + rstartS[i];
-    for (int l = hl; l < len; l += 32) dst[l] = fp.store ? acc[lo + l] : dst[l] + acc[lo + l];
-  }
+  fused_flush_rows(fp, l, nr);
 }
 
 double *g_scratch = nullptr;
@@ -1265,27 +1189,27 @@ int nh_gather_prepare_sym(nh_pattern *p, const nh_basis &test, const int32_t *el
 
 void nh_fused_free(nh_fused_plan *f) {
   if (!f) return;
-  hipFree(f->order), hipFree(f->loff), hipFree(f->rstart), hipFree(f->blen), hipFree(f->vptr), hipFree(f->vlist), hipFree(f->vrow), hipFree(f->cpos);
+  hipFree(f->order), hipFree(f->bptr), hipFree(f->rstart), hipFree(f->epos), hipFree(f->vptr), hipFree(f->vlist), hipFree(f->vrow), hipFree(f->cpos);
   delete f;
 }
 
-// the owner blocks of a pattern (once per pattern handle)
+// the owner blocks of a pattern (once per pattern handle); NH_ELIMIT: the plan does not fit this pattern, the caller keeps its other paths
 static int nh_fused_prepare(nh_pattern *p, const nh_matrix_args *a, hipStream_t s) {
   const i64 ne = p->nelems, nrows = p->nrows;
   const int nbt = p->nbt, nbr = p->nbr;
-  NH_REQUIRE(ne < (1ll << 31) && nrows < (1ll << 31) && p->emap_len == ne * nbt * nbr, "NH_MATRIX_FUSED: pattern too large / not uniform");
+  if (!(ne < (1ll << 31) && nrows < (1ll << 31) && p->emap_len == ne * nbt * nbr)) return NH_ELIMIT;
   const int32_t *dofs = a->test.dofs_dev;
-  nh_fused_plan *f = new nh_fused_plan();
-  memset(f, 0, sizeof *f);
-  f->p1hex = -1;
-  double *cent = nullptr;
-  unsigned long long *mm = nullptr;
-  unsigned *ekey = nullptr, *nkey = nullptr, *iota = nullptr, *nkey2 = nullptr, *order = nullptr, *vkey = nullptr, *vval = nullptr, *vkey2 = nullptr, *vval2 = nullptr;
-  int32_t *rank = nullptr, *cnt = nullptr, *bcount = nullptr;
-  int *flags = nullptr;  // [0] longest row, [1] largest block accumulator, [2] bad column position / colour, [3] colours
-  i64 *voff = nullptr;
-  void *tmp = nullptr;
-  int rc = NH_OK, hflags[3] = {0, 0, 0};
+  BpTmp t;
+  t.n = 0;
+  unsigned *order = nullptr, *skeys = nullptr, *vlist = nullptr, *pkey = nullptr, *pval = nullptr, *pkey2 = nullptr, *pval2 = nullptr;
+  int32_t *rank = nullptr, *blk = nullptr, *rlen = nullptr;
+  i64 *rstart = nullptr, *bptr = nullptr, *vptr = nullptr, *epos = nullptr;
+  uint16_t *vrow = nullptr;
+  uint8_t *cpos = nullptr;
+  int *flags = nullptr;  // [0] a turn / column position does not fit its field, [1] visitors of the busiest row, [2] entries of the fullest block
+  int maxlen = 0, hflags[3] = {0, 0, 0}, nblocks = 0, R = 0, rc = NH_OK;
+  i64 nvisits = 0;
+  nh_fused_plan *f = nullptr;
 #define FP_CHECK(expr)                                                                          \
   do {                                                                                          \
     hipError_t _e = (expr);                                                                     \
@@ -1296,147 +1220,75 @@ static int nh_fused_prepare(nh_pattern *p, const nh_matrix_args *a, hipStream_t 
     }                                                                                           \
   } while (0)
   {
-    const unsigned long long mm0[6] = {~0ull, ~0ull, ~0ull, 0, 0, 0};
-    const unsigned ge = (unsigned)((ne + 255) / 256), gr = (unsigned)((nrows + 255) / 256);
-    FP_CHECK(hipMalloc((void **)&cent, ne * 3 * sizeof(double)));
-    FP_CHECK(hipMalloc((void **)&mm, sizeof mm0));
-    FP_CHECK(hipMemcpyAsync(mm, mm0, sizeof mm0, hipMemcpyHostToDevice, s));
-    FP_CHECK(hipMalloc((void **)&flags, 4 * sizeof(int)));
-    FP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
-    hipLaunchKernelGGL(k_fp_centroid, dim3(ge), dim3(256), 0, s, ne, to_k(a->geom), a->ndims, a->nq, cent, mm);
-    FP_CHECK(hipMalloc((void **)&ekey, ne * 4));
-    unsigned long long mmh[6];
-    FP_CHECK(hipMemcpyAsync(mmh, mm, sizeof mmh, hipMemcpyDeviceToHost, s));
-    FP_CHECK(hipStreamSynchronize(s));
-    hipLaunchKernelGGL(k_fp_ekey, dim3(ge), dim3(256), 0, s, ne, cent, mm, bp_cell_size(mmh, ne), ekey);
-    FP_CHECK(hipMalloc((void **)&nkey, nrows * 4));
-    FP_CHECK(hipMalloc((void **)&iota, nrows * 4));
-    FP_CHECK(hipMalloc((void **)&nkey2, nrows * 4));
-    FP_CHECK(hipMalloc((void **)&order, nrows * 4));
-    hipLaunchKernelGGL(k_fp_fill, dim3(1024), dim3(256), 0, s, nrows, nkey, 0xffffffffu, iota);
-    hipLaunchKernelGGL(k_fp_nodekey, dim3((unsigned)((ne * nbt + 255) / 256)), dim3(256), 0, s, ne, nbt, dofs, ekey, nkey);
+    if ((rc = bp_cluster(t, p, a, &order, &rank, &maxlen, s, &skeys)) != NH_OK) goto done;
+    FP_CHECK(bp_alloc(t, &flags, 3));
+    FP_CHECK(hipMemsetAsync(flags, 0, 3 * sizeof(int), s));
+    FP_CHECK(bp_alloc(t, &rstart, (size_t)nrows));
+    FP_CHECK(bp_alloc(t, &rlen, (size_t)nrows + 1));
+    FP_CHECK(bp_alloc(t, &epos, (size_t)nrows + 1));
+    hipLaunchKernelGGL(k_fs_rowinfo, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, nrows, order, p->srowptr, rstart, rlen);
     FP_CHECK(hipGetLastError());
-    size_t tmpsz = 0, tmpsz2 = 0;
-    FP_CHECK(rocprim::radix_sort_pairs(nullptr, tmpsz, nkey, nkey2, iota, order, (size_t)nrows, 0, 32, s));
-    FP_CHECK(hipMalloc(&tmp, tmpsz));
-    FP_CHECK(rocprim::radix_sort_pairs(tmp, tmpsz, nkey, nkey2, iota, order, (size_t)nrows, 0, 32, s));  // stable: ties in dof order
-    FP_CHECK(hipMalloc((void **)&rank, nrows * 4));
-    hipLaunchKernelGGL(k_fp_rank, dim3(gr), dim3(256), 0, s, nrows, order, p->srowptr, rank, flags);
-    FP_CHECK(hipMemcpyAsync(hflags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
-    FP_CHECK(hipStreamSynchronize(s));
-    const int maxlen = std::max(hflags[0], 1);
-    int R = std::min(512, FUSED_CAP / maxlen);
+    if ((rc = nh_scan_exclusive(rlen, epos, nrows, s)) != NH_OK) goto done;  // entries in front of a row, rows in rank order
+    // rows per block: the largest candidate whose fullest block fits the LDS of a workgroup (two per CU)
+    const int cand[] = {512, 256, 128, 64};
+    int forced = 0;
 #ifdef NH_ABLATION
-    if (getenv("NH_FUSED_ROWS")) R = std::min(512, std::max(64, atoi(getenv("NH_FUSED_ROWS"))));
+    if (getenv("NH_FUSED_ROWS")) forced = std::min(512, std::max(16, atoi(getenv("NH_FUSED_ROWS"))));
 #endif
-    if (R < 64) {  // (rows too long for a useful block: the caller keeps its other paths)
+    for (int ci = 0; ci < 4 && !R; ++ci) {
+      const int Rc = forced ? forced : cand[ci];
+      const int tn = t.n;
+      FP_CHECK(hipMemsetAsync(flags + 2, 0, sizeof(int), s));
+      if ((rc = bp_blocks(t, skeys, nrows, Rc, &nblocks, &bptr, &blk, s)) != NH_OK) goto done;
+      hipLaunchKernelGGL(k_fs_maxents, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s, nblocks, bptr, epos, flags + 2);
+      FP_CHECK(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+      FP_CHECK(hipStreamSynchronize(s));
+      if (fused_lds_bytes(Rc, hflags[2]) <= FUSED_LDS || forced) R = Rc;
+      else {
+        for (int i = tn; i < t.n; ++i) hipFree(t.ptr[i]);  // (this candidate's arrays)
+        t.n = tn;
+      }
+    }
+    if (!R) {  // (rows too long for a useful block)
       rc = NH_ELIMIT;
       goto done;
     }
-    const int nblocks = (int)((nrows + R - 1) / R);
-    f->rows_per_block = R;
-    f->nblocks = nblocks;
-    FP_CHECK(hipMalloc((void **)&f->loff, nrows * 4));
-    FP_CHECK(hipMalloc((void **)&f->rstart, nrows * sizeof(i64)));
-    FP_CHECK(hipMalloc((void **)&f->blen, nblocks * 4));
-    hipLaunchKernelGGL(k_fp_loff, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nrows, R, nblocks, order, p->srowptr, f->loff, f->rstart, f->blen, flags + 1);
-    FP_CHECK(hipMalloc((void **)&cnt, (ne + 1) * 4));
-    FP_CHECK(hipMalloc((void **)&voff, (ne + 1) * sizeof(i64)));
-    hipLaunchKernelGGL((k_fp_visits<false>), dim3(ge), dim3(256), 0, s, ne, nbt, R, dofs, rank, cnt, (const i64 *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, (int32_t *)nullptr);
-    FP_CHECK(hipGetLastError());
-    if ((rc = nh_scan_exclusive(cnt, voff, ne, s)) != NH_OK) goto done;
-    i64 nvisits = 0;
-    FP_CHECK(hipMemcpyAsync(&nvisits, voff + ne, sizeof(i64), hipMemcpyDeviceToHost, s));
-    FP_CHECK(hipStreamSynchronize(s));
-    f->nvisits = nvisits;
-    FP_CHECK(hipMalloc((void **)&vkey, nvisits * 4));
-    FP_CHECK(hipMalloc((void **)&vval, nvisits * 4));
-    FP_CHECK(hipMalloc((void **)&vkey2, nvisits * 4));
-    FP_CHECK(hipMalloc((void **)&vval2, nvisits * 4));
-    FP_CHECK(hipMalloc((void **)&bcount, (nblocks + 1) * 4));
-    FP_CHECK(hipMemsetAsync(bcount, 0, (nblocks + 1) * 4, s));
-    hipLaunchKernelGGL((k_fp_visits<true>), dim3(ge), dim3(256), 0, s, ne, nbt, R, dofs, rank, (int32_t *)nullptr, voff, vkey, vval, bcount);
-    FP_CHECK(hipGetLastError());
-    int bits = 1;
-    while ((1ll << bits) < nblocks) ++bits;
-    FP_CHECK(rocprim::radix_sort_pairs(nullptr, tmpsz2, vkey, vkey2, vval, vval2, (size_t)nvisits, 0, bits, s));
-    if (tmpsz2 > tmpsz) {
-      hipFree(tmp);
-      tmp = nullptr;
-      FP_CHECK(hipMalloc(&tmp, tmpsz2));
+    if ((rc = bp_visits(t, p, dofs, rank, blk, nblocks, &nvisits, &vptr, &vlist, s)) != NH_OK) goto done;
+    const i64 np = nvisits * nbt;
+    if (np >= (1ll << 32)) {  // (32-bit pair indices)
+      rc = NH_ELIMIT;
+      goto done;
     }
-    FP_CHECK(rocprim::radix_sort_pairs(tmp, tmpsz2, vkey, vkey2, vval, vval2, (size_t)nvisits, 0, bits, s));  // stable: the visits of a block in element order
-    FP_CHECK(hipMalloc((void **)&f->vptr, (nblocks + 1) * sizeof(i64)));
-    if ((rc = nh_scan_exclusive(bcount, f->vptr, nblocks, s)) != NH_OK) goto done;
-    FP_CHECK(hipMalloc((void **)&f->vrow, std::max<i64>(nvisits * nbt, 1) * sizeof(uint16_t)));
-    f->ncol = 0;
-    if (getenv("NH_FUSED_ORDER") && !strcmp(getenv("NH_FUSED_ORDER"), "colours")) {
-      // colours (measured slower than the turns, not the default): greedy colouring of the visits of every block, one thread per block
-      FP_CHECK(hipMemsetAsync(flags + 3, 0, sizeof(int), s));
-      hipLaunchKernelGGL(k_fp_color, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nblocks, nbt, R, f->vptr, reinterpret_cast<const int32_t *>(vval2), dofs, rank, f->vrow, flags);
-      FP_CHECK(hipGetLastError());
-      int ncol = 0;
-      FP_CHECK(hipMemcpyAsync(&ncol, flags + 3, sizeof(int), hipMemcpyDeviceToHost, s));
-      FP_CHECK(hipStreamSynchronize(s));
-      f->ncol = ncol;
-    } else {
-      // the turn of every (visit, local row) within its row: stable sort of the pairs by row
-      const i64 np = nvisits * nbt;
-      if (np >= (1ll << 32)) {  // (32-bit pair indices)
-        rc = NH_ELIMIT;
-        goto done;
-      }
-      hipFree(vkey), hipFree(vval);
-      vkey = vval = nullptr;
-      unsigned *pk2 = nullptr, *pv2 = nullptr;
-      FP_CHECK(hipMalloc((void **)&vkey, np * 4));
-      FP_CHECK(hipMalloc((void **)&vval, np * 4));
-      FP_CHECK(hipMalloc((void **)&pk2, np * 4));
-      if (hipMalloc((void **)&pv2, np * 4) != hipSuccess) {
-        hipFree(pk2);
-        FP_CHECK(hipErrorOutOfMemory);
-      }
-      hipLaunchKernelGGL(k_fp_vkeys, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, nvisits, nbt, R, dofs, rank, vkey2, vval2, vkey, vval);
-      size_t tmpsz3 = 0;
-      hipError_t e3 = rocprim::radix_sort_pairs(nullptr, tmpsz3, vkey, pk2, vval, pv2, (size_t)np, 0, 32, s);
-      if (e3 == hipSuccess && tmpsz3 > std::max(tmpsz, tmpsz2)) {
-        hipFree(tmp);
-        tmp = nullptr;
-        e3 = hipMalloc(&tmp, tmpsz3);
-      }
-      if (e3 == hipSuccess) e3 = rocprim::radix_sort_pairs(tmp, tmpsz3, vkey, pk2, vval, pv2, (size_t)np, 0, 32, s);
-      if (e3 == hipSuccess) {
-        hipLaunchKernelGGL(k_fp_vrow, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, np, R, pk2, pv2, f->vrow, flags + 2);
-        e3 = hipStreamSynchronize(s);
-      }
-      hipFree(pk2), hipFree(pv2);
-      FP_CHECK(e3);
-    }
-    FP_CHECK(hipMalloc((void **)&f->cpos, p->emap_len));
-    hipLaunchKernelGGL(k_fp_cpos, dim3((unsigned)((p->emap_len + 255) / 256)), dim3(256), 0, s, p->emap_len, p->emap, f->cpos, flags + 2);
+    // the turn of every (visit, local row) within its row: stable sort of the pairs by row
+    FP_CHECK(bp_alloc(t, &pkey, (size_t)np));
+    FP_CHECK(bp_alloc(t, &pval, (size_t)np));
+    hipLaunchKernelGGL(k_fs_vkeys, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, nvisits, nbt, blk, dofs, rank, vptr, vlist, pkey, pval);
+    FP_CHECK(hipGetLastError());
+    if ((rc = bp_sort_pairs(t, pkey, pval, (size_t)np, 32, &pkey2, &pval2, s)) != NH_OK) goto done;
+    FP_CHECK(bp_alloc(t, &vrow, (size_t)np));
+    hipLaunchKernelGGL(k_fs_vrow, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, np, bptr, blk, pkey2, pval2, vrow, flags);
+    FP_CHECK(bp_alloc(t, &cpos, (size_t)p->emap_len));
+    hipLaunchKernelGGL(k_fs_cpos, dim3((unsigned)((p->emap_len + 255) / 256)), dim3(256), 0, s, p->emap_len, p->emap, cpos, flags);
     FP_CHECK(hipGetLastError());
     FP_CHECK(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
     FP_CHECK(hipStreamSynchronize(s));
-    if (hflags[2] || hflags[1] > 27 * 512 || hflags[1] >= 0xffff || R > 512) {
+    if (hflags[0] || R > 512) {
       rc = NH_ELIMIT;
       goto done;
     }
-    f->max_blen = hflags[1];
-    f->order = reinterpret_cast<int32_t *>(order);
-    order = nullptr;
-    f->vlist = reinterpret_cast<int32_t *>(vval2);
-    vval2 = nullptr;
+    f = new nh_fused_plan();
+    memset(f, 0, sizeof *f);
+    f->p1hex = -1;
+    f->nblocks = nblocks, f->rows_per_block = R, f->max_ents = hflags[2], f->nturns = hflags[1], f->nvisits = nvisits;
+    f->order = reinterpret_cast<int32_t *>(bp_keep(t, order));
+    f->bptr = bp_keep(t, bptr), f->rstart = bp_keep(t, rstart), f->epos = bp_keep(t, epos);
+    f->vptr = bp_keep(t, vptr), f->vlist = reinterpret_cast<int32_t *>(bp_keep(t, vlist)), f->vrow = bp_keep(t, vrow), f->cpos = bp_keep(t, cpos);
   }
 done:
 #undef FP_CHECK
-  hipFree(cent), hipFree(mm), hipFree(ekey), hipFree(nkey), hipFree(iota), hipFree(nkey2), hipFree(order), hipFree(vkey), hipFree(vval), hipFree(vkey2), hipFree(vval2);
-  hipFree(rank), hipFree(cnt), hipFree(bcount), hipFree(flags), hipFree(voff), hipFree(tmp);
-  if (rc != NH_OK) {
-    nh_fused_free(f);
-    return rc;
-  }
-  p->fused = f;
-  return NH_OK;
+  bp_free(t);
+  if (rc == NH_OK) p->fused = f;
+  return rc;
 }
 
 // Are these the tables of the trilinear 'std' basis at the tensor 2 x 2 x 2 Gauss points (nodes a = 4 a0 + 2 a1 + a2, points q = 4 qa + 2 qb + qc), for test, trial and
@@ -1541,15 +1393,13 @@ int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s) {
   for (int i = 0; i < S * S; ++i)
     if (i / S != i % S && a->C_host[i] != 0.) symd = false;
   l.ldst_doubles = ldst ? (int)(ldsb / sizeof(double)) : 0;
-  p.srowptr = pat->srowptr;
   p.values = a->values_dev;
   p.store = (a->flags & NH_MATRIX_STORE) != 0;
-  p.nrows = pat->nrows;
   p.R = f->rows_per_block;
-  p.max_blen = f->max_blen;
-  p.loff = f->loff, p.blen = f->blen, p.rstart = f->rstart, p.vlist = f->vlist, p.vptr = f->vptr, p.vrow = f->vrow, p.cpos = f->cpos;
-  p.ncol = f->ncol;
-  const size_t ldsx = (ldst ? ldsb : 0) + sizeof(double) * ((size_t)f->max_blen + f->rows_per_block + (f->rows_per_block + 2) / 2 + (f->rows_per_block + 1) / 2);
+  p.max_ents = f->max_ents, p.nturns = f->nturns, p.epos = f->epos;
+  p.bptr = f->bptr, p.vptr = f->vptr, p.rstart = f->rstart, p.vlist = f->vlist, p.vrow = f->vrow, p.cpos = f->cpos;
+  const size_t lds1 = fused_lds_bytes(f->rows_per_block, f->max_ents);  // row tables + accumulator
+  const size_t ldsx = (ldst ? ldsb : 0) + lds1;
   int nt = FUSED_NT;
 #ifdef NH_ABLATION
   if (getenv("NH_FUSED_NT")) nt = std::min(FUSED_NT_MAX, std::max(64, atoi(getenv("NH_FUSED_NT")) & ~63));
@@ -1573,7 +1423,6 @@ int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s) {
     if (fw->p1hex > 0) {
       memcpy(&p.tab, fw->p1hex_tab, sizeof p.tab);
       l.ldst_doubles = 0;
-      const size_t lds1 = sizeof(double) * ((size_t)f->max_blen + f->rows_per_block + (f->rows_per_block + 2) / 2 + (f->rows_per_block + 1) / 2);
       if (fw->p1hex == 2) {
         NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_fused_p1hex<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         hipLaunchKernelGGL((k_fused_p1hex<true>), grid, block, lds1, s, p);

@@ -134,6 +134,14 @@ struct OwnK {
 
 __device__ __forceinline__ i64 bfn(const BasisK &b, i64 e) { return b.tab ? (i64)b.tab[e] * b.nb : 0; }
 
+// stride of a visit's D table for a payload of n doubles and a point stride qs: odd (the lanes of phase 2 -- arbitrary visits -- are spread by an odd multiplier) and
+// not = +-qs mod 16: with vs = qs (201 and 25 for trilinear elasticity) the 64 lanes of phase 1, 8 visits x 8 points, hit bank pair 9 (v + q) mod 16 -- eight to a
+// pair where four is the optimum
+__host__ __device__ constexpr int own_vs(int n, int qs) {
+  int v = n | 1;
+  while ((v - qs) % 16 == 0 || (v + qs) % 16 == 0) v += 2;
+  return v;
+}
 constexpr int OWN_NT_MAX = 1024;  // (launch bound; the host picks 256 .. 1024 threads by the LDS a block takes)
 
 // ISOF: the isotropic three-parameter family on the gradient slots, applied in closed form; USE0: the form reads the value slot (then D holds S slots per node)
@@ -144,9 +152,9 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
   static_assert(!(ISOF && USE0), "the isotropic family has no value slot");
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int nq = p.nq, b = blockIdx.x, tid = threadIdx.x, OWN_NT = blockDim.x;
-  // strides of the D table, in doubles: odd per point and per visit, so that the lanes of phase 1 (consecutive points of consecutive visits) and of phase 2 (the nodes
-  // of arbitrary visits at one point) spread over the banks -- with 24 / 192 doubles they all met in two bank pairs
-  const int QS = (NB * SD) | 1, VS = (nq * QS) | 1, XS = (NG * ND) | 1;
+  // strides of the D table, in doubles: odd per point, odd and not +- the point stride mod 16 per visit (own_vs), so that the lanes of phase 1 (consecutive points of consecutive visits) and of
+  // phase 2 (the nodes of arbitrary visits at one point) spread over the banks -- with 24 / 192 doubles they all met in two bank pairs
+  const int QS = (NB * SD) | 1, VS = own_vs(nq * QS, QS), XS = (NG * ND) | 1;
   const bool iso = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG;
   // LDS: [row starts R x i64][row lengths R x int, padded][form 144][test table][geometry table][vertices vmax x NG x ND][weights vmax x nq][D vmax x nq x NB x SD]
   i64 *rs = reinterpret_cast<i64 *>(sm);
@@ -154,9 +162,14 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
   double *sC = sm + p.R + (p.R + 1) / 2;
   double *sT = sC + (ISOF ? 0 : 144);
   double *sgT = sT + (p.ldst ? NB * nq * S : 0);
-  double *sX = sgT + (p.ldst && iso ? NG * nq * S : 0);
-  double *sW = sX + (iso && XLDS ? p.vmax * XS : 0);
-  double *sD = sW + p.vmax * nq;
+  // staged vertices: in the LAST point slab of the visit's own D table when the nq lanes of a visit sit in one wave (64 % nq == 0) -- every lane of the wave has read
+  // them (to form J) before any lane stores its gradients, so the vertices cost no LDS of their own; else behind the weights
+  const bool xalias = XLDS && 64 % nq == 0 && NG * ND <= QS;
+  double *sW = sgT + (p.ldst && iso ? NG * nq * S : 0);
+  double *sX = sW + p.vmax * nq;
+  double *sD = sX + (iso && XLDS && !xalias ? p.vmax * XS : 0);
+  const int XV = xalias ? VS : XS;  // stride of the vertex sets
+  if (xalias) sX = sD + (nq - 1) * QS;
 #ifdef NH_ABLATION
   long long tlast = __builtin_readcyclecounter();
 #endif
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
       const i64 e = p.vlist[v0 + v];
       const i64 vert = p.geom.gdofs[e * NG + a];
 #pragma unroll
-      for (int d = 0; d < ND; ++d) sX[v * XS + a * ND + d] = p.geom.verts[vert * ND + d];
+      for (int d = 0; d < ND; ++d) sX[v * XV + a * ND + d] = p.geom.verts[vert * ND + d];
     }
   __syncthreads();
   OTICK(0);
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
 #pragma unroll
         for (int r = 0; r < ND; ++r)
 #pragma unroll
-          for (int c = 0; c < ND; ++c) J[r][c] += (XLDS ? sX[v * XS + a * ND + r] : Xr[XLDS ? 0 : a][r]) * t[1 + c];
+          for (int c = 0; c < ND; ++c) J[r][c] += (XLDS ? sX[v * XV + a * ND + r] : Xr[XLDS ? 0 : a][r]) * t[1 + c];
       }
       invert<ND>(J, Ji, det);
       if (p.geom.bnd_axis >= 0) {
@@ -349,9 +362,9 @@ void nh_owner_free(nh_owner_plan *o) {
 // LDS bytes of a block with `vmax` visits
 static size_t owner_lds(int R, int vmax, int nq, int nb, int nd, int sd, bool isof, bool ldst, bool iso, bool xlds = true) {
   const int S = 1 + nd, NG = 1 << nd;
-  const size_t QS = (size_t)(nb * sd) | 1, VS = (nq * QS) | 1, XS = (size_t)(NG * nd) | 1;  // (the odd strides of the kernel)
-  size_t d = (size_t)R + (R + 1) / 2 + (isof ? 0 : 144) + (ldst ? (size_t)nb * nq * S : 0) + (ldst && iso ? (size_t)NG * nq * S : 0) + (iso && xlds ? (size_t)vmax * XS : 0) +
-             (size_t)vmax * nq + (size_t)vmax * VS;
+  const size_t QS = (size_t)(nb * sd) | 1, VS = (size_t)own_vs((int)(nq * QS), (int)QS), XS = (size_t)(NG * nd) | 1;  // (the strides of the kernel)
+  size_t d = (size_t)R + (R + 1) / 2 + (isof ? 0 : 144) + (ldst ? (size_t)nb * nq * S : 0) + (ldst && iso ? (size_t)NG * nq * S : 0) + (iso && xlds && !(64 % nq == 0 && (size_t)(NG * nd) <= QS) ? (size_t)vmax * XS : 0) +
+             (size_t)vmax * nq + (size_t)vmax * VS;  // (vertices: inside the D tables when the lanes of a visit share a wave)
   return d * sizeof(double);
 }
 

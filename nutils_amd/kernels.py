@@ -138,8 +138,9 @@ def basis(T, dofs, nb=0, off=None, tab=None):
 
 
 FUSED_SIZES = {(1, 2), (1, 3), (2, 3), (2, 4), (2, 9), (3, 4), (3, 8)}  # (dimension, functions per element) of the owner-block kernels (NH_MATRIX_FUSED)
-# ... and those for which they are the DEFAULT: measured faster than the gather with the ordered sums (tools/generic_probe.py, round 4: 128^3 trilinear 0.94 against
-# 1.20 ms through the API; 2048^2 bilinear 0.87 against 0.59 and 1024^2 biquadratic 1.47 against 0.96 ms are NOT -- their rows are short, the turn protocol is not)
+# ... and those for which they are the DEFAULT: measured faster than the gather with the ordered sums (tools/generic_probe.py, round 5, ordered rounds: 128^3 trilinear
+# 0.55 against 0.90 ms; 2048^2 bilinear 0.43 against 0.45, 1024^2 quadratic splines 0.43 against 0.59, but 1024^2 biquadratic 0.88 against 0.69 ms -- the 2-D sizes stay
+# with the gather)
 FUSED_DEFAULT = {(3, 8)}
 # (dimension, functions per element, components) of the owner kernel for vector-valued blocks (nh_owner.hip: Gram sums per scalar entry from D tables in LDS, one pass)
 OWNER_VECTOR = {(3, 8, 3), (2, 4, 2), (2, 9, 2)}
@@ -150,7 +151,7 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
     '''K3+K4+K5 (nh_assemble_matrix); accumulates into `values`.  `first_touch=(grid_shape, nodes_per_axis)`: NH_MATRIX_FIRST_TOUCH.
     gather: NH_MATRIX_GATHER (deterministic owner-side reduction instead of atomics); None = from the second assembly on a pattern on (the gather
     map costs one device sort of the element map, which a one-off assembly does not earn back).  fused: NH_MATRIX_FUSED (owner blocks: one pass
-    without scratch or global atomics for scalar blocks on small uniform bases, contributions added in visit order: bit-reproducible; excludes gather;
+    without scratch or global atomics for scalar blocks on small uniform bases, contributions added in visit order: bit-reproducible, bit-identical to the gather; excludes gather;
     the default for those blocks -- NUTILS_AMD_NO_FUSED=1 restores the gather / atomics choice).  fresh: `values` is uninitialised -- the gather and
     owner-block paths STORE their sums (no zero fill, no read of the old values), every other path gets the array zero-filled first.'''
     C = numpy.ascontiguousarray(C, dtype=float)

@@ -1013,6 +1013,11 @@ def test_fused_owner_blocks_equal_the_reference(golden, name):
     if (c.nd, c.nb) in FUSED_SIZES:
         assert nblocks >= 1 and nvisits >= c.nelems, (nblocks, rpb, nvisits)
         assert c.pattern.fused_routine == 0  # (Case passes per-element tables: the tabulated any-element routine; the trilinear one is tested below)
+        # same element routine, and every entry summed over its slots in the order of the gather map: bit for bit the two-pass result
+        gathered = device.zeros(colidx.numel(), 'float64')
+        kernels.assemble_matrix(nelems=c.nelems, ndims=c.nd, nq=c.nq, weights=c.weights, geom=c.geom, test=c.basis, trial=c.basis, nct=1, ncr=1, C=C, mask=None,
+                                pattern=c.pattern, values=gathered, gather=True)
+        assert numpy.array_equal(device.to_host(values), device.to_host(gathered))
     else:
         assert nblocks == 0
 
@@ -1074,11 +1079,11 @@ def test_fused_many_blocks_any_numbering(shuffle):
         out.append(device.to_host(values))
     nblocks, rpb, nvisits = pattern.fused_info()
     assert pattern.fused_routine == 2  # (stiffness + mass on trilinear hexahedra: the sum-factorised routine with the mass term)
-    assert nblocks == -(-ndofs // rpb) and nblocks > 40, (nblocks, rpb)
-    assert ne < nvisits < 2.2 * ne, nvisits / ne  # bricks of ~8^3 nodes: (9/8)^3 = 1.42 in the interior, more at this size
+    assert nblocks >= -(-ndofs // rpb) and nblocks > 40, (nblocks, rpb)  # (Morton boxes of at most rpb rows)
+    assert ne < nvisits < 2.6 * ne, nvisits / ne  # boxes of 8 x 4 x 4 nodes: 9 * 5 * 5 / 128 = 1.76 in the interior, more at this size
     close(out[1], out[0])
     close(out[2], out[0])
-    # the contributions to a row are added in the order of the visits (turns of the block plan): two assemblies agree bit for bit
+    # every contribution has its own slot, the slots of an entry are summed in (element, m, n) order: two assemblies agree bit for bit
     assert numpy.array_equal(out[1], out[2])
 
 
