@@ -122,6 +122,14 @@ int nh_pattern_expanded_nnz(const nh_pattern *p, int nct, int ncr, const unsigne
 int nh_pattern_expand(const nh_pattern *p, int nct, int ncr, const unsigned char *mask, int64_t *rowptr_dev,
                       int64_t *colidx_dev, void *stream);
 
+/* Union of up to 8 sorted-unique CSR patterns with the same number of rows (the per-sample matrices of one integral: volume + Nitsche / Robin
+ * boundary terms; replaces the unique of evaluable.py:5560-5682 over the concatenated keys): a row of the union is the merge of the parts' sorted
+ * column lists -- no sort.  nh_pattern_union_count fills rowptr_u_dev [nrows + 1] and returns the union's nnz (host, synchronises the stream);
+ * nh_pattern_union_fill writes colidx_u_dev [nnz] and, for every entry k of part i, its position pos_dev[i][k] in the union. */
+int nh_pattern_union_count(int nparts, int64_t nrows, const int64_t *const *rowptr_dev, const int64_t *const *colidx_dev, int64_t *rowptr_u_dev, int64_t *nnz, void *stream);
+int nh_pattern_union_fill(int nparts, int64_t nrows, const int64_t *const *rowptr_dev, const int64_t *const *colidx_dev, const int64_t *rowptr_u_dev, int64_t *colidx_u_dev,
+                          int64_t *const *pos_dev, void *stream);
+
 /* ---- geometry descriptor ---------------------------------------------------------
  * replaces _TransformsCoords/_Jacobian lowering + numeric.inv + linalg.det
  * (function.py:1162-1181,1284-1295; evaluable.py:1403-1490; numeric.py:221-241). */
@@ -469,6 +477,8 @@ typedef struct {
   int layer_begin, layer_end;
   int owner_begin, owner_end;
   int max_workgroups;        /* 0: one persistent workgroup per CU */
+  int weights_positive;      /* nonzero: every quadrature weight is > 0 (the caller owns the array and knows): the kernel that forms its operands in registers
+                                carries sqrt(w |J|) on both of them; 0: signed weights, the table kernels */
 } nh_p2hex_args;
 
 int nh_p2hex_matrix(const nh_p2hex_args *args, void *stream);

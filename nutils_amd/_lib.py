@@ -108,7 +108,7 @@ class P1HexArgs(ctypes.Structure):
 class P2HexArgs(ctypes.Structure):
     _fields_ = [('shape', ctypes.c_int * 3), ('nq', ctypes.c_int), ('weights_dev', vp), ('geom', Geometry), ('T_dev', vp), ('ncomp', ctypes.c_int),
                 ('C_host', vp), ('values_dev', vp), ('scale_dev', vp), ('layer_begin', ctypes.c_int), ('layer_end', ctypes.c_int),
-                ('owner_begin', ctypes.c_int), ('owner_end', ctypes.c_int), ('max_workgroups', ctypes.c_int)]
+                ('owner_begin', ctypes.c_int), ('owner_end', ctypes.c_int), ('max_workgroups', ctypes.c_int), ('weights_positive', ctypes.c_int)]
 
 
 GEOM_ISO = 1
@@ -137,6 +137,8 @@ SIGNATURES = {
     'nh_pattern_info': (ctypes.c_int, [vp, c_i64p, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), c_i64p, ctypes.POINTER(vp)]),
     'nh_pattern_fused_info': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), c_i64p, ctypes.POINTER(ctypes.c_int)]),
     'nh_pattern_owner_info': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), c_i64p, c_i64p]),
+    'nh_pattern_union_count': (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, vp, vp, vp, c_i64p, vp]),
+    'nh_pattern_union_fill': (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, vp, vp, vp, vp, vp, vp]),
     'nh_pattern_expanded_nnz': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, c_i64p]),
     'nh_pattern_expand': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
     'nh_assemble_matrix': (ctypes.c_int, [ctypes.POINTER(MatrixArgs), vp]),

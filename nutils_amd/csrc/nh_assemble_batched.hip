@@ -1002,6 +1002,12 @@ __global__ __launch_bounds__(LT2_EPB *(NBR / NBK)) __attribute__((amdgpu_waves_p
                 if (j == p.geom.bnd_axis) s2 += Ji[j][i] * Ji[j][i];
             det *= sqrt(s2);
           }
+          if (p.geom.nograd) {  // (no term reads a gradient slot: the inverse -- NaN on an exactly singular element -- must not reach the folded tensor; as nh_geom.inc)
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+#pragma unroll
+              for (int j = 0; j < ND; ++j) Ji[i][j] = 0.;
+          }
         } else
           geometry_at<ND>(p.geom, eA, q, p.nq, nullptr, Ji, det, nullptr);
         const double w = p.weights[q] * fabs(det);

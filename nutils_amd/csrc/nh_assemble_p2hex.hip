@@ -1527,23 +1527,9 @@ int nh_p2hex_matrix(const nh_p2hex_args *a, void *stream) {
   auto lds_lock = [&](int ndb) { return fixed + sizeof(double) * ((size_t)ndb * p.dsz + 4 * p.nq * 10); };
   bool pipe = NS == 3 && p.ks == PKS && lds_pipe <= 160 * 1024;
   p.prio = 1;
-  bool inreg = pipe && !a->scale_dev;  // sqrt(w |J|) on both operands: not with a signed scale array
-  if (inreg) {
-    // ... nor with a quadrature weight <= 0 (sqrt of it: NaN in every entry of the touched elements; the table kernels carry signed weights).  The signs of a
-    // weight array are read once (the array belongs to the sample and does not change; keyed by pointer and length)
-    static const double *wkey = nullptr;
-    static int wn = 0;
-    static bool wpos = true;
-    if (wkey != a->weights_dev || wn != a->nq) {
-      std::vector<double> hw((size_t)a->nq);
-      NH_CHECK_HIP(hipMemcpyAsync(hw.data(), a->weights_dev, sizeof(double) * a->nq, hipMemcpyDeviceToHost, nh_stream(stream)));
-      NH_CHECK_HIP(hipStreamSynchronize(nh_stream(stream)));
-      wpos = true;
-      for (double w : hw) wpos = wpos && w > 0.;
-      wkey = a->weights_dev, wn = a->nq;
-    }
-    inreg = wpos;
-  }
+  // sqrt(w |J|) on both operands of the in-register kernel: not with a signed scale array, nor with a quadrature weight <= 0 (sqrt of it: NaN in every entry of the
+  // touched elements; the table kernels carry signed weights).  The caller, who owns the weight array, states the sign (nh_p2hex_args.weights_positive).
+  bool inreg = pipe && !a->scale_dev && a->weights_positive;
 #ifdef NH_ABLATION  // A/B switches of the ablation build only
   if (getenv("NH_P2HEX_PIPE") && atoi(getenv("NH_P2HEX_PIPE"))) inreg = false;
   if (getenv("NH_P2HEX_LOCKSTEP") && atoi(getenv("NH_P2HEX_LOCKSTEP"))) pipe = false;

@@ -227,6 +227,37 @@ static void launch_row_unique(i64 nrows, const i64 *estart, const int32_t *elist
                      rowcnt);
 }
 
+constexpr int NH_UNION_MAX = 8;
+struct UnionK {
+  int np;
+  const i64 *rowptr[NH_UNION_MAX], *colidx[NH_UNION_MAX];
+  i64 *pos[NH_UNION_MAX];
+};
+// merge of the sorted column lists of row r of all parts; FILL: write the union's columns and, for every entry of every part, its position in the union
+template <bool FILL>
+__global__ void k_union(i64 nrows, UnionK u, int32_t *cnt, const i64 *rowptr_u, i64 *colidx_u) {
+  const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  i64 at[NH_UNION_MAX], end[NH_UNION_MAX];
+  for (int i = 0; i < u.np; ++i) at[i] = u.rowptr[i][r], end[i] = u.rowptr[i][r + 1];
+  i64 out = FILL ? rowptr_u[r] : 0;
+  int n = 0;
+  for (;;) {
+    i64 c = -1;
+    for (int i = 0; i < u.np; ++i)
+      if (at[i] < end[i] && (c < 0 || u.colidx[i][at[i]] < c)) c = u.colidx[i][at[i]];
+    if (c < 0) break;
+    for (int i = 0; i < u.np; ++i)
+      if (at[i] < end[i] && u.colidx[i][at[i]] == c) {
+        if (FILL) u.pos[i][at[i]] = out;
+        ++at[i];
+      }
+    if (FILL) colidx_u[out] = c;
+    ++out, ++n;
+  }
+  if (!FILL) cnt[r] = n;
+}
+
 extern "C" {
 
 int nh_pattern_build(const nh_pattern_args *a, nh_pattern **out, void *stream) {
@@ -455,6 +486,46 @@ int nh_pattern_expand(const nh_pattern *p, int nct, int ncr, const unsigned char
   }
   hipLaunchKernelGGL(k_expand, dim3((unsigned)((p->nrows * 64 + 255) / 256)), dim3(256), 0, s, p->nrows, p->srowptr, p->scol, mk,
                      (i64 *)rowptr_dev, (i64 *)colidx_dev);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}
+
+
+// ---- union of sorted-unique CSR patterns (matrix integrals on several samples: volume + Nitsche / Robin boundary terms) ------------------------------------
+// Every row of every part is a strictly increasing column list, so the union of a row is an NP-way merge: no sort, no hash.  One thread per row.
+int nh_pattern_union_count(int nparts, int64_t nrows, const int64_t *const *rowptr_dev, const int64_t *const *colidx_dev, int64_t *rowptr_u_dev, int64_t *nnz, void *stream) {
+  NH_REQUIRE(nparts >= 1 && nparts <= NH_UNION_MAX && rowptr_dev && colidx_dev && rowptr_u_dev && nnz, "nh_pattern_union_count: 1 .. %d parts, no NULL arguments", NH_UNION_MAX);
+  hipStream_t s = nh_stream(stream);
+  UnionK u;
+  u.np = nparts;
+  for (int i = 0; i < nparts; ++i) u.rowptr[i] = (const i64 *)rowptr_dev[i], u.colidx[i] = (const i64 *)colidx_dev[i], u.pos[i] = nullptr;
+  *nnz = 0;
+  if (nrows == 0) {
+    NH_CHECK_HIP(hipMemsetAsync(rowptr_u_dev, 0, sizeof(i64), s));
+    return NH_OK;
+  }
+  int32_t *cnt = nullptr;
+  NH_CHECK_HIP(hipMalloc((void **)&cnt, (size_t)(nrows + 1) * 4));
+  hipLaunchKernelGGL((k_union<false>), dim3((unsigned)((nrows + 127) / 128)), dim3(128), 0, s, (i64)nrows, u, cnt, (const i64 *)nullptr, (i64 *)nullptr);
+  int rc = hipGetLastError() == hipSuccess ? nh_scan_exclusive(cnt, (i64 *)rowptr_u_dev, nrows, s) : NH_EHIP;
+  hipError_t e = hipSuccess;
+  if (rc == NH_OK) e = hipMemcpyAsync(nnz, (i64 *)rowptr_u_dev + nrows, sizeof(i64), hipMemcpyDeviceToHost, s);
+  if (rc == NH_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(cnt);
+  if (rc != NH_OK) return rc;
+  NH_CHECK_HIP(e);
+  return NH_OK;
+}
+
+int nh_pattern_union_fill(int nparts, int64_t nrows, const int64_t *const *rowptr_dev, const int64_t *const *colidx_dev, const int64_t *rowptr_u_dev, int64_t *colidx_u_dev,
+                          int64_t *const *pos_dev, void *stream) {
+  NH_REQUIRE(nparts >= 1 && nparts <= NH_UNION_MAX && rowptr_dev && colidx_dev && rowptr_u_dev && pos_dev, "nh_pattern_union_fill: 1 .. %d parts, no NULL arguments", NH_UNION_MAX);
+  if (nrows == 0) return NH_OK;
+  UnionK u;
+  u.np = nparts;
+  for (int i = 0; i < nparts; ++i) u.rowptr[i] = (const i64 *)rowptr_dev[i], u.colidx[i] = (const i64 *)colidx_dev[i], u.pos[i] = (i64 *)pos_dev[i];
+  hipLaunchKernelGGL((k_union<true>), dim3((unsigned)((nrows + 127) / 128)), dim3(128), 0, nh_stream(stream), (i64)nrows, u, (int32_t *)nullptr, (const i64 *)rowptr_u_dev,
+                     (i64 *)colidx_u_dev);
   NH_LAUNCH_CHECK();
   return NH_OK;
 }

@@ -35,7 +35,12 @@ class Factored:
         self.name = name
         grad = function.derivative(integral, name)
         hess = function.derivative(grad, name)
-        arg = next(a for _, itg, _ in integral.terms for a in (itg.test, itg.trial) if a is not None and a.name == name)
+        # the argument: a test / trial slot that carries the name, else the field of a polynomial factor (a pure value functional such as the integral of u^4)
+        arg = next((a for _, itg, _ in integral.terms for a in (itg.test, itg.trial) if a is not None and a.name == name), None)
+        if arg is None:
+            arg = next((a for _, itg, _ in integral.terms if itg.fscale is not None for a in itg.fscale.args if a.name == name), None)
+        if arg is None:
+            raise NotImplementedError(f'factor: argument {name!r} occurs neither as a test / trial slot nor in a polynomial factor')
         self.arg = arg
         self.shape = (arg.basis.ndofs, arg.ncomp) if arg.ncomp > 1 else (arg.basis.ndofs,)
         self.size = int(numpy.prod(self.shape))
@@ -64,16 +69,17 @@ class Factored:
                     continue
                 if bound or itg.qform is not None or itg.qscalar is not None:
                     raise NotImplementedError(f'factor: a term of degree {k} in {name!r} with gradient slots (rank-{k} tensor of a quasi-linear form)')
-                if sum(key) != key[i] or arg.ncomp != 1:
+                farg = fp.args[i]  # (the polynomial's OWN argument: the same dof space may come through another basis object -- rational tables per sample, a restricted view)
+                if sum(key) != key[i] or farg.ncomp != 1:
                     raise NotImplementedError('factor: polynomial of several fields / a vector field in a term of degree >= 3')
                 if k > 4:
                     raise NotImplementedError(f'factor: degree {k} (tensors up to rank 4 are built)')
-                pt = smp.tables(arg.basis)
+                pt = smp.tables(farg.basis)
                 if not pt.nb:
                     raise NotImplementedError('factor: rank >= 3 tensors on a ragged basis')
                 geom = itg.measure if itg.measure is not None else _sample._default_geometry(smp.topo)
                 values, indices = kernels.factor_tensor(nelems=smp.nlist, ndims=smp.ndims, nq=smp.points.npoints, rank=k, weights=smp._weights_dev, geom=smp.geometry(geom),
-                                                        basis=pt.struct, ndofs=arg.basis.ndofs, coeff=float(coef) * float(numpy.asarray(itg.f0)) * float(fac),
+                                                        basis=pt.struct, ndofs=farg.basis.ndofs, coeff=float(coef) * float(numpy.asarray(itg.f0)) * float(fac),
                                                         scale=smp.scale(itg.scale), elist=smp._elist_dev)
                 if values.numel():
                     self.T.append((k, values, indices))

@@ -95,6 +95,25 @@ class Pattern:
             self._handle = None
 
 
+def pattern_union(parts):
+    '''Union of sorted-unique CSR patterns [(rowptr, colidx)] with equal row counts (nh_pattern_union_*): (rowptr, colidx, [position of every entry of part i in
+    the union]).  Row-wise merge of sorted lists on the device; replaces the sort-based unique of the reference (evaluable.py:5560-5682).'''
+    n = len(parts)
+    nrows = parts[0][0].numel() - 1
+    if any(rp.numel() - 1 != nrows for rp, _ in parts):
+        raise ValueError('pattern_union: parts with different numbers of rows')
+    RP = (ctypes.c_void_p * n)(*[rp.data_ptr() for rp, _ in parts])
+    CI = (ctypes.c_void_p * n)(*[ci.data_ptr() for _, ci in parts])
+    rowptr = device.empty(nrows + 1, 'int64')
+    nnz = ctypes.c_int64()
+    _lib.call('nh_pattern_union_count', n, nrows, RP, CI, device.ptr(rowptr), ctypes.byref(nnz), device.stream())
+    colidx = device.empty(nnz.value, 'int64')
+    pos = [device.empty(ci.numel(), 'int64') for _, ci in parts]
+    PP = (ctypes.c_void_p * n)(*[p.data_ptr() for p in pos])
+    _lib.call('nh_pattern_union_fill', n, nrows, RP, CI, device.ptr(rowptr), device.ptr(colidx), PP, device.stream())
+    return rowptr, colidx, pos
+
+
 def geometry_iso(ngb, gT, gdofs, verts, bnd_axis=-1):
     g = _lib.Geometry(_lib.GEOM_ISO, ngb, device.ptr(gT), device.ptr(gdofs), device.ptr(verts), None, None, None, None, bnd_axis)
     g._keep = (gT, gdofs, verts)
@@ -170,7 +189,7 @@ def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, 
         args.pattern = pattern._handle  # ragged bases: launches per size class of the pattern
     whole = emap_offset == 0 and not flags and not first_touch and nelems == pattern.nelems
     if (not fused and gather is None and not os.environ.get('NUTILS_AMD_NO_FUSED') and whole and elist is None and nct == ncr == 1 and cq is None and ((ndims, test.nb) in FUSED_DEFAULT or os.environ.get('NUTILS_AMD_FUSED') and (ndims, test.nb) in FUSED_SIZES)
-            and test.nb == trial.nb and test.dofs_dev == trial.dofs_dev and not test.off_dev and not getattr(pattern, '_fused_refused', False)):
+            and test.nb == trial.nb and test.dofs_dev == trial.dofs_dev and not test.off_dev):
         # (default since round 4 for the blocks the owner-block kernels cover: one pass, 1.5 x instead of 4.6 x the algorithmic traffic, and -- with the
         # turns of the block plan -- bit-reproducible like the gather)
         fused = True
@@ -507,6 +526,7 @@ class P2HexMatrix:
         a.layer_begin, a.layer_end = (0, n0) if layers is None else layers
         a.owner_begin, a.owner_end = (0, n0) if owners is None else owners
         a.max_workgroups = int(max_workgroups)
+        a.weights_positive = int(bool((weights > 0).all().item()))  # (once per plan: the object lives as long as the weight array it keeps)
         self._keep = (weights, geom, T, C, scale)
         self._args = a
         self._ref = ctypes.byref(a)

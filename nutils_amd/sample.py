@@ -410,6 +410,10 @@ def _lib_error():
     return NutilsHipError
 
 
+_MERGES = {}  # (index arrays of the parts) -> union pattern + positions: symbolic merges of multi-sample matrix integrals, least recently used first
+MERGE_CACHE_SIZE = 32
+
+
 class _MatrixPlan:
     '''All matrix-type terms of one integral share test/trial basis; accumulate into one values buffer.'''
 
@@ -439,7 +443,6 @@ class _MatrixPlan:
             self.parts = [_MatrixPlan(ts) for ts in groups]
             self.mask = numpy.logical_or.reduce([p.mask for p in self.parts])
             self.smp0 = self.parts[0].smp0
-            self._merge = None
             return
         self.mask = numpy.zeros((self.test.ncomp, self.trial.ncomp), dtype=bool)
         for smp, itg, fac in terms:
@@ -682,32 +685,26 @@ class _MatrixPlan:
         return rest
 
     def _run_parts(self, arguments):
-        '''Sum of the per-sample matrices.  The symbolic part (union of the sorted-unique patterns, position of every entry of a part in it) is
-        computed once per set of index arrays (they are cached by the patterns, so re-assemblies find the same tensors); the values of a
-        re-assembly are added at the precomputed positions by nh_monomial (unique positions per part: no atomics, fixed order).'''
-        import torch
+        '''Sum of the per-sample matrices.  The symbolic part (union of the sorted-unique patterns, position of every entry of a part in it: kernels.pattern_union,
+        a row-wise merge of sorted column lists on the device) is computed once per set of index arrays -- they are cached by the patterns, so re-assemblies and
+        re-BUILT plans (function.eval makes a new _MatrixPlan per call) find the same tensors and hit _MERGES; the values of a re-assembly are added at the
+        precomputed positions by nh_monomial (unique positions per part: no atomics, fixed order).'''
         results = [p.run(arguments) for p in self.parts]
         ncols = results[0][3]
         key = tuple((r[1].data_ptr(), r[2].data_ptr(), r[2].numel()) for r in results)
-        if self._merge is None or self._merge['key'] != key:
-            keys = []
-            for values, rowptr, colidx, nc in results:
-                if nc != ncols or rowptr.numel() != results[0][1].numel():
-                    raise ValueError('matrix terms of different shape in one integral')
-                rows = torch.repeat_interleave(torch.arange(rowptr.numel() - 1, device=rowptr.device, dtype=torch.int64), rowptr[1:] - rowptr[:-1])
-                keys.append(rows * ncols + colidx)
-            ukeys = torch.unique(torch.cat(keys))  # sorted
-            if ukeys.numel() == keys[0].numel():  # the first pattern contains the others: its arrays ARE the union
-                rowptr_u, colidx_u, contained = results[0][1], results[0][2], True
-            else:
-                nrows = results[0][1].numel() - 1
-                rows_u = torch.div(ukeys, ncols, rounding_mode='floor')
-                colidx_u = (ukeys - rows_u * ncols).contiguous()
-                rowptr_u = torch.searchsorted(rows_u, torch.arange(nrows + 1, device=ukeys.device, dtype=torch.int64)).to(torch.int64).contiguous()
-                contained = False
-            pos = [None if contained and i == 0 else torch.searchsorted(ukeys, k).to(torch.int64).contiguous() for i, k in enumerate(keys)]
-            self._merge = dict(key=key, keep=[(r[1], r[2]) for r in results], rowptr=rowptr_u, colidx=colidx_u, pos=pos, n=ukeys.numel())
-        m = self._merge
+        m = _MERGES.get(key)
+        if m is None:
+            if any(nc != ncols or rowptr.numel() != results[0][1].numel() for _, rowptr, _, nc in results):
+                raise ValueError('matrix terms of different shape in one integral')
+            rowptr_u, colidx_u, pos = kernels.pattern_union([(r[1], r[2]) for r in results])
+            if colidx_u.numel() == results[0][2].numel():  # the first pattern contains the others: its arrays ARE the union, its values the start of the sum
+                rowptr_u, colidx_u, pos[0] = results[0][1], results[0][2], None
+            m = dict(keep=[(r[1], r[2]) for r in results], rowptr=rowptr_u, colidx=colidx_u, pos=pos, n=colidx_u.numel())  # (keep: the addresses of the key stay taken)
+            _MERGES[key] = m
+            while len(_MERGES) > MERGE_CACHE_SIZE:
+                _MERGES.pop(next(iter(_MERGES)))
+        else:
+            _MERGES[key] = _MERGES.pop(key)  # (most recently used last)
         if m['pos'][0] is None:
             out = results[0][0]  # (a fresh array of this assembly)
         else:

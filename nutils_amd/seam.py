@@ -1176,6 +1176,7 @@ def match(array, arguments=None):
     plan['kind'] = 'scalar' if nexposed == 0 else 'vector' if nexposed == 1 else 'matrix'
     if nexposed > 2:
         raise Unmatched('arrays with more than two dof axes')
+    plan['_source'] = array  # (not stored: tools/hip_plan_capture.py evaluates it through the un-hooked reference to pin the plan's expected result)
     return plan
 
 
@@ -1287,9 +1288,17 @@ class _SystemPlans:
         return tuple(rows)
 
 
+def device_initialised():
+    '''has this process touched the GPU (a HIP context exists)?'''
+    import sys
+    torch = sys.modules.get('torch')
+    return bool(torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized())
+
+
 def install(executor=None):
     '''Route the reference's evaluation through plans: patches nutils.function.evaluate / as_csr and nutils.solver.System.__init__.
-    `executor(plan, arguments)` defaults to `execute` (the C ABI); anything unmatched takes the reference's own path.  Returns the state
+    `executor(plan, arguments)` defaults to `execute` (the C ABI); anything unmatched takes the reference's own path.  nutils.parallel.fork is
+    guarded: once the device layer is initialised the reference's element loops are not forked any more (`forks_refused` counts them).  Returns the state
     (lists `matched` / `fallback`) for inspection; `uninstall()` restores the reference.'''
     global _STATE
     if _STATE is not None:
@@ -1297,12 +1306,21 @@ def install(executor=None):
     import nutils.function as rf
     import nutils.solver as rs
     import nutils.matrix as rmatrix
+    import nutils.parallel as rp
     import collections
     ex = executor or execute
     # plans / as_csr components are remembered per array OBJECT (id + identity check) in bounded LRU maps: a time loop that builds a fresh integral
     # every step must not grow host and device memory without bound -- an evicted plan drops its built tables ('_built') with it
     st = dict(evaluate=rf.evaluate, as_csr=rf.as_csr, system_init=rs.System.__init__, factor_class=rf._Factor, csr=collections.OrderedDict(),
-              plans=collections.OrderedDict(), matched=[], fallback=[], max_plans=PLAN_CACHE_SIZE)
+              plans=collections.OrderedDict(), matched=[], fallback=[], max_plans=PLAN_CACHE_SIZE, fork=rp.fork, forks_refused=0)
+
+    def fork_guard(nprocs=None):
+        '''parallel.fork (parallel.py:27-88) once the device layer is initialised in this process: NOT forked -- a child would inherit a HIP context it cannot use
+        (the reference's element loop then runs in this process, as with NUTILS_NPROCS=1); before that the reference forks as always.'''
+        if device_initialised():
+            st['forks_refused'] += 1
+            return rp._DontFork()
+        return st['fork'](nprocs)
 
     def remember(cache, key, value, limit):
         cache[key] = value
@@ -1463,6 +1481,7 @@ def install(executor=None):
                                                            lambda arguments: (sp.jacobian(arguments), sp.residual(arguments), numpy.float64(ex(sp.value, arguments))))
 
     rf.evaluate, rf.as_csr, rs.System.__init__, rf._Factor = evaluate, as_csr, system_init, factor_hook
+    rp.fork = fork_guard
     _STATE = st
     return st
 
@@ -1473,5 +1492,7 @@ def uninstall():
         return
     import nutils.function as rf
     import nutils.solver as rs
+    import nutils.parallel as rp
     rf.evaluate, rf.as_csr, rs.System.__init__, rf._Factor = _STATE['evaluate'], _STATE['as_csr'], _STATE['system_init'], _STATE['factor_class']
+    rp.fork = _STATE['fork']
     _STATE = None

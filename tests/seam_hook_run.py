@@ -42,8 +42,9 @@ def main(modules):
     import importlib
     import nutils.testing
     # The embedded vectors are compared with atol = 2e-15 (tied to their packing): entries that are exactly 0 in the reference's summation order
-    # come out as O(1e-15) rounding residue in any other order.  Entries below 1e-12 are snapped to 0 before the comparison; everything else is
-    # checked by the examples' own assertion unchanged.
+    # come out as O(1e-15) rounding residue in any other order.  Entries below 1e-12 are snapped to 0 before the examples' own assertion sees them: a
+    # WEAKENED form of the reference's test (its rtol 2e-3 decides the rest); the strict comparison -- every plan against the reference's own result for the
+    # same array, to 1e-13 -- is tools/hip_plan_capture.py / tests/plan_exec.py:compare_example.
     orig = nutils.testing.TestCase.assertAlmostEqual64
 
     def snapped(self, actual, desired, **kwargs):
@@ -92,6 +93,24 @@ def main(modules):
     same = same and numpy.abs(dense - scipy.sparse.csr_matrix((ref[0], ref[2], ref[1]), dense.shape).toarray()).max() <= 1e-13 * numpy.abs(ref[0]).max()
     print(f'as_csr of the basis-array stiffness form: matched {Counter(st["matched"])["matrix"]} evaluation(s), fallbacks {len(st["fallback"])}, equal to the reference: {same}')
     ok = ok and same and Counter(st['matched'])['matrix'] == 2 and not st['fallback']
+    # the fork guard (parallel.py:27-88): with the device layer initialised the reference's element loop is not forked; before that it is
+    import nutils.parallel as rp
+    st = seam.install(execute_oracle)
+    try:
+        with rp.maxprocs(3):
+            free = bool(rp.fork(3).__class__ is not rp._DontFork)
+            real = seam.device_initialised
+            seam.device_initialised = lambda: True
+            try:
+                guarded = rp.fork(3).__class__ is rp._DontFork and st['forks_refused'] == 1
+                unmatched = function.eval(domain.integral('basis_n dV' @ ns, degree=2) / 3.)  # (runs serially through the reference)
+            finally:
+                seam.device_initialised = real
+    finally:
+        seam.uninstall()
+    restored = rp.fork is st['fork']
+    print(f'fork guard: forks before the device layer exists {free}, refused after {guarded}, reference restored {restored}')
+    ok = ok and free and guarded and restored
     return ok
 
 

@@ -1227,3 +1227,27 @@ def test_fused_simplex_meshes(nd):
         close(out[name], vo)
     nblocks, rpb, nvisits = pattern.fused_info()
     assert nblocks >= 1 and pattern.fused_routine == 0 and nvisits >= ne
+
+
+def test_pattern_union_is_a_rowwise_merge():
+    '''nh_pattern_union_*: union of sorted-unique CSR patterns and the position of every entry of every part in it, against numpy (the union pattern of matrix
+    integrals on several samples: sample._run_parts; replaces the sort-based unique of evaluable.py:5560-5682).'''
+    from nutils_amd import device, kernels
+    rng = numpy.random.default_rng(4)
+    nrows, ncols = 300, 500
+    parts = []
+    for dens in (.05, .01, .2, .0):
+        mask = rng.uniform(size=(nrows, ncols)) < dens
+        mask[7] = False  # (an empty row in every part)
+        rp = numpy.concatenate([[0], numpy.cumsum(mask.sum(1))]).astype(numpy.int64)
+        ci = numpy.nonzero(mask)[1].astype(numpy.int64)
+        parts.append((mask, rp, ci))
+    rowptr, colidx, pos = kernels.pattern_union([(device.to_dev(rp, 'int64'), device.to_dev(ci, 'int64')) for _, rp, ci in parts])
+    union = numpy.logical_or.reduce([m for m, _, _ in parts])
+    assert numpy.array_equal(device.to_host(rowptr), numpy.concatenate([[0], numpy.cumsum(union.sum(1))]))
+    cu = device.to_host(colidx)
+    assert numpy.array_equal(cu, numpy.nonzero(union)[1])
+    ru = numpy.repeat(numpy.arange(nrows), union.sum(1))
+    for (m, rp, ci), p in zip(parts, pos):
+        ph = device.to_host(p)
+        assert numpy.array_equal(cu[ph], ci) and numpy.array_equal(ru[ph], numpy.repeat(numpy.arange(nrows), numpy.diff(rp)))

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 '''TEST INFRASTRUCTURE (build container only).  Sweep for the composition that cannot run in one process (the reference exists only in the
 build container, the GPU only on the box): the UNMODIFIED examples run with the seam installed and the CPU evaluator tests/af_oracle.py as executor; every
-distinct plan the hooks hand to the executor is written -- with the arguments of its first evaluation and the evaluator's result, which the example's own unit
-tests check against the reference's embedded vectors -- to a directory that tools/hip_plan_sweep.py replays through seam.execute (the C ABI) on the GPU box.
+distinct plan the hooks hand to the executor is written -- with the arguments of its first evaluation and the result of THE REFERENCE for the function-level
+array the plan was matched from (the un-hooked nutils.function.evaluate / as_csr saved by seam.install: function.py:2427-2452) -- to a directory that
+tools/hip_plan_sweep.py / tests/test_gpu_plans.py replay through seam.execute (the C ABI) on the GPU box.  The CPU evaluator's own result must agree with the
+reference's to 1e-13 of the largest entry, else the capture stops.
 
   python tools/hip_plan_capture.py OUTDIR [example ...]'''
 import os
@@ -23,6 +25,7 @@ import matplotlib  # noqa: E402
 matplotlib.use('Agg')
 from nutils_amd import seam  # noqa: E402
 import af_oracle  # noqa: E402
+import plan_exec  # noqa: E402
 import nutils.testing  # noqa: E402
 
 
@@ -41,27 +44,50 @@ def main(out, modules):
     import importlib
     out = os.path.abspath(out)
     os.makedirs(out, exist_ok=True)
-    orig = nutils.testing.TestCase.assertAlmostEqual64
-
-    def snapped(self, actual, desired, **kwargs):  # (as tests/seam_hook_run.py)
-        actual = numpy.asarray(actual, dtype=float)
-        return orig(self, numpy.where(numpy.abs(actual) < 1e-12, 0., actual), desired, **kwargs)
-    nutils.testing.TestCase.assertAlmostEqual64 = snapped
     os.chdir(tempfile.mkdtemp())
+    problems = []
     for name in modules:
         seen, count = {}, [0]
 
+        def reference(plan, arguments, nrows=None):
+            '''the reference's own result for the array the plan was matched from, through its un-hooked entry points'''
+            import nutils.function as rf
+            st = seam._STATE
+            arr = plan['_source']
+            if plan['kind'] != 'matrix':
+                return numpy.asarray(st['evaluate'](arr, arguments=arguments)[0], dtype=float)
+            # rows = the axes of the test argument, columns = those of the trial argument (solver.py:252-258 flattens its blocks the same way)
+            if arr.ndim != 2:
+                arr = numpy.reshape(arr, (nrows, -1))  # (the reference's own reshape of its Array: function.py:3485)
+            v, rp, ci = st['evaluate'](*st['as_csr'](arr), arguments=arguments)
+            return numpy.asarray(v, dtype=float), numpy.asarray(rp), numpy.asarray(ci)
+
         def executor(plan, arguments):
+            try:
+                return checked(plan, arguments)
+            except Exception as e:  # (the seam would turn it into a silent fall-back to the reference path)
+                problems.append(f'{name}: {plan["kind"]} plan: {type(e).__name__}: {e}')
+                raise
+
+        def checked(plan, arguments):
             res = af_oracle.evaluate(seam.build(plan).integral, seam.prepare_arguments(plan, arguments))
+            ref = reference(plan, arguments, len(res[1]) - 1 if plan['kind'] == 'matrix' else None)
             if plan['kind'] == 'matrix':
-                expect = dict(values=res[0], rowptr=res[1], colidx=res[2])
+                assert numpy.array_equal(res[1], ref[1]) and numpy.array_equal(res[2], ref[2]), 'index arrays differ from the reference'
+                scale = numpy.abs(ref[0]).max() if len(ref[0]) else 1.
+                assert not len(ref[0]) or numpy.abs(res[0] - ref[0]).max() <= 1e-13 * max(scale, 1e-300), ('values', numpy.abs(res[0] - ref[0]).max() / scale)
+                expect = dict(values=ref[0], rowptr=ref[1], colidx=ref[2])
                 ret = res
             elif plan['kind'] == 'scalar':
                 ret = float(res)
-                expect = dict(scalar=numpy.asarray(ret))
+                expect = dict(scalar=numpy.asarray(float(ref)))
             else:
                 ret = numpy.asarray(res, dtype=float).reshape(plan['shape'])
-                expect = dict(vector=ret)
+                expect = dict(vector=ref.reshape(plan['shape']))
+            if plan['kind'] != 'matrix':
+                err = plan_exec.compare_example(plan, ret, expect, arguments)
+                if os.environ.get('CAPTURE_VERBOSE'):
+                    print(f'  {name} {plan["kind"]}: |ref| {float(numpy.abs(ref).max()):.3e}, term scale {plan_exec.term_scale(plan, arguments):.3e}, error / tolerance {err:.2e}')
             numeric = {k: numpy.asarray(v, dtype=float) for k, v in (arguments or {}).items() if numpy.asarray(v).dtype.kind in 'fiub'}
             if id(plan) not in seen:
                 for k, v in numeric.items():
@@ -83,7 +109,7 @@ def main(out, modules):
                         both['arg2_' + k] = v
                     seam.save(rec['path'], {k: v for k, v in plan.items() if not k.startswith('_')}, both)
             return ret
-        if isinstance(name, tuple):  # a run of main(**kwargs) at a larger size: no embedded vectors to check, the evaluator's results are the expectation
+        if isinstance(name, tuple):  # a run of main(**kwargs) at a larger size (no embedded vectors there: the reference's result per plan is the only check)
             module, tag, kwargs = name
             name = f'{module}_{tag}'
             mod = importlib.import_module('examples.' + module)
@@ -101,6 +127,10 @@ def main(out, modules):
         finally:
             seam.uninstall()
         print(f'{name}: {res.testsRun} reference tests, {len(res.failures)} failures, {len(res.errors)} errors; {count[0]} distinct plans written')
+    for p in problems:
+        print('MISMATCH', p)
+    if problems:
+        raise SystemExit(1)
 
 
 if __name__ == '__main__':

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of one command on the GPU box: tools/r5_kt.sh <tag> <command...>  -> gpurun_out/kt_<tag>.txt (per-kernel table)
+# kernel trace of one command on the GPU box: tools/kt.sh <tag> <command...>  -> gpurun_out/kt_<tag>.txt (per-kernel table)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
