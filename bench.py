@@ -20,7 +20,8 @@ figure of the same launch (`weak`: every rank assembles its own n^3-element slab
 makes the weak figure the headline instead.  With the default `--halo recompute` no data moves between the ranks (each assembles its ghost element layer and
 writes the rows it owns); `--halo reduce` reduces the shared dof plane over RCCL (point to point, interface rows only).  At N = 1 the default line also carries `variants.c3` (BASELINE.json configs[2], measured in the
 same run: kernel time by HIP events, HBM fraction, CPU port), `variants.c4` (configs[3]: one Newton step of the 512^2 Cahn-Hilliard system, tools/c4_step.py) and
-`variants.c5` (the configs[4] class: 63 488 ragged rational hierarchical elements, parity-checked against the reference fixture, tools/ragged_probe.py).
+`variants.c5` (the configs[4] class: 63 488 ragged rational hierarchical elements, parity-checked against the reference fixture, tools/ragged_probe.py) and
+`variants.vector_any_mesh` (96^3 trilinear elasticity through the any-mesh entry: the owner kernel for vector-valued blocks, tools/vector_probe.py).
 
 Prints ONE JSON line on rank 0.
 '''
@@ -539,7 +540,7 @@ def main():
                                                      'note': 'nh_assemble_matrix with NH_MATRIX_GATHER | NH_MATRIX_STORE; bit-reproducible'}
                 del w3
                 torch.cuda.empty_cache()
-                # ... and through the owner blocks of NH_MATRIX_FUSED: one pass, no scratch, no global atomics (not bit-reproducible)
+                # ... and through the owner blocks of NH_MATRIX_FUSED: one pass, no scratch, no global atomics, ordered sums (the default of the any-mesh entry for this block)
                 w5 = workloads.PoissonSlab(n=a.n, rank=0, world=1, variant='iso', kernel='fused')
                 w5.setup()
                 w5.build_pattern()
@@ -551,7 +552,7 @@ def main():
                                                     'launch': l5, 'kernel_ms': kms5, 'hbm_frac': b3 * w5.nelems / (kms5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                     'algorithmic_bytes_per_element': b3, 'traffic': measured_traffic(w5.kernel_name, a.n),
                                                     'owner_blocks': dict(zip(('blocks', 'rows_per_block', 'element_visits'), w5.pattern.fused_info())),
-                                                    'note': 'nh_assemble_matrix with NH_MATRIX_FUSED | NH_MATRIX_STORE'}
+                                                    'note': 'nh_assemble_matrix with NH_MATRIX_FUSED | NH_MATRIX_STORE; ordered rounds: bit-reproducible, bit-identical to the gather'}
                 del w5
                 torch.cuda.empty_cache()
             if not a.no_c3 and a.n == 128:
@@ -575,7 +576,8 @@ def main():
                         v4['speedup_vs_cpu_port'] = v4['value'] / cb3['value']
                 out['variants']['c3'] = v4
                 # BASELINE.json configs[3] and the configs[4] class: the probes of tools/ in their own processes (their parity checks run there); a failure drops the entry
-                for key, cmd in (('c4', [sys.executable, 'tools/c4_step.py', '512']), ('c5', [sys.executable, 'tools/ragged_probe.py', '256', '10'])):
+                for key, cmd in (('c4', [sys.executable, 'tools/c4_step.py', '512']), ('c5', [sys.executable, 'tools/ragged_probe.py', '256', '10']),
+                                 ('vector_any_mesh', [sys.executable, 'tools/vector_probe.py', '96', '10'])):
                     try:
                         r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd=os.path.dirname(os.path.abspath(__file__)))
                         line = next(l for l in r.stdout.splitlines() if l.startswith('RESULT '))

@@ -19,6 +19,7 @@
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -66,9 +67,10 @@ __global__ void k_op_bstart(int nblocks, const i64 *bptr, i64 n, const u64 *key,
 }
 
 // the items of a block packed into chunks of 64 lanes, entries (runs of equal keys) never straddling a chunk; FILL = false: count the chunks
+// rows16: an entry of at most 16 items does not straddle a row of 16 lanes either (the segmented sum then runs on DPP row shifts)
 template <bool FILL>
 __global__ void k_op_pack(int nblocks, const i64 *bptr, const i64 *bstart, const u64 *key, const unsigned *val, int32_t *nch, const i64 *cptr, uint32_t *isrc, uint32_t *idst,
-                          int *maxseg) {
+                          int *maxseg, int rows16) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblocks) return;
   const i64 i1 = bstart[b + 1];
@@ -80,6 +82,7 @@ __global__ void k_op_pack(int nblocks, const i64 *bptr, const i64 *bstart, const
     while (j < i1 && key[j] == k) ++j;
     const int len = (int)(j - i);
     longest = max(longest, len);
+    if (rows16 && len <= 16 && (cur & 15) + len > 16) cur = (cur + 15) & ~(i64)15;
     if ((cur & 63) + len > 64) cur = (cur + 63) & ~(i64)63;
     if (FILL && len <= 64) {
       const i64 base = cptr[b] * 64 + cur;
@@ -117,7 +120,7 @@ struct OwnK {
   double *values;
   int store;
   i64 nrows;
-  int R, nsteps, vmax, ldst;
+  int R, nsteps, vmax, ldst, rows16;
   const int32_t *order, *vlist;
   const i64 *vptr, *cptr, *bptr;
   const uint32_t *isrc, *idst;
@@ -133,6 +136,15 @@ struct OwnK {
 #endif
 
 __device__ __forceinline__ i64 bfn(const BasisK &b, i64 e) { return b.tab ? (i64)b.tab[e] * b.nb : 0; }
+
+// the value of lane + D of this lane's row of 16 lanes (0 beyond the row): DPP row_shl on the two halves of the double
+template <int D>
+__device__ __forceinline__ double row_shl(double x) {
+  const long long u = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffll), 0x100 | D, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0x100 | D, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(unsigned)lo | ((long long)hi << 32));
+}
 
 // stride of a visit's D table for a payload of n doubles and a point stride qs: odd (the lanes of phase 2 -- arbitrary visits -- are spread by an odd multiplier) and
 // not = +-qs mod 16: with vs = qs (201 and 25 for trilinear elasticity) the 64 lanes of phase 1, 8 visits x 8 points, hit bank pair 9 (v + q) mod 16 -- eight to a
@@ -156,11 +168,12 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
   // phase 2 (the nodes of arbitrary visits at one point) spread over the banks -- with 24 / 192 doubles they all met in two bank pairs
   const int QS = (NB * SD) | 1, VS = own_vs(nq * QS, QS), XS = (NG * ND) | 1;
   const bool iso = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG;
-  // LDS: [row starts R x i64][row lengths R x int, padded][form 144][test table][geometry table][vertices vmax x NG x ND][weights vmax x nq][D vmax x nq x NB x SD]
+  // LDS: [row starts R x i64][row lengths R x int, padded][form 144][quadrature weights][test table][geometry table][vertices vmax x NG x ND][weights vmax x nq][D vmax x nq x NB x SD]
   i64 *rs = reinterpret_cast<i64 *>(sm);
   int *rl = reinterpret_cast<int *>(rs + p.R);
   double *sC = sm + p.R + (p.R + 1) / 2;
-  double *sT = sC + (ISOF ? 0 : 144);
+  double *sWq = sC + (ISOF ? 0 : 144);  // quadrature weights
+  double *sT = sWq + nq;
   double *sgT = sT + (p.ldst ? NB * nq * S : 0);
   // staged vertices: in the LAST point slab of the visit's own D table when the nq lanes of a visit sit in one wave (64 % nq == 0) -- every lane of the wave has read
   // them (to form J) before any lane stores its gradients, so the vertices cost no LDS of their own; else behind the weights
@@ -195,6 +208,7 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
   }
   if (!ISOF)
     for (int i = tid; i < 144; i += OWN_NT) sC[i] = p.C[i];
+  for (int i = tid; i < nq; i += OWN_NT) sWq[i] = p.weights[i];
   if (p.ldst) {
     for (int i = tid; i < NB * nq * S; i += OWN_NT) sT[i] = p.test.T[i];
     if (iso)
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
       }
     } else
       geometry_at<ND>(p.geom, e, q, nq, nullptr, Ji, det, nullptr);
-    sW[i] = p.weights[q] * fabs(det) * (p.scale ? p.scale[e * nq + q] : 1.);
+    sW[i] = sWq[q] * fabs(det) * (p.scale ? p.scale[e * nq + q] : 1.);
     const double *T = p.ldst ? sT : p.test.T + bfn(p.test, e) * nq * S;
     double *D = sD + v * VS + q * QS;
 #pragma unroll
@@ -304,15 +318,32 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
     const u64 hm = __ballot(head || !valid);
     const u64 behind = lane < 63 ? hm >> (lane + 1) : 0ull;
     const int rem = behind ? __builtin_ctzll(behind) : 63 - lane;
-    for (int s = 0, d = 1; s < p.nsteps && !(ODBG(p) & 4); ++s, d <<= 1) {
+    if (p.rows16) {
+      // (the plan kept every entry inside a row of 16 lanes: DPP row shifts -- VALU moves -- instead of ds_bpermute through the LDS pipe: 9 % of the kernel at 96^3)
+      auto step = [&](auto dtag) {
+        constexpr int D = decltype(dtag)::value;
 #pragma unroll
-      for (int a = 0; a < SD; ++a)
+        for (int a = 0; a < SD; ++a)
 #pragma unroll
-        for (int bb = 0; bb < SD; ++bb) {
-          const double o = __shfl_down(G[a][bb], d);
-          if (d <= rem) G[a][bb] += o;
-        }
-    }
+          for (int bb = 0; bb < SD; ++bb) {
+            const double o = row_shl<D>(G[a][bb]);
+            if (D <= rem) G[a][bb] += o;
+          }
+      };
+      if (p.nsteps > 0 && !(ODBG(p) & 4)) step(std::integral_constant<int, 1>());
+      if (p.nsteps > 1 && !(ODBG(p) & 4)) step(std::integral_constant<int, 2>());
+      if (p.nsteps > 2 && !(ODBG(p) & 4)) step(std::integral_constant<int, 4>());
+      if (p.nsteps > 3 && !(ODBG(p) & 4)) step(std::integral_constant<int, 8>());
+    } else
+      for (int s = 0, d = 1; s < p.nsteps && !(ODBG(p) & 4); ++s, d <<= 1) {
+#pragma unroll
+        for (int a = 0; a < SD; ++a)
+#pragma unroll
+          for (int bb = 0; bb < SD; ++bb) {
+            const double o = __shfl_down(G[a][bb], d);
+            if (d <= rem) G[a][bb] += o;
+          }
+      }
     if (valid && head && !(ODBG(p) & 8)) {
       const int rowl = dst >> 16, pos = dst & 0xffff;
       const i64 a0 = rs[rowl];
@@ -363,7 +394,7 @@ void nh_owner_free(nh_owner_plan *o) {
 static size_t owner_lds(int R, int vmax, int nq, int nb, int nd, int sd, bool isof, bool ldst, bool iso, bool xlds = true) {
   const int S = 1 + nd, NG = 1 << nd;
   const size_t QS = (size_t)(nb * sd) | 1, VS = (size_t)own_vs((int)(nq * QS), (int)QS), XS = (size_t)(NG * nd) | 1;  // (the strides of the kernel)
-  size_t d = (size_t)R + (R + 1) / 2 + (isof ? 0 : 144) + (ldst ? (size_t)nb * nq * S : 0) + (ldst && iso ? (size_t)NG * nq * S : 0) + (iso && xlds && !(64 % nq == 0 && (size_t)(NG * nd) <= QS) ? (size_t)vmax * XS : 0) +
+  size_t d = (size_t)R + (R + 1) / 2 + (isof ? 0 : 144) + (size_t)nq + (ldst ? (size_t)nb * nq * S : 0) + (ldst && iso ? (size_t)NG * nq * S : 0) + (iso && xlds && !(64 % nq == 0 && (size_t)(NG * nd) <= QS) ? (size_t)vmax * XS : 0) +
              (size_t)vmax * nq + (size_t)vmax * VS;  // (vertices: inside the D tables when the lanes of a visit share a wave)
   return d * sizeof(double);
 }
@@ -443,8 +474,17 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
     OP_CHECK(bp_alloc(t, &cptr, (size_t)nblocks + 1));
     hipLaunchKernelGGL(k_op_bstart, dim3((unsigned)((nblocks + 256) / 256)), dim3(256), 0, s, nblocks, bptr, ni, key2, bstart);
     hipLaunchKernelGGL((k_op_pack<false>), dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nblocks, bptr, bstart, key2, val2, nch, (const i64 *)nullptr, (uint32_t *)nullptr,
-                       (uint32_t *)nullptr, flags + 1);
+                       (uint32_t *)nullptr, flags + 1, 0);
     OP_CHECK(hipGetLastError());
+    OP_CHECK(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+    OP_CHECK(hipStreamSynchronize(s));
+    // entries of at most 16 contributions (hexahedra: 8, quadrilaterals: 4): kept inside rows of 16 lanes, summed with DPP row shifts instead of ds_bpermute
+    const int rows16 = hflags[1] <= 16 && !getenv("NH_OWNER_NO_DPP");
+    if (rows16) {
+      hipLaunchKernelGGL((k_op_pack<false>), dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nblocks, bptr, bstart, key2, val2, nch, (const i64 *)nullptr, (uint32_t *)nullptr,
+                         (uint32_t *)nullptr, flags + 1, 1);
+      OP_CHECK(hipGetLastError());
+    }
     if ((rc = nh_scan_exclusive(nch, cptr, nblocks, s)) != NH_OK) goto done;
     i64 nchunks = 0;
     OP_CHECK(hipMemcpyAsync(&nchunks, cptr + nblocks, sizeof(i64), hipMemcpyDeviceToHost, s));
@@ -458,7 +498,7 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
     OP_CHECK(bp_alloc(t, &idst, (size_t)nchunks * 64));
     OP_CHECK(hipMemsetAsync(isrc, 0, (size_t)nchunks * 64 * 4, s));
     OP_CHECK(hipMemsetAsync(idst, 0, (size_t)nchunks * 64 * 4, s));
-    hipLaunchKernelGGL((k_op_pack<true>), dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nblocks, bptr, bstart, key2, val2, (int32_t *)nullptr, cptr, isrc, idst, (int *)nullptr);
+    hipLaunchKernelGGL((k_op_pack<true>), dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, s, nblocks, bptr, bstart, key2, val2, (int32_t *)nullptr, cptr, isrc, idst, (int *)nullptr, rows16);
     OP_CHECK(hipGetLastError());
     OP_CHECK(hipStreamSynchronize(s));
     o = new nh_owner_plan();
@@ -466,6 +506,7 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
     o->nblocks = nblocks, o->rows_per_block = R, o->max_visits = vmax, o->nvisits = nvisits, o->nchunks = nchunks;
     o->nsteps = 0;
     while ((1 << o->nsteps) < hflags[1]) ++o->nsteps;
+    o->rows16 = rows16;
     o->order = reinterpret_cast<int32_t *>(bp_keep(t, order));
     o->bptr = bp_keep(t, bptr);
     o->vptr = bp_keep(t, vptr);
@@ -548,7 +589,7 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
   p.values = a->values_dev;
   p.store = (a->flags & NH_MATRIX_STORE) != 0;
   p.nrows = pat->nrows;
-  p.R = o->rows_per_block, p.nsteps = o->nsteps, p.vmax = o->max_visits, p.ldst = ldst;
+  p.R = o->rows_per_block, p.nsteps = o->nsteps, p.vmax = o->max_visits, p.ldst = ldst, p.rows16 = o->rows16;
   p.order = o->order, p.vlist = o->vlist, p.vptr = o->vptr, p.cptr = o->cptr, p.bptr = o->bptr, p.isrc = o->isrc, p.idst = o->idst;
   // threads: enough waves for the chunks of a block, and for the latencies of phase 1 when one block takes most of a CU's LDS
   int nt = lds > 80 * 1024 ? 1024 : lds > 52 * 1024 ? 512 : 256;

@@ -25,6 +25,7 @@ class Factored:
         if not isinstance(integral, function.Integral):
             raise TypeError('factor expects an Integral')
         names = {a.name for _, itg, _ in integral.terms for a in (itg.test, itg.trial) if a is not None and a.name is not None}
+        names |= {a.name for _, itg, _ in integral.terms if itg.fscale is not None for a in itg.fscale.args if a.name is not None}  # (fields inside polynomial factors)
         if name is None:
             if len(names) != 1:
                 raise NotImplementedError(f'factor needs exactly one field argument, found {sorted(names)}')
