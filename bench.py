@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 F64_MFMA_PEAK_TF = 78.6  # dense f64 MFMA (= f64 vector) peak, 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz
-TRAFFIC_FILE = 'profiles/r04_traffic.json'
+TRAFFIC_FILE = 'profiles/r05_traffic.json'
 
 
 def parse():
