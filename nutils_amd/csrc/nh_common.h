@@ -108,6 +108,7 @@ struct nh_fused_plan {
 // (row, position in the row, element) and packed into chunks of 64 lanes such that the items of one entry never straddle a chunk
 struct nh_owner_plan {
   int nblocks, rows_per_block, max_visits, nsteps;  // rows_per_block: at most; nsteps: doubling steps of the segmented sum (2^nsteps >= contributions of the fullest entry)
+  int qc;           // points per chunk of the D tables (= all points unless the elements have more than 9 functions)
   int rows16;       // no entry straddles a row of 16 lanes (entries of at most 16 items): the sums run on DPP row shifts
   i64 nvisits, nchunks;
   int32_t *order;   // [nrows]: dof at rank position i

@@ -120,7 +120,7 @@ struct OwnK {
   double *values;
   int store;
   i64 nrows;
-  int R, nsteps, vmax, ldst, rows16;
+  int R, nsteps, vmax, ldst, rows16, qc;
   const int32_t *order, *vlist;
   const i64 *vptr, *cptr, *bptr;
   const uint32_t *isrc, *idst;
@@ -158,15 +158,18 @@ constexpr int OWN_NT_MAX = 1024;  // (launch bound; the host picks 256 .. 1024 t
 
 // ISOF: the isotropic three-parameter family on the gradient slots, applied in closed form; USE0: the form reads the value slot (then D holds S slots per node)
 // XLDS: the vertices of the visiting elements are staged in LDS; else every (visit, point) lane keeps them in registers (at most 512 threads then)
-template <int ND, int NB, int NC, bool ISOF, bool USE0, bool XLDS>
-__global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_rows_v(OwnK p) {
+// GK > 0: the points are taken in chunks of p.qc (elements of 27 functions: the D tables of all points of the 8 visits of a box do not fit) -- a wave holds the
+// Gram sums of GK chunks of contributions in registers across the point chunks; at most 256 threads then
+template <int ND, int NB, int NC, bool ISOF, bool USE0, bool XLDS, int GK = 0>
+__global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_rows_v(OwnK p) {
   constexpr int S = 1 + ND, NG = 1 << ND, SD = USE0 ? S : ND, O = USE0 ? 0 : 1;  // D slot a is operator slot O + a
   static_assert(!(ISOF && USE0), "the isotropic family has no value slot");
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int nq = p.nq, b = blockIdx.x, tid = threadIdx.x, OWN_NT = blockDim.x;
   // strides of the D table, in doubles: odd per point, odd and not +- the point stride mod 16 per visit (own_vs), so that the lanes of phase 1 (consecutive points of consecutive visits) and of
   // phase 2 (the nodes of arbitrary visits at one point) spread over the banks -- with 24 / 192 doubles they all met in two bank pairs
-  const int QS = (NB * SD) | 1, VS = own_vs(nq * QS, QS), XS = (NG * ND) | 1;
+  const int qc = p.qc;  // points per chunk (= nq unless GK)
+  const int QS = (NB * SD) | 1, VS = own_vs(qc * QS, QS), XS = (NG * ND) | 1;
   const bool iso = p.geom.kind == NH_GEOM_ISO && p.geom.ngb == NG;
   // LDS: [row starts R x i64][row lengths R x int, padded][form 144][quadrature weights][test table][geometry table][vertices vmax x NG x ND][weights vmax x nq][D vmax x nq x NB x SD]
   i64 *rs = reinterpret_cast<i64 *>(sm);
@@ -177,12 +180,12 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
   double *sgT = sT + (p.ldst ? NB * nq * S : 0);
   // staged vertices: in the LAST point slab of the visit's own D table when the nq lanes of a visit sit in one wave (64 % nq == 0) -- every lane of the wave has read
   // them (to form J) before any lane stores its gradients, so the vertices cost no LDS of their own; else behind the weights
-  const bool xalias = XLDS && 64 % nq == 0 && NG * ND <= QS;
+  const bool xalias = XLDS && !GK && 64 % nq == 0 && NG * ND <= QS;
   double *sW = sgT + (p.ldst && iso ? NG * nq * S : 0);
-  double *sX = sW + p.vmax * nq;
+  double *sX = sW + p.vmax * qc;
   double *sD = sX + (iso && XLDS && !xalias ? p.vmax * XS : 0);
   const int XV = xalias ? VS : XS;  // stride of the vertex sets
-  if (xalias) sX = sD + (nq - 1) * QS;
+  if (xalias) sX = sD + (qc - 1) * QS;
 #ifdef NH_ABLATION
   long long tlast = __builtin_readcyclecounter();
 #endif
@@ -224,9 +227,10 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
     }
   __syncthreads();
   OTICK(0);
-  // phase 1: lanes over (visit, point) -- inverse Jacobian, weight, physical gradients of the NB functions
-  for (int i = tid; i < nv * nq && !(ODBG(p) & 1); i += OWN_NT) {
-    const int v = i / nq, q = i - v * nq;
+  // phase 1: lanes over (visit, point of the chunk q0 .. q0 + nql) -- inverse Jacobian, weight, physical gradients of the NB functions
+  auto element_phase = [&](const int q0, const int nql) {
+  for (int i = tid; i < nv * nql && !(ODBG(p) & 1); i += OWN_NT) {
+    const int v = i / nql, ql = i - v * nql, q = q0 + ql;
     const i64 e = p.vlist[v0 + v];
     double Ji[ND][ND], det;
     if (iso) {
@@ -272,9 +276,9 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
       }
     } else
       geometry_at<ND>(p.geom, e, q, nq, nullptr, Ji, det, nullptr);
-    sW[i] = sWq[q] * fabs(det) * (p.scale ? p.scale[e * nq + q] : 1.);
+    sW[v * qc + ql] = sWq[q] * fabs(det) * (p.scale ? p.scale[e * nq + q] : 1.);
     const double *T = p.ldst ? sT : p.test.T + bfn(p.test, e) * nq * S;
-    double *D = sD + v * VS + q * QS;
+    double *D = sD + v * VS + ql * QS;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const double *t = T + (n * nq + q) * S;
@@ -288,21 +292,15 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
       }
     }
   }
-  OTICK(1);
-  __syncthreads();
-  OTICK(2);
+  };
   // phase 2: a wave per chunk of 64 contributions (the item words of the wave's first chunks were requested before phase 0: their latency is behind the element phase)
-  auto process = [&](const uint32_t item, const uint32_t dst) {
-    const bool valid = item >> 31, head = (item >> 30) & 1;
+  // Gram sums of one contribution over the nql points of the tables in LDS
+  auto accumulate = [&](const uint32_t item, double (&G)[SD][SD], const int nql) {
+    const bool valid = item >> 31;
     const int v = (item >> 10) & 0xfff, m = (item >> 5) & 31, n = item & 31;
-    double G[SD][SD];
-#pragma unroll
-    for (int a = 0; a < SD; ++a)
-#pragma unroll
-      for (int bb = 0; bb < SD; ++bb) G[a][bb] = 0;
     if (valid && !(ODBG(p) & 2)) {
-      const double *Dv = sD + v * VS, *Wv = sW + v * nq;
-      for (int q = 0; q < nq; ++q) {
+      const double *Dv = sD + v * VS, *Wv = sW + v * qc;
+      for (int q = 0; q < nql; ++q) {
         const double w = Wv[q];
         const double *dm = Dv + q * QS + m * SD, *dn = Dv + q * QS + n * SD;
         double wm[SD], tn[SD];
@@ -314,6 +312,10 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
           for (int bb = 0; bb < SD; ++bb) G[a][bb] += wm[a] * tn[bb];
       }
     }
+  };
+  // sum over the contributions of every entry, form tensor, store
+  auto finish = [&](const uint32_t item, const uint32_t dst, double (&G)[SD][SD]) {
+    const bool valid = item >> 31, head = (item >> 30) & 1;
     // segmented sum over the lanes of an entry (ascending elements), total in the first lane: rem = lanes of my entry behind me
     const u64 hm = __ballot(head || !valid);
     const u64 behind = lane < 63 ? hm >> (lane + 1) : 0ull;
@@ -375,11 +377,54 @@ __global__ __launch_bounds__(XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void k_owner_ro
         }
     }
   };
+  if constexpr (GK == 0) {
+    element_phase(0, nq);
+    OTICK(1);
+    __syncthreads();
+    OTICK(2);
+    auto process = [&](const uint32_t item, const uint32_t dst) {
+      double G[SD][SD];
 #pragma unroll
-  for (int k = 0; k < PRE; ++k)
-    if (c0 + wave + (i64)k * nw < c1) process(pit[k], pds[k]);
-  for (i64 c = c0 + wave + (i64)PRE * nw; c < c1; c += nw) process(p.isrc[c * 64 + lane], p.idst[c * 64 + lane]);
-  OTICK(3);
+      for (int a = 0; a < SD; ++a)
+#pragma unroll
+        for (int bb = 0; bb < SD; ++bb) G[a][bb] = 0;
+      accumulate(item, G, nq);
+      finish(item, dst, G);
+    };
+#pragma unroll
+    for (int k = 0; k < PRE; ++k)
+      if (c0 + wave + (i64)k * nw < c1) process(pit[k], pds[k]);
+    for (i64 c = c0 + wave + (i64)PRE * nw; c < c1; c += nw) process(p.isrc[c * 64 + lane], p.idst[c * 64 + lane]);
+    OTICK(3);
+  } else {
+    static_assert(GK <= PRE, "the preloaded item words cover the first group");
+    // groups of GK chunks per wave (one group unless a block has more chunks than the workgroup holds); per group the points in chunks of qc
+    for (i64 g0 = c0; g0 < c1; g0 += (i64)GK * nw) {
+      uint32_t it[GK ? GK : 1], ds[GK ? GK : 1];
+      double G[GK ? GK : 1][SD][SD];
+#pragma unroll
+      for (int k = 0; k < GK; ++k) {
+        const i64 c = g0 + wave + (i64)k * nw;
+        it[k] = g0 == c0 ? pit[k] : (c < c1 ? p.isrc[c * 64 + lane] : 0u);
+        ds[k] = g0 == c0 ? pds[k] : (c < c1 ? p.idst[c * 64 + lane] : 0u);
+#pragma unroll
+        for (int a = 0; a < SD; ++a)
+#pragma unroll
+          for (int bb = 0; bb < SD; ++bb) G[k][a][bb] = 0;
+      }
+      for (int q0 = 0; q0 < nq; q0 += qc) {
+        const int nql = min(qc, nq - q0);
+        if (q0 || g0 != c0) __syncthreads();  // the tables of the previous chunk have been read
+        element_phase(q0, nql);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GK; ++k) accumulate(it[k], G[k], nql);
+      }
+#pragma unroll
+      for (int k = 0; k < GK; ++k)
+        if (g0 + wave + (i64)k * nw < c1) finish(it[k], ds[k], G[k]);
+    }
+  }
 }
 
 }  // namespace
@@ -391,11 +436,12 @@ void nh_owner_free(nh_owner_plan *o) {
 }
 
 // LDS bytes of a block with `vmax` visits
-static size_t owner_lds(int R, int vmax, int nq, int nb, int nd, int sd, bool isof, bool ldst, bool iso, bool xlds = true) {
+static size_t owner_lds(int R, int vmax, int nq, int qc, int nb, int nd, int sd, bool isof, bool ldst, bool iso, bool xlds = true) {
   const int S = 1 + nd, NG = 1 << nd;
-  const size_t QS = (size_t)(nb * sd) | 1, VS = (size_t)own_vs((int)(nq * QS), (int)QS), XS = (size_t)(NG * nd) | 1;  // (the strides of the kernel)
-  size_t d = (size_t)R + (R + 1) / 2 + (isof ? 0 : 144) + (size_t)nq + (ldst ? (size_t)nb * nq * S : 0) + (ldst && iso ? (size_t)NG * nq * S : 0) + (iso && xlds && !(64 % nq == 0 && (size_t)(NG * nd) <= QS) ? (size_t)vmax * XS : 0) +
-             (size_t)vmax * nq + (size_t)vmax * VS;  // (vertices: inside the D tables when the lanes of a visit share a wave)
+  const size_t QS = (size_t)(nb * sd) | 1, VS = (size_t)own_vs((int)(qc * QS), (int)QS), XS = (size_t)(NG * nd) | 1;  // (the strides of the kernel)
+  const bool xalias = qc == nq && 64 % nq == 0 && (size_t)(NG * nd) <= QS;  // (vertices inside the D tables when the lanes of a visit share a wave)
+  size_t d = (size_t)R + (R + 1) / 2 + (isof ? 0 : 144) + (size_t)nq + (ldst ? (size_t)nb * nq * S : 0) + (ldst && iso ? (size_t)NG * nq * S : 0) + (iso && xlds && !xalias ? (size_t)vmax * XS : 0) +
+             (size_t)vmax * qc + (size_t)vmax * VS;
   return d * sizeof(double);
 }
 
@@ -437,9 +483,13 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
     if (getenv("NH_OWNER_LDS")) budget = (size_t)std::max(16, std::min(160, atoi(getenv("NH_OWNER_LDS")))) * 1024;
     int R = 0, vmax = 0, nblocks = 0;
     i64 nvisits = 0;
+    // (elements of more than 9 functions -- triquadratic: 27 -- take their points in chunks and hold the sums of a block's contributions in registers meanwhile: boxes of at
+    // most 8 rows, the nodes one element owns, so that a workgroup of four waves holds them in four chunks of 64 each)
+    const bool big = nbt > 9;
     const int cand[] = {64, 32, 16, 8, 4, 2, 1};
     int forced = getenv("NH_OWNER_ROWS") ? std::max(1, std::min(256, atoi(getenv("NH_OWNER_ROWS")))) : 0;
-    for (int ci = 0; ci < 7; ++ci) {
+    int qc = a->nq;
+    for (int ci = big ? 3 : 0; ci < 7; ++ci) {
       const int Rc = forced ? forced : cand[ci];
       const int tn = t.n;
       OP_CHECK(hipMemsetAsync(flags, 0, 3 * sizeof(int), s));
@@ -448,11 +498,12 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
       hipLaunchKernelGGL(k_op_maxvisits, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s, nblocks, vptr, flags + 2);
       OP_CHECK(hipMemcpyAsync(hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
       OP_CHECK(hipStreamSynchronize(s));
-      if (hflags[2] < 4096 && owner_lds(Rc, hflags[2], a->nq, nbt, a->ndims, sd, isof, ldst, iso, false) <= budget) {  // (without the staged vertices if need be)
-        R = Rc, vmax = hflags[2];
-        break;
+      for (int parts = 1; parts <= (big ? 8 : 1) && !R; ++parts) {
+        const int q = (a->nq + parts - 1) / parts;
+        if (hflags[2] < 4096 && owner_lds(Rc, hflags[2], a->nq, q, nbt, a->ndims, sd, isof, ldst, iso, parts > 1) <= budget) R = Rc, vmax = hflags[2], qc = q;  // (without the staged vertices if need be)
       }
-      if (getenv("NH_OWNER_VERBOSE")) fprintf(stderr, "nh_owner plan: %d rows per block -> at most %d visits, %zu B of LDS: over the budget\n", Rc, hflags[2], owner_lds(Rc, hflags[2], a->nq, nbt, a->ndims, sd, isof, ldst, iso));
+      if (R) break;
+      if (getenv("NH_OWNER_VERBOSE")) fprintf(stderr, "nh_owner plan: %d rows per block -> at most %d visits, %zu B of LDS: over the budget\n", Rc, hflags[2], owner_lds(Rc, hflags[2], a->nq, a->nq, nbt, a->ndims, sd, isof, ldst, iso));
       if (forced) break;
       for (int i = tn; i < t.n; ++i) hipFree(t.ptr[i]);  // (this candidate's arrays)
       t.n = tn;
@@ -507,6 +558,7 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
     o->nsteps = 0;
     while ((1 << o->nsteps) < hflags[1]) ++o->nsteps;
     o->rows16 = rows16;
+    o->qc = qc;
     o->order = reinterpret_cast<int32_t *>(bp_keep(t, order));
     o->bptr = bp_keep(t, bptr);
     o->vptr = bp_keep(t, vptr);
@@ -517,7 +569,7 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
     if (getenv("NH_OWNER_VERBOSE"))
       fprintf(stderr, "nh_owner plan: %d blocks of %d rows, %lld visits (%.2f per element, at most %d per block), %lld chunks for %lld items (%.2f lanes used), entries of up to %d items, %zu B of LDS\n",
               nblocks, R, (long long)nvisits, (double)nvisits / (double)ne, vmax, (long long)nchunks, (long long)ni, (double)ni / (64. * (double)nchunks), hflags[1],
-              owner_lds(R, vmax, a->nq, nbt, a->ndims, sd, isof, ldst, iso));
+              owner_lds(R, vmax, a->nq, qc, nbt, a->ndims, sd, isof, ldst, iso));
   }
 done:
 #undef OP_CHECK
@@ -535,7 +587,7 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
   if (!pat || pat->nelems != a->nelems || pat->eoff || pat->owner_failed || pat->nbt != a->test.nb || pat->nbr != a->trial.nb) return NH_OK;
   const int key = a->ndims * 1000 + a->test.nb * 10 + nc;
   switch (key) {
-    case 3083: case 2042: case 2092: break;
+    case 3083: case 2042: case 2092: case 3273: break;
     default: return NH_OK;
   }
   const int S = 1 + a->ndims;
@@ -561,7 +613,7 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
   }
   const bool iso = a->geom.kind == NH_GEOM_ISO && a->geom.ngb == (1 << a->ndims);
   const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + (iso ? (1 << a->ndims) : 0));
-  const bool ldst = !a->test.tab_dev && ldsb <= 24 * 1024;
+  const bool ldst = !a->test.tab_dev && ldsb <= 32 * 1024;
   const int sd = use0 ? S : a->ndims;
   if (!pat->owner) {
     const int rc = nh_owner_prepare(pat, a, sd, isof, ldst, iso, s);
@@ -572,10 +624,11 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
     if (rc != NH_OK) return rc;
   }
   const nh_owner_plan *o = pat->owner;
-  size_t lds = owner_lds(o->rows_per_block, o->max_visits, a->nq, a->test.nb, a->ndims, sd, isof, ldst, iso);
+  const bool chunked = o->qc < a->nq;
+  size_t lds = owner_lds(o->rows_per_block, o->max_visits, a->nq, o->qc, a->test.nb, a->ndims, sd, isof, ldst, iso);
   // the staged vertices are given up where they cost a workgroup per CU (two of 80 kB fit, three of 53 kB)
-  const size_t lds0 = owner_lds(o->rows_per_block, o->max_visits, a->nq, a->test.nb, a->ndims, sd, isof, ldst, iso, false);
-  bool xlds = iso && (160 * 1024 / lds0 == 160 * 1024 / std::max<size_t>(lds, 1)) && lds <= 160 * 1024;
+  const size_t lds0 = owner_lds(o->rows_per_block, o->max_visits, a->nq, o->qc, a->test.nb, a->ndims, sd, isof, ldst, iso, false);
+  bool xlds = iso && ((160 * 1024 / lds0 == 160 * 1024 / std::max<size_t>(lds, 1)) || chunked) && lds <= 160 * 1024;
   if (getenv("NH_OWNER_XLDS")) xlds = iso && atoi(getenv("NH_OWNER_XLDS")) != 0;
   if (!xlds) lds = lds0;
   if (lds > 160 * 1024) return NH_OK;  // (a plan built for other tables / forms: the caller keeps its other paths)
@@ -589,12 +642,13 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
   p.values = a->values_dev;
   p.store = (a->flags & NH_MATRIX_STORE) != 0;
   p.nrows = pat->nrows;
-  p.R = o->rows_per_block, p.nsteps = o->nsteps, p.vmax = o->max_visits, p.ldst = ldst, p.rows16 = o->rows16;
+  p.R = o->rows_per_block, p.nsteps = o->nsteps, p.vmax = o->max_visits, p.ldst = ldst, p.rows16 = o->rows16, p.qc = o->qc;
   p.order = o->order, p.vlist = o->vlist, p.vptr = o->vptr, p.cptr = o->cptr, p.bptr = o->bptr, p.isrc = o->isrc, p.idst = o->idst;
   // threads: enough waves for the chunks of a block, and for the latencies of phase 1 when one block takes most of a CU's LDS
   int nt = lds > 80 * 1024 ? 1024 : lds > 52 * 1024 ? 512 : 256;
   if (getenv("NH_OWNER_NT")) nt = std::max(64, std::min(OWN_NT_MAX, atoi(getenv("NH_OWNER_NT")) & ~63));
   if (!xlds) nt = std::min(nt, OWN_NT_MAX / 2);
+  if (chunked || a->test.nb > 9) nt = 256;
 #ifdef NH_ABLATION
   if (getenv("NH_OWNER_DEBUG")) p.debug = atoi(getenv("NH_OWNER_DEBUG"));
   if (getenv("NH_OWNER_TICKS")) {
@@ -619,7 +673,18 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
     else if (use0) OWN2(ND, NB, NC, false, true);    \
     else OWN2(ND, NB, NC, false, false);             \
   } while (0)
+#define OWNG(ND, NB, NC, IS, U0)                                                                                                                   \
+  do {                                                                                                                                            \
+    NH_CHECK_HIP(hipFuncSetAttribute((const void *)k_owner_rows_v<ND, NB, NC, IS, U0, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_owner_rows_v<ND, NB, NC, IS, U0, true, 4>), grid, block, lds, s, p);                                                      \
+  } while (0)
   switch (key) {
+    case 3273:  // triquadratic hexahedra, 3 components: points in chunks (a multilinear isoparametric geometry: with staged vertices only)
+      if (iso && !xlds) return NH_OK;
+      if (isof) OWNG(3, 27, 3, true, false);
+      else if (use0) OWNG(3, 27, 3, false, true);
+      else OWNG(3, 27, 3, false, false);
+      break;
     case 3083: OWN(3, 8, 3); break;  // trilinear hexahedra, 3 components
     case 2042: OWN(2, 4, 2); break;  // bilinear quadrilaterals, 2 components
     case 2092: OWN(2, 9, 2); break;  // biquadratic quadrilaterals / quadratic splines, 2 components
@@ -627,6 +692,7 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
 #undef OWN
 #undef OWN2
 #undef OWN3
+#undef OWNG
   NH_LAUNCH_CHECK();
 #ifdef NH_ABLATION
   if (p.tdbg) {

@@ -162,7 +162,7 @@ FUSED_SIZES = {(1, 2), (1, 3), (2, 3), (2, 4), (2, 9), (3, 4), (3, 8)}  # (dimen
 # with the gather)
 FUSED_DEFAULT = {(3, 8)}
 # (dimension, functions per element, components) of the owner kernel for vector-valued blocks (nh_owner.hip: Gram sums per scalar entry from D tables in LDS, one pass)
-OWNER_VECTOR = {(3, 8, 3), (2, 4, 2), (2, 9, 2)}
+OWNER_VECTOR = {(3, 8, 3), (2, 4, 2), (2, 9, 2), (3, 27, 3)}
 
 
 def assemble_matrix(*, nelems, ndims, nq, weights, geom, test, trial, nct, ncr, C, mask, pattern, values, elist=None, emap_offset=0, scale=None, flags=0,

@@ -591,9 +591,15 @@ class _MatrixPlan:
         '''Scalar blocks of 27 (3-D quadratic) / 16 (2-D cubic) functions: from the second assembly on, the owner-side reduction with its row-blocked
         thread pass (k_local_rows) instead of the coloured MFMA launches -- 64^3 triquadratic 3.9 against 13.0 ms, 1024^2 bicubic splines 3.3
         against 14.4 ms (tools/generic_probe.py).'''
-        if self.test.ncomp != 1 or self.trial.ncomp != 1 or smp.elist is not None or itg.qform is not None or os.environ.get('NUTILS_AMD_NO_GATHER'):
+        if smp.elist is not None or itg.qform is not None:
             return False
         tt, tr = smp.tables(itg.test.basis), smp.tables(itg.trial.basis)
+        # ... and vector-valued blocks of 27 functions: the owner kernel (nh_owner.hip, points in chunks) from the FIRST assembly on -- one pass instead of 8 coloured launches
+        if (self.test.ncomp == self.trial.ncomp and (smp.ndims, tt.nb, self.test.ncomp) in kernels.OWNER_VECTOR and tt.nb > 9 and itg.test.basis is itg.trial.basis
+                and not os.environ.get('NUTILS_AMD_NO_FUSED') and itg.fscale is None and itg.qscalar is None):
+            return True
+        if self.test.ncomp != 1 or self.trial.ncomp != 1 or os.environ.get('NUTILS_AMD_NO_GATHER'):
+            return False
         if (smp.ndims, tt.nb, tr.nb) not in ((2, 16, 16), (3, 27, 27), (2, 25, 25), (3, 64, 64)):  # (the instantiations of k_local_rows, nh_gather.hip)
             return False
         pat = smp.pattern(itg.test.basis, itg.trial.basis)

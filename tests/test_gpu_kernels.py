@@ -422,7 +422,8 @@ def test_first_touch_coloured_assembly(case, monkeypatch):
     from nutils_amd import mesh, function, device, sample
     monkeypatch.setenv('NUTILS_AMD_NO_GATHER', '1')  # (16-function scalar blocks take the owner-side reduction from the second assembly on)
     if case == '3d_p2_vector':
-        monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')  # this test is about the coloured generic path (the write-once kernel nh_p2hex_matrix would take the form)
+        monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')  # this test is about the coloured generic path (the write-once kernel nh_p2hex_matrix would take the form,
+        monkeypatch.setenv('NUTILS_AMD_NO_FUSED', '1')      # and the owner kernel for vector-valued 27-function blocks after it)
         shape = [16, 16, 17]
         domain, geom = mesh.rectilinear(shape)
         gb = domain.basis('std', degree=1)

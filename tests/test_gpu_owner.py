@@ -57,7 +57,7 @@ def _mesh(nd, n, degree, shuffle, seed=5):
     return dict(nelems=ne, ndims=nd, nq=len(pts), weights=device.to_dev(w, 'float64'), geom=geom, test=basis, trial=basis, pattern=pattern), ndofs, rng
 
 
-@pytest.mark.parametrize('nd,n,degree,shuffle', [(3, 14, 1, False), (3, 14, 1, True), (2, 40, 1, True), (2, 24, 2, False), (2, 24, 2, True)])
+@pytest.mark.parametrize('nd,n,degree,shuffle', [(3, 14, 1, False), (3, 14, 1, True), (2, 40, 1, True), (2, 24, 2, False), (2, 24, 2, True), (3, 6, 2, False), (3, 5, 2, True)])
 @pytest.mark.parametrize('form', ['elasticity', 'dense', 'masked'])
 def test_owner_rows_many_blocks_any_numbering(nd, n, degree, shuffle, form):
     '''Meshes of many row blocks with a perturbed geometry, natural or random numbering of elements and dofs: the one-pass owner kernel against the two-pass gather
@@ -87,7 +87,7 @@ def test_owner_rows_many_blocks_any_numbering(nd, n, degree, shuffle, form):
         kernels.assemble_matrix(nct=nd, ncr=nd, C=C, mask=mask, values=values, scale=scale, **common, **kw)
         out.append(device.to_host(values))
     nblocks, rpb, nvisits, nchunks = pattern.owner_info()
-    assert nblocks >= -(-ndofs // rpb) and nblocks > 20, (nblocks, rpb)  # (Morton boxes of at most rpb rows)
+    assert nblocks >= -(-ndofs // rpb) and nblocks > 20, (nblocks, rpb)  # (Morton boxes of at most rpb rows; triquadratic elements: points in chunks)
     assert nchunks * 64 >= common['nelems'] * common['test'].nb ** 2
     for o in out[1:]:
         close(o, out[0])
