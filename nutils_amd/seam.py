@@ -59,7 +59,7 @@ def save(path, plan, expect=None):
         if isinstance(obj, numpy.floating):
             return float(obj)
         return obj
-    spec = json.dumps(enc(plan))
+    spec = json.dumps(enc({k: v for k, v in plan.items() if not k.startswith('_')}))  # ('_built', '_source': run-time attachments)
     out = dict(arrays, spec=numpy.array(spec))
     for k, v in (expect or {}).items():
         out['expect_' + k] = numpy.asarray(v)
