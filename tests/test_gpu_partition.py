@@ -131,7 +131,7 @@ def test_pipelined_exchange_matches_serial():
     assert plast.data_ptr() != 0
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])  # (8: the driver's widest launch, `--gpus 8`, eight processes on the one GPU of this box)
 def test_bench_multiprocess_on_one_gpu(world):
     '''`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank), except that all ranks
     share the one GPU of this box and the interface rows travel through gloo (host staging) instead of RCCL: exercises rank
