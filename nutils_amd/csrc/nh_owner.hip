@@ -439,7 +439,7 @@ void nh_owner_free(nh_owner_plan *o) {
 static size_t owner_lds(int R, int vmax, int nq, int qc, int nb, int nd, int sd, bool isof, bool ldst, bool iso, bool xlds = true) {
   const int S = 1 + nd, NG = 1 << nd;
   const size_t QS = (size_t)(nb * sd) | 1, VS = (size_t)own_vs((int)(qc * QS), (int)QS), XS = (size_t)(NG * nd) | 1;  // (the strides of the kernel)
-  const bool xalias = qc == nq && 64 % nq == 0 && (size_t)(NG * nd) <= QS;  // (vertices inside the D tables when the lanes of a visit share a wave)
+  const bool xalias = nb <= 9 && 64 % nq == 0 && (size_t)(NG * nd) <= QS;  // (vertices inside the D tables when the lanes of a visit share a wave; not with point chunks)
   size_t d = (size_t)R + (R + 1) / 2 + (isof ? 0 : 144) + (size_t)nq + (ldst ? (size_t)nb * nq * S : 0) + (ldst && iso ? (size_t)NG * nq * S : 0) + (iso && xlds && !xalias ? (size_t)vmax * XS : 0) +
              (size_t)vmax * qc + (size_t)vmax * VS;
   return d * sizeof(double);
@@ -624,10 +624,14 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
     if (rc != NH_OK) return rc;
   }
   const nh_owner_plan *o = pat->owner;
-  const bool chunked = o->qc < a->nq;
-  size_t lds = owner_lds(o->rows_per_block, o->max_visits, a->nq, o->qc, a->test.nb, a->ndims, sd, isof, ldst, iso);
+  // points per chunk: the plan's choice for elements of more than 9 functions (made for the quadrature of its first launch: any other takes more or fewer chunks of that
+  // size), all points otherwise
+  const bool big = a->test.nb > 9;
+  const int qc = big ? std::min(o->qc, a->nq) : a->nq;
+  const bool chunked = big;
+  size_t lds = owner_lds(o->rows_per_block, o->max_visits, a->nq, qc, a->test.nb, a->ndims, sd, isof, ldst, iso);
   // the staged vertices are given up where they cost a workgroup per CU (two of 80 kB fit, three of 53 kB)
-  const size_t lds0 = owner_lds(o->rows_per_block, o->max_visits, a->nq, o->qc, a->test.nb, a->ndims, sd, isof, ldst, iso, false);
+  const size_t lds0 = owner_lds(o->rows_per_block, o->max_visits, a->nq, qc, a->test.nb, a->ndims, sd, isof, ldst, iso, false);
   bool xlds = iso && ((160 * 1024 / lds0 == 160 * 1024 / std::max<size_t>(lds, 1)) || chunked) && lds <= 160 * 1024;
   if (getenv("NH_OWNER_XLDS")) xlds = iso && atoi(getenv("NH_OWNER_XLDS")) != 0;
   if (!xlds) lds = lds0;
@@ -642,13 +646,13 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
   p.values = a->values_dev;
   p.store = (a->flags & NH_MATRIX_STORE) != 0;
   p.nrows = pat->nrows;
-  p.R = o->rows_per_block, p.nsteps = o->nsteps, p.vmax = o->max_visits, p.ldst = ldst, p.rows16 = o->rows16, p.qc = o->qc;
+  p.R = o->rows_per_block, p.nsteps = o->nsteps, p.vmax = o->max_visits, p.ldst = ldst, p.rows16 = o->rows16, p.qc = qc;
   p.order = o->order, p.vlist = o->vlist, p.vptr = o->vptr, p.cptr = o->cptr, p.bptr = o->bptr, p.isrc = o->isrc, p.idst = o->idst;
   // threads: enough waves for the chunks of a block, and for the latencies of phase 1 when one block takes most of a CU's LDS
   int nt = lds > 80 * 1024 ? 1024 : lds > 52 * 1024 ? 512 : 256;
   if (getenv("NH_OWNER_NT")) nt = std::max(64, std::min(OWN_NT_MAX, atoi(getenv("NH_OWNER_NT")) & ~63));
   if (!xlds) nt = std::min(nt, OWN_NT_MAX / 2);
-  if (chunked || a->test.nb > 9) nt = 256;
+  if (big) nt = 256;
 #ifdef NH_ABLATION
   if (getenv("NH_OWNER_DEBUG")) p.debug = atoi(getenv("NH_OWNER_DEBUG"));
   if (getenv("NH_OWNER_TICKS")) {
