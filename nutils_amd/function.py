@@ -505,8 +505,13 @@ class Integrand:
 
     __array_ufunc__ = None
 
-    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False, scale=None, fscale=None, qform=None, qscalar=None):
+    def __init__(self, test=None, trial=None, B=None, L=None, f0=None, geom=None, measure=None, rows=False, cols=False, scale=None, fscale=None, qform=None, qscalar=None,
+                 pvars=()):
         self.test, self.trial, self.B, self.L, self.f0 = test, trial, B, L, f0
+        # point variables: the whole integrand is multiplied by prod_k U_arg_k[comp_k][slot_k] at the point -- components of values (slot 0) and gradients (slot 1 + i)
+        # of bound, possibly vector-valued fields (the convection u_j d_j(u_i) v_i of Navier-Stokes, function.py:1207-1295 of the reference).  (Arg, comp, slot) triples;
+        # evaluated on the device into the scale array of the term (sample._bind_pvars), differentiated by the product rule in `derivative` below.
+        self.pvars = tuple(pvars)
         # product-rule terms of Newton Jacobians / Hessians of energies: forms whose coefficients depend on the point through the VALUES
         # (value and gradient) U of a field there.  With B the tensor of this integrand,
         #   qform = ('trial', arg):    C_q[c][a][0][0] = sum_db B[c][a][d][b] U_arg[d][b]     (result on the value slot of the trial function)
@@ -523,7 +528,7 @@ class Integrand:
 
     def _copy(self, **kw):
         d = dict(test=self.test, trial=self.trial, B=self.B, L=self.L, f0=self.f0, geom=self.geom, measure=self.measure, rows=self.rows, cols=self.cols,
-                 scale=self.scale, fscale=self.fscale, qform=self.qform, qscalar=self.qscalar)
+                 scale=self.scale, fscale=self.fscale, qform=self.qform, qscalar=self.qscalar, pvars=self.pvars)
         d.update(kw)
         return Integrand(**d)
 
@@ -724,12 +729,54 @@ class Integral:
         return eval(self, **arguments)
 
 
+def _pvar_derivative(itg, k):
+    '''d/d(point variable k) of the integrand: the variable U[comp][slot] becomes the basis function phi_n of its argument at (comp, slot) -- a new test or trial slot.
+    Slots that are bound to argument values (a trial field in a residual form, both fields of an energy) are moved into point variables first: B(v, u) with u bound is
+    sum_db L_db(v) u[d][b], every summand a constant form times a point variable, so that the result is again (constant form) x (point variables) and nothing of
+    the product rule needs per-point coefficient tensors.'''
+    varg, comp, slot = itg.pvars[k]
+    rest = itg.pvars[:k] + itg.pvars[k + 1:]
+    if itg.qform is not None or itg.qscalar is not None:
+        raise NotImplementedError('point variables together with the product-rule tensors of scalar coefficient functions')
+    if (itg.B if itg.B is not None else itg.L if itg.L is not None else numpy.zeros(())).ndim > itg._keep:
+        raise NotImplementedError('point variables on an integrand with free axes')
+    S = 1 + varg.basis.ndims
+    out = []
+    if itg.test is None:  # f0 x variables -> linear form in the test function of varg
+        L = numpy.zeros((varg.ncomp, S))
+        L[comp, slot] = float(itg.f0)
+        return [itg._copy(test=varg, L=L, f0=None, rows=True, pvars=rest)]
+    if itg.B is None:
+        if itg.rows:      # L(test) x variables -> bilinear form (test x varg)
+            B = numpy.zeros(itg.L.shape + (varg.ncomp, S))
+            B[..., comp, slot] = itg.L
+            return [itg._copy(trial=varg, B=B, L=None, cols=True, pvars=rest)]
+        for c, a in zip(*numpy.nonzero(itg.L)):  # L(u) with u bound: the slots of u become variables
+            out += _pvar_derivative(itg._copy(test=None, L=None, f0=numpy.asarray(float(itg.L[c, a])), pvars=rest + ((itg.test, int(c), int(a)), itg.pvars[k])), len(rest) + 1)
+        return out
+    if itg.rows and itg.cols:
+        raise NotImplementedError('derivative of a matrix with respect to a point variable (rank-3 tensor)')
+    if itg.cols:
+        raise NotImplementedError('point variables on a form whose trial slot is exposed before its test slot')
+    if itg.rows:          # B(test, u) with u bound -> sum over the slots of u: L_db(test) u[d][b]
+        for d, b in zip(*numpy.nonzero(numpy.abs(itg.B).sum(axis=(0, 1)))):
+            out += _pvar_derivative(itg._copy(trial=None, B=None, L=numpy.ascontiguousarray(itg.B[:, :, d, b]), pvars=rest + ((itg.trial, int(d), int(b)), itg.pvars[k])), len(rest) + 1)
+        return out
+    for c, a, d, b in zip(*numpy.nonzero(itg.B)):  # energy density B(u, w) x variables: everything becomes a variable
+        out += _pvar_derivative(itg._copy(test=None, trial=None, B=None, f0=numpy.asarray(float(itg.B[c, a, d, b])),
+                                          pvars=rest + ((itg.test, int(c), int(a)), (itg.trial, int(d), int(b)), itg.pvars[k])), len(rest) + 2)
+    return out
+
+
 def derivative(integral, name):
     '''Derivative with respect to the named field argument (function.derivative):
     exposes that argument's dof axis.  Terms that do not depend on it vanish.'''
     out = []
     T = lambda B: numpy.moveaxis(B, (-4, -3, -2, -1), (-2, -1, -4, -3))
     for smp, itg, fac in integral.terms:
+        for k, (varg, comp, slot) in enumerate(itg.pvars):
+            if varg.name == name:  # product rule on a point variable: the basis function of (varg, comp, slot) takes its place
+                out += [(smp, t, fac) for t in _pvar_derivative(itg, k)]
         if itg.fscale is not None and itg.fscale.depends_on(name):
             g = itg.fscale.derivative(name)
             varg = itg.fscale.arg_named(name)

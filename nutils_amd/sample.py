@@ -120,7 +120,11 @@ class Sample:
         values (FieldPoly, re-evaluated on the device for the current arguments); None if neither is present.'''
         out = None
         if pf is not None:
-            if isinstance(pf, function.PointTable):
+            if isinstance(pf, _DeviceTable):
+                if pf.dev.numel() != self.nlist * self.points.npoints:
+                    raise ValueError('device-side coefficient does not match this sample')
+                out = pf.dev
+            elif isinstance(pf, function.PointTable):
                 if pf.values.size != self.nlist * self.points.npoints:
                     raise ValueError('tabulated coefficient does not match this sample')
                 out = _cached(self._scales, pf, lambda: device.to_dev(pf(), 'float64'), limit=16)
@@ -387,6 +391,55 @@ def _field_values(smp, arg, geom, arguments):
     kernels.sample_eval(nelems=smp.nlist, ndims=smp.ndims, nq=nq, geom=smp.geometry(geom), trial=smp.tables(arg.basis).struct, ncr=1,
                         points=smp._points_dev, u=_argument_dev(arguments, arg), U=U, elist=smp._elist_dev)
     return U.reshape(smp.nlist * nq, S)
+
+
+class _DeviceTable(function.PointTable):
+    '''a coefficient [nlist][nq] that exists on the device only: the product of a term's point variables for the current arguments (times its tabulated coefficient)'''
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.geom = None
+
+    @property
+    def values(self):
+        return device.to_host(self.dev)
+
+    def __call__(self, x=None):
+        return device.to_host(self.dev)
+
+
+def _bind_pvars(terms, arguments):
+    '''Terms with point variables (function.Integrand.pvars: components of values / gradients of bound fields as factors) -> the same terms with the product of the
+    variables, evaluated on the device for the current arguments, as their pointwise coefficient: nh_sample_eval of every field the variables name (once per (sample,
+    field, geometry) of the call), nh_pointwise_poly over the strided (component, slot) columns.  Everything downstream sees an ordinary tabulated coefficient.'''
+    if not any(itg.pvars for _, itg, _ in terms):
+        return terms
+    out, fields = [], {}
+    for smp, itg, fac in terms:
+        if not itg.pvars:
+            out.append((smp, itg, fac))
+            continue
+        geom = itg.geom if itg.geom is not None else itg.measure
+        nq, S, n = smp.points.npoints, 1 + smp.ndims, smp.nlist * smp.points.npoints
+        xs, strides = [], []
+        for arg, comp, slot in itg.pvars:
+            key = id(smp), id(arg.basis), arg.name, arg.ncomp, id(geom)
+            U = fields.get(key)
+            if U is None:
+                U = device.empty(n * arg.ncomp * S, 'float64')
+                kernels.sample_eval(nelems=smp.nlist, ndims=smp.ndims, nq=nq, geom=smp.geometry(geom), trial=smp.tables(arg.basis).struct, ncr=arg.ncomp,
+                                    points=smp._points_dev, u=_argument_dev(arguments, arg), U=U, elist=smp._elist_dev)
+                fields[key] = U
+            xs.append(U[comp * S + slot:])
+            strides.append(arg.ncomp * S)
+        if itg.scale is not None:
+            xs.append(smp.scale(itg.scale).reshape(-1))
+            strides.append(1)
+        while len(xs) > 4:  # (nh_pointwise_poly takes four variables)
+            xs, strides = [kernels.pointwise_poly(xs[:4], strides[:4], [1.], [[1] * 4], n)] + xs[4:], [1] + strides[4:]
+        prod = kernels.pointwise_poly(xs, strides, [1.], [[1] * len(xs)], n)
+        out.append((smp, itg._copy(scale=_DeviceTable(prod), pvars=()), fac))
+    return out
 
 
 def _point_scale(smp, itg, arguments):
@@ -1232,6 +1285,14 @@ def evaluate(f, arguments):
         return f.eval(arguments)
     if isinstance(f, function._AsCSR) and isinstance(f.integral, _factor0.FactoredMatrix):
         return f.integral.as_csr()
+    if type(f) is function.Integral:
+        bound = _bind_pvars(f.terms, arguments)
+        if bound is not f.terms:
+            f = function.Integral(bound)
+    elif isinstance(f, (function._AsCSR, function._AsCOO)) and type(f.integral) is function.Integral:
+        bound = _bind_pvars(f.integral.terms, arguments)
+        if bound is not f.integral.terms:
+            f = type(f)(function.Integral(bound))
     if isinstance(f, (function._AsCSR, function._AsCOO)):
         terms = f.integral.terms
         if not terms:

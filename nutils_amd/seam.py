@@ -158,7 +158,8 @@ class Built:
             arr = lambda k: None if t.get(k) is None else numpy.asarray(t[k], dtype=float)
             itg = function.Integrand(test=None if int(t['test']) < 0 else self.args[int(t['test'])], trial=None if int(t['trial']) < 0 else self.args[int(t['trial'])],
                                      B=arr('B'), L=arr('L'), f0=arr('f0'), geom=None if int(t['geom']) < 0 else self.geoms[int(t['geom'])],
-                                     measure=self.geoms[int(t['measure'])], rows=bool(t['rows']), cols=bool(t['cols']), scale=sc, fscale=fp)
+                                     measure=self.geoms[int(t['measure'])], rows=bool(t['rows']), cols=bool(t['cols']), scale=sc, fscale=fp,
+                                     pvars=[(self.args[int(a)], int(c), int(sl)) for a, c, sl in (t.get('pvars') or [])])
             terms.append((self.samples[int(t['sample'])], itg, float(t['fac'])))
         integral = function.Integral(terms)
         for name in plan.get('derivs', []):
@@ -1088,8 +1089,24 @@ def match(array, arguments=None):
                 form.append(i)
             else:
                 poly.append(i)
+        # more than two such factors (the convection u_j d_j(u_i) v_i: v, u, u): two stay in the form -- the exposed ones, then bound ones that the array is
+        # differentiated to (in that order), then the first -- the others become POINT VARIABLES, one term per non-zero (component, slot) of each: the term is
+        # (constant form) x U_arg[comp][slot] at the point, which the front end evaluates on the device and differentiates by the product rule (function.Integrand.pvars)
+        pv = []
         if len(form) > 2:
-            raise Unmatched('more than two basis-dependent factors with gradients / components in one term')
+            keep = [i for i in form if i in exposed]
+            cand = [i for i in form if i not in exposed]
+            cand.sort(key=lambda i: (derivs.index(facs[i].name) if facs[i].name in derivs else len(derivs), i))
+            seen_names = set()
+            first = [i for i in cand if facs[i].name in derivs and not (facs[i].name in seen_names or seen_names.add(facs[i].name))]
+            order_c = first + [i for i in cand if i not in first]
+            keep += order_c[:max(0, 2 - len(keep))]
+            if len(keep) > 2:
+                raise Unmatched('more than two exposed basis factors in one term')
+            pv = [i for i in form if i not in keep]
+            form = keep
+            if len(pv) > 6:
+                raise Unmatched('more than six bound field factors beside the form')
         # array axes: exposed dof axes in array order define (rows, cols); free axes are component axes tied to them
         nexp = len(exposed) + len(derivs)
         if nexposed is None:
@@ -1098,13 +1115,25 @@ def match(array, arguments=None):
             raise Unmatched('terms of different rank')
         form.sort(key=lambda i: (dofpos.index(i) if i in dofpos else len(dofpos) + bound.index(i)))
         # contract A to the form tensor: indices [free..., (c, s) of form factors]; polynomial factors contribute their value slot
-        idx = [slice(None)] * nf
-        for i in range(len(facs)):
-            idx += [slice(None), slice(None)] if i in form else [0, 0]
-        T = A[tuple(idx)]
-        if nf:
-            # free axes of the array are component axes: each must be tied (identity) to the component of one exposed factor
-            T = _tie_components(T, nf, len(form), m, facs, form)
+        # (point variables: every non-zero (component, slot) combination of the factors in `pv` is a term of its own)
+        pv_shapes = [A.shape[nf + 2 * i: nf + 2 * i + 2] for i in pv]
+        combos = []
+        for combo in numpy.ndindex(*[n for sh in pv_shapes for n in sh]):
+            idx = [slice(None)] * nf
+            for i in range(len(facs)):
+                if i in form:
+                    idx += [slice(None), slice(None)]
+                elif i in pv:
+                    j = pv.index(i)
+                    idx += [combo[2 * j], combo[2 * j + 1]]
+                else:
+                    idx += [0, 0]
+            Tc = A[tuple(idx)]
+            if nf:
+                # free axes of the array are component axes: each must be tied (identity) to the component of one exposed factor
+                Tc = _tie_components(Tc, nf, len(form), m, facs, form)
+            if not pv or numpy.abs(Tc).sum():
+                combos.append((combo, Tc))
         if form:
             home = E.basis_transforms(facs[form[0]].basis)
         elif anybasis is not None:
@@ -1114,12 +1143,12 @@ def match(array, arguments=None):
         else:
             raise Unmatched('boundary integral without any basis: the parent topology is unknown')
         sis = E.sample(smp, home)
-        for si in (sis if isinstance(sis, list) else [sis]):
+        for si, (combo, T) in [(si, ct) for si in (sis if isinstance(sis, list) else [sis]) for ct in combos]:
             s = E.plan['samples'][si]
             gnode, tip = m.measure
             gi = _geom_index(E, gnode, smp, si, home)
             gg = -1
-            gnodes = {id(facs[i].geom): facs[i].geom for i in form if facs[i].geom is not None}
+            gnodes = {id(facs[i].geom): facs[i].geom for i in form + pv if facs[i].geom is not None}
             if len(gnodes) > 1:
                 raise Unmatched('gradients with respect to different geometries')
             if gnodes:
@@ -1148,6 +1177,12 @@ def match(array, arguments=None):
                 term.update(test=ai[0], rows=form[0] in exposed, L=numpy.ascontiguousarray(T))
             else:
                 term.update(f0=numpy.asarray(float(T)))
+            if pv:
+                term['pvars'] = []
+                for j, i in enumerate(pv):
+                    f = facs[i]
+                    bi = on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None))
+                    term['pvars'].append([E.arg(f.name, bi, f.ncomp), int(combo[2 * j]), int(combo[2 * j + 1])])
             if m.pw:
                 node = m.pw[0]
                 for p in m.pw[1:]:
@@ -1200,7 +1235,8 @@ def _merge_terms(plan):
     out = []
     for t in plan['terms']:
         for u in out:
-            same = all(t[k] == u[k] for k in ('sample', 'measure', 'test', 'trial', 'rows', 'cols')) and t['scale'] is None and u['scale'] is None
+            same = (all(t[k] == u[k] for k in ('sample', 'measure', 'test', 'trial', 'rows', 'cols')) and t['scale'] is None and u['scale'] is None
+                    and sorted(map(tuple, t.get('pvars') or [])) == sorted(map(tuple, u.get('pvars') or [])))
             if not same or (t['geom'] != u['geom'] and min(t['geom'], u['geom']) >= 0):
                 continue
             u['geom'] = max(t['geom'], u['geom'])

@@ -112,6 +112,8 @@ def evaluate(integral, arguments=None):
                         term = term * v ** p
                     poly = poly + term
                 w = w * poly
+            for arg, comp, slot in itg.pvars:  # point variables: components of values / gradients of bound fields as factors
+                w = w * _field(smp, arg, geo, l, arguments)[:, comp, slot]
             if itg.qscalar is not None:
                 Bs, at, ar = itg.qscalar
                 w = w * numpy.einsum('cadb,qca,qdb->q', Bs, _field(smp, at, geo, l, arguments), _field(smp, ar, geo, l, arguments))
