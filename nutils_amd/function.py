@@ -202,8 +202,13 @@ class FieldPoly:
     __array_ufunc__ = None
 
     def __init__(self, args, terms):
-        self.args = tuple(args)
-        self.terms = {k: v for k, v in terms.items() if v != 0}
+        terms = {k: v for k, v in terms.items() if v != 0}
+        used = [i for i in range(len(args)) if any(k[i] for k in terms)]  # (a variable no monomial uses is dropped: its field need not be bound at evaluation)
+        self.args = tuple(args[i] for i in used)
+        self.terms = {}
+        for k, v in terms.items():
+            kk = tuple(k[i] for i in used)
+            self.terms[kk] = self.terms.get(kk, 0.) + v
 
     @staticmethod
     def _merge(a, b):
@@ -729,6 +734,15 @@ class Integral:
         return eval(self, **arguments)
 
 
+def _expand_fscale(itg, fac):
+    '''the coefficient polynomial of a term written out: one term per monomial, its field values as point variables (value slot) -> [(integrand, factor)]'''
+    out = []
+    for powers, c in itg.fscale.terms.items():
+        pv = tuple((a, 0, 0) for a, p in zip(itg.fscale.args, powers) for _ in range(p))
+        out.append((itg._copy(fscale=None, pvars=itg.pvars + pv), fac * c))
+    return out
+
+
 def _pvar_derivative(itg, k):
     '''d/d(point variable k) of the integrand: the variable U[comp][slot] becomes the basis function phi_n of its argument at (comp, slot) -- a new test or trial slot.
     Slots that are bound to argument values (a trial field in a residual form, both fields of an energy) are moved into point variables first: B(v, u) with u bound is
@@ -799,6 +813,11 @@ def derivative(integral, name):
                     L = numpy.zeros((1, S))
                     L[0, 0] = 1.
                     out.append((smp, itg._copy(test=varg, trial=None, B=None, L=L, rows=True, fscale=g, qscalar=(itg.B, itg.test, itg.trial)), fac))
+                elif itg.qform is None and itg.qscalar is None:
+                    # any other position (a coefficient polynomial on a form with a bound trial field of several components, ...): the polynomial's monomials as point
+                    # variables, differentiated by the product rule of _pvar_derivative -- again constant forms times point variables
+                    out += derivative(Integral([(smp, t, f) for t, f in _expand_fscale(itg, fac)]), name).terms
+                    continue
                 else:
                     raise NotImplementedError('derivative of a field-dependent coefficient in this position (rank-3 tensor)')
         if itg.qscalar is not None:

@@ -140,7 +140,15 @@ class Built:
                 self.geoms.append(function.TabulatedGeometry(numpy.asarray(g['x'], dtype=float), numpy.asarray(g['jac'], dtype=float)))
             else:
                 raise ValueError(f'unknown geometry kind {g["kind"]!r}')
-        self.args = [function.Arg(self.bases[int(a['basis'])], int(a['ncomp']), a['name']) for a in plan['args']]
+        # an argument that is the concatenation of several coefficient vectors (function.vectorize: `part` = index, offset, length, total) is one field per part here,
+        # named `name#index`; prepare_arguments slices the caller's array, derivatives with respect to `name` become one block per part (self.blocks)
+        internal = lambda a: a['name'] if a.get('part') is None else f"{a['name']}#{int(a['part'][0])}"
+        self.args = [function.Arg(self.bases[int(a['basis'])], int(a['ncomp']), internal(a)) for a in plan['args']]
+        self.parts = {}
+        for a in plan['args']:
+            if a.get('part') is not None:
+                k, off, n, total = (int(x) for x in a['part'])
+                self.parts.setdefault(a['name'], {})[k] = (internal(a), off, n, total)
         self.scalar_args = sorted({a['name'] for a in plan['args'] if a.get('scalar')})  # bare scalar arguments: passed as the one coefficient of a constant basis
 
         # (samples of element subsets on ragged bases: the front end rewrites them as samples of their own element list, sample._SubsetView)
@@ -162,9 +170,34 @@ class Built:
                                      pvars=[(self.args[int(a)], int(c), int(sl)) for a, c, sl in (t.get('pvars') or [])])
             terms.append((self.samples[int(t['sample'])], itg, float(t['fac'])))
         integral = function.Integral(terms)
-        for name in plan.get('derivs', []):
-            integral = function.derivative(integral, name)
-        self.integral = integral
+        derivs = list(plan.get('derivs', []))
+        self.split = any(name in self.parts for name in derivs)
+        if not self.split:
+            for name in derivs:
+                integral = function.derivative(integral, name)
+            self.integral = integral
+            self.blocks = [((), integral)]
+        else:
+            # one block per combination of parts: (offsets along the dof axes, integral); dims: total length of every dof axis
+            choices, self.dims = [], []
+            for name in derivs:
+                if name in self.parts:
+                    ps = [self.parts[name][k] for k in sorted(self.parts[name])]
+                    choices.append([(iname, off) for iname, off, n, total in ps])
+                    self.dims.append(ps[0][3])
+                else:
+                    arg = next(a for a in self.args if a.name == name)
+                    choices.append([(name, 0)])
+                    self.dims.append(arg.basis.ndofs * arg.ncomp)
+            self.blocks = []
+            import itertools
+            for combo in itertools.product(*choices):
+                blk = integral
+                for iname, _ in combo:
+                    blk = function.derivative(blk, iname)
+                if blk.terms:
+                    self.blocks.append((tuple(off for _, off in combo), blk))
+            self.integral = function.Integral([t for _, blk in self.blocks for t in blk.terms])  # (for `.terms`: is anything left?  not evaluable as one)
 
 
 def build(plan):
@@ -178,22 +211,56 @@ def build(plan):
 def prepare_arguments(plan, arguments):
     '''arguments as the built integral expects them: a bare scalar argument becomes the coefficient vector (length 1) of its constant basis'''
     arguments = dict(arguments or {})
-    for name in build(plan).scalar_args:
+    b = build(plan)
+    for name in b.scalar_args:
         if name in arguments:
             arguments[name] = numpy.reshape(numpy.asarray(arguments[name], dtype=float), (1,))
+    for name, parts in b.parts.items():  # concatenated coefficient vectors: one field per part
+        if name in arguments:
+            whole = numpy.asarray(arguments[name], dtype=float).ravel()
+            for iname, off, n, total in parts.values():
+                if len(whole) != total:
+                    raise ValueError(f'argument {name!r} has {len(whole)} coefficients, the plan expects {total}')
+                arguments[iname] = whole[off:off + n]
     return arguments
+
+
+def run(plan, arguments, evaluator):
+    '''Evaluate a plan with `evaluator(integral, arguments, kind)` -> float | array | (values, rowptr, colidx): the whole array at once, or -- when it is differentiated
+    to an argument that is a concatenation of coefficient vectors -- block by block, the blocks placed at their offsets (vectors) / merged into one CSR (matrices: the
+    blocks are disjoint, every row is the concatenation of its blocks' rows in column order, as matrix/__init__.py:103-151 merges the blocks of a System).'''
+    b = build(plan)
+    arguments = prepare_arguments(plan, arguments)
+    kind = plan['kind']
+    if not b.split:
+        return evaluator(b.integral, arguments, kind)
+    if kind == 'vector':
+        out = numpy.zeros(b.dims[0])
+        for (off,), blk in b.blocks:
+            r = numpy.asarray(evaluator(blk, arguments, kind), dtype=float).ravel()
+            out[off:off + len(r)] = r
+        return out
+    vals, rows, cols = [], [], []
+    for (roff, coff), blk in b.blocks:
+        v, rp, ci = evaluator(blk, arguments, kind)
+        rp = numpy.asarray(rp)
+        vals.append(numpy.asarray(v, dtype=float))
+        rows.append(numpy.repeat(numpy.arange(len(rp) - 1, dtype=numpy.int64), numpy.diff(rp)) + roff)
+        cols.append(numpy.asarray(ci, dtype=numpy.int64) + coff)
+    v, r, c = (numpy.concatenate(x) if x else numpy.zeros(0, dtype=t) for x, t in ((vals, float), (rows, numpy.int64), (cols, numpy.int64)))
+    order = numpy.lexsort((c, r))
+    rowptr = numpy.concatenate([[0], numpy.cumsum(numpy.bincount(r, minlength=b.dims[0]))]).astype(numpy.int64)
+    return v[order], rowptr, c[order]
 
 
 def execute(plan, arguments=None):
     '''Evaluate a plan through the C ABI.  kind 'matrix': (values, rowptr, colidx) as function.as_csr of the array flattened to two axes
     (function.py:2443-2452; index arrays int64); 'vector': the array in the reference's shape; 'scalar': float.'''
     from . import function
-    b = build(plan)
-    arguments = prepare_arguments(plan, arguments)
+    out = run(plan, arguments, lambda integral, args, kind: function.eval(function.as_csr(integral) if kind == 'matrix' else integral, args))
     kind = plan['kind']
     if kind == 'matrix':
-        return function.eval(function.as_csr(b.integral), arguments)
-    out = function.eval(b.integral, arguments)
+        return out
     if kind == 'scalar':
         return float(out)
     return numpy.asarray(out, dtype=float).reshape([int(n) for n in plan['shape']])
@@ -241,12 +308,13 @@ class _Factor:
     '''What a monomial is linear in: a basis (identity = the reference object), as exposed dof axis (`name` None), bound to a named argument, or
     bound to a constant coefficient array (`cvals` [ndofs][ncomp]: `gbasis @ verts`, `bsplinebasis @ controlweights`).'''
 
-    def __init__(self, basis, name=None, ncomp=1, cvals=None, rational=None):
+    def __init__(self, basis, name=None, ncomp=1, cvals=None, rational=None, part=None):
         self.basis, self.name, self.ncomp, self.cvals, self.rational = basis, name, int(ncomp), cvals, rational
         self.geom = None  # the reference geometry node the gradient slots refer to
+        self.part = part  # (index, offset, length, total): the argument is the concatenation of the coefficient vectors of several bases (function.vectorize), this is one of them
 
     def copy(self):
-        f = _Factor(self.basis, self.name, self.ncomp, self.cvals, self.rational)
+        f = _Factor(self.basis, self.name, self.ncomp, self.cvals, self.rational, self.part)
         f.geom = self.geom
         return f
 
@@ -458,6 +526,9 @@ class Matcher:
         if _kind(node) != '_Wrapper' or _name(node) != 'Sum':
             return None
         prod = node._args[0]
+        transposed = False
+        while _kind(prod) == '_Transpose':  # (the dof axis moved to the end for the sum: a vectorized basis [dofs, components] dotted with its argument)
+            prod, transposed = prod._arg, True
         if _kind(prod) != '_Wrapper' or _name(prod) != 'multiply':
             return None
 
@@ -470,6 +541,21 @@ class Matcher:
                     return None
             return n
         a, b = prod._args
+        for x, y in ((a, b), (b, a)):
+            # function.vectorize of scalar bases (function.py:2556-2570: concatenate of kronecker-ed bases) dotted with ONE argument: the argument is the concatenation of
+            # one coefficient vector per basis -- a scalar field per part, each on its own component of the result
+            parts = self.vector_parts(y) if node.ndim == 1 else None
+            varg = strip_to(x, rf.Argument) if parts is not None else None
+            if varg is not None and len(varg.shape) == 1 and varg.shape[0] == parts[0][4]:
+                nc = parts[0][5]
+                out = []
+                for k, (pb, comp, off, n, total, _) in enumerate(parts):
+                    A = numpy.zeros((nc, 1, self.S))
+                    A[comp, 0, 0] = 1.
+                    out.append(_Mono(A, [('free', 0)], [_Factor(pb[0], self.rename.get(varg.name, varg.name), 1, rational=pb[1], part=(k, off, n, total))]))
+                return out
+        if transposed:
+            return None
         arg, basis = strip_to(a, rf.Argument), self.as_basis(b)
         if arg is None or basis is None:
             arg, basis = strip_to(b, rf.Argument), self.as_basis(a)
@@ -483,6 +569,29 @@ class Matcher:
         A = numpy.zeros((1, self.S))
         A[0, 0] = 1.
         return [_Mono(A, [], [_Factor(basis[0], self.rename.get(arg.name, arg.name), 1, rational=basis[1])])]
+
+    def vector_parts(self, node):
+        '''function.vectorize([basis_0, basis_1, ...]) -> [((basis, rational), component, offset, length, total length, components)] or None'''
+        rf = self.rf
+        if _kind(node) != '_Concatenate' or node.axis != 0 or node.ndim != 2:
+            return None
+        parts, off = [], 0
+        for arr in node.arrays:
+            if _kind(arr) != '_Wrapper' or _name(arr) != 'Inflate' or len(arr._args) != 3:
+                return None
+            pb = self.as_basis(arr._args[0])
+            if pb is None or arr._args[0].ndim != 1:
+                return None
+            try:
+                comp, nc = numpy.asarray(rf.eval(arr._args[1]._arg)), int(rf.eval(arr._args[2]._arg))
+            except Exception:
+                return None
+            if comp.ndim != 0 or nc != node.shape[1]:
+                return None
+            n = int(arr.shape[0])
+            parts.append([pb, int(comp), off, n, None, nc])
+            off += n
+        return [(pb, comp, o, n, off, nc) for pb, comp, o, n, _, nc in parts]
 
     def as_basis(self, node):
         '''(Basis, None) for a basis seen through broadcast wrappers; (Basis, (weights, W node)) for the rational form `basis * w / W`
@@ -1024,10 +1133,10 @@ class Emitter:
         self._geom[key] = len(self.plan['geoms']) - 1
         return self._geom[key]
 
-    def arg(self, name, bi, ncomp):
-        key = (name, bi, ncomp) if name is not None else ('$basis', bi, ncomp)
+    def arg(self, name, bi, ncomp, part=None):
+        key = (name, bi, ncomp, part) if name is not None else ('$basis', bi, ncomp)
         if key not in self._arg:
-            self.plan['args'].append(dict(name=name, basis=bi, ncomp=int(ncomp)))
+            self.plan['args'].append(dict(name=name, basis=bi, ncomp=int(ncomp), part=None if part is None else [int(x) for x in part]))
             self._arg[key] = len(self.plan['args']) - 1
         return self._arg[key]
 
@@ -1166,7 +1275,7 @@ def match(array, arguments=None):
             for i in form:
                 f = facs[i]
                 bi = on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None))
-                ai.append(E.arg(f.name, bi, f.ncomp))
+                ai.append(E.arg(f.name, bi, f.ncomp, f.part))
             if len(form) == 2:
                 Bt = numpy.ascontiguousarray(T)
                 if not exposed and ai[0] > ai[1]:  # both bound: canonical order, so that B(u, w) and B(w, u) merge
@@ -1182,7 +1291,7 @@ def match(array, arguments=None):
                 for j, i in enumerate(pv):
                     f = facs[i]
                     bi = on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None))
-                    term['pvars'].append([E.arg(f.name, bi, f.ncomp), int(combo[2 * j]), int(combo[2 * j + 1])])
+                    term['pvars'].append([E.arg(f.name, bi, f.ncomp, f.part), int(combo[2 * j]), int(combo[2 * j + 1])])
             if m.pw:
                 node = m.pw[0]
                 for p in m.pw[1:]:
@@ -1196,7 +1305,7 @@ def match(array, arguments=None):
                         a = E.arg(f.name, on_home(E.scalar_basis(home)), 1)
                         E.plan['args'][a]['scalar'] = True
                     else:
-                        a = E.arg(f.name, on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None)), 1)
+                        a = E.arg(f.name, on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None)), 1, f.part)
                     pargs.append(a)
                 uniq = sorted(set(pargs))
                 term['fpoly'] = dict(args=uniq, powers=numpy.array([[pargs.count(a) for a in uniq]]), coeffs=[1.])

@@ -32,7 +32,7 @@ import af_oracle  # noqa: E402
 
 
 def execute_oracle(plan, arguments):
-    out = af_oracle.evaluate(seam.build(plan).integral, seam.prepare_arguments(plan, arguments))
+    out = seam.run(plan, arguments, lambda integral, args, kind: af_oracle.evaluate(integral, args))
     if plan['kind'] == 'matrix':
         return out
     return float(out) if plan['kind'] == 'scalar' else numpy.asarray(out, dtype=float).reshape(plan['shape'])

@@ -71,5 +71,5 @@ def test_example_plans_on_the_cpu_evaluator(example):
     for name in names:
         plan, args, expect, later = plan_exec.load_example(name)
         for a, e in [(args, expect)] + ([later] if later else []):
-            out = af_oracle.evaluate(seam.build(plan).integral, seam.prepare_arguments(plan, a))
+            out = seam.run(plan, a, lambda integral, args, kind: af_oracle.evaluate(integral, args))
             plan_exec.compare_example(plan, out, e, a)  # (1e-13 of the reference's largest entry + the rounding floor of the terms)

@@ -70,7 +70,7 @@ def main(out, modules):
                 raise
 
         def checked(plan, arguments):
-            res = af_oracle.evaluate(seam.build(plan).integral, seam.prepare_arguments(plan, arguments))
+            res = seam.run(plan, arguments, lambda integral, args, kind: af_oracle.evaluate(integral, args))
             ref = reference(plan, arguments, len(res[1]) - 1 if plan['kind'] == 'matrix' else None)
             if plan['kind'] == 'matrix':
                 assert numpy.array_equal(res[1], ref[1]) and numpy.array_equal(res[2], ref[2]), 'index arrays differ from the reference'
