@@ -1136,7 +1136,7 @@ class Emitter:
     def arg(self, name, bi, ncomp, part=None):
         key = (name, bi, ncomp, part) if name is not None else ('$basis', bi, ncomp)
         if key not in self._arg:
-            self.plan['args'].append(dict(name=name, basis=bi, ncomp=int(ncomp), part=None if part is None else [int(x) for x in part]))
+            self.plan['args'].append(dict(name=name, basis=bi, ncomp=int(ncomp), **({} if part is None else dict(part=[int(x) for x in part]))))
             self._arg[key] = len(self.plan['args']) - 1
         return self._arg[key]
 
