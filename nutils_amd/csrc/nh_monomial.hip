@@ -60,11 +60,14 @@ extern "C" {
 int nh_index_copy(int64_t n, const double *src_dev, const int64_t *src_index_dev, const int64_t *dst_index_dev, double *dst, void *stream) {
   NH_REQUIRE(n >= 0 && src_dev && dst, "nh_index_copy: invalid argument");
   if (!n) return NH_OK;
-  // host destination: the copy is PCIe bound and usually runs beside the next assembly on another stream -- a few waves per CU keep the link busy
+  // host destination: the copy is PCIe bound (64-byte posted writes: ~43 GB/s) and runs beside the next assembly on another stream.  Its stores must not outrun the link: with
+  // 512 workgroups in flight the posted writes fill the write queues of the L2 channels and EVERY kernel beside it waits for them (a one-element fill: 206 us; the
+  // Cahn-Hilliard Newton step 2.29 ms); 64 workgroups keep the link just as busy (1.22 against 1.15 ms) and leave the queues open (step 2.07 ms; 32: 2.12, 128: 2.10,
+  // profiles/r05_c4_c5_traces.md)
   hipPointerAttribute_t attr;
   const bool host = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeHost;
   if (!host) (void)hipGetLastError();
-  static const int hostwgs = getenv("NH_INDEX_COPY_WGS") ? atoi(getenv("NH_INDEX_COPY_WGS")) : 256 * 2;
+  static const int hostwgs = getenv("NH_INDEX_COPY_WGS") ? atoi(getenv("NH_INDEX_COPY_WGS")) : 64;
   const unsigned grid = (unsigned)std::min<i64>((n + 255) / 256, host ? hostwgs : 256 * 32);
   hipLaunchKernelGGL(k_index_copy, dim3(grid), dim3(256), 0, nh_stream(stream), (i64)n, src_dev, (const i64 *)src_index_dev, (const i64 *)dst_index_dev, dst);
   NH_LAUNCH_CHECK();

@@ -332,6 +332,25 @@ def prefetch_arguments(integrals, arguments):
                     _argument_dev(arguments, arg)
 
 
+_SIDE_UPLOADS = None
+
+
+def prefetch_beside(integrals, arguments):
+    '''prefetch_arguments on a stream of its own: the copies run beside the kernels already enqueued on the launch stream (the Jacobian pass of a Newton step) instead of
+    in front of them.  -> join(): makes the launch stream wait for the copies (call it before anything that reads the fields is enqueued).'''
+    global _SIDE_UPLOADS
+    t = device.torch()
+    if _SIDE_UPLOADS is None:
+        _SIDE_UPLOADS = t.cuda.Stream()
+    main = t.cuda.current_stream()
+    before = set(_UPLOADS or ())
+    with t.cuda.stream(_SIDE_UPLOADS):
+        prefetch_arguments(integrals, arguments)
+    for name in set(_UPLOADS or ()) - before:  # (allocated on the side stream, read on the launch stream)
+        _UPLOADS[name][1].record_stream(main)
+    return lambda: main.wait_stream(_SIDE_UPLOADS)
+
+
 def _argument_dev(arguments, arg):
     '''Device copy [ndofs][ncomp] of the array bound to `arg`.'''
     u = _argument(arguments, arg)
@@ -773,7 +792,12 @@ class _MatrixPlan:
                 kernels.monomial(values, [], [], out, out_index=pos)
         return out, m['rowptr'], m['colidx'], ncols
 
-    def run(self, arguments=None):
+    def run(self, arguments=None, into=None):
+        '''-> values, rowptr, colidx, ncols.  `into`: a device array over the plan's own entries that the values are ADDED to (entry-wise: old + sum of the
+        contributions, the same rounding as adding the result afterwards) -- the merged Jacobian's array of field-dependent entries (solver._dyn_values): no array
+        of its own, no pass that adds it.'''
+        if into is not None:
+            return self._run_into(arguments, into)
         if self.parts is not None:
             return self._run_parts(arguments)
         fast = self._p1hex_laplace(arguments)
@@ -783,7 +807,33 @@ class _MatrixPlan:
         nct, ncr = self.test.ncomp, self.trial.ncomp
         mask = None if self.mask.all() else self.mask
         rowptr, colidx = pat.expand(nct, ncr, mask)
+        return self._run_generic(arguments, fast, rowptr, colidx, None)
+
+    def _run_into(self, arguments, into):
+        generic = self.parts is None and not self._fast_candidates()
+        if not generic:  # (paths that write a whole array of their own)
+            values, rowptr, colidx, ncols = self.run(arguments)
+            kernels.monomial(values, [], [], into)
+            return into, rowptr, colidx, ncols
+        rowptr, colidx = self.smp0.pattern(self.test.basis, self.trial.basis).expand(self.test.ncomp, self.trial.ncomp, None if self.mask.all() else self.mask)
+        if into.numel() != colidx.numel():
+            raise ValueError('run(into=...): the array does not match the pattern')
+        return self._run_generic(arguments, None, rowptr, colidx, into)
+
+    def _fast_candidates(self):
+        '''Could a write-once kernel (nh_p1hex_laplace / nh_p2hex_elasticity) take this plan?  Their recognisers need constant forms: a plan with a
+        coefficient function never qualifies.'''
+        return not any(itg.fscale is not None or itg.qform is not None or getattr(itg, 'pvars', ()) for _, itg, _ in self.terms)
+
+    def _run_generic(self, arguments, fast, rowptr, colidx, into):
+        nct, ncr = self.test.ncomp, self.trial.ncomp
+        mask = None if self.mask.all() else self.mask
         first_touch, fresh = None, [False]
+        if into is not None:
+            values, terms = into, self.terms
+            if not os.environ.get('NUTILS_AMD_NO_BATCHED'):
+                terms = self._batched(terms, values, mask, arguments, fresh)
+            return self._run_terms(arguments, terms, self.terms, values, rowptr, colidx, first_touch, fresh)
         if fast is None:
             values = self._p2hex(rowptr, colidx)
             if values is not None:
@@ -800,6 +850,11 @@ class _MatrixPlan:
             fresh = [not first_touch]
         if first_touch is None and not os.environ.get('NUTILS_AMD_NO_BATCHED'):
             terms = self._batched(terms, values, mask, arguments, fresh)
+        return self._run_terms(arguments, terms, self.terms, values, rowptr, colidx, first_touch, fresh)
+
+    def _run_terms(self, arguments, terms, allterms, values, rowptr, colidx, first_touch, fresh):
+        nct, ncr = self.test.ncomp, self.trial.ncomp
+        mask = None if self.mask.all() else self.mask
         for iterm, (smp, itg, fac) in enumerate(terms):
             if itg.measure is None:
                 raise NotImplementedError('integrand without J(geom): reference-space integrals are outside the accelerated path')
@@ -830,7 +885,7 @@ class _MatrixPlan:
                 if fresh[0]:
                     values.zero_()
                     fresh[0] = False
-                ft = first_touch if iterm == 0 and terms is self.terms else None
+                ft = first_touch if iterm == 0 and terms is allterms else None
                 for el in colors:
                     kernels.assemble_matrix(nelems=el.numel(), elist=el, flags=1 | 2, scale=scale, first_touch=ft, **common)
                 common['pattern']._assemblies = getattr(common['pattern'], '_assemblies', 0) + 1  # (a re-assembly may take the gather path: _rows_pass)

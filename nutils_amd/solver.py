@@ -143,7 +143,11 @@ class System:
             if grp['constant']:
                 kernels.monomial(grp.pop('values'), [], [], self._base, out_index=device.to_dev(slot, 'int64'))
             else:
-                grp['dslot'] = device.to_dev(numpy.searchsorted(self._dynpos, slot), 'int64')
+                dslot = numpy.searchsorted(self._dynpos, slot)
+                grp['dslot'] = device.to_dev(dslot, 'int64')
+                # the group's entries ARE the dynamic entries, in the same order (one field-dependent block on one sample, Cahn-Hilliard): it is assembled
+                # straight into the compact array (no array of its own, no pass that adds it)
+                grp['direct'] = len(dslot) == len(self._dynpos) and bool((dslot == numpy.arange(len(dslot))).all())
         self._dyn_base = device.empty(len(self._dynpos), 'float64')
         kernels.index_copy(self._base, self._dyn_base, src_index=self._dynpos_dev)
         self._groups = [grp for grp in groups if not grp['constant']]
@@ -154,7 +158,10 @@ class System:
         from . import kernels
         dyn = self._dyn_base.clone()
         for grp in self._groups:
-            kernels.monomial(grp['plan'].run(arguments)[0], [], [], dyn, out_index=grp['dslot'])
+            if grp['direct']:
+                grp['plan'].run(arguments, into=dyn)
+            else:
+                kernels.monomial(grp['plan'].run(arguments)[0], [], [], dyn, out_index=grp['dslot'])
         return dyn
 
     def _merged_values(self, arguments):
@@ -188,9 +195,10 @@ class System:
             if m is not None:
                 m.drain()
 
-    def _start_jacobian(self, arguments, free):
+    def _start_jacobian(self, arguments, free, enqueued=None):
         '''Launches the device work of a (reduced, if `free` is given) Jacobian and returns finish() -> Matrix.  Between the two calls the
-        changed entries travel to the host on a side stream; `assemble_jacobian_residual` puts the residual of the step there.'''
+        changed entries travel to the host on a side stream; `assemble_jacobian_residual` puts the residual of the step there.
+        `enqueued`: called once the assembly kernels are enqueued, before the copy to the host is.'''
         from . import device, kernels
         if free is None and self._jac is not None and self.is_constant_matrix:
             return lambda copy=False: self._jac
@@ -205,7 +213,10 @@ class System:
                     self._jac = jac
                     return lambda copy=False: jac
                 return lambda copy=False: _matrix.reassemble_csr(numpy.array(first), self._merged_rowptr, self._merged_colidx, self.size) if copy else jac
-            pending = self._mirror.publish(self._dyn_values(arguments))
+            dyn = self._dyn_values(arguments)
+            if enqueued:
+                enqueued()
+            pending = self._mirror.publish(dyn)
             return lambda copy=False: _matrix.reassemble_csr(numpy.array(pending()) if copy else pending(), self._merged_rowptr, self._merged_colidx, self.size)
         key = free.tobytes()
         plan = getattr(self, '_free_plan', None)
@@ -234,7 +245,10 @@ class System:
                 plan['matrix'] = jac
                 return lambda copy=False: jac
             return lambda copy=False: _matrix.reassemble_csr(numpy.array(first), plan['rowptr'], plan['colidx'], plan['n']) if copy else jac
-        pending = plan['mirror'].publish(self._dyn_values(arguments))
+        dyn = self._dyn_values(arguments)
+        if enqueued:
+            enqueued()
+        pending = plan['mirror'].publish(dyn)
         return lambda copy=False: _matrix.reassemble_csr(numpy.array(pending()) if copy else pending(), plan['rowptr'], plan['colidx'], plan['n'])
 
     def assemble_residual(self, arguments):
@@ -268,12 +282,24 @@ class System:
         '''Jacobian (reduced to the free dofs if `free` is given) and residual of one Newton step, as the reference evaluates them: in one go
         (solver.py:358-387; its Newton drivers call nothing else, :633,659,751-760).  `copy`: see assemble_jacobian (`solve` passes False).'''
         with _sample.upload_scope():  # (every field is copied to the device once, before the Jacobian entries start to travel the other way)
-            _sample.prefetch_arguments(self.block_residual, arguments)
+            # (the fields the Jacobian kernels read go first; the others follow on a stream of their own while those kernels run -- all of them before the copy starts)
+            groups = getattr(self, '_groups', None)
+            join = []
+            if groups:
+                _sample.prefetch_arguments([grp['plan'] for grp in groups], arguments)
+                late = lambda: join.append(_sample.prefetch_beside(self.block_residual, arguments))
+            else:
+                _sample.prefetch_arguments(self.block_residual, arguments)
+                late = None
             # Jacobian kernels, then -- while the changed entries are written to the host by a side stream -- the residual.  (Measured alternatives,
             # profiles/r02_c4.md: the residual on a third stream beside the Jacobian kernels gains nothing, both fill the register files; kernels
             # next to the host-bound stores run at half speed, the stores back up the write queues of the L2 channels -- still the best order.)
-            finish = self._start_jacobian(arguments, free)
+            finish = self._start_jacobian(arguments, free, late)
             try:
+                if late and not join:  # (a path of _start_jacobian that enqueues nothing)
+                    late()
+                for wait in join:
+                    wait()
                 res = self.assemble_residual(arguments)
             except BaseException:
                 self._drain()
@@ -291,9 +317,21 @@ class System:
         if not self.is_symmetric:
             raise Exception('value is not defined')
         with _sample.upload_scope():
-            _sample.prefetch_arguments(self.block_residual, arguments)
-            finish = self._start_jacobian(arguments, free)
+            # (the fields the Jacobian kernels read go first; the others follow on a stream of their own while those kernels run -- all of them before the copy starts)
+            groups = getattr(self, '_groups', None)
+            join = []
+            if groups:
+                _sample.prefetch_arguments([grp['plan'] for grp in groups], arguments)
+                late = lambda: join.append(_sample.prefetch_beside(self.block_residual, arguments))
+            else:
+                _sample.prefetch_arguments(self.block_residual, arguments)
+                late = None
+            finish = self._start_jacobian(arguments, free, late)
             try:
+                if late and not join:  # (a path of _start_jacobian that enqueues nothing)
+                    late()
+                for wait in join:
+                    wait()
                 res = self.assemble_residual(arguments)
                 val = function.eval(self.value, arguments)
             except BaseException:

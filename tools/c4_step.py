@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 '''C4 Newton steps only (timeline runs); C4 probe (BASELINE.json configs[3]): Cahn-Hilliard 512^2, p=2, nonlinear residual + Jacobian re-assembly per Newton step.'''
-import sys, time
+import os, sys, time
 sys.path.insert(0, '.')
 import numpy, torch
 from nutils_amd import mesh, function, device
@@ -36,13 +36,14 @@ for it in range(3):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f'n={n} {btype} p=2 nelems={n*n} ndofs/field={nd} nnz={jac.core.nnz}: residual {1e3*(t1-t0):.1f} ms, jacobian (4 blocks, D2H + host block merge) {1e3*(t2-t1):.1f} ms')
 steps, res_ms, jac_ms = [], 1e3 * (t1 - t0), 1e3 * (t2 - t1)
-for it in range(3):  # the Newton step as the reference evaluates it (solver.py:358-387): Jacobian and residual in one call
+for it in range(int(os.environ.get('C4_STEPS', 3))):  # the Newton step as the reference evaluates it (solver.py:358-387): Jacobian and residual in one call
     args['φ'] = rng.normal(0, .5, nd)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     jac, res = system.assemble_jacobian_residual(args, copy=False)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     steps.append(1e3 * (t1 - t0))
     print(f'  assemble_jacobian_residual (residual beside the PCIe copy of the changed Jacobian entries): {1e3*(t1-t0):.1f} ms')
+print(f'STEPS min {min(steps):.3f} median {sorted(steps)[len(steps)//2]:.3f} ms')
 import json
 print('RESULT ' + json.dumps({'workload': f'Cahn-Hilliard {n}^2, p = 2 {btype} basis, 25 Gauss points, two fields (BASELINE.json configs[3]): one Newton step = residual (2 blocks) + Jacobian (4 blocks, '
                                           'merged CSR in host memory) in one call', 'value': n * n / min(steps) * 1e3, 'unit': 'elements/s', 'ms_per_step': min(steps), 'steps': len(steps),
