@@ -48,6 +48,30 @@ def index(powers, total):
 
 
 @functools.lru_cache(maxsize=None)
+def _raise_targets(nvars, old, new):
+    '''Position in a polynomial of degree `new` of every monomial of a polynomial of degree `old` <= `new`, in layout order.'''
+    tgt = numpy.empty(ncoeffs(nvars, old), dtype=int)
+    for powers in numpy.ndindex(*[old + 1] * nvars):
+        if sum(powers) <= old:
+            tgt[index(powers, old)] = index(powers, new)
+    return tgt
+
+
+def change_degree(coeffs, nvars, new):
+    '''The same polynomials (last axis: coefficients) written at the higher degree `new`: the coefficients move to the positions of their monomials,
+    the new ones are zero (what nutils_poly.change_degree does for the reference, evaluable.py:4470-4478).'''
+    coeffs = numpy.asarray(coeffs, dtype=float)
+    old = degree(nvars, coeffs.shape[-1])
+    if old == new:
+        return coeffs
+    if old > new:
+        raise ValueError('change_degree: cannot lower the degree')
+    out = numpy.zeros(coeffs.shape[:-1] + (ncoeffs(nvars, new),))
+    out[..., _raise_targets(nvars, old, new)] = coeffs
+    return out
+
+
+@functools.lru_cache(maxsize=None)
 def _outer_targets(degrees):
     '''For 1-D polynomials of the given degrees in separate variables: flat index of
     x0^(p0-a0) ... x_{n-1}^(p_{n-1}-a_{n-1}) in the product polynomial, for every

@@ -1287,6 +1287,8 @@ class _SubsetView:
             kw['qform'] = (itg.qform[0], self.arg(itg.qform[1])) + tuple(itg.qform[2:])
         if itg.qscalar is not None:
             kw['qscalar'] = (itg.qscalar[0], self.arg(itg.qscalar[1]), self.arg(itg.qscalar[2]))
+        if itg.pvars:
+            kw['pvars'] = tuple((self.arg(a), comp, slot) for a, comp, slot in itg.pvars)
         return itg._copy(**kw)
 
 
@@ -1297,6 +1299,7 @@ def _restrict_ragged_subsets(terms):
         args = [a for a in (itg.test, itg.trial) if a is not None] + (list(itg.fscale.args) if itg.fscale is not None else [])
         args += [itg.qform[1]] if itg.qform is not None else []
         args += [itg.qscalar[1], itg.qscalar[2]] if itg.qscalar is not None else []
+        args += [a for a, _, _ in itg.pvars]
         bases = [a.basis for a in args] + [g.basis for g in (itg.geom, itg.measure) if isinstance(g, function.IsoGeometry)]
         # also: a geometry tabulated per LIST position (a side of a NURBS patch) -- spreading it to element rows (Sample._per_element) costs the memory of
         # the whole topology for the sake of a side

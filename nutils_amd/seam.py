@@ -969,8 +969,13 @@ class Emitter:
                 ne = len(tr)
                 dofs = [numpy.asarray(basis.get_dofs(e), dtype=numpy.int64) for e in range(ne)]
                 coeffs = [numpy.asarray(basis.get_coefficients(e), dtype=float) for e in range(ne)]
-                if len({c.shape[1:] for c in coeffs}) != 1:
-                    raise Unmatched('basis with mixed polynomial degrees')
+                if len({c.shape[1:] for c in coeffs}) != 1:  # (triangles beside squares: every element's polynomials written at the highest degree that occurs)
+                    from . import poly as _poly
+                    if any(c.ndim != 2 for c in coeffs):
+                        raise Unmatched('basis with mixed polynomial degrees')
+                    nv = int(tr.fromdims)
+                    top = max(_poly.degree(nv, c.shape[1]) for c in coeffs)
+                    coeffs = [_poly.change_degree(c, nv, top) for c in coeffs]
                 spec = dict(kind='plain', topo=self.topo(tr), dofs=numpy.concatenate(dofs), coeffs=numpy.concatenate(coeffs, axis=0),
                             offsets=numpy.cumsum([0] + [len(d) for d in dofs]).astype(numpy.int64), ndofs=len(basis))
         if spec['kind'] == 'structured' and spec in self.plan['bases']:  # another reference object of the same structured basis (`gbasis` / `ns.basis`)
@@ -1032,30 +1037,41 @@ class Emitter:
                                 and tr.fromdims == tr.todims and [int(ax.j - ax.i) for ax in tr._axes] == self.plan['topos'][ti]['shape']
                                 and all(ax.i == 0 for ax in tr._axes)):
             p0 = pts[0]
-            if _kind(pts) != '_Uniform' and any(pts[i] != p0 for i in range(1, len(pts))):
-                raise Unmatched('elements with different quadrature tables')
-            spec = dict(topo=ti, points=numpy.asarray(p0.coords, dtype=float), weights=self.weights(p0), elist=None, bnd_axis=-1, _nl=len(tr), _ne=len(transforms))
+            if _kind(pts) == '_Uniform' or all(pts[i] == p0 for i in range(1, len(pts))):  # (else: groups of elements with the same table, below)
+                spec = dict(topo=ti, points=numpy.asarray(p0.coords, dtype=float), weights=self.weights(p0), elist=None, bnd_axis=-1, _nl=len(tr), _ne=len(transforms))
         if spec is None:
             # generic: every element of the sample located in `transforms`; groups of elements that see the same points in parent coordinates
             groups = {}
+            face = tr.fromdims < tr.todims
+            corners = numpy.vstack([numpy.zeros((1, tr.fromdims)), numpy.eye(tr.fromdims)])
             for i in range(len(tr)):
                 ie, tail = transforms.index_with_tail(tr[i])
                 p = pts[i]
                 c = rtransform.apply(tail, numpy.asarray(p.coords, dtype=float))
-                k = (c.round(12).tobytes(), numpy.asarray(self.weights(p)).round(14).tobytes())
-                groups.setdefault(k, dict(ielems=[], pos=[], coords=c, weights=self.weights(p)))
+                nu = b''
+                if face:  # reference normal of the face scaled by its measure (the generalised cross product of the face's edge vectors in the parent element), up to sign
+                    v = rtransform.apply(tail, corners)
+                    nu = _ext_normal((v[1:] - v[0]).T)
+                    nu = (nu * (1 if nu[numpy.flatnonzero(numpy.abs(nu) > 1e-12)[0]] > 0 else -1)).round(12)
+                k = (c.round(12).tobytes(), numpy.asarray(self.weights(p)).round(14).tobytes(), nu if not face else nu.tobytes())
+                groups.setdefault(k, dict(ielems=[], pos=[], coords=c, weights=self.weights(p), nu=nu))
                 groups[k]['ielems'].append(ie)
                 groups[k]['pos'].append(i)
             specs = []
             for g in groups.values():
-                axis = -1
-                if tr.fromdims < tr.todims:
+                axis, oblique = -1, {}
+                if face:
                     const = [a for a in range(g['coords'].shape[1]) if numpy.ptp(g['coords'][:, a]) == 0 and g['coords'][0, a] in (0., 1.)]
-                    if len(const) != 1:
+                    if len(const) == 1:
+                        axis = const[0]
+                    elif tr.fromdims != tr.todims - 1:
                         raise Unmatched('cannot identify the face axis')
-                    axis = const[0]
+                    else:
+                        # a face that is no coordinate plane of its parent (the hypotenuse of a triangle): dS = w |det J| |J^-T nu| -- the kernels take the volume
+                        # measure and the terms of this sample carry |J^-T nu| as a pointwise factor (match: `_bnd_normal`)
+                        oblique = dict(_bnd_normal=g['nu'])
                 specs.append(dict(topo=ti, points=g['coords'], weights=g['weights'], elist=numpy.array(g['ielems'], dtype=numpy.int64), bnd_axis=axis,
-                                  _nl=len(g['ielems']), _ne=len(transforms), _pos=numpy.array(g['pos'], dtype=numpy.int64)))
+                                  _nl=len(g['ielems']), _ne=len(transforms), _pos=numpy.array(g['pos'], dtype=numpy.int64), **oblique))
             idx = []
             for s in specs:
                 self.plan['samples'].append(s)
@@ -1139,6 +1155,16 @@ class Emitter:
             self.plan['args'].append(dict(name=name, basis=bi, ncomp=int(ncomp), **({} if part is None else dict(part=[int(x) for x in part]))))
             self._arg[key] = len(self.plan['args']) - 1
         return self._arg[key]
+
+
+def _ext_normal(T):
+    '''T: (n, n - 1) edge vectors of a face as columns -> the vector orthogonal to them whose length is the measure they span (2-D: the edge turned by 90 degrees, 3-D: the cross product)'''
+    n = T.shape[0]
+    if T.shape != (n, n - 1):
+        raise Unmatched('cannot identify the face axis')
+    if n == 1:
+        return numpy.ones(1)
+    return numpy.array([(-1) ** i * numpy.linalg.det(numpy.delete(T, i, axis=0)) for i in range(n)])
 
 
 def _point_values(smp, node, s, tail=()):
@@ -1297,6 +1323,14 @@ def match(array, arguments=None):
                 for p in m.pw[1:]:
                     node = node * p
                 term['scale'] = _point_values(smp, node, s)
+            if s.get('_bnd_normal') is not None:  # (oblique face: see Emitter.sample)
+                if E.plan['geoms'][gi]['kind'] != 'tab':
+                    term['measure'] = gi = E.geom_tab(gnode, smp, si, home)
+                    if gg >= 0 and g is gnode:
+                        term['geom'] = gi
+                J = E.plan['geoms'][gi]['jac']
+                r = numpy.linalg.norm(numpy.linalg.solve(numpy.swapaxes(J, -1, -2), numpy.broadcast_to(s['_bnd_normal'], J.shape[:-1])[..., None])[..., 0], axis=-1)
+                term['scale'] = r if term['scale'] is None else term['scale'] * r
             if poly:
                 pargs = []
                 for i in poly:

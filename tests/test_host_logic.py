@@ -40,6 +40,25 @@ def test_poly_layout():
     assert numpy.array_equal(t[3], [0, 1, 0, 0, 0, 0]) and numpy.array_equal(t[0], [0, 1, -1, 0, -1, 1])
 
 
+def test_poly_change_degree_keeps_the_polynomial():
+    '''poly.change_degree (bases of triangles beside squares written at one degree, seam.Emitter.basis) against the oracle's restatement of nutils_poly.change_degree
+    (pinned by the reference's own poly tests) and by evaluation at random points'''
+    from oracle import poly as opoly
+    from nutils_amd import poly
+    rng = numpy.random.default_rng(3)
+    for nv in (1, 2, 3):
+        x = rng.uniform(size=(5, nv))
+        for old in range(4):
+            c = rng.normal(size=(3, poly.ncoeffs(nv, old)))
+            for new in range(old, 5):
+                up = poly.change_degree(c, nv, new)
+                assert numpy.array_equal(up, opoly.change_degree(c, nv, new))
+                for k in range(3):
+                    assert numpy.allclose(opoly.eval_outer(up[k], x), opoly.eval_outer(c[k], x), rtol=1e-14, atol=1e-14)
+    with pytest.raises(ValueError):
+        poly.change_degree(numpy.ones(6), 2, 1)
+
+
 def test_form_algebra():
     from nutils_amd import mesh, function
     domain, geom = mesh.rectilinear([2, 2, 2])
