@@ -575,6 +575,24 @@ def main():
                         v4['cpu_baseline'] = cb3
                         v4['speedup_vs_cpu_port'] = v4['value'] / cb3['value']
                 out['variants']['c3'] = v4
+                # the same matrix on UNIFORM cells (mesh.rectilinear with equidistant vertices, what examples/elasticity.py builds): all element matrices equal, the rows of
+                # the 2 x 2 x 2 mesh replicated by node class -- a write stream (nh_p2hex_rows_uniform)
+                w6 = workloads.ElasticityP2(n=64, rank=0, world=1, variant='uniform')
+                w6.setup()
+                w6.build_pattern()
+                el6, kms6, l6, _ = settle_and_time(w6, 10, 3, 10, 1, None, a.graph)
+                c6 = w6.check(1, None)
+                b6 = w6.algorithmic_bytes_per_element()
+                v6 = {'value': w6.nelems * 10 / el6, 'unit': 'elements/s', 'steps': 10, 'ms_per_step': el6 / 10 * 1e3, 'kernel': w6.kernel_name, 'launch': l6,
+                      'workload': '3D linear elasticity stiffness, 64^3 structured hex, p=2 vector basis, 3x3x3 Gauss, uniform cells (BASELINE.json configs[2] on the geometry of examples/elasticity.py)',
+                      'roofline': {'bound': 'hbm', 'achieved': b6 * w6.nelems / (kms6 * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': b6 * w6.nelems / (kms6 * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': measured_traffic(w6.kernel_name, 64), 'kernel': w6.kernel_name,
+                                   'kernel_ms': kms6, 'algorithmic_bytes_per_element': b6}, 'checks': c6}
+                if not all(x < 1e-10 for x in c6.values()):
+                    v6['error'] = 'correctness gate failed'
+                del w6
+                torch.cuda.empty_cache()
+                out['variants']['c3_uniform'] = v6
                 # BASELINE.json configs[3] and the configs[4] class: the probes of tools/ in their own processes (their parity checks run there); a failure drops the entry
                 for key, cmd in (('c4', [sys.executable, 'tools/c4_step.py', '512']), ('c5', [sys.executable, 'tools/ragged_probe.py', '256', '10']),
                                  ('vector_any_mesh', [sys.executable, 'tools/vector_probe.py', '96', '10'])):

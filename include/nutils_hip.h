@@ -483,6 +483,12 @@ typedef struct {
 
 int nh_p2hex_matrix(const nh_p2hex_args *args, void *stream);
 int nh_p2hex_rowptr(const int *shape, int64_t node, int64_t *rowptr_out);
+/* Meshes of UNIFORM cells (mesh.rectilinear with equidistant vertices: x = offset + scale * (multi-index + xi), mesh.py:45-52) with a constant form and no pointwise
+ * factor: all element matrices are equal (the reference evaluates the same numbers for every element), so the rows of a node depend only on its class per axis (first,
+ * odd, even, last) and equal the rows of the node of that class in a mesh of 2 x 2 x 2 such cells.  cell_values_dev: the values of nh_p2hex_matrix for shape {2, 2, 2}
+ * on those cells (nh_p2hex_rowptr({2,2,2}, 125) * ncomp^2 doubles); this call replicates them into values_dev for the node planes [plane_begin, plane_end) of axis 0
+ * (all of them: 0 .. 2 shape[0] + 1): a pure write stream.  Same layout and result as nh_p2hex_matrix on the box geometry of the same cells. */
+int nh_p2hex_rows_uniform(const int *shape, int ncomp, const double *cell_values_dev, double *values_dev, int plane_begin, int plane_end, void *stream);
 /* closed-form CSR index arrays of the component-expanded pattern (all ncomp x ncomp blocks): rowptr_dev int64[nnodes*ncomp+1],
  * colidx_dev int64[nh_p2hex_rowptr(shape, nnodes) * ncomp^2]; equal to nh_pattern_build + nh_pattern_expand for this basis */
 int nh_p2hex_pattern(const int *shape, int ncomp, int64_t *rowptr_dev, int64_t *colidx_dev, void *stream);

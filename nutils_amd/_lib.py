@@ -165,6 +165,7 @@ SIGNATURES = {
     'nh_p2hex_matrix': (ctypes.c_int, [ctypes.POINTER(P2HexArgs), vp]),
     'nh_p2hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, vp, vp, vp]),
     'nh_p2hex_rowptr': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64p]),
+    'nh_p2hex_rows_uniform': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     'nh_p1hex_unit_matrix': (ctypes.c_int, [ctypes.POINTER(P1HexArgs), vp, vp]),
 }
 

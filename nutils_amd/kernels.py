@@ -540,6 +540,34 @@ class P2HexMatrix:
         _lib.check(self._fn(self._ref, device.stream()))
 
 
+class P2HexUniform:
+    '''The same matrix on a mesh of UNIFORM cells (`cell`: the three edge lengths; constant form, no pointwise factor): the mesh of 2 x 2 x 2 such cells is assembled once by
+    nh_p2hex_matrix, a (re-)assembly replicates its rows (nh_p2hex_rows_uniform: one write stream).  `owners` as for P2HexMatrix (slabs: owner io holds the node planes
+    2 io and 2 io + 1).'''
+
+    def __init__(self, *, shape, nq, weights, T, ncomp, C, cell, owners=None):
+        idx = numpy.stack(numpy.meshgrid(*[numpy.arange(2.)] * 3, indexing='ij'), -1).reshape(-1, 3)
+        cell = numpy.asarray(cell, dtype=float).reshape(3)
+        small = (2, 2, 2)
+        rp = ctypes.c_int64()
+        _lib.call('nh_p2hex_rowptr', (ctypes.c_int * 3)(*small), 125, ctypes.byref(rp))
+        self.table = device.empty(rp.value * ncomp * ncomp, 'float64')
+        geom = geometry_box(device.to_dev(idx * cell, 'float64'), device.to_dev(numpy.broadcast_to(cell, idx.shape), 'float64'))
+        P2HexMatrix(shape=small, nq=nq, weights=weights, geom=geom, T=T, ncomp=ncomp, C=C)(self.table)
+        n0 = int(shape[0])
+        ob, oe = (0, n0) if owners is None else owners
+        self._shape = (ctypes.c_int * 3)(*[int(n) for n in shape])
+        self._planes = 2 * int(ob), min(2 * int(oe) + 2, 2 * n0 + 1)
+        self._nc = int(ncomp)
+        self._name = 'nh_p2hex_rows_uniform'
+        self._fn = getattr(_lib.load(), self._name)
+
+    def __call__(self, values):
+        if _lib.TRACE is not None:
+            _lib.TRACE.append(self._name)
+        _lib.check(self._fn(self._shape, self._nc, self.table.data_ptr(), values.data_ptr(), self._planes[0], self._planes[1], device.stream()))
+
+
 def p2hex_matrix(*, values, **kwargs):
     P2HexMatrix(**kwargs)(values)
 

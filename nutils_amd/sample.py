@@ -627,8 +627,12 @@ class _MatrixPlan:
         fn = by_form.get(key)
         if fn is None:
             try:
-                fn = kernels.P2HexMatrix(shape=basis.shape, nq=smp.points.npoints, weights=smp._weights_dev, geom=smp.geometry(geom), T=smp.tables(basis).T,
-                                         ncomp=nc, C=C)
+                if isinstance(geom, function.RectilinearGeometry) and geom.topo.shape == basis.shape and not os.environ.get('NUTILS_AMD_NO_UNIFORM'):
+                    # equidistant vertices: every element matrix is the same -- the rows of the 2 x 2 x 2 mesh of such cells, replicated (a write stream)
+                    fn = kernels.P2HexUniform(shape=basis.shape, nq=smp.points.npoints, weights=smp._weights_dev, T=smp.tables(basis).T, ncomp=nc, C=C, cell=geom.scale)
+                else:
+                    fn = kernels.P2HexMatrix(shape=basis.shape, nq=smp.points.npoints, weights=smp._weights_dev, geom=smp.geometry(geom), T=smp.tables(basis).T,
+                                             ncomp=nc, C=C)
                 probe = device.empty(colidx.numel(), 'float64')
                 fn(probe)  # NH_ELIMIT (tables do not fit the LDS for this quadrature) surfaces here
             except _lib_error() as e:

@@ -230,7 +230,7 @@ class ElasticityP2:
         self.n, self.rank, self.world, self.variant, self.seed = int(n), int(rank), int(world), variant, seed
         self.layers = int(layers) if layers else self.n
         self.C = self.form_tensor(lam, mu)
-        self.kernel_name = 'k_p2hex_inreg<3,1,1>'
+        self.kernel_name = 'k_p2hex_inreg<3,1,1>' if variant == 'iso' else 'k_p2hex_rows_uniform'  # ('uniform': unit cells, every element matrix the same)
         self.slab = partition.Slab(self.layers, self.rank, self.world, shape_jk=(self.n, self.n), degree=2, ncomp=3, halo=halo)
 
     @staticmethod
@@ -268,8 +268,13 @@ class ElasticityP2:
         self.rowptr, self.colidx = kernels.p2hex_pattern(self.shape, 3)
         self.nnz = int(self.colidx.numel())
         self.values = device.zeros(self.nnz, 'float64')  # write-once kernel: no zero-fill per step (rows of a ghost plane are never written)
-        self._launch = kernels.P2HexMatrix(shape=self.shape, nq=self.smp.points.npoints, weights=self.smp._weights_dev, geom=self.kgeom, T=self.tables.T, ncomp=3,
-                                           C=self.C, layers=s.value_layers, owners=(s.written_planes[0] // 2, (s.written_planes[1] - 1) // 2))
+        owners = s.written_planes[0] // 2, (s.written_planes[1] - 1) // 2
+        if self.variant == 'uniform':
+            self._launch = kernels.P2HexUniform(shape=self.shape, nq=self.smp.points.npoints, weights=self.smp._weights_dev, T=self.tables.T, ncomp=3, C=self.C,
+                                                cell=(1., 1., 1.), owners=owners)
+        else:
+            self._launch = kernels.P2HexMatrix(shape=self.shape, nq=self.smp.points.npoints, weights=self.smp._weights_dev, geom=self.kgeom, T=self.tables.T, ncomp=3,
+                                               C=self.C, layers=s.value_layers, owners=owners)
         self.halo = partition.HaloPlan(s, self.rowptr) if self.world > 1 and s.halo == 'reduce' else None
 
     def step(self, kernel_events=None, exchange=True):
@@ -289,7 +294,7 @@ class ElasticityP2:
     def algorithmic_bytes_per_element(self):
         '''unique vertex coordinates + CSR values written once (structured connectivity is generated in-kernel).'''
         n = self.n
-        return (n + 1) ** 3 / n ** 3 * 24 + (8 * n + 1) ** 3 * 9 / n ** 3 * 8
+        return (0 if self.variant == 'uniform' else (n + 1) ** 3 / n ** 3 * 24) + (8 * n + 1) ** 3 * 9 / n ** 3 * 8
 
     def algorithmic_flops_per_element(self):
         '''Gram-matrix formulation: G = D^T W D over (27 nodes x 3 gradient slots)^2 x 27 points, multiply-add = 2 flops; the form

@@ -205,3 +205,81 @@ def test_value_slot_window_vs_oracle(nc):
     C = numpy.zeros((nc, 4, nc, 4))
     C[:, :3, :, :3] = rng.normal(size=(nc, 3, nc, 3))
     _check(Dev(inp).fast(C, nc), _oracle(inp, C))
+
+
+def _uniform_inputs(shape, cell):
+    inp = _inputs(shape, False)
+    inp['verts'] = inp['verts'] * numpy.asarray(cell, dtype=float)
+    return inp
+
+
+@pytest.mark.parametrize('shape,cell,nc', [((1, 1, 1), (1., 1., 1.), 3), ((1, 2, 3), (.5, 1., 2.), 3), ((2, 2, 2), (1., .25, .75), 3), ((3, 4, 5), (.3, .2, .7), 3),
+                                           ((6, 5, 7), (1., 1., 1.), 3), ((4, 3, 2), (2., 1., .5), 2), ((3, 3, 3), (1., 2., 3.), 1)])
+def test_uniform_cells_vs_oracle(shape, cell, nc):
+    '''nh_p2hex_rows_uniform (equidistant vertices: the rows of the 2 x 2 x 2 mesh of the same cells, replicated by node class) against the oracle's element loop over
+    EVERY element: index arrays bit-exact, every value written, values 1e-13; meshes with one element along an axis (no even interior node) included.'''
+    from oracle import assemble as oa
+    from nutils_amd import device, kernels, _lib
+    inp = _uniform_inputs(shape, cell)
+    rng = numpy.random.default_rng(5)
+    C = oa.elasticity_coefficient(3, 1., .5 / .3 - 1) if nc == 3 else rng.normal(size=(nc, 4, nc, 4))
+    d = Dev(inp)
+    rowptr, colidx = d.pattern.expand(nc, nc, None)
+    values = device.to_dev(numpy.full(colidx.numel(), numpy.nan), 'float64')
+    with _lib.trace() as calls:
+        kernels.P2HexUniform(shape=shape, nq=d.nq, weights=d.w, T=d.T, ncomp=nc, C=C, cell=cell)(values)
+    assert calls.count('nh_p2hex_rows_uniform') == 1
+    _check((device.to_host(values), device.to_host(rowptr), device.to_host(colidx)), _oracle(inp, C))
+
+
+def test_uniform_cells_slabs():
+    '''owner ranges (multi-GPU slabs): the node planes of the owners are written, nothing else'''
+    from oracle import assemble as oa
+    from nutils_amd import device, kernels
+    shape, cell = (5, 3, 4), (1., .5, 2.)
+    inp = _uniform_inputs(shape, cell)
+    C = oa.elasticity_coefficient(3, 1., .5)
+    d = Dev(inp)
+    vo, rpo, cio = _oracle(inp, C)
+    rowptr, colidx = d.pattern.expand(3, 3, None)
+    rp = device.to_host(rowptr)
+    nplane = 7 * 9 * 3
+    parts = []
+    for owners in ((0, 1), (2, 5)):
+        values = device.to_dev(numpy.full(colidx.numel(), numpy.nan), 'float64')
+        kernels.P2HexUniform(shape=shape, nq=d.nq, weights=d.w, T=d.T, ncomp=3, C=C, cell=cell, owners=owners)(values)
+        parts.append(device.to_host(values))
+    r = rp[4 * nplane]
+    assert not numpy.isnan(parts[0][:r]).any() and numpy.isnan(parts[0][r:]).all()
+    assert not numpy.isnan(parts[1][r:]).any() and numpy.isnan(parts[1][:r]).all()
+    full = numpy.concatenate([parts[0][:r], parts[1][r:]])
+    assert numpy.abs(full - vo).max() < RTOL * numpy.abs(vo).max()
+
+
+def test_uniform_mesh_through_the_api(monkeypatch):
+    '''mesh.rectilinear with equidistant vertices: the front end takes nh_p2hex_rows_uniform; the same call with NUTILS_AMD_NO_UNIFORM goes through nh_p2hex_matrix on
+    the box geometry, NUTILS_AMD_NO_FAST_PATH through the generic kernels -- all three agree (index arrays exactly).'''
+    from nutils_amd import mesh, function, _lib
+
+    def run():
+        domain, geom = mesh.rectilinear([numpy.linspace(0, 1, 5), numpy.linspace(0, 2, 4), numpy.linspace(-1, 1, 6)])
+        u = domain.field('u', btype='std', degree=2, shape=[3])
+        v = domain.field('v', btype='std', degree=2, shape=[3])
+        eps = lambda w: function.symgrad(w, geom)
+        sigma = 1. * function.div(u, geom) * function.eye(3) + 2 * .6 * eps(u)
+        res = domain.integral(function.inner(eps(v), sigma) * function.J(geom), degree=4)
+        with _lib.trace() as calls:
+            out = function.eval(function.as_csr(function.derivative(function.derivative(res, 'v'), 'u')))
+        return out, calls
+
+    uni, calls = run()
+    assert 'nh_p2hex_rows_uniform' in calls
+    monkeypatch.setenv('NUTILS_AMD_NO_UNIFORM', '1')
+    box, calls = run()
+    assert 'nh_p2hex_rows_uniform' not in calls and 'nh_p2hex_matrix' in calls
+    monkeypatch.setenv('NUTILS_AMD_NO_FAST_PATH', '1')
+    gen, calls = run()
+    assert 'nh_p2hex_matrix' not in calls
+    for other in (box, gen):
+        assert numpy.array_equal(uni[1], other[1]) and numpy.array_equal(uni[2], other[2])
+        assert numpy.abs(uni[0] - other[0]).max() < RTOL * numpy.abs(other[0]).max()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-'''Kernel-level timing of BASELINE.json configs[2] (64^3 P2 vector elasticity): python tools/c3_bench.py [n] [steps]'''
+'''Kernel-level timing of BASELINE.json configs[2] (64^3 P2 vector elasticity): python tools/c3_bench.py [n] [steps] [iso|uniform]'''
 import sys
 sys.path.insert(0, '.')
 import torch
@@ -7,7 +7,7 @@ from nutils_amd import workloads
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-wl = workloads.ElasticityP2(n=n)
+wl = workloads.ElasticityP2(n=n, variant=sys.argv[3] if len(sys.argv) > 3 else 'iso')
 wl.setup()
 wl.build_pattern()
 for _ in range(3):
