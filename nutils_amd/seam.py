@@ -630,6 +630,30 @@ class Matcher:
         A = numpy.broadcast_to(numpy.expand_dims(m.A, nf), m.A.shape[:nf] + (length,) + m.A.shape[nf:])
         return _Mono(A, m.axes + [('free', nf)], m.factors, m.pw, m.measure)
 
+    def constants_to_pointwise(self, m):
+        '''A factor bound to a CONSTANT coefficient array that is not the geometry (`weightfunc = nurbsbasis @ weights` inside an integrand, examples/platewithhole.py:83) is a
+        function of the point: one monomial per non-zero (component, slot) of the factor, the reference's own value / gradient node of the field as its pointwise factor.'''
+        i = next((i for i, f in enumerate(m.factors) if f.cvals is not None), None)
+        if i is None:
+            return [m]
+        f = m.factors[i]
+        if f.rational is not None or any(k in ('dof', 'cdof') and j == i for k, j in m.axes):
+            raise Unmatched('field with constant coefficients inside an integrand (other than the geometry)')
+        nf = m.nfree
+        val = f.basis @ f.cvals  # [ncomp]
+        grad = self.rf.grad(val, f.geom) if f.geom is not None else None
+        out = []
+        for c in range(f.ncomp):
+            for sl in range(self.S):
+                A = m.A[(slice(None),) * (nf + 2 * i) + (c, sl)]
+                if not numpy.abs(A).sum():
+                    continue
+                if sl and grad is None:
+                    raise Unmatched('gradient slot of a constant field without a geometry')
+                axes = [(k, j - 1 if k in ('dof', 'cdof') and j > i else j) for k, j in m.axes]
+                out.extend(self.constants_to_pointwise(_Mono(A, axes, m.factors[:i] + m.factors[i + 1:], m.pw + [val[c] if sl == 0 else grad[c, sl - 1]], m.measure)))
+        return out
+
     def sum_last(self, m):
         kind, j = m.axes[-1]
         if kind == 'cdof':  # basis @ constant: the factor is now bound to its coefficient array
@@ -1149,6 +1173,17 @@ class Emitter:
         self._geom[key] = len(self.plan['geoms']) - 1
         return self._geom[key]
 
+    def geom_unit(self, si):
+        '''the identity map of every element of sample si: x = the local coordinates of the points, dx/dxi = 1 (reference-space integrals)'''
+        key = ('unit', si)
+        if key not in self._geom:
+            s = self.plan['samples'][si]
+            pts = numpy.asarray(s['points'], dtype=float)
+            nl, (nq, nd) = s['_nl'], pts.shape
+            self.plan['geoms'].append(dict(kind='tab', sample=si, x=numpy.broadcast_to(pts, (nl, nq, nd)).copy(), jac=numpy.broadcast_to(numpy.eye(nd), (nl, nq, nd, nd)).copy()))
+            self._geom[key] = len(self.plan['geoms']) - 1
+        return self._geom[key]
+
     def arg(self, name, bi, ncomp, part=None):
         key = (name, bi, ncomp, part) if name is not None else ('$basis', bi, ncomp)
         if key not in self._arg:
@@ -1188,9 +1223,8 @@ def match(array, arguments=None):
     nexposed = None
     # terms without any basis (constants, coefficient functions: `sigma_wall dS`) are located in the topology of the bases seen elsewhere
     anybasis = next((f.basis for _, m, _ in terms for f in m.factors if f.basis is not _SCALAR), None)
+    terms = [(smp, m2, fac) for smp, m, fac in terms for m2 in M.constants_to_pointwise(m)]
     for smp, m, fac in terms:
-        if m.measure is None:
-            raise Unmatched('term without J(geom)')
         if any(k == 'cdof' for k, _ in m.axes):
             raise Unmatched('basis weighted per dof outside a rational form')
         # constant-bound factors that are not the geometry: pointwise functions
@@ -1280,8 +1314,12 @@ def match(array, arguments=None):
         sis = E.sample(smp, home)
         for si, (combo, T) in [(si, ct) for si in (sis if isinstance(sis, list) else [sis]) for ct in combos]:
             s = E.plan['samples'][si]
-            gnode, tip = m.measure
-            gi = _geom_index(E, gnode, smp, si, home)
+            if m.measure is None:
+                # an integral over the REFERENCE elements (no J(geom): the weight-function projection of examples/platewithhole.py:83): the measure of the identity map
+                gnode, gi = None, E.geom_unit(si)
+            else:
+                gnode, tip = m.measure
+                gi = _geom_index(E, gnode, smp, si, home)
             gg = -1
             gnodes = {id(facs[i].geom): facs[i].geom for i in form + pv if facs[i].geom is not None}
             if len(gnodes) > 1:
@@ -1323,7 +1361,7 @@ def match(array, arguments=None):
                 for p in m.pw[1:]:
                     node = node * p
                 term['scale'] = _point_values(smp, node, s)
-            if s.get('_bnd_normal') is not None:  # (oblique face: see Emitter.sample)
+            if s.get('_bnd_normal') is not None and gnode is not None:  # (oblique face: see Emitter.sample; the reference measure of a face is that of its own parameters)
                 if E.plan['geoms'][gi]['kind'] != 'tab':
                     term['measure'] = gi = E.geom_tab(gnode, smp, si, home)
                     if gg >= 0 and g is gnode:

@@ -80,8 +80,18 @@ def load_example(name):
 
 
 def term_scale(plan, args):
-    '''(largest term coefficient) x (argument scale): what a vector / scalar of this plan is made of, whatever cancels in it'''
-    coef = max([1.] + [abs(float(t['fac'])) * max([float(numpy.abs(numpy.asarray(t[k], dtype=float)).max()) for k in ('B', 'L', 'f0') if t.get(k) is not None] + [0.])
+    '''(largest term coefficient x pointwise factor x measure) x (argument scale): what a vector / scalar of this plan is made of, whatever cancels in it'''
+    def measure(t):
+        # what the term is integrated over, where the plan says so: sum of w |det J| (a reference-space integral -- the identity map per element -- has the number of
+        # elements as its measure) and the largest value of its pointwise factor; at least 1
+        g = plan['geoms'][int(t['measure'])]
+        w = numpy.abs(numpy.asarray(plan['samples'][int(t['sample'])]['weights'], dtype=float))
+        m = 1.
+        if g['kind'] == 'tab':
+            m = float((numpy.abs(numpy.linalg.det(numpy.asarray(g['jac'], dtype=float))) * w).sum())
+        sc = t.get('scale')
+        return max(1., m) * max(1., float(numpy.abs(numpy.asarray(sc, dtype=float)).max()) if sc is not None else 1.)
+    coef = max([1.] + [abs(float(t['fac'])) * measure(t) * max([float(numpy.abs(numpy.asarray(t[k], dtype=float)).max()) for k in ('B', 'L', 'f0') if t.get(k) is not None] + [0.])
                        for t in plan['terms']])
     return coef * max([1.] + [float(numpy.abs(numpy.asarray(v, dtype=float)).max()) ** (2 if plan['kind'] == 'scalar' else 1) for v in (args or {}).values()
                               if numpy.size(v) and numpy.asarray(v).dtype.kind in 'fiub'])
