@@ -817,7 +817,9 @@ class _MatrixPlan:
         generic = self.parts is None and not self._fast_candidates()
         if not generic:  # (paths that write a whole array of their own)
             values, rowptr, colidx, ncols = self.run(arguments)
-            kernels.monomial(values, [], [], into)
+            if into.numel() != values.numel():
+                raise ValueError('run(into=...): the array does not match the pattern')
+            into.add_(values)
             return into, rowptr, colidx, ncols
         rowptr, colidx = self.smp0.pattern(self.test.basis, self.trial.basis).expand(self.test.ncomp, self.trial.ncomp, None if self.mask.all() else self.mask)
         if into.numel() != colidx.numel():
