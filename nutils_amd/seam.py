@@ -208,10 +208,27 @@ def build(plan):
     return b
 
 
+def _scalar_value(ast, arguments):
+    '''value of an expression of scalar arguments (Matcher.scalar_ast) for the caller's arguments'''
+    op = ast[0]
+    if op == 'const':
+        return float(ast[1])
+    if op == 'arg':
+        if ast[1] not in arguments:
+            raise KeyError(f'argument {ast[1]!r} of a derived scalar parameter is missing')
+        return float(numpy.asarray(arguments[ast[1]], dtype=float).reshape(()))
+    v = [_scalar_value(a, arguments) for a in ast[1:]]
+    if op == 'negative':
+        return -v[0]
+    return {'add': lambda a, b: a + b, 'subtract': lambda a, b: a - b, 'multiply': lambda a, b: a * b, 'divide': lambda a, b: a / b, 'power': lambda a, b: a ** b}[op](*v)
+
+
 def prepare_arguments(plan, arguments):
     '''arguments as the built integral expects them: a bare scalar argument becomes the coefficient vector (length 1) of its constant basis'''
     arguments = dict(arguments or {})
     b = build(plan)
+    for name, ast in (plan.get('derived') or {}).items():  # derived scalar parameters (1 / (t - t0): Matcher.divide)
+        arguments[name] = _scalar_value(ast, arguments)
     for name in b.scalar_args:
         if name in arguments:
             arguments[name] = numpy.reshape(numpy.asarray(arguments[name], dtype=float), (1,))
@@ -345,6 +362,7 @@ class Matcher:
         self.sample = None
         self._sym, self._symkeep = {}, []
         self.rename = {}
+        self.derived = {}   # derived scalar parameters: name -> expression of scalar arguments (scalar_ast)
 
     # ---- helpers -------------------------------------------------------------------------------------------------------------------
 
@@ -683,7 +701,25 @@ class Matcher:
         x, idx = args[0], args[1]
         if _kind(x) == '_Wrapper' and _name(x) == 'InsertAxis' and node.shape == x._args[0].shape:
             return self.conv(x._args[0])
-        raise Unmatched('Take')
+        # components of an array picked by constant indices along its last axis (`u_0`, `X_1` of expression_v2: function.get -> numpy.take, function.py take):
+        # the same entries of the coefficient tensor
+        inode = idx._arg if _kind(idx) == '_WithoutPoints' else idx
+        if self.has_symbols(inode) or inode.spaces:
+            raise Unmatched('Take with an index that is no constant')
+        ind = numpy.asarray(self.const_value(inode))
+        if ind.ndim > 1 or ind.dtype.kind not in 'iu':
+            raise Unmatched('Take with an index array of rank > 1')
+        out = []
+        for m in self.conv(x):
+            kind, j = m.axes[-1]
+            if kind != 'free':
+                raise Unmatched('Take along a dof axis')
+            if (ind < 0).any() or (ind >= m.A.shape[j]).any():
+                raise Unmatched('Take: index out of range')
+            A = m.A.take(ind, axis=j)
+            axes = m.axes if ind.ndim else [(k, a - 1 if k == 'free' and a > j else a) for k, a in m.axes[:-1]]
+            out.append(_Mono(A, axes, m.factors, m.pw, m.measure))
+        return out
 
     def grad(self, m, geom):
         if not m.factors:
@@ -793,12 +829,58 @@ class Matcher:
             if core.ndim == 0:
                 r = self.rebroadcast(_Mono(numpy.ones(()), [], pw=[1. / core]), den)
                 return [self.mul(m, r) for m in self.conv(args[0])]
+        ast = self.scalar_ast(den)
+        if ast is not None:
+            # division by an expression of scalar parameters only (`v du / dt`, dt = t - t0: examples/burgers.py:51-56): its reciprocal is a DERIVED scalar parameter,
+            # computed from the caller's arguments when the plan runs (prepare_arguments) and used like a bare scalar argument
+            A = numpy.zeros((1, self.S))
+            A[0, 0] = 1.
+            r = self.rebroadcast(_Mono(A, [], [_Factor(_SCALAR, self.derive(['divide', ['const', 1.], ast]), 1)]), den)
+            return [self.mul(m, r) for m in self.conv(args[0])]
         rat = self.as_basis(node)
         if rat is not None and rat[1] is not None:  # rational basis used as an array
             A = numpy.zeros((1, self.S))
             A[0, 0] = 1.
             return [_Mono(A, [('dof', 0)], [_Factor(rat[0], rational=rat[1])])]
         raise Unmatched('division by an expression with unknowns')
+
+    def scalar_ast(self, node):
+        '''[op, operands...] if `node` is an expression of scalar arguments and constants only (broadcast wrappers aside), else None'''
+        rf = self.rf
+        node = self.strip_broadcast(node, 0)
+        if node.ndim or node.spaces:
+            return None
+        if isinstance(node, rf.Argument):
+            return ['arg', self.rename.get(node.name, node.name)] if node.shape == () and node.dtype == float else None
+        if not any(isinstance(c, rf.Argument) for c in self.walk(node)):
+            return ['const', float(self.const_value(node))]
+        t = _kind(node)
+        if t == '_Replace':
+            ren = {}
+            for old, new in node._replacements.items():
+                if not isinstance(new, rf.Argument):
+                    return None
+                ren[old] = new.name
+            saved, self.rename = self.rename, dict(self.rename, **ren)
+            try:
+                return self.scalar_ast(node._arg)
+            finally:
+                self.rename = saved
+        if t == '_Wrapper' and _name(node) in ('add', 'subtract', 'multiply', 'divide', 'negative', 'power'):
+            ops = [self.scalar_ast(a) for a in node._args]
+            if any(o is None for o in ops):
+                return None
+            if _name(node) == 'power' and ops[1][0] != 'const':
+                return None
+            return [_name(node)] + ops
+        return None
+
+    def derive(self, ast):
+        import hashlib
+        import json
+        name = '_derived_' + hashlib.sha1(json.dumps(ast).encode()).hexdigest()[:10]
+        self.derived[name] = ast
+        return name
 
     # ---- integrals ---------------------------------------------------------------------------------------------------------------------
 
@@ -1148,6 +1230,11 @@ class Emitter:
         # (3) anything else (NURBS maps ...): tabulated at the points of the sample by geom_tab
         if spec is None:
             raise Unmatched('geometry without a structural description')
+        # the same map seen through two nodes (a scalar coordinate of a line given its axis once by the gradient, once by the measure): one geometry
+        for gi, g in enumerate(self.plan['geoms']):
+            if g['kind'] == spec['kind'] and g.keys() == spec.keys() and all(numpy.array_equal(g[k], spec[k]) for k in spec):
+                self._geom[key] = gi
+                return gi
         self.plan['geoms'].append(spec)
         self._geom[key] = len(self.plan['geoms']) - 1
         return self._geom[key]
@@ -1388,6 +1475,9 @@ def match(array, arguments=None):
         for k in [k for k in s if k.startswith('_')]:
             del s[k]
     plan['derivs'] = derivs
+    used = {a['name'] for a in plan['args']}
+    if any(n in used for n in M.derived):
+        plan['derived'] = {n: ast for n, ast in M.derived.items() if n in used}
     plan['shape'] = [int(n) for n in array.shape]
     plan['kind'] = 'scalar' if nexposed == 0 else 'vector' if nexposed == 1 else 'matrix'
     if nexposed > 2:

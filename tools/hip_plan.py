@@ -194,6 +194,27 @@ def main():
         for a in 'up':
             if (t, a) != ('q', 'p'):  # (no pressure-pressure block)
                 emit(f'stokes_th_jacobian_{t}{a}', rf.derivative(rt, a), args, row_axes=len(shapes[t]))
+    # ---- the volume terms of examples/burgers.py:44-57 in its own words (periodic line, time step as two scalar arguments): `v du / dt` divides by an expression
+    # of scalar parameters -- a derived scalar parameter of the plan (1 / (t - t0)); the interface terms of the example (jumps, means: `_Opposite`) are not matched --
+    for btype, degree in (('std', 1), ('spline', 2)):
+        domain, geom = mesh.line(numpy.linspace(-.5, .5, 21), periodic=True)
+        ns = Namespace()
+        ns.x = geom
+        ns.define_for('x', gradient='∇', normal='n', jacobians=('dV', 'dS'))
+        ns.u = domain.field('u', btype=btype, degree=degree)
+        ns.du = ns.u - rf.replace_arguments(ns.u, 'u:u0')
+        ns.v = domain.field('v', btype=btype, degree=degree)
+        ns.t = rf.field('t')
+        ns.dt = ns.t - rf.field('t0')
+        ns.f = '.5 u^2'
+        res = domain.integral('(v du / dt - ∇(v) f) dV' @ ns, degree=degree * 2)
+        shapes = {k: v.shape for k, v in rf.arguments_for(res).items()}
+        rngb = numpy.random.default_rng(13)
+        args = {k: rngb.normal(size=shp) for k, shp in shapes.items() if k != 'v'}
+        args['t'], args['t0'] = numpy.array(.7), numpy.array(.45)
+        rv = rf.derivative(res, 'v')
+        emit(f'burgers_volume_{btype}{degree}_residual', rv, args)
+        emit(f'burgers_volume_{btype}{degree}_jacobian', rf.derivative(rv, 'u'), args)
     # ---- component blocks per sample: a block-diagonal volume form + a boundary form that couples all components.  The reference runs one loop per
     # sample and concatenates the triplets, so the off-diagonal blocks exist in the rows of the boundary elements only (nnz 364, not 520) --------------
     domain, geom = mesh.rectilinear([3, 4])
