@@ -98,6 +98,67 @@ def test_c3_full_size_rigid_body_modes():
     assert float((y - yt).abs().max()) < 1e-11 * scale
 
 
+def test_c3_full_size_every_entry_vs_the_c_port_in_slabs():
+    '''BASELINE.json configs[2] at full size, entry-wise: the 64^3 P2 vector-elasticity matrix of the perturbed mesh through the API (nh_p2hex_matrix) against the C port of
+    the oracle (oracle/c: element loop + stable-sort dedup as the reference).  The full COO (1.7e9 entries) does not fit a test, so the port assembles SLABS of ten
+    element layers of the same mesh (same vertices); a row of a slab matrix whose node lies on no cut plane has received all of its elements, and its columns are those of
+    the full matrix minus the slab's dof offset (node numbering is layer-major).  The slabs overlap by two layers: every one of the 6 440 067 rows is compared -- row
+    lengths and column indices exactly, values to 1e-13 of the largest entry.'''
+    import torch
+    from oracle import assemble as oa, port
+    from nutils_amd import mesh, function, sample, _lib
+    if not port.available():
+        pytest.skip('oracle/c is not built')
+    n = 64
+    domain, geom = mesh.rectilinear([n] * 3)
+    gb = domain.basis('std', degree=1)
+    rng = numpy.random.default_rng(0)
+    verts = numpy.stack(numpy.meshgrid(*[numpy.arange(n + 1.)] * 3, indexing='ij'), -1).reshape(-1, 3) + rng.uniform(-.2, .2, (len(gb), 3))
+    geom = gb @ verts
+    u = domain.field('u', btype='std', degree=2, shape=[3])
+    v = domain.field('v', btype='std', degree=2, shape=[3])
+    lam, mu = 1., .5 / .3 - 1
+    eps = lambda w: function.symgrad(w, geom)
+    sigma = lam * function.div(u, geom) * function.eye(3) + 2 * mu * eps(u)
+    res = domain.integral(function.inner(eps(v), sigma) * function.J(geom), degree=4)
+    jac = function.derivative(function.derivative(res, 'v'), 'u')
+    with _lib.trace() as calls:
+        values, rowptr, colidx, ncols = sample._MatrixPlan(jac.terms).run()
+    assert 'nh_p2hex_matrix' in calls
+    dev = values.device
+    scale = float(values.abs().max())
+    # the oracle's tables of one element (uniform over the mesh) and the form
+    _, coeffs, _ = oa.structured_basis((1, 1, 1), 'std', 2)
+    _, gcoeffs, _ = oa.structured_basis((1, 1, 1), 'std', 1)
+    pts, w = oa.gauss(4, 3)
+    N, dN = oa.tabulate(coeffs[0], pts)
+    gN, gdN = oa.tabulate(gcoeffs[0], pts)
+    T = numpy.concatenate([N.T[:, :, None], dN.transpose(1, 0, 2)], axis=2)
+    gT = numpy.concatenate([gN.T[:, :, None], gdN.transpose(1, 0, 2)], axis=2)
+    C = oa.elasticity_coefficient(3, 1., .5 / .3 - 1)
+    V = verts.reshape(n + 1, n + 1, n + 1, 3)
+    plane = 3 * (2 * n + 1) ** 2  # dofs per node plane
+    step, checked, worst = 8, 0, 0.
+    for a in range(0, n, step):
+        lo, hi = max(0, a - 1), min(n, a + step + 1)  # element layers of the slab
+        vo, rpo, cio, _ = port.form3d((hi - lo, n, n), 2, C, T, gT, w, V[lo:hi + 1].reshape(-1, 3))
+        # node planes whose rows are complete in the slab matrix and belong to this step: [2 a, 2 (a + step)) (+ the last plane of the mesh)
+        p0, p1 = 2 * a, (2 * (a + step) if a + step < n else 2 * n + 1)
+        r0, r1 = (p0 - 2 * lo) * plane, (p1 - 2 * lo) * plane  # rows of the slab matrix
+        R0, R1 = p0 * plane, p1 * plane                         # the same rows of the full matrix
+        rps = torch.as_tensor(rpo[r0:r1 + 1], device=dev)
+        rpf = rowptr[R0:R1 + 1]
+        assert bool((rps[1:] - rps[:-1] == rpf[1:] - rpf[:-1]).all()), f'row lengths differ in node planes {p0}..{p1}'
+        k0, k1, K0, K1 = int(rpo[r0]), int(rpo[r1]), int(rpf[0]), int(rpf[-1])
+        assert bool((torch.as_tensor(cio[k0:k1], device=dev) + 2 * lo * plane == colidx[K0:K1]).all()), f'column indices differ in node planes {p0}..{p1}'
+        err = float((torch.as_tensor(vo[k0:k1], device=dev) - values[K0:K1]).abs().max())
+        worst = max(worst, err)
+        checked += r1 - r0
+        del vo, rpo, cio
+    assert checked == len(rowptr) - 1 == 3 * (2 * n + 1) ** 3
+    assert worst < 1e-13 * scale, worst / scale
+
+
 def test_c2_full_size_through_the_api():
     '''The same 128^3 isoparametric Poisson stiffness written as a user script writes it (mesh.rectilinear, basis, `basis @ verts`,
     domain.integral, function.eval(as_csr)): the front end recognises the form and takes the write-once kernel; indices and values
