@@ -13,4 +13,4 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize('seed', [101, 102])
 def test_random_integrals_equal_the_cpu_evaluator(seed):
     out = subprocess.run([sys.executable, 'tools/fuzz_frontend.py', '40', str(seed)], cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and f'40 cases, 0 not ok (seed {seed})' in out.stdout, (out.stdout + out.stderr)[-3000:]
+    assert out.returncode == 0 and f'40 of 40 cases' in out.stdout and f', 0 not ok (seed {seed})' in out.stdout, (out.stdout + out.stderr)[-3000:]

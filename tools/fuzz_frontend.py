@@ -3,7 +3,7 @@
 argument, form tensor B [nct][S][ncr][S] / linear form L / constant, sample, geometry) on random structured meshes -- dimension 1-3, std / spline bases of
 degree 1-4, periodic axes, scalar and vector valued, rectilinear / graded / isoparametric geometry, volume samples and boundary sides, several terms and
 several samples per integral -- evaluated through the C ABI (function.eval) and by the CPU evaluator tests/af_oracle.py (the checker of the plan tests).
-Index arrays must be equal, values within 1e-12 of the largest entry.   python tools/fuzz_frontend.py [ncases] [seed]'''
+Index arrays must be equal, values within 1e-12 of the largest entry.   python tools/fuzz_frontend.py [ncases] [seed]   (FUZZ_SECONDS=<s>: time budget, FUZZ_HUGE=<fraction> of meshes past the executor's size thresholds)'''
 import os
 import sys
 import traceback
@@ -160,9 +160,14 @@ def random_case(rng):
 
 
 def main(ncases, seed):
+    import time
     rng = numpy.random.default_rng(seed)
-    bad = 0
+    bad, done, t0 = 0, 0, time.perf_counter()
+    budget = float(os.environ.get('FUZZ_SECONDS', 0))  # stop after this many seconds (the summary says how many cases ran: a run cut off from outside prints none)
     for i in range(ncases):
+        if budget and time.perf_counter() - t0 > budget:
+            break
+        done += 1
         sub = numpy.random.default_rng(rng.integers(1 << 62))
         if os.environ.get('FUZZ_ONLY') and i != int(os.environ['FUZZ_ONLY']):  # (replay of one case of a run: FUZZ_ONLY=<case>, same count and seed)
             continue
@@ -209,7 +214,7 @@ def main(ncases, seed):
         if status != 'ok':
             bad += 1
             print(f'case {i}: {desc}: {status}', flush=True)
-    print(f'{ncases} cases, {bad} not ok (seed {seed})')
+    print(f'{done} of {ncases} cases in {time.perf_counter() - t0:.0f} s, {bad} not ok (seed {seed})')
 
 
 if __name__ == '__main__':
