@@ -709,6 +709,19 @@ class Matcher:
         ind = numpy.asarray(self.const_value(inode))
         if ind.ndim > 1 or ind.dtype.kind not in 'iu':
             raise Unmatched('Take with an index array of rank > 1')
+        if self.as_basis(x) is not None and self.as_basis(x)[1] is None and x.ndim == 1:
+            # single functions of a basis, `basis[i]` (the patch indicators of a multipatch geometry: mesh.unitcircle, examples/cahnhilliard.py test_multipatchcircle): no unknown
+            # left -- coefficient functions of the point, evaluated by the reference at the points of the sample like every other one (conv_plain)
+            if ind.ndim == 0:
+                return [_Mono(numpy.ones(()), [], pw=[node])]
+            if ind.size > 16:
+                raise Unmatched('large array-valued coefficient function of the point')
+            out = []
+            for k in range(ind.size):
+                A = numpy.zeros(ind.shape)
+                A[k] = 1.
+                out.append(_Mono(A, [('free', 0)], pw=[node[k]]))
+            return out
         out = []
         for m in self.conv(x):
             kind, j = m.axes[-1]
