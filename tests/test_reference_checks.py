@@ -42,11 +42,13 @@ def test_seam_installed_in_the_reference():
 
 
 def test_seam_installed_examples_with_declined_systems():
-    '''examples whose functionals are only PARTLY inside the matched class (Navier-Stokes convection, finite-strain energies, DG interface
+    '''examples whose functionals are only PARTLY inside the matched class (Navier-Stokes convection on mixed meshes, DG interface
     terms): the Systems the matcher recognises are assembled from plans, the others take the reference's evaluator inside the same script, and the
     examples' own unit tests pass unchanged'''
-    out = run('tests/seam_hook_run.py', 'drivencavity:test_baseline', 'burgers:test_1d_p1,test_1d_p2_legendre', 'finitestrain:test_simple')  # (all tests of the three: ~95 s)
-    for name in ('drivencavity', 'burgers', 'finitestrain'):
+    # (finitestrain.py is matched entirely since round 5 -- 9 Systems, 0 declined; its 27 plans are replayed by tests/test_plans_host.py -- and its Newton minimisation through the CPU
+    # evaluator alone takes 45 s: not run here)
+    out = run('tests/seam_hook_run.py', 'drivencavity:test_baseline', 'burgers:test_1d_p1,test_1d_p2_legendre')
+    for name in ('drivencavity', 'burgers'):
         line = next(l for l in out.splitlines() if l.startswith(name + ':'))
         assert ' 0 failures, 0 errors' in line and 'from plans: 0;' not in line, line
 
