@@ -310,6 +310,8 @@ def _children(node):
         return [node._arg]
     if t == '_Integral':
         return [node._integrand]
+    if t == '_Concatenate':
+        return list(node.arrays)
     return []
 
 
@@ -441,6 +443,10 @@ class Matcher:
                 A = numpy.zeros((1, self.S))
                 A[0, 0] = 1.
                 return [_Mono(A, [], [_Factor(_SCALAR, self.rename.get(node.name, node.name), 1)])]
+            if len(node.shape) == 1 and node.dtype == float:
+                # a coefficient vector used on its own (function.field(name, <array with a dof axis>): a basis transformed before it is contracted -- Piola maps,
+                # examples/cylinderflow.py:122-125): the product with an exposed basis along the same array axis binds that basis to the argument (mul), the sum removes the axis
+                return [_Mono(numpy.ones(()), [('avec', self.rename.get(node.name, node.name))])]
             raise Unmatched(f'argument {node.name!r} outside function.field')
         if t == '_Jacobian':
             return [_Mono(numpy.ones(()), [], measure=(self.strip_broadcast(node._geom, 1), node._tip_dim))]
@@ -477,7 +483,7 @@ class Matcher:
         if t == '_Wrapper':
             name, args = _name(node), node._args
             if name == 'multiply':
-                return [self.mul(a, b) for a in self.conv(args[0]) for b in self.conv(args[1])]
+                return self.merge([self.mul(a, b) for a in self.conv(args[0]) for b in self.conv(args[1])])
             if name == 'add':
                 return self.conv(args[0]) + self.conv(args[1])
             if name == 'subtract':
@@ -487,7 +493,7 @@ class Matcher:
             if name == 'divide':
                 return self.divide(node, args)
             if name == 'Sum':
-                return [self.sum_last(m) for m in self.conv(args[0])]
+                return self.merge([self.sum_last(m) for m in self.conv(args[0])])
             if name == 'InsertAxis':
                 length = int(self.const_value(args[1]._arg if _kind(args[1]) == '_WithoutPoints' else args[1]))
                 return [self.insert_axis(m, length) for m in self.conv(args[0])]
@@ -511,6 +517,16 @@ class Matcher:
                     out = self.conv_plain(self.rf.Array.cast(numpy.ones(node.shape)))
                 return out
             raise Unmatched(f'operation {name}')
+        if t == '_Concatenate':
+            parts = self.vector_parts(node)
+            if parts is not None:
+                # function.vectorize([basis_0, basis_1, ...]) as an array [dofs, components]: one exposed basis per part, each on its own component
+                out = []
+                for k, (pb, comp, off, n, total, nc) in enumerate(parts):
+                    A = numpy.zeros((nc, 1, self.S))
+                    A[comp, 0, 0] = 1.
+                    out.append(_Mono(A, [('dof', 0), ('free', 0)], [_Factor(pb[0], None, 1, rational=pb[1], part=(k, off, n, total))]))
+                return out
         raise Unmatched(f'node {t}')
 
     def conv_plain(self, node):
@@ -674,7 +690,7 @@ class Matcher:
 
     def sum_last(self, m):
         kind, j = m.axes[-1]
-        if kind == 'cdof':  # basis @ constant: the factor is now bound to its coefficient array
+        if kind in ('cdof', 'adof'):  # basis @ constant / basis @ argument: the factor is now bound to its coefficients
             return _Mono(m.A, m.axes[:-1], m.factors, m.pw, m.measure)
         if kind != 'free':
             raise Unmatched('sum over a dof axis')
@@ -735,11 +751,22 @@ class Matcher:
         return out
 
     def grad(self, m, geom):
+        nd = self.S - 1
+        out = []
+        if m.pw:
+            # product rule over the coefficient functions of the point: their gradients are coefficient functions too (evaluated by the reference at the points of the sample)
+            if any(numpy.abs(m.A[..., 1:]).sum() != 0 for _ in m.factors):
+                raise Unmatched('second derivatives')
+            nf = m.nfree
+            for i, pnode in enumerate(m.pw):
+                g = self.rf.grad(pnode, geom)
+                for j in range(nd):
+                    A = numpy.zeros(m.A.shape[:nf] + (nd,) + m.A.shape[nf:])
+                    A[(slice(None),) * nf + (j,)] = m.A
+                    out.append(_Mono(A, m.axes + [('free', nf)], m.factors, m.pw[:i] + [g[j]] + m.pw[i + 1:], m.measure))
         if not m.factors:
-            if m.pw:
-                raise Unmatched('gradient of a coefficient function')
-            return []  # gradient of a constant
-        if len(m.factors) != 1 or m.pw:
+            return out  # (gradient of a constant: nothing)
+        if len(m.factors) != 1:
             raise Unmatched('gradient of a product')
         if numpy.abs(m.A[..., 1:]).sum() != 0:
             raise Unmatched('second derivatives')
@@ -751,7 +778,7 @@ class Matcher:
         A = numpy.zeros(m.A.shape[:nf] + (nd,) + m.A.shape[nf:])
         for j in range(nd):
             A[(slice(None),) * nf + (j, slice(None), 1 + j)] = m.A[..., 0]
-        return [_Mono(A, m.axes + [('free', nf)], [f], m.pw, m.measure)]
+        return out + [_Mono(A, m.axes + [('free', nf)], [f], m.pw, m.measure)]
 
     def mul(self, a, b):
         if len(a.axes) != len(b.axes):
@@ -773,17 +800,27 @@ class Matcher:
         Ab, Bb = a.A, b.A
         out_axes, out_free = [], []
         drop_a, drop_b = [], []
+        bind = []  # (factor of a | None, factor of b | None, argument name): an exposed basis meets a coefficient vector on its dof axis
         for (ka, ia), (kb, ib) in zip(a.axes, b.axes):
             if ka == 'free' and kb == 'free':
                 lb[ib] = la[ia]                                     # elementwise
                 out_free.append(la[ia])
                 out_axes.append(('free', len(out_free) - 1))
-            elif ka in ('dof', 'cdof') and kb == 'free':
+            elif (ka == 'dof' and kb == 'avec') or (kb == 'dof' and ka == 'avec'):
+                bind.append((ia, None, ib) if ka == 'dof' else (None, ib, ia))
+                out_axes.append(('adof', ia if ka == 'dof' else ib + fa))
+            elif ka in ('dof', 'cdof', 'adof') and kb == 'free':
                 drop_b.append(ib)
                 out_axes.append((ka, ia))
-            elif kb in ('dof', 'cdof') and ka == 'free':
+            elif kb in ('dof', 'cdof', 'adof') and ka == 'free':
                 drop_a.append(ia)
                 out_axes.append((kb, ib + fa))
+            elif ka == 'avec' and kb == 'free':
+                drop_b.append(ib)
+                out_axes.append((ka, ia))
+            elif kb == 'avec' and ka == 'free':
+                drop_a.append(ia)
+                out_axes.append((kb, ib))
             else:
                 raise Unmatched('product of two dof axes (diagonal in the dofs)')
         for j in drop_a:
@@ -798,7 +835,15 @@ class Matcher:
         lb = [l for j, l in enumerate(lb) if j not in drop_b] + list(range(ob_, ob_ + 2 * fb))
         # equal labels with different sizes cannot occur: the reference broadcasts explicitly
         A = numpy.einsum(Ab, la, Bb, lb, out_free + list(range(oa_, oa_ + 2 * fa)) + list(range(ob_, ob_ + 2 * fb)))
-        return _Mono(A, out_axes, a.factors + b.factors, a.pw + b.pw, a.measure or b.measure)
+        factors = a.factors + b.factors
+        for ia, ib, name in bind:
+            i = ia if ia is not None else ib + fa
+            if factors[i].name is not None or factors[i].cvals is not None:
+                raise Unmatched('coefficient vector against a basis that is bound already')
+            f = factors[i].copy()
+            f.name = name
+            factors = factors[:i] + [f] + factors[i + 1:]
+        return _Mono(A, out_axes, factors, a.pw + b.pw, a.measure or b.measure)
 
     @staticmethod
     def varies(A, j):
@@ -856,6 +901,37 @@ class Matcher:
             A[0, 0] = 1.
             return [_Mono(A, [('dof', 0)], [_Factor(rat[0], rational=rat[1])])]
         raise Unmatched('division by an expression with unknowns')
+
+    def merge(self, monos):
+        '''Monomials that differ in their coefficient functions of the point only -- same coefficient tensor, factors, axes, measure -- are one monomial whose
+        coefficient function is the sum of the products (a reference expression like its terms).  Transformed bases (Piola maps: every component of the field is a
+        pointwise combination of the components of the basis) multiply the monomials of a product by the square of the dimension per factor; after the contraction over
+        the components most of them coincide up to that function.'''
+        if len(monos) < 8 or not any(m.pw for m in monos):
+            return monos
+        groups = {}
+        for m in monos:
+            key = (m.A.shape, m.A.tobytes(), tuple(m.axes), None if m.measure is None else (id(m.measure[0]), m.measure[1]),
+                   tuple((id(f.basis), f.name, f.ncomp, f.part, None if f.rational is None else id(f.rational[1]), id(f.geom), id(f.cvals)) for f in m.factors))
+            groups.setdefault(key, []).append(m)
+        if len(groups) == len(monos):
+            return monos
+        out = []
+        for ms in groups.values():
+            if len(ms) == 1:
+                out.append(ms[0])
+                continue
+            total = None
+            for m in ms:
+                prod = None
+                for pnode in m.pw:
+                    prod = pnode if prod is None else prod * pnode
+                if prod is None:
+                    prod = self.rf.Array.cast(1.)
+                total = prod if total is None else total + prod
+            m0 = ms[0]
+            out.append(_Mono(m0.A, m0.axes, m0.factors, [total], m0.measure))
+        return out
 
     def scalar_ast(self, node):
         '''[op, operands...] if `node` is an expression of scalar arguments and constants only (broadcast wrappers aside), else None'''
@@ -1324,6 +1400,11 @@ def match(array, arguments=None):
     # terms without any basis (constants, coefficient functions: `sigma_wall dS`) are located in the topology of the bases seen elsewhere
     anybasis = next((f.basis for _, m, _ in terms for f in m.factors if f.basis is not _SCALAR), None)
     terms = [(smp, m2, fac) for smp, m, fac in terms for m2 in M.constants_to_pointwise(m)]
+    if len(terms) >= 8:  # (monomials that differ in their coefficient functions only: Matcher.merge)
+        by = {}
+        for smp, m, fac in terms:
+            by.setdefault((id(smp), fac), (smp, fac, []))[2].append(m)
+        terms = [(smp, m, fac) for smp, fac, ms in by.values() for m in M.merge(ms)]
     for smp, m, fac in terms:
         if any(k == 'cdof' for k, _ in m.axes):
             raise Unmatched('basis weighted per dof outside a rational form')

@@ -194,6 +194,45 @@ def main():
         for a in 'up':
             if (t, a) != ('q', 'p'):  # (no pressure-pressure block)
                 emit(f'stokes_th_jacobian_{t}{a}', rf.derivative(rt, a), args, row_axes=len(shapes[t]))
+    # ---- examples/cylinderflow.py:110-146 in its own words (6 x 3 elements of the periodic annulus): velocity and pressure on Piola-transformed bases --
+    # `function.field('u', function.vectorize([...]) @ J.T / detJ)`: the argument meets its basis only after the basis was multiplied by the Jacobian of the polar map --,
+    # the potential-flow functional of the initial condition and the time-step residual (convection, stress, Nitsche terms on the rotating cylinder, `dt` a scalar argument)
+    nel, deg = 6, 2
+    angle = 2 * numpy.pi / nel
+    domain, geom = mesh.rectilinear([3, nel], periodic=(1,))
+    domain = domain.withboundary(inner='left', inflow=domain.boundary['right'][nel // 2:])
+    ns = Namespace()
+    ns.δ = rf.eye(domain.ndims)
+    ns.Σ = rf.ones([domain.ndims])
+    ns.ε = rf.levicivita(2)
+    ns.uinf_i = 'δ_i0'
+    ns.Re = 1000.
+    ns.grid = geom * angle
+    ns.x_i = '.5 exp(grid_0) (sin(grid_1) δ_i0 + cos(grid_1) δ_i1)'
+    ns.define_for('x', gradient='∇', normal='n', jacobians=('dV', 'dS'))
+    J = ns.x.grad(geom)
+    detJ = numpy.linalg.det(J)
+    ns.u = rf.field('u', rf.vectorize([domain.basis('spline', degree=(deg, deg - 1), removedofs=((0,), None)), domain.basis('spline', degree=(deg - 1, deg))]) @ J.T / detJ)
+    ns.p = domain.field('p', btype='spline', degree=deg - 1) / detJ
+    ns.v = rf.replace_arguments(ns.u, 'u:v')
+    ns.q = rf.replace_arguments(ns.p, 'p:q')
+    ns.du = ns.u - rf.replace_arguments(ns.u, 'u:u0')
+    ns.dt = rf.field('dt')
+    ns.σ_ij = '(∇_j(u_i) + ∇_i(u_j)) / Re - p δ_ij'
+    ns.N = 10 * deg / angle
+    ns.nitsche_i = '(N v_i - (∇_j(v_i) + ∇_i(v_j)) n_j) / Re'
+    ns.rotation = 1.
+    ns.uwall_i = 'rotation ε_ij x_j'
+    sqr = domain.integral('(.5 Σ_i (u_i - uinf_i)^2 - ∇_k(u_k) p) dV' @ ns, degree=deg * 2)
+    res = domain.integral('v_i du_i dV' @ ns, degree=deg * 3)
+    res += domain.integral('(v_i ∇_j(u_i) u_j + ∇_j(v_i) σ_ij + q ∇_k(u_k)) dt dV' @ ns, degree=deg * 3)
+    res += domain.boundary['inner'].integral('(nitsche_i (u_i - uwall_i) - v_i σ_ij n_j) dt dS' @ ns, degree=deg * 2)
+    rngp = numpy.random.default_rng(17)
+    args = {k: rngp.normal(size=v.shape) for k, v in rf.arguments_for(res).items() if k not in 'vq'}
+    args['dt'] = numpy.array(.25)
+    emit('cylinderflow_potential_residual_u', rf.derivative(sqr, 'u'), args)
+    emit('cylinderflow_step_residual_v', rf.derivative(res, 'v'), args)
+    emit('cylinderflow_step_jacobian_vu', rf.derivative(rf.derivative(res, 'v'), 'u'), args)
     # ---- the volume terms of examples/burgers.py:44-57 in its own words (periodic line, time step as two scalar arguments): `v du / dt` divides by an expression
     # of scalar parameters -- a derived scalar parameter of the plan (1 / (t - t0)); the interface terms of the example (jumps, means: `_Opposite`) are not matched --
     for btype, degree in (('std', 1), ('spline', 2)):
