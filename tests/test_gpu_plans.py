@@ -36,7 +36,7 @@ def test_reexecution_reuses_the_built_plan():
 @pytest.mark.parametrize('name', plan_exec.example_names())
 def test_example_plan_through_the_c_abi(name):
     '''Every distinct plan the installed seam emitted while the unit tests of nine UNMODIFIED reference examples ran (laplace, elasticity, poisson,
-    platewithhole, adaptivity, cahnhilliard, drivencavity, burgers, finitestrain; tools/hip_plan_capture.py in the build container), replayed through
+    platewithhole, adaptivity, cahnhilliard, drivencavity, burgers, finitestrain, cylinderflow; tools/hip_plan_capture.py in the build container), replayed through
     seam.execute = the C ABI: the half of "seam + HIP + reference in one process" that can run on the GPU box.  Boundary sides as element subsets with
     tabulated NURBS geometries, hierarchical (ragged) bases, rational bases tabulated per sample, Taylor-Hood blocks, DG projections.  Expected results: the
     reference's own (its un-hooked function.evaluate / as_csr of the array each plan was matched from), index arrays bit-exact, values to 1e-13 of the largest
