@@ -788,6 +788,7 @@ def derivative(integral, name):
     out = []
     T = lambda B: numpy.moveaxis(B, (-4, -3, -2, -1), (-2, -1, -4, -3))
     for smp, itg, fac in integral.terms:
+        mark = len(out)
         for k, (varg, comp, slot) in enumerate(itg.pvars):
             if varg.name == name:  # product rule on a point variable: the basis function of (varg, comp, slot) takes its place
                 out += [(smp, t, fac) for t in _pvar_derivative(itg, k)]
@@ -816,6 +817,8 @@ def derivative(integral, name):
                 elif itg.qform is None and itg.qscalar is None:
                     # any other position (a coefficient polynomial on a form with a bound trial field of several components, ...): the polynomial's monomials as point
                     # variables, differentiated by the product rule of _pvar_derivative -- again constant forms times point variables
+                    # (the expanded terms carry the term's own point variables: their derivatives come out of the recursion, not of the loop above)
+                    del out[mark:]
                     out += derivative(Integral([(smp, t, f) for t, f in _expand_fscale(itg, fac)]), name).terms
                     continue
                 else:

@@ -327,6 +327,7 @@ def prefetch_arguments(integrals, arguments):
             need = [itg.trial if itg.B is not None else None, itg.test if not itg.rows else None]
             need += list(itg.fscale.args) if itg.fscale is not None else []
             need += [itg.qscalar[1], itg.qscalar[2]] if itg.qscalar is not None else []
+            need += [a for a, _, _ in itg.pvars]
             for arg in need:
                 if arg is not None and getattr(arg, 'name', None) in arguments:
                     _argument_dev(arguments, arg)
@@ -800,6 +801,10 @@ class _MatrixPlan:
         '''-> values, rowptr, colidx, ncols.  `into`: a device array over the plan's own entries that the values are ADDED to (entry-wise: old + sum of the
         contributions, the same rounding as adding the result afterwards) -- the merged Jacobian's array of field-dependent entries (solver._dyn_values): no array
         of its own, no pass that adds it.'''
+        if any(itg.pvars for _, itg, _ in self.terms):
+            # point variables are products of field values at the points: bound per call (the Jacobian blocks of a native System arrive here unbound,
+            # solver._build_merge_plan / _dyn_values), then an ordinary plan over tabulated coefficients
+            return _MatrixPlan(_bind_pvars(self.terms, arguments or {})).run(arguments, into)
         if into is not None:
             return self._run_into(arguments, into)
         if self.parts is not None:
@@ -1168,6 +1173,11 @@ def _vector_blocks(blocks, arguments, scalar):
             kernels.scatter_gather(pairs[i:i + 8], blocks[b][0].ncomp, blocks[b][1], accumulate=True)
 
 
+def _bound_terms(f, arguments):
+    '''the term list of an Integral with its point variables bound for this call (the list itself if it has none: the term plans are keyed by its identity)'''
+    return _bind_pvars(f.terms, arguments)
+
+
 def _exposed_test(f):
     '''Test argument of a vector-valued integral (all terms expose the same test space), or None.'''
     exposed = [itg for _, itg, _ in f.terms if itg.rows]
@@ -1201,7 +1211,7 @@ def start_blocks(fs, arguments, flat=False):
         for i, (f, a0) in enumerate(zip(fs, tests)):
             if a0 is not None:
                 index[i] = len(blocks)
-                blocks.append((a0, buf[int(offsets[i]):int(offsets[i + 1])], f.terms))
+                blocks.append((a0, buf[int(offsets[i]):int(offsets[i + 1])], _bound_terms(f, arguments)))
         _vector_blocks(blocks, arguments, [device.zeros(1, 'float64'), 0.])
         host = t.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
         host.copy_(buf, non_blocking=True)

@@ -21,6 +21,11 @@ def _names(spec):
     return tuple(spec.split(',')) if isinstance(spec, str) else tuple(spec)
 
 
+def _field_dependent(itg):
+    '''Does the term's coefficient depend on the arguments of the call (a polynomial of field values, point variables, product-rule tensors)?'''
+    return itg.fscale is not None or bool(itg.pvars) or itg.qform is not None or itg.qscalar is not None
+
+
 class _HostMirror:
     '''The CSR value array of the (merged, possibly reduced) Jacobian in page-locked host memory, kept up to date in place: the first
     assembly copies everything, a later one lets the device write only the entries of the field-dependent blocks (compact array `dyn`,
@@ -99,9 +104,10 @@ class System:
         self.offsets = numpy.cumsum([0] + sizes)
         self.size = int(self.offsets[-1])
         # linear <=> no Jacobian term carries a coefficient function of a trial field (solver.py:255-256)
-        self.is_linear = not any(itg.fscale is not None and any(itg.fscale.depends_on(t) for t in self.trials)
+        # (point variables -- function.Integrand.pvars: values / gradients of bound fields as factors -- are coefficient functions like fscale)
+        self.is_linear = not any(itg.fscale is not None and any(itg.fscale.depends_on(t) for t in self.trials) or any(a.name in self.trials for a, _, _ in itg.pvars)
                                  for row in self.block_jacobian for blk in row for _, itg, _ in blk.terms)
-        self.is_constant_matrix = not any(itg.fscale is not None for row in self.block_jacobian for blk in row for _, itg, _ in blk.terms)
+        self.is_constant_matrix = not any(_field_dependent(itg) for row in self.block_jacobian for blk in row for _, itg, _ in blk.terms)
         self._jac = None
 
     # -- assembly (solver.py:318-386) --
@@ -126,7 +132,7 @@ class System:
                     rp, ci = device.to_host(rowptr), device.to_host(colidx)
                     rows = numpy.repeat(numpy.arange(len(rp) - 1, dtype=numpy.int64), numpy.diff(rp)) + int(self.offsets[i])
                     key = rows * self.size + ci + int(self.offsets[j])
-                    constant = not any(itg.fscale is not None for _, itg, _ in terms)
+                    constant = not any(_field_dependent(itg) for _, itg, _ in terms)
                     groups.append(dict(plan=plan, constant=constant, values=values if constant else None, n=len(key)))
                     keys.append(key)
         allkeys = numpy.concatenate(keys) if keys else numpy.zeros(0, dtype=numpy.int64)
