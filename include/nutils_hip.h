@@ -574,6 +574,18 @@ int nh_scatter_gather(int count, const nh_scatter_plan *const *plans, const doub
 int nh_point_forms(int kind, int64_t npoints, int S, const double *Ut_dev, const double *Ur_dev, const double *B_host, const double *L_host,
                    const double *scale_dev, double *out_dev, void *stream);
 
+/* ---- array-valued expressions of field values at the points of a sample ----------------------------
+ * Sample.eval / Sample.bind (sample.py:192-232; _ConcatenatePoints.lower :966-975, _ReorderPoints :978-989) of a function that is a sum of
+ * (constant coefficient tensor) x (product of values / gradients of bound fields and of coordinates) x (coefficient function of the point):
+ *   out[i][f] (+)= sc_i sum_{t : out_index[t] == f} coef[t] prod_v x_v[i*strides[v] + offsets[t*nvars+v]],   f < nout, nvars <= 6.
+ * x_dev: HOST array of nvars device pointers (U arrays of nh_sample_eval: stride ncomp*(1+ndims), offset comp*(1+ndims)+slot; coordinate
+ * arrays: stride ndims, offset = axis); strides: HOST array.  out_index / offsets / coef: DEVICE tables of the nentries non-zeros of the
+ * coefficient tensor, out_index ascending (an output that is met again later is added to).  scale_dev [npoints] or NULL.
+ * accumulate = 0 stores (outputs without an entry become 0), 1 adds to out_dev[npoints][nout].  Replaces the reference's per-element
+ * evaluation of the lowered function inside loop_concatenate (evaluable.py:5383-5508). */
+int nh_point_expr(int64_t npoints, int nvars, const double *const *x_dev, const int64_t *strides, int64_t nentries, const int32_t *out_index_dev,
+                  const int32_t *offsets_dev, const double *coef_dev, const double *scale_dev, int nout, double *out_dev, int accumulate, void *stream);
+
 /* ---- rational bases (NURBS) ------------------------------------------------------------------
  * In-place transform of per-element tabulated functions T[(e, i)][q][S] (function (e,i) = e*nb+i, or off[e]+i for ragged bases)
  * into N_i = w_i B_i / W,  dN_i = w_i (dB_i W - B_i dW) / W^2  with the dof weights w[dofs[e][i]] and the weight function W

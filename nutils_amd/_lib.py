@@ -157,6 +157,7 @@ SIGNATURES = {
     'nh_scatter_plan_build': (ctypes.c_int, [c_i64, c_i64, ctypes.c_int, vp, vp, vp, c_i64, ctypes.POINTER(vp), vp]),
     'nh_scatter_plan_free': (ctypes.c_int, [vp]),
     'nh_scatter_gather': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_int, vp, ctypes.c_int, vp]),
+    'nh_point_expr': (ctypes.c_int, [c_i64, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(c_i64), c_i64, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_int, vp]),
     'nh_point_forms': (ctypes.c_int, [ctypes.c_int, c_i64, ctypes.c_int, vp, vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), vp, vp, vp]),
     'nh_rationalize': (ctypes.c_int, [vp, c_i64, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     'nh_p1hex_pattern': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), c_i64, c_i64, vp, vp, vp]),

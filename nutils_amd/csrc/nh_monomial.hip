@@ -242,3 +242,67 @@ extern "C" int nh_point_forms(int kind, int64_t npoints, int S, const double *Ut
   NH_LAUNCH_CHECK();
   return NH_OK;
 }
+
+// ---- array-valued expressions of field values at the points of a sample -----------------------------------------------------
+// Sample.eval / Sample.bind of the reference (sample.py:192-232; _ConcatenatePoints.lower :966-975: a loop_concatenate of the lowered function over the
+// elements) for functions that are sums of (constant coefficient tensor) x (product of values / gradients of bound fields and coordinates) x (coefficient
+// function of the point): stresses, displaced coordinates, fluxes.  The field values come from nh_sample_eval; this kernel contracts them with the
+// sparse coefficient tensor,
+//   out[i][f] (+)= sc_i sum_{t: oidx[t] == f} coef[t] prod_v x_v[i * stride_v + off[t][v]],
+// one thread per point, the entries in ascending f (a thread keeps the running sum of one f in a register and writes each output once).
+namespace {
+struct PExprK {
+  i64 n, nentries;
+  int nvars, nout, accumulate;
+  const double *x[6];
+  i64 stride[6];
+  const int *oidx, *off;
+  const double *coef, *scale;
+  double *out;
+};
+
+__global__ void k_point_expr(PExprK p) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  const double sc = p.scale ? p.scale[i] : 1.;
+  double *o = p.out + i * p.nout;
+  if (!p.accumulate)
+    for (int f = 0; f < p.nout; ++f) o[f] = 0.;
+  const double *xb[6];
+  for (int v = 0; v < p.nvars; ++v) xb[v] = p.x[v] + i * p.stride[v];
+  int cur = -1;
+  double acc = 0.;
+  for (i64 t = 0; t < p.nentries; ++t) {  // (oidx / off / coef are the same for every thread: scalar loads)
+    const int f = p.oidx[t];
+    if (f != cur) {
+      if (cur >= 0) o[cur] += sc * acc;
+      cur = f;
+      acc = 0.;
+    }
+    double m = p.coef[t];
+    for (int v = 0; v < p.nvars; ++v) m *= xb[v][p.off[t * p.nvars + v]];
+    acc += m;
+  }
+  if (cur >= 0) o[cur] += sc * acc;
+}
+}  // namespace
+
+extern "C" int nh_point_expr(int64_t npoints, int nvars, const double *const *x_dev, const int64_t *strides, int64_t nentries, const int32_t *out_index_dev,
+                             const int32_t *offsets_dev, const double *coef_dev, const double *scale_dev, int nout, double *out_dev, int accumulate, void *stream) {
+  NH_REQUIRE(npoints >= 0 && nentries >= 0 && nout >= 1 && out_dev, "nh_point_expr: invalid argument");
+  NH_REQUIRE(nvars >= 0 && nvars <= 6, "nh_point_expr: at most 6 factors (got %d)", nvars);
+  NH_REQUIRE(!nentries || (out_index_dev && coef_dev && (!nvars || offsets_dev)), "nh_point_expr: NULL entry table");
+  if (!npoints) return NH_OK;
+  PExprK p;
+  memset(&p, 0, sizeof p);
+  p.n = npoints; p.nentries = nentries; p.nvars = nvars; p.nout = nout; p.accumulate = accumulate;
+  for (int v = 0; v < nvars; ++v) {
+    NH_REQUIRE(x_dev[v] && strides[v] >= 0, "nh_point_expr: NULL factor %d", v);
+    p.x[v] = x_dev[v];
+    p.stride[v] = strides[v];
+  }
+  p.oidx = out_index_dev; p.off = offsets_dev; p.coef = coef_dev; p.scale = scale_dev; p.out = out_dev;
+  hipLaunchKernelGGL(k_point_expr, dim3((unsigned)((npoints + 255) / 256)), dim3(256), 0, nh_stream(stream), p);
+  NH_LAUNCH_CHECK();
+  return NH_OK;
+}

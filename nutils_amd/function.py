@@ -327,6 +327,47 @@ class Arg:
         return self is other or (self.name is not None and self.name == other.name and self.basis is other.basis and self.ncomp == other.ncomp)
 
 
+class PointTerm:
+    '''One term of a PointExpr: A[free..., (component, slot) per factor] x prod_k F_k[c_k][s_k] x scale(point).  Factors: ('field', Arg, geometry) -- value
+    (slot 0) and gradient with respect to the geometry (slots 1 .. ndims) of a bound field; ('x', geometry) -- the coordinates (components = axes, one slot).'''
+
+    def __init__(self, A, factors, scale=None):
+        self.A = numpy.array(A, dtype=float, order='C')  # (ascontiguousarray would turn a scalar into a vector)
+        self.factors = list(factors)
+        self.scale = scale  # PointTable [nlist][nq] or None
+        self._entries = {}
+
+    def entries(self, ndims):
+        '''The non-zeros of A as (output index, offset of (component, slot) in the point block of every factor, coefficient), outputs ascending.'''
+        hit = self._entries.get(ndims)
+        if hit is None:
+            S = 1 + ndims
+            nf = len(self.factors)
+            slots = [S if f[0] == 'field' else 1 for f in self.factors]
+            comps = [f[1].ncomp if f[0] == 'field' else ndims for f in self.factors]
+            free = self.A.shape[:self.A.ndim - 2 * nf]
+            if self.A.shape[len(free):] != tuple(n for c, sl in zip(comps, slots) for n in (c, sl)):
+                raise ValueError(f'coefficient tensor {self.A.shape} does not match its factors')
+            if self.A.ndim:
+                idx = numpy.nonzero(self.A)
+                out = numpy.ravel_multi_index(idx[:len(free)], free) if free else numpy.zeros(len(idx[0]), dtype=numpy.int64)
+                coef = self.A[idx]
+            else:  # a constant
+                idx, out, coef = (), numpy.zeros(int(self.A != 0), dtype=numpy.int64), self.A.reshape(1)[:int(self.A != 0)]
+            off = numpy.stack([idx[len(free) + 2 * k] * slots[k] + idx[len(free) + 2 * k + 1] for k in range(nf)], axis=1) if nf else numpy.zeros((len(out), 0), dtype=numpy.int64)
+            hit = self._entries[ndims] = (out.astype(numpy.int32), off.astype(numpy.int32), numpy.asarray(coef, dtype=float), free)
+        return hit
+
+
+class PointExpr:
+    '''Array-valued function of the point for Sample.eval / Sample.bind (sample.py:192-232 of the reference): a sum of PointTerms with the same free shape --
+    displaced coordinates x + u, stresses C : grad(u), fluxes, products of fields.  Evaluated on the device: nh_sample_eval per (field, geometry), nh_point_expr per term.'''
+
+    def __init__(self, shape, terms):
+        self.shape = tuple(int(n) for n in shape)
+        self.terms = list(terms)
+
+
 def _bcast(a, b, keep):
     '''Broadcast the leading (free) axes of a and b numpy-style, keeping `keep` trailing axes of each aside.'''
     fa, fb = a.shape[:a.ndim - keep[0]], b.shape[:b.ndim - keep[1]]

@@ -608,6 +608,20 @@ def pointwise_poly(xs, strides, coeffs, powers, n):
     return out
 
 
+def point_expr(xs, strides, out_index, offsets, coef, n, nout, scale=None, out=None):
+    '''out[i][f] (+)= scale_i sum_{t: out_index[t] == f} coef[t] prod_v xs[v][i*strides[v] + offsets[t][v]] (nh_point_expr): the contraction of field values at
+    the points of a sample with a sparse constant tensor.  out_index (int32, ascending), offsets (int32 [nentries][nvars]), coef: device tables; `out`: added to if given.'''
+    nv = len(xs)
+    fresh = out is None
+    if fresh:
+        out = device.empty(n * nout, 'float64')
+    X = (ctypes.c_void_p * max(nv, 1))(*[x.data_ptr() for x in xs])
+    S = (ctypes.c_int64 * max(nv, 1))(*[int(s) for s in strides])
+    _lib.call('nh_point_expr', n, nv, X, S, int(coef.numel()), device.ptr(out_index), device.ptr(offsets) if nv else None, device.ptr(coef),
+              device.ptr(scale) if scale is not None else None, nout, device.ptr(out), 0 if fresh else 1, device.stream())
+    return out
+
+
 def point_forms(kind, Ut, B, Ur=None, L=None, scale=None):
     '''Per-point forms of field values (nh_point_forms): kind 0 -> [npoints] point factor Ut.B.Ur; kind 1 / 2 -> [npoints][S][S] coefficient
     tensors of the product-rule terms (sample._MatrixPlan.run).  Ut, Ur: [npoints][S] on the device; B [S][S], L [S] on the host.'''

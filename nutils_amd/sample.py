@@ -257,6 +257,8 @@ class Sample:
             dj = device.empty(n, 'float64')
             kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(f.geom), points=self._points_dev, detj=dj, elist=el)
             return device.to_host(dj)
+        if isinstance(f, function.PointExpr):
+            return self._eval_expr(f, arguments)
         if isinstance(f, function.Operand):
             if f.arg.name is None:
                 raise NotImplementedError('evaluating a basis array at all points is a dense (npoints x ndofs) result; evaluate a field instead')
@@ -272,6 +274,55 @@ class Sample:
             # tiny host contraction with the operand's constant tensor: value[free] = P[free,c,s] U[c,s]
             return numpy.einsum('...cs,ncs->n...', f.P, Uh)
         raise NotImplementedError(f'Sample.eval of {type(f).__name__}')
+
+
+def _eval_expr(self, f, arguments):
+    '''Sample.eval of a function.PointExpr: field values / coordinates at the points once per (field, geometry) (nh_sample_eval), then one contraction with the
+    sparse coefficient tensor per term (nh_point_expr); -> host array [npoints, *shape].'''
+    nq, nd, ne = self.points.npoints, self.ndims, self.nlist
+    n, S = ne * nq, 1 + nd
+    nout = int(numpy.prod(f.shape)) if f.shape else 1
+    el = self._elist_dev
+    cache, out = {}, None
+    for term in f.terms:
+        oidx, off, coef, free = term.entries(nd)
+        if tuple(free) != f.shape:
+            raise ValueError(f'term of shape {tuple(free)} in an expression of shape {f.shape}')
+        if not len(coef):
+            continue
+        xs, strides = [], []
+        for fac in term.factors:
+            geom = fac[-1] if fac[-1] is not None else _default_geometry(self.topo)
+            if fac[0] == 'field':
+                arg = fac[1]
+                key = 'f', arg.name, id(arg.basis), arg.ncomp, id(geom)
+                if key not in cache:
+                    U = device.empty(n * arg.ncomp * S, 'float64')
+                    kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(geom), trial=self.tables(arg.basis).struct, ncr=arg.ncomp,
+                                        points=self._points_dev, u=_argument_dev(arguments, arg), U=U, elist=el)
+                    cache[key] = U
+                xs.append(cache[key])
+                strides.append(arg.ncomp * S)
+            elif fac[0] == 'x':
+                key = 'x', id(geom)
+                if key not in cache:
+                    X = device.empty(n * nd, 'float64')
+                    kernels.sample_eval(nelems=ne, ndims=nd, nq=nq, geom=self.geometry(geom), points=self._points_dev, x=X, elist=el)
+                    cache[key] = X
+                xs.append(cache[key])
+                strides.append(nd)
+            else:
+                raise ValueError(f'unknown factor kind {fac[0]!r}')
+        tabs = term.__dict__.get('_dev')
+        if tabs is None or tabs[0] != nd:
+            tabs = term.__dict__['_dev'] = (nd, device.to_dev(oidx, 'int32'), device.to_dev(off.reshape(-1), 'int32'), device.to_dev(coef, 'float64'))
+        out = kernels.point_expr(xs, strides, tabs[1], tabs[2], tabs[3], n, nout, scale=None if term.scale is None else self.scale(term.scale), out=out)
+    if out is None:
+        return numpy.zeros((n,) + f.shape)
+    return device.to_host(out).reshape((n,) + f.shape)
+
+
+Sample._eval_expr = _eval_expr
 
 
 class _Bound:

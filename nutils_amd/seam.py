@@ -150,6 +150,8 @@ class Built:
                 k, off, n, total = (int(x) for x in a['part'])
                 self.parts.setdefault(a['name'], {})[k] = (internal(a), off, n, total)
         self.scalar_args = sorted({a['name'] for a in plan['args'] if a.get('scalar')})  # bare scalar arguments: passed as the one coefficient of a constant basis
+        # fields with CONSTANT coefficients (`nurbsbasis @ controlpoints`, `gbasis @ verts` evaluated at points: kind 'points'): bound like arguments, their values are in the plan
+        self.consts = {a['name']: numpy.asarray(a['values'], dtype=float) for a in plan['args'] if a.get('values') is not None}
 
         # (samples of element subsets on ragged bases: the front end rewrites them as samples of their own element list, sample._SubsetView)
         terms = []
@@ -169,6 +171,23 @@ class Built:
                                      measure=self.geoms[int(t['measure'])], rows=bool(t['rows']), cols=bool(t['cols']), scale=sc, fscale=fp,
                                      pvars=[(self.args[int(a)], int(c), int(sl)) for a, c, sl in (t.get('pvars') or [])])
             terms.append((self.samples[int(t['sample'])], itg, float(t['fac'])))
+        # kind 'points' (Sample.eval / Sample.bind, sample.py:192-232): one array-valued point expression per plan sample, `dest` = the rows of the result its points fill
+        self.exprs = []
+        if plan.get('kind') == 'points':
+            shape = [int(n) for n in plan['shape'][1:]]
+            by_sample = {}
+            for t in plan['pterms']:
+                facs = []
+                for f in t['factors']:
+                    if f.get('x') is not None:
+                        facs.append(('x', self.geoms[int(f['x'])]))
+                    else:
+                        facs.append(('field', self.args[int(f['arg'])], None if int(f['geom']) < 0 else self.geoms[int(f['geom'])]))
+                sc = None if t.get('scale') is None else function.PointTable(numpy.asarray(t['scale'], dtype=float))
+                by_sample.setdefault(int(t['sample']), []).append(function.PointTerm(numpy.asarray(t['A'], dtype=float).reshape([int(n) for n in t['Ashape']]), facs, sc))
+            for ps in plan['psamples']:
+                si = int(ps['sample'])
+                self.exprs.append((self.samples[si], function.PointExpr(shape, by_sample.get(si, [])), None if ps.get('dest') is None else numpy.asarray(ps['dest'], dtype=numpy.int64)))
         integral = function.Integral(terms)
         derivs = list(plan.get('derivs', []))
         self.split = any(name in self.parts for name in derivs)
@@ -232,6 +251,7 @@ def prepare_arguments(plan, arguments):
     for name in b.scalar_args:
         if name in arguments:
             arguments[name] = numpy.reshape(numpy.asarray(arguments[name], dtype=float), (1,))
+    arguments.update(b.consts)
     for name, parts in b.parts.items():  # concatenated coefficient vectors: one field per part
         if name in arguments:
             whole = numpy.asarray(arguments[name], dtype=float).ravel()
@@ -249,6 +269,17 @@ def run(plan, arguments, evaluator):
     b = build(plan)
     arguments = prepare_arguments(plan, arguments)
     kind = plan['kind']
+    if kind == 'points':
+        # the point axis of the result: the elements of the sample in order, each with its points (loop_concatenate, sample.py:966-975), placed by the sample's point
+        # indices (_ReorderPoints: Inflate, sample.py:978-989); a sample whose elements carry different point tables arrives as one plan sample per table
+        out = numpy.zeros([int(n) for n in plan['shape']])
+        for smp, expr, dest in b.exprs:
+            vals = numpy.asarray(evaluator((smp, expr), arguments, kind), dtype=float)
+            if dest is None:
+                out += vals.reshape(out.shape)
+            else:  # (the rows of one plan sample are distinct; terms located in different topologies arrive as different plan samples over the same rows)
+                out[dest] += vals.reshape((len(dest),) + out.shape[1:])
+        return out
     if not b.split:
         return evaluator(b.integral, arguments, kind)
     if kind == 'vector':
@@ -274,9 +305,10 @@ def execute(plan, arguments=None):
     '''Evaluate a plan through the C ABI.  kind 'matrix': (values, rowptr, colidx) as function.as_csr of the array flattened to two axes
     (function.py:2443-2452; index arrays int64); 'vector': the array in the reference's shape; 'scalar': float.'''
     from . import function
-    out = run(plan, arguments, lambda integral, args, kind: function.eval(function.as_csr(integral) if kind == 'matrix' else integral, args))
+    out = run(plan, arguments, lambda integral, args, kind: integral[0].eval(integral[1], args) if kind == 'points' else
+              function.eval(function.as_csr(integral) if kind == 'matrix' else integral, args))
     kind = plan['kind']
-    if kind == 'matrix':
+    if kind in ('matrix', 'points'):
         return out
     if kind == 'scalar':
         return float(out)
@@ -323,6 +355,14 @@ class _ScalarBasis:
 _SCALAR = _ScalarBasis()
 
 
+class _Coordinates:
+    '''stands for the "basis" of a bare vector-valued function of the point that may be a GEOMETRY (`'x_i' @ ns` in Sample.eval): a pseudo-factor whose components are
+    the coordinates; the emitter of a points plan describes it structurally (rectilinear map) or, failing that, tabulates its components like any coefficient function'''
+
+
+_XGEOM = _Coordinates()
+
+
 class _Factor:
     '''What a monomial is linear in: a basis (identity = the reference object), as exposed dof axis (`name` None), bound to a named argument, or
     bound to a constant coefficient array (`cvals` [ndofs][ncomp]: `gbasis @ verts`, `bsplinebasis @ controlweights`).'''
@@ -335,6 +375,8 @@ class _Factor:
     def copy(self):
         f = _Factor(self.basis, self.name, self.ncomp, self.cvals, self.rational, self.part)
         f.geom = self.geom
+        if hasattr(self, 'xnode'):
+            f.xnode = self.xnode
         return f
 
 
@@ -365,6 +407,7 @@ class Matcher:
         self._sym, self._symkeep = {}, []
         self.rename = {}
         self.derived = {}   # derived scalar parameters: name -> expression of scalar arguments (scalar_ast)
+        self.points_mode = False  # match_points: functions evaluated at points (no measure, no exposed dof axes; coordinates kept as factors)
 
     # ---- helpers -------------------------------------------------------------------------------------------------------------------
 
@@ -535,6 +578,13 @@ class Matcher:
         if not node.spaces:
             v = numpy.asarray(self.const_value(node), dtype=float)
             return [_Mono(v, [('free', j) for j in range(v.ndim)])]
+        if self.points_mode and node.ndim == 1 and node.shape[0] == self.S - 1 and node.dtype == float:
+            nd = self.S - 1
+            A = numpy.zeros((nd, nd, self.S))
+            A[numpy.arange(nd), numpy.arange(nd), 0] = 1.
+            f = _Factor(_XGEOM, None, nd)
+            f.xnode = node
+            return [_Mono(A, [('free', 0)], [f])]
         if core.ndim == 0:  # scalar coefficient function, broadcast over the array axes
             m = _Mono(numpy.ones(()), [], pw=[core])
             return [self.rebroadcast(m, node)]
@@ -770,6 +820,8 @@ class Matcher:
             raise Unmatched('gradient of a product')
         if numpy.abs(m.A[..., 1:]).sum() != 0:
             raise Unmatched('second derivatives')
+        if m.factors[0].basis is _XGEOM:
+            raise Unmatched('gradient of a coordinate function')
         f = m.factors[0].copy()
         if f.geom is not None and f.geom is not geom:
             raise Unmatched('gradients with respect to different geometries')
@@ -790,6 +842,10 @@ class Matcher:
             for i, (k, f) in enumerate(x.axes):
                 if k == 'dof' and y.axes[i][0] == 'free' and not y.factors and self.varies(y.A, y.axes[i][1]):
                     return self.bind_constant(x, y, i)
+                # per-dof coefficients twice (`bsplinebasis * controlweights / weightfunc @ controlpoints` evaluated at points: the weights, then the control points)
+                if (k == 'cdof' and y.axes[i][0] == 'free' and not y.factors and not y.pw and y.measure is None and self.varies(y.A, y.axes[i][1])
+                        and len(x.factors) == 1 and x.factors[0].ncomp == 1 and x.measure is None):
+                    return self.bind_constant(x, y, i, again=True)
         fa, fb = len(a.factors), len(b.factors)
         # einsum labels (numpy accepts 0..51): a's free axes, b's free axes, then the (comp, slot) pairs of the factors
         la = list(range(a.nfree))
@@ -849,10 +905,11 @@ class Matcher:
     def varies(A, j):
         return A.shape[j] > 1 and A.strides[j] != 0 and bool(numpy.ptp(A, axis=j).any())
 
-    def bind_constant(self, x, y, i):
+    def bind_constant(self, x, y, i, again=False):
         '''x: a bare basis (one factor, coefficient 1 on the value slot, other axes broadcast) with its dof axis at array position i;
-        y: a constant array.  Result: the factor carries y as per-dof coefficients; the other array axes of y become its components.'''
-        if len(x.factors) != 1 or x.pw or x.measure is not None or x.factors[0].cvals is not None or x.factors[0].name is not None:
+        y: a constant array.  Result: the factor carries y as per-dof coefficients; the other array axes of y become its components.
+        again: x carries scalar per-dof coefficients already (and possibly coefficient functions of the point): they multiply y.'''
+        if len(x.factors) != 1 or (x.pw and not again) or x.measure is not None or (x.factors[0].cvals is not None) != again or x.factors[0].name is not None:
             raise Unmatched('constant coefficients on a composite expression')
         base = x.A[(0,) * x.nfree]
         if not (x.factors[0].ncomp == 1 and base[0, 0] == 1. and numpy.abs(base).sum() == 1. and not any(self.varies(x.A, j) for j in range(x.nfree))):
@@ -863,7 +920,10 @@ class Matcher:
         C = numpy.transpose(y.A, order)                      # [ndofs, other axes in array order]
         other = C.shape[1:]
         nc = int(numpy.prod(other)) if other else 1
-        f = _Factor(x.factors[0].basis, None, nc, cvals=numpy.ascontiguousarray(C.reshape(C.shape[0], nc)), rational=x.factors[0].rational)
+        cv = C.reshape(C.shape[0], nc)
+        if again:
+            cv = cv * numpy.asarray(x.factors[0].cvals, dtype=float).reshape(-1, 1)
+        f = _Factor(x.factors[0].basis, None, nc, cvals=numpy.ascontiguousarray(cv), rational=x.factors[0].rational)
         A = numpy.zeros(other + (nc, self.S))
         for c, idx in enumerate(numpy.ndindex(*other)):
             A[idx + (c, 0)] = 1.
@@ -874,7 +934,7 @@ class Matcher:
             else:
                 axes.append(('free', nfree))
                 nfree += 1
-        return _Mono(A, axes, [f])
+        return _Mono(A, axes, [f], x.pw if again else ())
 
     def divide(self, node, args):
         den = args[1]
@@ -912,7 +972,7 @@ class Matcher:
         groups = {}
         for m in monos:
             key = (m.A.shape, m.A.tobytes(), tuple(m.axes), None if m.measure is None else (id(m.measure[0]), m.measure[1]),
-                   tuple((id(f.basis), f.name, f.ncomp, f.part, None if f.rational is None else id(f.rational[1]), id(f.geom), id(f.cvals)) for f in m.factors))
+                   tuple((id(f.basis), f.name, f.ncomp, f.part, None if f.rational is None else id(f.rational[1]), id(f.geom), id(f.cvals), id(getattr(f, 'xnode', None))) for f in m.factors))
             groups.setdefault(key, []).append(m)
         if len(groups) == len(monos):
             return monos
@@ -1340,9 +1400,8 @@ class Emitter:
         xi = rf.transforms_coords(smp.spaces[0], transforms)
         x = numpy.asarray(smp.eval(node), dtype=float)
         jac = numpy.asarray(smp.eval(rf.grad(node, xi)), dtype=float)
-        if '_pos' in s:  # a group of the sample's elements
-            npts = numpy.cumsum([0] + [smp.points[i].npoints for i in range(len(smp.points))])
-            sel = numpy.concatenate([numpy.arange(npts[i], npts[i + 1]) for i in s['_pos']])
+        sel = _sample_rows(smp, s)
+        if sel is not None:
             x, jac = x[sel], jac[sel]
         spec = dict(kind='tab', sample=si, x=x.reshape(nl, nq, nd), jac=jac.reshape(nl, nq, nd, nd))
         self.plan['geoms'].append(spec)
@@ -1381,11 +1440,21 @@ def _ext_normal(T):
 def _point_values(smp, node, s, tail=()):
     v = numpy.asarray(smp.eval(node), dtype=float)
     nq = len(s['weights'])
-    if '_pos' in s:
-        npts = numpy.cumsum([0] + [smp.points[i].npoints for i in range(len(smp.points))])
-        sel = numpy.concatenate([numpy.arange(npts[i], npts[i + 1]) for i in s['_pos']])
+    sel = _sample_rows(smp, s)
+    if sel is not None:
         v = v[sel]
     return v.reshape((s['_nl'], nq) + tuple(tail))
+
+
+def _sample_rows(smp, s):
+    '''rows of `smp.eval(...)` that belong to the points of plan sample `s`, element by element in its list order: the sample's own point indices (sample.py:129:
+    consecutive for default samples, a permutation for samples with custom indices such as `topology.locate`); None: all rows in order'''
+    custom = _kind(smp) != '_DefaultIndex'
+    if '_pos' not in s and not custom:
+        return None
+    pos = s['_pos'] if '_pos' in s else range(smp.nelems)
+    rows = [numpy.asarray(smp.getindex(int(i))) for i in pos]
+    return numpy.concatenate(rows) if rows else numpy.zeros(0, dtype=numpy.int64)
 
 
 def match(array, arguments=None):
@@ -1580,6 +1649,160 @@ def match(array, arguments=None):
     return plan
 
 
+def match_points(array):
+    '''`sample.bind(func)` of the reference (sample.py:217-237: `_ConcatenatePoints`, for samples with their own point indices inside `_ReorderPoints`; what
+    `Sample.eval` hands to function.eval) -> plan of kind 'points'.  `func` must be a sum of (constant tensor) x (values / gradients of fields bound to arguments or to
+    constant coefficient arrays, coordinates) x (coefficient function of the point): no exposed dof axis, no measure.  The result has the reference's shape
+    (npoints, *func.shape) and point order.'''
+    node, reorder = array, False
+    if _kind(node) == '_ReorderPoints':
+        node, reorder = node._func, True
+    if _kind(node) != '_ConcatenatePoints':
+        raise Unmatched(f'node {_kind(array)} at the top of an array')
+    func, smp = node._func, node._sample
+    if len(getattr(smp, 'spaces', ())) != 1 or not hasattr(smp, 'transforms') or not hasattr(smp, 'points'):
+        raise Unmatched(f'points of a {_kind(smp)} sample')
+    if func.dtype not in (float, int, bool) or array.dtype != float:
+        raise Unmatched(f'point function of type {func.dtype}')
+    M = Matcher()
+    M.points_mode = True
+    tr = smp.transforms[0]
+    M.sample, M.S = smp, 1 + tr.todims
+    monos = M.conv(func)
+    E = Emitter(M)
+    anybasis = next((f.basis for m in monos for f in m.factors if f.basis is not _SCALAR and f.basis is not _XGEOM), None)
+
+    def home_of(m):
+        '''the topology a term's elements are numbered in: that of its own first basis (a geometry on the unrefined topology beside a field on the refined one: each term
+        sees the sample's elements located in ITS topology), else that of any basis of the function, else the sample's own'''
+        b = next((f.basis for f in m.factors if f.basis is not _SCALAR and f.basis is not _XGEOM), anybasis)
+        if b is not None:
+            return E.basis_transforms(b)
+        if tr.fromdims == tr.todims:
+            return tr
+        raise Unmatched('boundary sample without any basis: the parent topology is unknown')
+    nd = M.S - 1
+    pterms = []
+    nconst = [0]
+
+    def const_arg(f, bi):
+        key = ('$const', id(f.cvals), bi)
+        if key not in E._arg:
+            E._keep.append(f.cvals)
+            E.plan['args'].append(dict(name=f'_const{nconst[0]}', basis=bi, ncomp=int(f.ncomp), values=numpy.asarray(f.cvals, dtype=float).reshape(-1, f.ncomp)))
+            nconst[0] += 1
+            E._arg[key] = len(E.plan['args']) - 1
+        return E._arg[key]
+
+    def emit(m, si, home):
+        s = E.plan['samples'][si]
+        if m.measure is not None:
+            raise Unmatched('measure inside a function evaluated at points')
+        if any(k != 'free' for k, _ in m.axes):
+            raise Unmatched('basis array evaluated at points (dense npoints x ndofs result)')
+        nf = m.nfree
+        A = numpy.transpose(m.A, [j for _, j in m.axes] + list(range(nf, m.A.ndim)))  # free axes in array order
+        if len(m.factors) > 6:
+            raise Unmatched('more than six field factors in a point function')
+        facs, blocks = [], []
+        for i, f in enumerate(m.factors):
+            blk = [slice(None)] * A.ndim
+            if f.basis is _XGEOM:
+                blk[nf + 2 * i + 1] = slice(1, None)
+                if numpy.abs(A[tuple(blk)]).sum():
+                    raise Unmatched('gradient of a coordinate function')
+                try:
+                    gi = E.geom(f.xnode, smp, si)
+                    if E.plan['geoms'][gi]['kind'] != 'rectilinear':
+                        raise Unmatched('coordinate function without a structural description')
+                except Unmatched:
+                    # not a map the kernels evaluate: its components are coefficient functions of the point like any other
+                    out = []
+                    for c in range(nd):
+                        sub = A[(slice(None),) * (nf + 2 * i) + (c, 0)]
+                        if numpy.abs(sub).sum():
+                            axes = [('free', j) for j in range(nf)]
+                            out += emit(_Mono(sub, axes, m.factors[:i] + m.factors[i + 1:], m.pw + [f.xnode[c]], None), si, home)
+                    return out
+                facs.append(dict(x=gi))
+                blocks.append((nd, 1))
+                continue
+            uses_grad = False
+            blk[nf + 2 * i + 1] = slice(1, None)
+            if numpy.abs(A[tuple(blk)]).sum():
+                uses_grad = True
+            if f.basis is _SCALAR:
+                if uses_grad:
+                    raise Unmatched('gradient of a scalar argument')
+                ai = E.arg(f.name, E.scalar_basis(home), 1)
+                E.plan['args'][ai]['scalar'] = True
+            else:
+                bi = E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None)
+                b = E.plan['bases'][bi]
+                while b['kind'] == 'rational':
+                    b = E.plan['bases'][b['parent']]
+                if b['topo'] != s['topo']:
+                    raise Unmatched('bases of different topologies in one term')
+                if f.cvals is not None:
+                    ai = const_arg(f, bi)
+                elif f.name is None:
+                    raise Unmatched('basis array evaluated at points (dense npoints x ndofs result)')
+                else:
+                    ai = E.arg(f.name, bi, f.ncomp, f.part)
+                if f.part is not None:
+                    raise Unmatched('vectorized bases in a point function')
+            gi = -1
+            if uses_grad:
+                if f.geom is None:
+                    raise Unmatched('gradient slot without a geometry')
+                gi = _geom_index(E, f.geom, smp, si, home)
+            facs.append(dict(arg=ai, geom=gi))
+            blocks.append((f.ncomp, M.S))
+        # the x factors keep their value slot only
+        idx = [slice(None)] * nf
+        for (nc, sl) in blocks:
+            idx += [slice(None), slice(0, sl)]
+        A = numpy.array(A[tuple(idx)], dtype=float, order='C')  # (ascontiguousarray would turn a scalar into a vector)
+        term = dict(sample=si, A=A.reshape(-1), Ashape=list(A.shape), factors=facs, scale=None)
+        if m.pw:
+            pnode = m.pw[0]
+            for q in m.pw[1:]:
+                pnode = pnode * q
+            term['scale'] = _point_values(smp, pnode, s)
+        return [term]
+
+    sis = []
+    for m in monos:
+        home = home_of(m)
+        these = E.sample(smp, home)
+        for si in these if isinstance(these, list) else [these]:
+            pterms += emit(m, si, home)
+            if si not in sis:
+                sis.append(si)
+    plan = E.plan
+    plan['pterms'] = pterms
+    # rows of the result: element i of the sample owns the rows off[i] .. off[i+1] of the concatenation, which the sample's indices place (identity for default samples)
+    psamples = []
+    for si in sis:
+        dest = _sample_rows(smp, plan['samples'][si])
+        if dest is None:
+            dest = numpy.arange(int(array.shape[0]))
+        identity = len(sis) == 1 and len(dest) == int(array.shape[0]) and numpy.array_equal(dest, numpy.arange(len(dest)))
+        psamples.append(dict(sample=si, dest=None if identity else numpy.asarray(dest, dtype=numpy.int64)))
+    plan['psamples'] = psamples
+    for s in plan['samples'] + plan['topos']:
+        for k in [k for k in s if k.startswith('_')]:
+            del s[k]
+    plan['derivs'] = []
+    used = {a['name'] for a in plan['args']}
+    if any(n in used for n in M.derived):
+        plan['derived'] = {n: ast for n, ast in M.derived.items() if n in used}
+    plan['shape'] = [int(n) for n in array.shape]
+    plan['kind'] = 'points'
+    plan['_source'] = array
+    return plan
+
+
 def _tie_components(T, nf, nform, m, facs, form):
     '''Free array axes left at the integral are component axes of exposed vector-valued factors ((ndofs, ncomp) arguments exposed by a
     derivative are handled by the front end; here: basis arrays carry no components): not supported beyond trivial axes.'''
@@ -1713,7 +1936,7 @@ def install(executor=None):
     # plans / as_csr components are remembered per array OBJECT (id + identity check) in bounded LRU maps: a time loop that builds a fresh integral
     # every step must not grow host and device memory without bound -- an evicted plan drops its built tables ('_built') with it
     st = dict(evaluate=rf.evaluate, as_csr=rf.as_csr, system_init=rs.System.__init__, factor_class=rf._Factor, csr=collections.OrderedDict(),
-              plans=collections.OrderedDict(), matched=[], fallback=[], max_plans=PLAN_CACHE_SIZE, fork=rp.fork, forks_refused=0)
+              plans=collections.OrderedDict(), matched=[], fallback=[], max_plans=PLAN_CACHE_SIZE, fork=rp.fork, forks_refused=0, busy=0, declined_points=[], internal_points=[])
 
     def fork_guard(nprocs=None):
         '''parallel.fork (parallel.py:27-88) once the device layer is initialised in this process: NOT forked -- a child would inherit a HIP context it cannot use
@@ -1735,14 +1958,26 @@ def install(executor=None):
     def plan_of(array):
         hit = st['plans'].get(id(array))
         if hit is None or hit[0] is not array:
+            st['busy'] += 1  # (the matcher tabulates coefficient functions through Sample.eval: those evaluations belong to the reference)
             try:
-                plan = match(array)
-                if not build(plan).integral.terms:
-                    raise Unmatched('empty integral')
+                if _kind(array) in ('_ConcatenatePoints', '_ReorderPoints'):  # sample.bind(func): Sample.eval (sample.py:192-232)
+                    plan = match_points(array)
+                    build(plan)
+                else:
+                    plan = match(array)
+                    if not build(plan).integral.terms:
+                        raise Unmatched('empty integral')
             except Unmatched as e:
                 plan = e
+                if _kind(array) in ('_ConcatenatePoints', '_ReorderPoints'):
+                    # (integer / boolean functions -- element indices, masks: topology.select / locate / trim evaluate those -- are not the class of Sample.eval)
+                    st['internal_points' if array.dtype != float else 'declined_points'].append(str(e))
             except Exception as e:  # (an expression shape the matcher does not know must never break the user's script: reference path)
                 plan = Unmatched(f'{type(e).__name__}: {e}')
+                if _kind(array) in ('_ConcatenatePoints', '_ReorderPoints'):
+                    st['declined_points'].append(str(plan))
+            finally:
+                st['busy'] -= 1
             hit = (array, plan)
             remember(st['plans'], id(array), hit, st['max_plans'])
         else:
@@ -1780,6 +2015,8 @@ def install(executor=None):
         return st['factor_class'](array)
 
     def evaluate(*arrays, arguments={}):
+        if st['busy']:  # an evaluation from inside the matcher (coefficient functions, tabulated geometries): the reference's
+            return st['evaluate'](*arrays, arguments=arguments)
         results, rest = [None] * len(arrays), []
         done = {}
         for i, a in enumerate(arrays):
@@ -1811,7 +2048,7 @@ def install(executor=None):
                 dense[numpy.repeat(numpy.arange(n), numpy.diff(rp)), ci] = v
                 results[i] = dense.reshape(plan['shape'])
             else:
-                results[i] = numpy.asarray(out) if plan['kind'] == 'vector' else numpy.float64(out)
+                results[i] = numpy.asarray(out) if plan['kind'] in ('vector', 'points') else numpy.float64(out)
         if rest:
             st['fallback'].append(len(rest))
             for i, r in zip(rest, st['evaluate'](*[arrays[i] for i in rest], arguments=arguments)):
@@ -1820,6 +2057,7 @@ def install(executor=None):
 
     def system_init(self, residual, /, trial, test=None):
         st['system_init'](self, residual, trial=trial, test=test)
+        st['busy'] += 1
         try:
             if isinstance(residual, (tuple, list)):
                 raise Unmatched('residual given as a list of vectors')
@@ -1831,6 +2069,8 @@ def install(executor=None):
         except Exception as e:  # (see plan_of)
             st['fallback'].append(f'System: {type(e).__name__}: {e}')
             return
+        finally:
+            st['busy'] -= 1
         st['matched'].append('System')
         cache = self._System__cache
         zero = lambda arguments: dict(arguments, **{t: numpy.zeros(shape) for t, shape in zip(self.trials, self.trial_shapes)})

@@ -10,7 +10,7 @@ travels to the GPU box except those data files.
 
 Usage:  python oracle/gen_golden.py            (regenerates tests/golden/*.npz)
         python oracle/gen_golden.py --check    (regenerates into a scratch directory and compares with the committed
-                                                files: integer arrays identical, floats to 1e-12; exit status 1 on a difference)
+                                                files: integer arrays identical, floats to 1e-13; exit status 1 on a difference)
 '''
 
 import os
@@ -612,7 +612,7 @@ def check():
                         bad.append(f'{f}[{k}]: integer data differs')
                 elif a.size and not numpy.array_equal(numpy.isnan(a), numpy.isnan(b)):  # (constraint vectors: NaN = free dof)
                     bad.append(f'{f}[{k}]: NaN pattern differs')
-                elif a.size and not numpy.nanmax(numpy.abs(a - b), initial=0.) <= 1e-12 * max(1., numpy.nanmax(numpy.abs(b), initial=0.)):
+                elif a.size and not numpy.nanmax(numpy.abs(a - b), initial=0.) <= 1e-13 * max(1., numpy.nanmax(numpy.abs(b), initial=0.)):
                     bad.append(f'{f}[{k}]: float data differs by {numpy.nanmax(numpy.abs(a - b)):.2e}')
     print(f'{len(names)} fixtures regenerated, {len(bad)} differences')
     for line in bad:

@@ -72,8 +72,56 @@ def _field(smp, arg, geo, l, arguments):
     return numpy.einsum('qns,nc->qcs', D, u[dofs])
 
 
+def evaluate_points(smp, expr, arguments=None):
+    '''Sample.eval of a function.PointExpr on the CPU: [npoints, *shape], elements in list order, each with its points'''
+    arguments = arguments or {}
+    nq, nd = smp.points.npoints, smp.ndims
+    out = numpy.zeros((smp.nlist, nq) + expr.shape)
+    geos = {}
+    from nutils_amd import sample as _s
+    for term in expr.terms:
+        sc = None if term.scale is None else term.scale().reshape(smp.nlist, nq)
+        nf = len(term.factors)
+        nfree = term.A.ndim - 2 * nf
+        for l in range(smp.nlist):
+            ops = []
+            for fac in term.factors:
+                geom = fac[-1] if fac[-1] is not None else _s._default_geometry(smp.topo)
+                if id(geom) not in geos:
+                    geos[id(geom)] = (geom, _Geo(smp, geom))
+                geo = geos[id(geom)][1]
+                if fac[0] == 'field':
+                    ops.append(_field(smp, fac[1], geo, l, arguments))  # [q][c][s]
+                else:
+                    ops.append(_coords(smp, geom, l)[:, :, None])  # [q][axis][1]
+            # value[q][free] = sum A[free, c0, s0, c1, s1, ...] prod_k ops_k[q][c_k][s_k]
+            labels = list(range(1, 1 + term.A.ndim))
+            args = [term.A, labels]
+            for k, op in enumerate(ops):
+                args += [op, [0, 1 + nfree + 2 * k, 2 + nfree + 2 * k]]
+            val = numpy.einsum(*args, [0] + labels[:nfree]) if ops else numpy.broadcast_to(term.A, (nq,) + term.A.shape)
+            out[l] += val * (1. if sc is None else sc[l].reshape((nq,) + (1,) * nfree))
+    return out.reshape((smp.nlist * nq,) + expr.shape)
+
+
+def _coords(smp, geom, l):
+    '''x[q][axis] of list element l'''
+    pts = smp.points.coords
+    ie = l if smp.elist is None else int(smp.elist[l])
+    if isinstance(geom, af.TabulatedGeometry):
+        x = geom.x
+        return x[l] if (smp.elist is not None and len(x) == smp.nlist != smp.nelems) else x[ie]
+    if isinstance(geom, af.IsoGeometry):
+        N, _ = _ref_tables(geom.basis, ie, pts)
+        return N @ geom.verts[_dofs(geom.basis, ie)]
+    origin, size = geom.element_boxes()
+    return origin[ie] + size[ie] * pts
+
+
 def evaluate(integral, arguments=None):
-    '''-> float (no dof axis), array [ndofs(, ncomp)] (one), or (values, rowptr, colidx) (two dof axes; int64 index arrays)'''
+    '''-> float (no dof axis), array [ndofs(, ncomp)] (one), or (values, rowptr, colidx) (two dof axes; int64 index arrays); a (sample, PointExpr) pair: evaluate_points'''
+    if isinstance(integral, tuple):
+        return evaluate_points(integral[0], integral[1], arguments)
     arguments = arguments or {}
     kinds = {(itg.rows, itg.cols) for _, itg, _ in integral.terms}
     if len(kinds) != 1:

@@ -39,6 +39,8 @@ def run_hip(name):
 def _pack(plan, out):
     if plan['kind'] == 'matrix':
         return dict(values=out[0], rowptr=out[1], colidx=out[2])
+    if plan['kind'] == 'points':
+        return dict(points=numpy.asarray(out, dtype=float))
     if plan['kind'] == 'vector':
         return dict(vector=numpy.asarray(out, dtype=float))
     return dict(scalar=numpy.asarray(float(out)))
@@ -52,6 +54,10 @@ def compare(out, expect, rtol=1e-13):
     elif 'vector' in expect:
         ref = expect['vector']
         err = numpy.abs(out['vector'].reshape(ref.shape) - ref).max() / numpy.abs(ref).max()
+    elif 'points' in expect:
+        ref = expect['points']
+        assert out['points'].shape == ref.shape
+        err = numpy.abs(out['points'] - ref).max() / max(numpy.abs(ref).max(), 1e-300)
     else:
         err = abs(float(out['scalar']) - float(expect['scalar'])) / abs(float(expect['scalar']))
     assert err < rtol, err
@@ -74,8 +80,8 @@ def load_example(name):
     plan, expect = seam.load(os.path.join(EXAMPLE_PLANS, name + '.npz'))
     args = {k[4:]: v for k, v in expect.items() if k.startswith('arg_')}
     args2 = {k[5:]: v for k, v in expect.items() if k.startswith('arg2_')}
-    later = {k[:-1]: v for k, v in expect.items() if k in ('values2', 'rowptr2', 'colidx2', 'vector2', 'scalar2')}
-    first = {k: v for k, v in expect.items() if k in ('values', 'rowptr', 'colidx', 'vector', 'scalar')}
+    later = {k[:-1]: v for k, v in expect.items() if k in ('values2', 'rowptr2', 'colidx2', 'vector2', 'scalar2', 'points2')}
+    first = {k: v for k, v in expect.items() if k in ('values', 'rowptr', 'colidx', 'vector', 'scalar', 'points')}
     return plan, args, first, (args2, later) if later else None
 
 
@@ -105,6 +111,15 @@ def compare_example(plan, out, expect, args, rtol=1e-13, floor=32 * 2.3e-16):
     if plan['kind'] == 'matrix':
         assert numpy.array_equal(out[1], expect['rowptr']) and numpy.array_equal(out[2], expect['colidx'])
         err = numpy.abs(out[0] - expect['values']).max() / (rtol * max(numpy.abs(expect['values']).max(), 1e-300)) if len(expect['values']) else 0.
+    elif plan['kind'] == 'points':
+        # function values at the points of a sample (Sample.eval): the reference's shape exactly, every entry to 1e-13 of the largest entry PLUS 1e-13 of what the entry is a sum
+        # of (x + u with x = O(1): the arguments' largest coefficient and 1 for the coordinates / coefficient functions) -- a difference u - uexact near zero cancels
+        ref = numpy.asarray(expect['points'], dtype=float)
+        mine = numpy.asarray(out, dtype=float)
+        assert mine.shape == ref.shape, (mine.shape, ref.shape)
+        scale = max([numpy.abs(ref).max() if ref.size else 0., 1.] + [float(numpy.abs(numpy.asarray(v, dtype=float)).max()) for v in (args or {}).values()
+                                                                    if numpy.size(v) and numpy.asarray(v).dtype.kind in 'fiub'])
+        err = (numpy.abs(mine - ref).max() / (rtol * scale)) if ref.size else 0.
     else:
         ref = numpy.asarray(expect['vector'] if plan['kind'] == 'vector' else expect['scalar'], dtype=float)
         mine = numpy.asarray(out, dtype=float).reshape(ref.shape)

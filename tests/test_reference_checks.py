@@ -4,7 +4,7 @@
     Rust dependency nutils_poly (oracle/run_reference_checks.py: examples + the Polyval/PolyMul/PolyGrad checks of
     tests/test_evaluable.py; the 2130 tests of tests.test_basis run in the script's full mode);
   * the committed fixtures tests/golden/*.npz are what oracle/gen_golden.py produces from the real reference today
-    (index arrays identical, floats to 1e-12).
+    (index arrays identical, floats to 1e-13).
 '''
 import os
 import subprocess

@@ -47,7 +47,7 @@ def main(out, modules):
     os.chdir(tempfile.mkdtemp())
     problems = []
     for name in modules:
-        seen, count = {}, [0]
+        seen, count, pcount = {}, [0], [0]  # (point-evaluation plans are numbered apart: `<example>_pts_NNN`, so that the integral plans keep their names)
 
         def reference(plan, arguments, nrows=None):
             '''the reference's own result for the array the plan was matched from, through its un-hooked entry points'''
@@ -78,6 +78,9 @@ def main(out, modules):
                 assert not len(ref[0]) or numpy.abs(res[0] - ref[0]).max() <= 1e-13 * max(scale, 1e-300), ('values', numpy.abs(res[0] - ref[0]).max() / scale)
                 expect = dict(values=ref[0], rowptr=ref[1], colidx=ref[2])
                 ret = res
+            elif plan['kind'] == 'points':
+                ret = numpy.asarray(res, dtype=float)
+                expect = dict(points=ref)
             elif plan['kind'] == 'scalar':
                 ret = float(res)
                 expect = dict(scalar=numpy.asarray(float(ref)))
@@ -92,15 +95,16 @@ def main(out, modules):
             if id(plan) not in seen:
                 for k, v in numeric.items():
                     expect['arg_' + k] = v
-                seen[id(plan)] = dict(plan=plan, path=os.path.join(out, f'{name}_{count[0]:03d}.npz'), first=expect, args=numeric, later=False)  # (plan kept alive: ids are not recycled)
+                ctr, tag = (pcount, 'pts_') if plan['kind'] == 'points' else (count, '')
+                seen[id(plan)] = dict(plan=plan, path=os.path.join(out, f'{name}_{tag}{ctr[0]:03d}.npz'), first=expect, args=numeric, later=False)  # (plan kept alive: ids are not recycled)
                 seam.save(seen[id(plan)]['path'], {k: v for k, v in plan.items() if not k.startswith('_')}, expect)
-                count[0] += 1
+                ctr[0] += 1
             else:
                 # a LATER evaluation of the same plan with other arguments (a Newton iteration, the next time step): stored once, as `*2` / `arg2_*`,
                 # so that the replay re-executes the built plan with new arguments
                 rec = seen[id(plan)]
                 same = set(numeric) == set(rec['args']) and all(numpy.array_equal(numeric[k], rec['args'][k]) for k in numeric)
-                if not rec['later'] and not same and plan['kind'] != 'matrix' or not rec['later'] and not same and any(t.get('fpoly') is not None for t in plan['terms']):
+                if not rec['later'] and not same and plan['kind'] != 'matrix' or not rec['later'] and not same and any(t.get('fpoly') is not None for t in plan.get('terms', [])):
                     rec['later'] = True
                     both = dict(rec['first'])
                     for k, v in expect.items():
@@ -118,7 +122,7 @@ def main(out, modules):
                 mod.main(**kwargs)
             finally:
                 seam.uninstall()
-            print(f'{name}: main({kwargs}); {count[0]} distinct plans written')
+            print(f'{name}: main({kwargs}); {count[0]} + {pcount[0]} (points) distinct plans written')
             continue
         mod = importlib.import_module('examples.' + name)
         st = seam.install(executor)
@@ -126,12 +130,55 @@ def main(out, modules):
             res = unittest.TextTestRunner(verbosity=0, stream=open(os.devnull, 'w')).run(unittest.defaultTestLoader.loadTestsFromTestCase(mod.test))
         finally:
             seam.uninstall()
-        print(f'{name}: {res.testsRun} reference tests, {len(res.failures)} failures, {len(res.errors)} errors; {count[0]} distinct plans written')
+        print(f'{name}: {res.testsRun} reference tests, {len(res.failures)} failures, {len(res.errors)} errors; {count[0]} + {pcount[0]} (points) distinct plans written')
     for p in problems:
         print('MISMATCH', p)
     if problems:
         raise SystemExit(1)
 
 
+def check(committed, modules):
+    '''--check: capture the plans of `modules` again (into a scratch directory) and compare every file with the committed fixture of the same name: the plan
+    (structure and every array) and the reference's results stored beside it.  -> number of files compared; raises SystemExit on the first difference.'''
+    scratch = tempfile.mkdtemp()
+    main(scratch, modules)
+    names = sorted(os.listdir(scratch))
+    bad = []
+    for f in names:
+        path = os.path.join(committed, f)
+        if not os.path.exists(path):
+            bad.append(f'{f}: not among the committed fixtures')
+            continue
+        new, old = numpy.load(os.path.join(scratch, f), allow_pickle=False), numpy.load(path, allow_pickle=False)
+        if sorted(new.files) != sorted(old.files) or str(new['spec']) != str(old['spec']):
+            bad.append(f'{f}: plan structure differs')
+            continue
+        for k in new.files:
+            if k == 'spec':
+                continue
+            a, b = new[k], old[k]
+            if a.shape != b.shape or a.dtype != b.dtype:
+                bad.append(f'{f}: array {k} differs in shape / type')
+            elif a.dtype.kind == 'f':
+                if not numpy.array_equal(numpy.isnan(a), numpy.isnan(b)) or (a.size and numpy.abs(numpy.nan_to_num(a - b)).max() > 1e-13 * max(1e-300, numpy.abs(numpy.nan_to_num(b)).max())):
+                    bad.append(f'{f}: array {k} differs by more than 1e-13 of its largest entry')
+            elif not numpy.array_equal(a, b):
+                bad.append(f'{f}: index array {k} differs')
+    committed_names = {f for f in os.listdir(committed) if any(f.startswith(m + '_') for m in modules)}
+    missing = sorted(committed_names - set(names))
+    bad += [f'{f}: committed, not reproduced' for f in missing]
+    for b in bad:
+        print('DIFFERENT', b)
+    print(f'check: {len(names)} plans of {", ".join(modules)} captured again, {len(bad)} differences from {committed}')
+    if bad:
+        raise SystemExit(1)
+    return len(names)
+
+
+ALL = ['laplace', 'elasticity', 'poisson', 'platewithhole', 'adaptivity', 'cahnhilliard', 'drivencavity', 'burgers', 'finitestrain', 'cylinderflow']
+
 if __name__ == '__main__':
-    main(sys.argv[1], MEDIUM if sys.argv[2:] == ['--medium'] else sys.argv[2:] or ['laplace', 'elasticity', 'poisson', 'platewithhole', 'adaptivity', 'cahnhilliard', 'drivencavity', 'burgers', 'finitestrain'])
+    if sys.argv[1] == '--check':  # python tools/hip_plan_capture.py --check tests/golden/plans_examples [example ...]
+        check(os.path.abspath(sys.argv[2]), sys.argv[3:] or ALL)
+    else:
+        main(sys.argv[1], MEDIUM if sys.argv[2:] == ['--medium'] else sys.argv[2:] or ALL)
