@@ -427,6 +427,8 @@ __global__ __launch_bounds__(256) void k_matrix_generic(MatK p, FormK formarg) {
   }
 }
 
+#include "nh_gram_sym.inc"
+
 // ---------------------------------------------------------------------------------------------------------------------
 // MFMA path for large local matrices (p >= 2, vector fields): one WORKGROUP (4 waves) per element, the local contraction as
 // GEMMs on v_mfma_f64_16x16x4_f64.  For each test component c:
@@ -1007,6 +1009,11 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   }
   hipStream_t s = nh_stream(stream);
   auto launch_generic = [&](MatK q) -> int {  // q.nelems / elist / maxnb* select the elements, LDS sized for them
+    if (q.local) {  // symmetric two-component blocks on the way to the gather scratch: the instruction-lean kernel of nh_gram_sym.inc
+      bool taken = false;
+      const int rg = nh_gram_sym_launch(q, form, a->ndims, &taken, s);
+      if (rg != NH_OK || taken) return rg;
+    }
     const int per_q0 = (q.same ? q.maxnbt : q.maxnbt + q.maxnbr) * S * (int)sizeof(double);
     const int per_qw = per_q0 + q.maxnbr * a->nct * a->ncr * S * (int)sizeof(double);
     const size_t fixed = sizeof(double) * ((size_t)form.formd + (size_t)a->nq * JW);

@@ -1936,7 +1936,7 @@ def install(executor=None):
     # plans / as_csr components are remembered per array OBJECT (id + identity check) in bounded LRU maps: a time loop that builds a fresh integral
     # every step must not grow host and device memory without bound -- an evicted plan drops its built tables ('_built') with it
     st = dict(evaluate=rf.evaluate, as_csr=rf.as_csr, system_init=rs.System.__init__, factor_class=rf._Factor, csr=collections.OrderedDict(),
-              plans=collections.OrderedDict(), matched=[], fallback=[], max_plans=PLAN_CACHE_SIZE, fork=rp.fork, forks_refused=0, busy=0, declined_points=[], internal_points=[])
+              plans=collections.OrderedDict(), point_plans=collections.OrderedDict(), matched=[], fallback=[], max_plans=PLAN_CACHE_SIZE, fork=rp.fork, forks_refused=0, busy=0, declined_points=[], internal_points=[])
 
     def fork_guard(nprocs=None):
         '''parallel.fork (parallel.py:27-88) once the device layer is initialised in this process: NOT forked -- a child would inherit a HIP context it cannot use
@@ -1956,7 +1956,10 @@ def install(executor=None):
                 plan.pop('_built', None)
 
     def plan_of(array):
-        hit = st['plans'].get(id(array))
+        # (sample.bind builds a fresh array per Sample.eval call: those plans live in a small map of their own, so that a time loop that plots every step does not evict
+        # the integral plans of its Systems)
+        cache, limit = (st['point_plans'], 16) if _kind(array) in ('_ConcatenatePoints', '_ReorderPoints') else (st['plans'], st['max_plans'])
+        hit = cache.get(id(array))
         if hit is None or hit[0] is not array:
             st['busy'] += 1  # (the matcher tabulates coefficient functions through Sample.eval: those evaluations belong to the reference)
             try:
@@ -1979,9 +1982,9 @@ def install(executor=None):
             finally:
                 st['busy'] -= 1
             hit = (array, plan)
-            remember(st['plans'], id(array), hit, st['max_plans'])
+            remember(cache, id(array), hit, limit)
         else:
-            st['plans'].move_to_end(id(array))
+            cache.move_to_end(id(array))
         return hit[1]
 
     def run(plan, arguments):

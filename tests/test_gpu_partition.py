@@ -177,3 +177,59 @@ def test_bench_modes_multiprocess_on_one_gpu(args, nel):
     assert ('strong' if '--scaling' in args else 'weak') in rec  # the other mode rides along
     assert rec['config']['nelems_per_gpu'] == nel and rec['value'] > 0
     assert rec['checks']['owned_row_sums_rel'] < 1e-12
+
+
+@pytest.mark.parametrize('halo', ['reduce', 'recompute'])
+@pytest.mark.parametrize('shape,degree,ncomp,world', [([7, 6, 5], 1, 1, 3), ([10, 9], 2, 2, 4)])
+def test_element_partition_of_an_unstructured_mesh(shape, degree, ncomp, world, halo):
+    '''partition.ElementPartition on an element list in shuffled order (what an imported unstructured mesh gives): every "rank" assembles its local mesh -- own + ghost elements,
+    GLOBAL dof numbers -- with the real kernels through the front end; with halo='reduce' the ghosts contribute structural zeros (a 0 / 1 coefficient per element) and the partial
+    shared rows travel as SharedRowPlan prescribes (nh_index_copy to pack, nh_monomial with an output index to add; the network hop is left out), with halo='recompute' the ghosts
+    are assembled as well.  The owners' rows merged in row order equal the single-mesh matrix: index arrays bit-exact, values to 1e-13.'''
+    import torch
+    from nutils_amd import mesh, function, topology, partition, device
+    rng = numpy.random.default_rng(4)
+    axes = [numpy.cumsum(numpy.r_[0., rng.uniform(.5, 1.5, n)]) for n in shape]
+    sdomain, sgeom = mesh.rectilinear(axes)
+    sbasis = sdomain.basis('std', degree=degree)
+    perm = rng.permutation(len(sdomain))
+    origin, size = sgeom.element_boxes()
+    coeffs, dofs = [sbasis.get_coefficients(e) for e in perm], [numpy.asarray(sbasis.get_dofs(e)) for e in perm]
+    nd = len(shape)
+
+    def matrix(elements, live):
+        topo = topology.ElementList(origin[perm][elements], size[perm][elements])
+        basis = topo.plain_basis([coeffs[e] for e in elements], [dofs[e] for e in elements], sbasis.ndofs)
+        smp = topo.sample('gauss', 2 * degree)
+        if ncomp == 1:
+            itg = function.outer(function.grad(basis, topo.geom)).sum(-1) + .3 * function.outer(basis)
+            K = smp.integral(itg * function.J(topo.geom) * function.PointTable(numpy.repeat(live.astype(float), smp.points.npoints).reshape(len(elements), -1)))
+        else:
+            u, v = function.field('u', basis, shape=[ncomp]), function.field('v', basis, shape=[ncomp])
+            sig = 1.3 * function.div(u, topo.geom) * function.eye(nd) + 2 * function.symgrad(u, topo.geom)
+            res = smp.integral(function.inner(function.symgrad(v, topo.geom), sig) * function.J(topo.geom)
+                               * function.PointTable(numpy.repeat(live.astype(float), smp.points.npoints).reshape(len(elements), -1)))
+            K = function.derivative(function.derivative(res, 'v'), 'u')
+        return function.eval(function.as_csr(K))
+
+    offsets = numpy.cumsum([0] + [len(d) for d in dofs])
+    part = partition.ElementPartition(offsets, numpy.concatenate(dofs), sbasis.ndofs, world, ncomp=ncomp, halo=halo)
+    plans, vals = [], []
+    for rank in range(world):
+        el, live = part.local_elements(rank)
+        v, rp, ci = matrix(el, live)
+        plans.append(partition.SharedRowPlan(part, rank, rp, ci))
+        vals.append(device.to_dev(v, 'float64'))
+    offers = [p.offer() for p in plans]
+    for p in plans:
+        p.accept(offers)
+    assert any(p.send for p in plans) == (halo == 'reduce')
+    for dst in range(world):  # what batch_isend_irecv moves in SharedRowPlan.exchange; the owner adds its sources in rank order
+        for src in sorted(plans[dst].recv):
+            plans[dst].add(vals[dst], src, plans[src].pack(vals[src], dst))
+    torch.cuda.synchronize()
+    v, rp, ci = partition.merge_rows([p.owned_block(x) for p, x in zip(plans, vals)], sbasis.ndofs * ncomp)
+    ne = len(perm)
+    vo, rpo, cio = matrix(numpy.arange(ne), numpy.ones(ne, dtype=bool))
+    assert numpy.array_equal(rp, rpo) and numpy.array_equal(ci, cio)
+    assert numpy.abs(v - vo).max() <= 1e-13 * numpy.abs(vo).max()

@@ -114,3 +114,117 @@ def test_slab_bookkeeping():
     assert (r0.value_layers, r0.written_planes) == ((0, 4), (0, 4)) and (r2.value_layers, r2.written_planes) == ((0, 5), (1, 6))
     t1 = partition.Slab(4, 1, 3, (5, 6), degree=2, ncomp=3, halo='recompute')
     assert (t1.value_layers, t1.written_planes) == ((0, 5), (2, 10))
+
+
+# ---- any mesh: ElementPartition / SharedRowPlan (element ranges after a dof-locality sort, shared rows from host index lists) -------------------------------
+
+def simplex_mesh(n, seed=3):
+    '''an unstructured mesh of triangles with P1 dofs: n x n squares split along alternating diagonals, elements in a shuffled order'''
+    idx = numpy.arange((n + 1) * (n + 1)).reshape(n + 1, n + 1)
+    tri = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = idx[i, j], idx[i + 1, j], idx[i, j + 1], idx[i + 1, j + 1]
+            tri += [[a, b, d], [a, d, c]] if (i + j) % 2 else [[a, b, c], [b, d, c]]
+    tri = numpy.array(tri)[numpy.random.default_rng(seed).permutation(2 * n * n)]
+    return numpy.arange(len(tri) + 1) * 3, tri.ravel(), (n + 1) ** 2
+
+
+def plate_mesh():
+    '''the ragged connectivity of the hierarchical NURBS fixture (BASELINE.json configs[4]: p = 3 th-splines over 10 levels, 16-24 functions per element)'''
+    g = numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'iga_plate_p3_l10.npz'))
+    return g['dof_offsets'].astype(numpy.int64), g['dofs'].astype(numpy.int64), int(g['ndofs'])
+
+
+def local_matrices(offsets, ncomp):
+    '''seeded stand-in for the element kernels: one (nb ncomp) x (nb ncomp) matrix per element, the same whoever computes it'''
+    rng = numpy.random.default_rng(11)
+    return [rng.normal(size=(int(nb) * ncomp, int(nb) * ncomp)) for nb in numpy.diff(offsets)]
+
+
+def coo_of(elements, live, offsets, dofs, A, ncomp):
+    v, r, c = [], [], []
+    for e, alive in zip(elements, live):
+        d = dofs[offsets[e]:offsets[e + 1]]
+        flat = (d[:, None] * ncomp + numpy.arange(ncomp)).ravel()
+        v.append((A[e] if alive else numpy.zeros_like(A[e])).ravel())  # (ghosts of halo='reduce': pattern only -- structural zeros)
+        r.append(numpy.repeat(flat, len(flat)))
+        c.append(numpy.tile(flat, len(flat)))
+    return numpy.concatenate(v), numpy.concatenate(r), numpy.concatenate(c)
+
+
+def mesh_of(name):
+    return simplex_mesh(7) if name == 'simplex' else plate_mesh()
+
+
+def partition_worker(rank, world, port, name, ncomp, halo, tmp):
+    import torch
+    import torch.distributed as dist
+    from nutils_amd import partition
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    offsets, dofs, ndofs = mesh_of(name)
+    part = partition.ElementPartition(offsets, dofs, ndofs, world, ncomp=ncomp, halo=halo)
+    el, live = part.local_elements(rank)
+    # oracle stand-in for this rank's device assembly: the local mesh (own + ghost elements) in GLOBAL numbering, the reference's dedup (oracle/assemble.py)
+    values, rowptr, colidx = oa.dedup_csr(*coo_of(el, live, offsets, dofs, local_matrices(offsets, ncomp), ncomp), ndofs * ncomp, ndofs * ncomp)
+    plan = partition.SharedRowPlan(part, rank, rowptr, colidx)
+    plan.setup()
+    assert bool(plan.send or plan.recv) == (halo == 'reduce')
+    tv = torch.from_numpy(values.copy())
+    plan.exchange(tv)
+    rows, lens, cols, vals = plan.owned_block(tv)
+    numpy.savez(os.path.join(tmp, f'rows{rank}.npz'), rows=rows, lens=lens, cols=cols, vals=vals, nsent=sum(len(p) for _, p in plan.send.values()), nlocal=len(values))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,world,ncomp,halo', [('simplex', 2, 1, 'reduce'), ('simplex', 3, 2, 'reduce'), ('simplex', 3, 1, 'recompute'),
+                                                   ('plate', 2, 2, 'reduce'), ('plate', 3, 2, 'reduce'), ('plate', 3, 2, 'recompute')])
+def test_element_partition_gloo(tmp_path, name, world, ncomp, halo):
+    '''An unstructured simplex mesh (shuffled element order) and the ragged hierarchical connectivity of the configs[4] fixture, partitioned over 2 / 3 gloo ranks: the owners'
+    rows merged in row order are the single-process CSR -- index arrays bit-exact, structural zeros included --, values equal up to the order of the sums (1e-13); with
+    halo='reduce' only the values of shared rows travel.'''
+    import torch.multiprocessing as mp
+    from nutils_amd import partition
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(partition_worker, args=(world, port, name, ncomp, halo, str(tmp_path)), nprocs=world, join=True)
+    offsets, dofs, ndofs = mesh_of(name)
+    blocks, sent, local = [], 0, 0
+    for r in range(world):
+        d = numpy.load(tmp_path / f'rows{r}.npz')
+        blocks.append((d['rows'], d['lens'], d['cols'], d['vals']))
+        sent += int(d['nsent'])
+        local += int(d['nlocal'])
+    v, rp, ci = partition.merge_rows(blocks, ndofs * ncomp)
+    ne = len(offsets) - 1
+    vo, rpo, cio = oa.dedup_csr(*coo_of(numpy.arange(ne), numpy.ones(ne, dtype=bool), offsets, dofs, local_matrices(offsets, ncomp), ncomp), ndofs * ncomp, ndofs * ncomp)
+    assert numpy.array_equal(rp, rpo) and numpy.array_equal(ci, cio) and rp.dtype == numpy.int64 and ci.dtype == numpy.int64
+    assert numpy.abs(v - vo).max() <= 1e-13 * numpy.abs(vo).max()
+    assert (sent > 0) == (halo == 'reduce') and sent < local  # (the payload is a part of the shared rows, never whole matrices)
+
+
+def test_element_partition_bookkeeping():
+    from nutils_amd import partition
+    offsets, dofs, ndofs = simplex_mesh(6)
+    part = partition.ElementPartition(offsets, dofs, ndofs, 4)
+    ne = len(offsets) - 1
+    own = [part.own_elements(r) for r in range(4)]
+    assert sorted(numpy.concatenate(own).tolist()) == list(range(ne)) and min(len(o) for o in own) >= ne // 4 - 1
+    rows = numpy.concatenate([part.owned_rows(r) for r in range(4)])
+    assert sorted(rows.tolist()) == list(range(ndofs))  # every row has exactly one owner
+    for r in range(4):
+        ghosts = part.ghost_elements(r)
+        assert not numpy.isin(ghosts, own[r]).any()
+        # every element that touches an owned row is in the local mesh: the owner's pattern is complete
+        touch = numpy.unique(numpy.repeat(numpy.arange(ne), 3)[numpy.isin(dofs, part.owned_rows(r))])
+        assert numpy.isin(touch, part.local_elements(r)[0]).all()
+        for o, frows in part.foreign_rows(r).items():
+            assert o < r and (part.owner[frows] == o).all()  # (the owner is the LOWEST rank that touches a row)
+    with pytest.raises(ValueError):
+        partition.ElementPartition(offsets, dofs, ndofs, ne + 1)
+    # weights: equal element counts when every element weighs the same; vector fields own whole dofs
+    p2 = partition.ElementPartition(offsets, dofs, ndofs, 3, ncomp=2)
+    assert numpy.array_equal(p2.owned_rows(1).reshape(-1, 2)[:, 1], p2.owned_rows(1).reshape(-1, 2)[:, 0] + 1)
