@@ -223,11 +223,11 @@ typedef struct {
                                         one call, no elist, test and trial on one dof array).  The dofs are clustered by the Morton code of the
                                         centroid of the first element that contains them; Morton boxes of at most R rows form a block, and a
                                         block recomputes what it needs of every element touching one of its rows and writes each of its CSR rows
-                                        once.  SCALAR blocks on small uniform bases (2 .. 9 functions per element): every contribution (element,
-                                        m, n) to a row of the block has its own LDS slot, the slots of a CSR entry adjacent and in ascending
-                                        (element, m, n) order; the visiting elements STORE their local matrices there and every entry is summed
-                                        over its slots front to back -- the order of NH_MATRIX_GATHER, i.e. of the reference's numpy.add.at:
-                                        bit-identical to the gather path, 1.5 x the algorithmic bytes instead of 4.6 x.  Trilinear hexahedra at
+                                        once.  SCALAR blocks on small uniform bases (2 .. 9 functions per element): the rows of a block are ONE
+                                        set of accumulators in LDS; the visiting elements add their local matrices in TURNS -- turn t holds the
+                                        t-th visitor of every row in ascending (element, m) order, so no two threads meet in a row, a workgroup
+                                        barrier separates the turns -- which is the order of NH_MATRIX_GATHER, i.e. of the reference's
+                                        numpy.add.at: bit-identical to the gather path, 1.4 x the algorithmic bytes instead of 4.6 x.  Trilinear hexahedra at
                                         the 2 x 2 x 2 Gauss points with a form kappa grad.grad + mass phi phi (recognised from the tables passed)
                                         take the sum-factorised element routine of nh_p1hex_laplace (an exactly singular element then gives inf /
                                         NaN instead of numeric.inv's all-NaN inverse).  VECTOR-VALUED blocks (nct = ncr = 2 or 3 on trilinear

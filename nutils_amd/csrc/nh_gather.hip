@@ -182,6 +182,40 @@ __global__ void k_gather_values_v(i64 nnz, const unsigned *gptr, const int32_t *
     }
 }
 
+// 2 x 2 blocks, all four component blocks present (plane elasticity): the general kernel above with its run-time component count keeps 48 registers of accumulators and
+// staging and two contributions in flight; here four accumulators, FOUR contributions in flight (index loads, then 32-byte value loads, then the sums in the order of the
+// map) and two 16-byte stores.  The same sums in the same order: bit-identical.
+__global__ void k_gather_values_2x2(i64 nnz, const unsigned *gptr, const int32_t *gsrc, const int32_t *grow, const i64 *srowptr, const double *local, GSlots gs, double *values,
+                                    int store) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const unsigned b = gptr[k], e = gptr[k + 1];
+  const i64 r = grow[k], a0 = srowptr[r], len = srowptr[r + 1] - a0, pos = k - a0;
+  double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+  for (unsigned i0 = b; i0 < e; i0 += 4) {
+    unsigned idx[4];
+    double2 lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) idx[u] = i0 + u < e ? (unsigned)gsrc[i0 + u] : 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double2 *src = reinterpret_cast<const double2 *>(local + (i64)(idx[u] != 0xffffffffu ? idx[u] : 0u) * 4);
+      lo[u] = src[0], hi[u] = src[1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u < e) s00 += lo[u].x, s01 += lo[u].y, s10 += hi[u].x, s11 += hi[u].y;
+  }
+  // rows (node, c) of the expanded pattern: the entries (n, d = 0, 1) of a row are adjacent
+  double *d0 = values + a0 * gs.tot + len * gs.cum[0] + pos * gs.cnt[0] + gs.dpos[0][0];
+  double *d1 = values + a0 * gs.tot + len * gs.cum[1] + pos * gs.cnt[1] + gs.dpos[1][0];
+  if (store) {
+    d0[0] = s00, d0[1] = s01, d1[0] = s10, d1[1] = s11;
+  } else {
+    d0[0] += s00, d0[1] += s01, d1[0] += s10, d1[1] += s11;
+  }
+}
+
 // ---- pass 1 for small scalar elements: ONE THREAD per element, the local matrix in registers --------------------------------------------
 // (the one-wave-per-element kernel spends ~500 wave instructions on a trilinear element: lanes idle in the pointwise stages, LDS staging,
 // barriers; a thread that keeps the NBT x NBR sums in registers needs ~90 per element and no LDS at all)
@@ -1154,6 +1188,9 @@ int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSl
   if (sym_sources) {
     NH_REQUIRE(p->gsrc_sym && slots.nct == slots.ncr && (slots.nct == 2 || slots.nct == 3), "gather: symmetric sources need their map and 2 x 2 / 3 x 3 blocks");
     hipLaunchKernelGGL(k_gather_values_v<true>, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc_sym, p->grow, p->srowptr, local, slots, values, store);
+  } else if (slots.nct == 2 && slots.ncr == 2 && slots.mask[0][0] && slots.mask[0][1] && slots.mask[1][0] && slots.mask[1][1] && slots.dpos[0][1] == slots.dpos[0][0] + 1 &&
+             slots.dpos[1][1] == slots.dpos[1][0] + 1 && !getenv("NUTILS_AMD_NO_GATHER_2X2")) {
+    hipLaunchKernelGGL(k_gather_values_2x2, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, slots, values, store);
   } else if (slots.nct * slots.ncr == 1)
     hipLaunchKernelGGL(k_gather_values, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc, p->grow, p->srowptr, local, ld, p->nbt * p->nbr, slots,
                        values, store);

@@ -95,6 +95,9 @@ class Pattern:
             self._handle = None
 
 
+UNION_MAX = 8  # NH_UNION_MAX of nh_pattern.hip
+
+
 def pattern_union(parts):
     '''Union of sorted-unique CSR patterns [(rowptr, colidx)] with equal row counts (nh_pattern_union_*): (rowptr, colidx, [position of every entry of part i in
     the union]).  Row-wise merge of sorted lists on the device; replaces the sort-based unique of the reference (evaluable.py:5560-5682).'''
@@ -102,6 +105,18 @@ def pattern_union(parts):
     nrows = parts[0][0].numel() - 1
     if any(rp.numel() - 1 != nrows for rp, _ in parts):
         raise ValueError('pattern_union: parts with different numbers of rows')
+    if n > UNION_MAX:
+        # more parts than one merge takes (NH_UNION_MAX): fold -- the union of the first UNION_MAX parts, then that union with the next UNION_MAX - 1, ...; the positions of a
+        # part in an intermediate union are carried through the later ones
+        rowptr, colidx, pos = pattern_union(parts[:UNION_MAX])
+        at = UNION_MAX
+        while at < n:
+            more = parts[at:at + UNION_MAX - 1]
+            rowptr2, colidx2, pos2 = pattern_union([(rowptr, colidx)] + more)
+            pos = [pos2[0][q] for q in pos] + pos2[1:]
+            rowptr, colidx = rowptr2, colidx2
+            at += len(more)
+        return rowptr, colidx, pos
     RP = (ctypes.c_void_p * n)(*[rp.data_ptr() for rp, _ in parts])
     CI = (ctypes.c_void_p * n)(*[ci.data_ptr() for _, ci in parts])
     rowptr = device.empty(nrows + 1, 'int64')

@@ -270,6 +270,9 @@ class ElasticityP2:
         self.values = device.zeros(self.nnz, 'float64')  # write-once kernel: no zero-fill per step (rows of a ghost plane are never written)
         owners = s.written_planes[0] // 2, (s.written_planes[1] - 1) // 2
         if self.variant == 'uniform':
+            if self.world > 1 and s.halo == 'reduce':
+                # (the uniform-cell kernel replicates COMPLETE rows into every written plane: the received partial rows of the interface would be counted twice)
+                raise ValueError("variant='uniform' writes complete rows: use halo='recompute' with more than one rank")
             self._launch = kernels.P2HexUniform(shape=self.shape, nq=self.smp.points.npoints, weights=self.smp._weights_dev, T=self.tables.T, ncomp=3, C=self.C,
                                                 cell=(1., 1., 1.), owners=owners)
         else:

@@ -59,17 +59,24 @@ class _Geo:
         self.wdet = det * smp.points.weights
 
 
+_ABS = False  # evaluate(..., absolute=True): every factor by its absolute value -- the result bounds the sum of the |products| an entry is made of
+
+
+def _a(x):
+    return numpy.abs(x) if _ABS else x
+
+
 def _tables(smp, basis, geo, l):
     ie = l if smp.elist is None else int(smp.elist[l])
     N, dN = _ref_tables(basis, ie, smp.points.coords)
-    G = numpy.einsum('qmj,qji->qmi', dN, geo.Jinv[l])
-    return numpy.concatenate([N[..., None], G], axis=-1), _dofs(basis, ie)
+    G = numpy.einsum('qmj,qji->qmi', _a(dN), _a(geo.Jinv[l]))
+    return numpy.concatenate([_a(N)[..., None], G], axis=-1), _dofs(basis, ie)
 
 
 def _field(smp, arg, geo, l, arguments):
     D, dofs = _tables(smp, arg.basis, geo, l)
     u = numpy.asarray(arguments[arg.name], dtype=float).reshape(arg.basis.ndofs, arg.ncomp)
-    return numpy.einsum('qns,nc->qcs', D, u[dofs])
+    return numpy.einsum('qns,nc->qcs', D, _a(u[dofs]))
 
 
 def evaluate_points(smp, expr, arguments=None):
@@ -118,8 +125,17 @@ def _coords(smp, geom, l):
     return origin[ie] + size[ie] * pts
 
 
-def evaluate(integral, arguments=None):
-    '''-> float (no dof axis), array [ndofs(, ncomp)] (one), or (values, rowptr, colidx) (two dof axes; int64 index arrays); a (sample, PointExpr) pair: evaluate_points'''
+def evaluate(integral, arguments=None, absolute=False):
+    '''-> float (no dof axis), array [ndofs(, ncomp)] (one), or (values, rowptr, colidx) (two dof axes; int64 index arrays); a (sample, PointExpr) pair: evaluate_points.
+    absolute: the same sums with every factor replaced by its absolute value (tables, inverse Jacobians, coefficients, argument values): an upper bound of the sum of the
+    |products| each entry is made of -- the scale of its rounding error whatever cancels in it (tests/plan_exec.py: the floor of vector / scalar comparisons).'''
+    global _ABS
+    if absolute:
+        _ABS = True
+        try:
+            return evaluate(integral, arguments)
+        finally:
+            _ABS = False
     if isinstance(integral, tuple):
         return evaluate_points(integral[0], integral[1], arguments)
     arguments = arguments or {}
@@ -146,16 +162,16 @@ def evaluate(integral, arguments=None):
         geo = geos[gkey]
         if itg.geom is not None and itg.geom is not itg.measure:
             raise NotImplementedError('gradient geometry differs from the measure')
-        sc = None if itg.scale is None else itg.scale().reshape(smp.nlist, -1)
+        sc = None if itg.scale is None else _a(itg.scale().reshape(smp.nlist, -1))
         for l in range(smp.nlist):
-            w = geo.wdet[l] * fac
+            w = _a(geo.wdet[l] * fac)
             if sc is not None:
                 w = w * sc[l]
             if itg.fscale is not None:
                 vals = [_field(smp, a, geo, l, arguments)[:, 0, 0] for a in itg.fscale.args]
                 poly = 0.
                 for pw, c in itg.fscale.terms.items():
-                    term = c
+                    term = _a(c)
                     for v, p in zip(vals, pw):
                         term = term * v ** p
                     poly = poly + term
@@ -164,9 +180,9 @@ def evaluate(integral, arguments=None):
                 w = w * _field(smp, arg, geo, l, arguments)[:, comp, slot]
             if itg.qscalar is not None:
                 Bs, at, ar = itg.qscalar
-                w = w * numpy.einsum('cadb,qca,qdb->q', Bs, _field(smp, at, geo, l, arguments), _field(smp, ar, geo, l, arguments))
+                w = w * numpy.einsum('cadb,qca,qdb->q', _a(Bs), _field(smp, at, geo, l, arguments), _field(smp, ar, geo, l, arguments))
             if itg.test is None:  # constant integrand
-                scalar += float(numpy.sum(w) * float(itg.f0))
+                scalar += float(numpy.sum(w) * _a(float(itg.f0)))
                 continue
             Dt, tdofs = _tables(smp, itg.test.basis, geo, l)
             nct = itg.test.ncomp
@@ -175,14 +191,14 @@ def evaluate(integral, arguments=None):
                 ncr = itg.trial.ncomp
                 nq = len(w)
                 if itg.qform is None:
-                    Cq = numpy.broadcast_to(itg.B, (nq,) + itg.B.shape)
+                    Cq = numpy.broadcast_to(_a(itg.B), (nq,) + itg.B.shape)
                 elif itg.qform[0] == 'trial':
                     U = _field(smp, itg.qform[1], geo, l, arguments)
                     Cq = numpy.zeros((nq,) + itg.B.shape[:2] + (ncr, Dr.shape[-1]))
-                    Cq[:, :, :, 0, 0] = numpy.einsum('cadb,qdb->qca', itg.B, U)
+                    Cq[:, :, :, 0, 0] = numpy.einsum('cadb,qdb->qca', _a(itg.B), U)
                 else:
                     U = _field(smp, itg.qform[1], geo, l, arguments)
-                    Cq = numpy.einsum('ca,xydb,qxy->qcadb', numpy.asarray(itg.qform[2], dtype=float), itg.B, U)
+                    Cq = numpy.einsum('ca,xydb,qxy->qcadb', _a(numpy.asarray(itg.qform[2], dtype=float)), _a(itg.B), U)
                 A = numpy.einsum('q,qma,qcadb,qnb->mcnd', w, Dt, Cq, Dr)
                 for c in range(nct):
                     for d in range(ncr):
@@ -193,9 +209,9 @@ def evaluate(integral, arguments=None):
                 continue
             if itg.B is not None:
                 U = _field(smp, itg.trial, geo, l, arguments)
-                F = numpy.einsum('cadb,qdb->qca', itg.B, U)
+                F = numpy.einsum('cadb,qdb->qca', _a(itg.B), U)
             else:
-                F = numpy.broadcast_to(itg.L, (len(w),) + itg.L.shape)
+                F = numpy.broadcast_to(_a(itg.L), (len(w),) + itg.L.shape)
             if rows:
                 r = numpy.einsum('q,qma,qca->mc', w, Dt, F)
                 if vec is None:

@@ -80,8 +80,8 @@ def load_example(name):
     plan, expect = seam.load(os.path.join(EXAMPLE_PLANS, name + '.npz'))
     args = {k[4:]: v for k, v in expect.items() if k.startswith('arg_')}
     args2 = {k[5:]: v for k, v in expect.items() if k.startswith('arg2_')}
-    later = {k[:-1]: v for k, v in expect.items() if k in ('values2', 'rowptr2', 'colidx2', 'vector2', 'scalar2', 'points2')}
-    first = {k: v for k, v in expect.items() if k in ('values', 'rowptr', 'colidx', 'vector', 'scalar', 'points')}
+    later = {k[:-1]: v for k, v in expect.items() if k in ('values2', 'rowptr2', 'colidx2', 'vector2', 'scalar2', 'points2', 'abssum2')}
+    first = {k: v for k, v in expect.items() if k in ('values', 'rowptr', 'colidx', 'vector', 'scalar', 'points', 'abssum')}
     return plan, args, first, (args2, later) if later else None
 
 
@@ -126,7 +126,18 @@ def compare_example(plan, out, expect, args, rtol=1e-13, floor=32 * 2.3e-16):
     else:
         ref = numpy.asarray(expect['vector'] if plan['kind'] == 'vector' else expect['scalar'], dtype=float)
         mine = numpy.asarray(out, dtype=float).reshape(ref.shape)
-        tol = rtol * numpy.abs(ref).max() + floor * term_scale(plan, args)
-        err = numpy.abs(mine - ref).max() / max(tol, 1e-300)
+        if 'abssum' in expect:
+            # per ENTRY: 1e-13 of the largest entry of the reference's result + 32 ulp of the sum of the |products| the entry is made of (stored at capture: the same integral
+            # with every factor by its absolute value).  MARGINS records how much of each tolerance is that floor.
+            ab = numpy.asarray(expect['abssum'], dtype=float).reshape(ref.shape)
+            tol = rtol * numpy.abs(ref).max() + floor * ab
+            err = float((numpy.abs(mine - ref) / numpy.maximum(tol, 1e-300)).max())
+            MARGINS.append((plan['kind'], err, float(floor * ab.max() / max(rtol * numpy.abs(ref).max(), 1e-300))))
+        else:  # (fixtures without the stored sums: the coarser bound from the plan's tensors and arguments)
+            tol = rtol * numpy.abs(ref).max() + floor * term_scale(plan, args)
+            err = numpy.abs(mine - ref).max() / max(tol, 1e-300)
     assert err < 1, err
     return err
+
+
+MARGINS = []  # (kind, error / tolerance, floor / relative part of the tolerance) of every vector / scalar comparison with stored |product| sums

@@ -254,3 +254,74 @@ def test_c2_full_size_generic_gather_path():
     gen.step()
     assert torch.equal(first, gen.values)
     assert float((gen.values - fast.values).abs().max()) <= 1e-13 * float(fast.values.abs().max())
+
+
+def test_c4_full_size_entries_vs_the_cpu_evaluator_in_strips():
+    '''BASELINE.json configs[3] at its full size, ENTRY BY ENTRY: the four Jacobian blocks and both residual blocks of the 512^2 Cahn-Hilliard functional (p = 2 splines, the
+    double-well polynomial as coefficient, boundary terms on all sides) against the CPU evaluator of tests/af_oracle.py (numpy element loop, the reference's stable-sort
+    dedup) on STRIPS of element rows -- the first rows of the mesh, two interior strips, the last rows: every CSR row whose elements all lie in a strip is complete there
+    and is compared whole (column indices exact, values to 1e-13 of the block's largest entry; residual entries to 1e-13 of the largest + 32 ulp of the sum of their |terms|).
+    The Python evaluator does ~1 500 elements per second and term, so the strips cover 6 % of the rows; test_c4_full_size_consistency holds the rest to the finite-difference
+    and symmetry properties.'''
+    import af_oracle
+    from nutils_amd import mesh, function, sample as _sample
+    n = 512
+    size, eps_, M, stens, wn, wp, dt = 10., 1., 1., 50., 30., 20., .5
+    domain, geom = mesh.rectilinear([numpy.linspace(0, size, n + 1)] * 2)
+    phi = domain.field('φ', btype='spline', degree=2)
+    phi0 = domain.field('φ0', btype='spline', degree=2)
+    eta = domain.field('η', btype='spline', degree=2) * (stens / eps_)
+    p, p0 = function.value(phi), function.value(phi0)
+    dp = p - p0
+    psi = .25 * (p ** 2 - 1) ** 2
+    dpsi = .25 * dp ** 2 * (1 - p ** 2 + 2 * p * dp / 3 - dp ** 2 / 6)
+    dV = function.J(geom)
+    grad = lambda w: function.grad(w, geom)
+    nrg = domain.integral((psi + dpsi) * (stens / eps_) * dV, degree=8) \
+        + domain.integral(.5 * stens * eps_ * (grad(phi) * grad(phi)).sum(-1) * dV, degree=8) \
+        - domain.integral(eta * phi * dV, degree=8) + domain.integral(eta * phi0 * dV, degree=8) \
+        - domain.integral(.5 * dt * M * (grad(eta) * grad(eta)).sum(-1) * dV, degree=8) \
+        + domain.boundary.integral((wp + wn) / 2 * dV, degree=4) + domain.boundary.integral((wp - wn) / 2 * phi * dV, degree=4)
+    N = n + 2
+    rng = numpy.random.default_rng(1)
+    args = {'φ': rng.normal(0, .5, N * N), 'φ0': rng.normal(0, .5, N * N), 'η': rng.normal(0, .1, N * N)}
+    names = ['φ', 'η']
+    res = [function.derivative(nrg, t) for t in names]
+    jac = [[function.derivative(r, t) for t in names] for r in res]
+
+    def restrict(integral, a, b):
+        '''the terms of `integral` on the elements of the element rows [a, b) (first axis) only'''
+        subs, out = {}, []
+        for smp, itg, fac in integral.terms:
+            if id(smp) not in subs:
+                el = numpy.arange(smp.nelems) if smp.elist is None else numpy.asarray(smp.elist)
+                keep = el[(el // n >= a) & (el // n < b)]
+                subs[id(smp)] = _sample.Sample(smp.topo, smp.points, elist=keep, bnd_axis=smp.bnd_axis) if len(keep) else None
+            if subs[id(smp)] is not None:
+                out.append((subs[id(smp)], itg, fac))
+        return function.Integral(out)
+
+    gpu_res = [numpy.asarray(function.eval(r, args)).ravel() for r in res]
+    gpu_jac = [[function.eval(function.as_csr(blk), args) if blk.terms else None for blk in row] for row in jac]
+    checked = 0
+    for a, b in [(0, 6), (170, 176), (341, 347), (n - 6, n)]:
+        lo, hi = (0 if a == 0 else a + 2), (N if b == n else b)  # dof rows (first axis) whose elements all lie in [a, b)
+        rows = (numpy.arange(lo, hi)[:, None] * N + numpy.arange(N)).ravel()
+        for i in range(2):
+            ref = numpy.asarray(af_oracle.evaluate(restrict(res[i], a, b), args)).ravel()
+            ab = numpy.asarray(af_oracle.evaluate(restrict(res[i], a, b), args, absolute=True)).ravel()
+            tol = 1e-13 * numpy.abs(gpu_res[i]).max() + 32 * 2.3e-16 * ab[rows]
+            assert (numpy.abs(gpu_res[i][rows] - ref[rows]) <= tol).all(), (names[i], a, b)
+            for j in range(2):
+                if gpu_jac[i][j] is None:
+                    assert not restrict(jac[i][j], a, b).terms
+                    continue
+                v, rp, ci = af_oracle.evaluate(restrict(jac[i][j], a, b), args)
+                gv, grp, gci = gpu_jac[i][j]
+                scale = numpy.abs(gv).max()
+                for r in rows[:: 7] if (a, b) != (0, 6) else rows:  # (every row of the first strip, every seventh of the others: the row loop is Python)
+                    s0, s1, g0, g1 = rp[r], rp[r + 1], grp[r], grp[r + 1]
+                    assert s1 - s0 == g1 - g0 and numpy.array_equal(ci[s0:s1], gci[g0:g1]), (names[i], names[j], r)
+                    assert numpy.abs(v[s0:s1] - gv[g0:g1]).max() <= 1e-13 * scale, (names[i], names[j], r)
+                    checked += 1
+    assert checked > 4000

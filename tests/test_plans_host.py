@@ -68,8 +68,14 @@ def test_example_plans_on_the_cpu_evaluator(example):
     import af_oracle
     names = [n for n in plan_exec.example_names() if n.rsplit('_', 1)[0] == example]
     assert names
+    del plan_exec.MARGINS[:]
     for name in names:
         plan, args, expect, later = plan_exec.load_example(name)
         for a, e in [(args, expect)] + ([later] if later else []):
             out = seam.run(plan, a, lambda integral, args, kind: af_oracle.evaluate(integral, args))
-            plan_exec.compare_example(plan, out, e, a)  # (1e-13 of the reference's largest entry + the rounding floor of the terms)
+            plan_exec.compare_example(plan, out, e, a)  # (1e-13 of the reference's largest entry + 32 ulp of the sum of the |products| of an entry, stored at capture)
+    if plan_exec.MARGINS:  # (shown with pytest -s / on failure: how close the comparisons came, and how much of their tolerance was the rounding floor)
+        worst = max(m[1] for m in plan_exec.MARGINS)
+        share = sorted(m[2] for m in plan_exec.MARGINS)
+        print(f'{example}: {len(plan_exec.MARGINS)} vector / scalar comparisons, largest error / tolerance {worst:.2e}; floor / (1e-13 of the largest entry): '
+              f'median {share[len(share) // 2]:.1e}, largest {share[-1]:.1e}')

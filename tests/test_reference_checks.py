@@ -53,6 +53,17 @@ def test_seam_installed_examples_with_declined_systems():
         assert ' 0 failures, 0 errors' in line and 'from plans: 0;' not in line, line
 
 
+def test_example_plan_fixtures_reproduce():
+    '''tests/golden/plans_examples is what tools/hip_plan_capture.py writes TODAY: the unit tests of the unmodified examples laplace, elasticity and poisson run again with
+    the seam installed, every plan the hooks hand out -- Systems, constraint functionals, the post-processing evaluations of Sample.eval -- is captured again with the
+    reference's own result and compared with the committed fixture of the same name: the plan (order-free signature: the reference visits terms in hash order), the arguments
+    and every reference result to 1e-13.  (The capture of ALL ten examples takes 15 minutes through the CPU evaluator -- cylinderflow and finitestrain 8 of them --:
+    `python tools/hip_plan_capture.py --check tests/golden/plans_examples`, run before the fixtures were committed.)'''
+    out = run('tools/hip_plan_capture.py', '--check', 'tests/golden/plans_examples', 'laplace', 'elasticity', 'poisson')
+    line = next(l for l in out.splitlines() if l.startswith('check:'))
+    assert ' 0 differences' in line and int(line.split()[1]) >= 40, line
+
+
 def test_plans_of_the_reference_scripts_reproduce(tmp_path):
     '''tools/hip_plan.py matches the integrals of the unmodified examples/laplace.py and examples/elasticity.py (captured where they are handed to
     solver.System) and of the Namespace scripts for BASELINE.json configs[1..4], and must give the committed plans again'''

@@ -48,4 +48,11 @@ import json
 print('RESULT ' + json.dumps({'workload': f'Cahn-Hilliard {n}^2, p = 2 {btype} basis, 25 Gauss points, two fields (BASELINE.json configs[3]): one Newton step = residual (2 blocks) + Jacobian (4 blocks, '
                                           'merged CSR in host memory) in one call', 'value': n * n / min(steps) * 1e3, 'unit': 'elements/s', 'ms_per_step': min(steps), 'steps': len(steps),
                               'launch': 'eager (wall clock around System.assemble_jacobian_residual, device synchronised)', 'residual_alone_ms': res_ms, 'jacobian_alone_ms': jac_ms,
-                              'nnz': int(jac.core.nnz), 'ndofs_per_field': int(nd)}))
+                              'nnz': int(jac.core.nnz), 'ndofs_per_field': int(nd),
+                              # what a step has to move: the entries of the field-dependent block (the only ones that change) cross PCIe into the host CSR, the three
+                              # fields go up, the two residual blocks come down; on the device the same entries are written once and the fields read once
+                              'pcie_bytes': int(8 * (len(system._dynpos) + 3 * nd + 2 * nd)), 'pcie_peak_GBs': 63.0,
+                              'pcie_frac': 8 * (len(system._dynpos) + 5 * nd) / (min(steps) * 1e-3) / 63e9,
+                              'algorithmic_bytes': int(8 * (len(system._dynpos) + 3 * nd + 2 * nd)),
+                              'hbm_frac': 8 * (len(system._dynpos) + 5 * nd) / (min(steps) * 1e-3) / 8e12,
+                              'bound': 'pcie (the changed Jacobian entries travel to the host matrix of the scipy solver every step)'}))

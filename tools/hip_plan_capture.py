@@ -47,6 +47,7 @@ def main(out, modules):
     os.chdir(tempfile.mkdtemp())
     problems = []
     for name in modules:
+        contents = set()
         seen, count, pcount = {}, [0], [0]  # (point-evaluation plans are numbered apart: `<example>_pts_NNN`, so that the integral plans keep their names)
 
         def reference(plan, arguments, nrows=None):
@@ -87,6 +88,11 @@ def main(out, modules):
             else:
                 ret = numpy.asarray(res, dtype=float).reshape(plan['shape'])
                 expect = dict(vector=ref.reshape(plan['shape']))
+            if plan['kind'] in ('vector', 'scalar'):
+                # what every entry is a sum OF: the same integral with every factor replaced by its absolute value (af_oracle absolute=True) -- the scale of the rounding
+                # error of an entry whatever cancels in it (a residual at its own solution, an energy difference); stored beside the result, 32 ulp of it is the floor of the comparison
+                ab = seam.run(plan, arguments, lambda integral, args, kind: af_oracle.evaluate(integral, args, absolute=True))
+                expect['abssum'] = numpy.asarray(ab, dtype=float).reshape(numpy.shape(expect['vector' if plan['kind'] == 'vector' else 'scalar']))
             if plan['kind'] != 'matrix':
                 err = plan_exec.compare_example(plan, ret, expect, arguments)
                 if os.environ.get('CAPTURE_VERBOSE'):
@@ -96,6 +102,12 @@ def main(out, modules):
                 for k, v in numeric.items():
                     expect['arg_' + k] = v
                 ctr, tag = (pcount, 'pts_') if plan['kind'] == 'points' else (count, '')
+                # (an example whose tests repeat a computation hands over equal plans with equal arguments again: one fixture per content)
+                digest = content_digest(plan, expect)
+                if digest in contents:
+                    seen[id(plan)] = dict(plan=plan, path=None, first=expect, args=numeric, later=True)
+                    return ret
+                contents.add(digest)
                 seen[id(plan)] = dict(plan=plan, path=os.path.join(out, f'{name}_{tag}{ctr[0]:03d}.npz'), first=expect, args=numeric, later=False)  # (plan kept alive: ids are not recycled)
                 seam.save(seen[id(plan)]['path'], {k: v for k, v in plan.items() if not k.startswith('_')}, expect)
                 ctr[0] += 1
@@ -137,6 +149,37 @@ def main(out, modules):
         raise SystemExit(1)
 
 
+def signature(plan):
+    '''What a plan IS, independent of the order in which the reference happened to visit its terms and samples (that order follows object hashes inside the reference's
+    simplifier and changes from process to process): kind, shape, derivatives, the multiset of its terms (tensor, factor, exposure, coefficient kinds) and of its tables.'''
+    import json
+
+    def arr(x):
+        return None if x is None else [round(float(v), 10) for v in numpy.asarray(x, dtype=float).ravel()]
+    terms = []
+    for t in plan.get('terms', []):
+        k = 'B' if t.get('B') is not None else 'L' if t.get('L') is not None else 'f0'
+        v = numpy.asarray(t[k], dtype=float) * float(t['fac'])
+        fp = t.get('fpoly')
+        terms.append(json.dumps([k, list(v.shape), arr(v), bool(t['rows']), bool(t['cols']), t.get('scale') is not None, int(t['geom']) >= 0,
+                                 None if fp is None else sorted(zip(map(tuple, numpy.asarray(fp['powers']).tolist()), arr(fp['coeffs']))), len(t.get('pvars') or [])]))
+    for t in plan.get('pterms', []):
+        terms.append(json.dumps(['P', [int(n) for n in t['Ashape']], arr(t['A']), len(t['factors']), t.get('scale') is not None]))
+    tables = sorted([json.dumps(['topo', t['kind']]) for t in plan['topos']] + [json.dumps(['basis', b['kind']]) for b in plan['bases']]
+                    + [json.dumps(['geom', g['kind']]) for g in plan['geoms']]
+                    + [json.dumps(['sample', len(s['weights']), int(s.get('bnd_axis', -1)), None if s.get('elist') is None else len(s['elist'])]) for s in plan['samples']])
+    return json.dumps([plan['kind'], [int(n) for n in plan['shape']], list(plan.get('derivs', [])), sorted(terms), tables])
+
+
+def content_digest(plan, expect):
+    import hashlib
+    h = hashlib.sha1(signature(plan).encode())
+    for k in sorted(expect):
+        h.update(k.encode())
+        h.update(numpy.ascontiguousarray(numpy.asarray(expect[k])).tobytes())
+    return h.hexdigest()
+
+
 def check(committed, modules):
     '''--check: capture the plans of `modules` again (into a scratch directory) and compare every file with the committed fixture of the same name: the plan
     (structure and every array) and the reference's results stored beside it.  -> number of files compared; raises SystemExit on the first difference.'''
@@ -149,14 +192,12 @@ def check(committed, modules):
         if not os.path.exists(path):
             bad.append(f'{f}: not among the committed fixtures')
             continue
-        new, old = numpy.load(os.path.join(scratch, f), allow_pickle=False), numpy.load(path, allow_pickle=False)
-        if sorted(new.files) != sorted(old.files) or str(new['spec']) != str(old['spec']):
+        (pn, en), (po, eo) = seam.load(os.path.join(scratch, f)), seam.load(path)
+        if signature(pn) != signature(po) or sorted(en) != sorted(eo):
             bad.append(f'{f}: plan structure differs')
             continue
-        for k in new.files:
-            if k == 'spec':
-                continue
-            a, b = new[k], old[k]
+        for k in en:  # the reference's results and the arguments they belong to
+            a, b = numpy.asarray(en[k]), numpy.asarray(eo[k])
             if a.shape != b.shape or a.dtype != b.dtype:
                 bad.append(f'{f}: array {k} differs in shape / type')
             elif a.dtype.kind == 'f':
