@@ -1749,8 +1749,6 @@ def match_points(array):
                     raise Unmatched('basis array evaluated at points (dense npoints x ndofs result)')
                 else:
                     ai = E.arg(f.name, bi, f.ncomp, f.part)
-                if f.part is not None:
-                    raise Unmatched('vectorized bases in a point function')
             gi = -1
             if uses_grad:
                 if f.geom is None:

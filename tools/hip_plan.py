@@ -170,7 +170,7 @@ def main():
                                        circle=False)
     finally:
         seam.uninstall()
-    assert st['matched'].count('factor') == 4, st['matched']  # the four energy terms of examples/cahnhilliard.py:181-184 were unwrapped
+    assert st['matched'].count('factor') == 6, st['matched']  # the four energy terms of examples/cahnhilliard.py:181-184 and the two bound post-processing fields (:188,192: `factor(bezier.bind(...))`, point plans) were unwrapped
     nrgx = captured[0][0]
     rngx = numpy.random.default_rng(7)
     nbx = chargs['φ'].shape[0]
