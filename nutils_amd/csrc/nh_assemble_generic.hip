@@ -124,7 +124,9 @@ struct MatK {
   int exclusive;  // NH_MATRIX_EXCLUSIVE: no two elements of this launch share a matrix entry -> plain read-modify-write (deterministic)
   double *local;  // NH_MATRIX_GATHER: element-major local matrices [emap position][nct * ncr] instead of the scatter
   int sym;        // Gram path: test == trial (tables AND dofs) and C[c][a][d][b] == C[d][b][c][a]: the node pairs m >= n only, each written to both of its places
-                  // (2 with NH_MATRIX_GATHER: to its own place only -- the gather map for symmetric producers mirrors it)
+                  // (2 with NH_MATRIX_GATHER: to its own place only -- the gather map for symmetric producers mirrors it; 3: triangular scratch, nh_gram_sym.inc)
+  const unsigned char *trirank;  // sym == 3: position of a node among the dofs of its element, [sum nb_e]
+  const i64 *tribase;            // sym == 3: first packed node pair of an element, [nelems + 1]
 };
 
 template <int ND>
@@ -868,6 +870,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   p.same = (a->test.T_dev == a->trial.T_dev && a->test.off_dev == a->trial.off_dev && a->test.tab_dev == a->trial.tab_dev &&
             a->test.nb == a->trial.nb);
   p.sym = 0;
+  p.trirank = nullptr, p.tribase = nullptr;
   if (p.same && a->test.dofs_dev == a->trial.dofs_dev && a->nct == a->ncr && !a->cq_dev && !(a->flags & (NH_MATRIX_EXCLUSIVE | NH_MATRIX_FIRST_TOUCH)) && !getenv("NUTILS_AMD_NO_SYM_GRAM")) {
     const int S2 = 1 + a->ndims, nc2 = a->nct;
     p.sym = 1;
@@ -955,6 +958,25 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     if (p.sym && a->nct * a->ncr > 1 && (a->nct == 2 || a->nct == 3) && getenv("NUTILS_AMD_SYM_SCRATCH") && atoi(getenv("NUTILS_AMD_SYM_SCRATCH"))) {
       if ((rc = nh_gather_prepare_sym(pat, a->test, a->elist_dev, nh_stream(stream))) != NH_OK) return rc;
       p.sym = 2;
+    }
+    // Triangular scratch (default where it applies: k_gram_sym takes EVERY launch of this call, the sums are stored, the pattern is symmetric): node pairs of the
+    // dof-sorted nodes, m' >= n', packed -- half the scratch written and read; the upper triangle of the matrix is mirrored from the lower (nh_gather.hip)
+    static const bool notri = getenv("NUTILS_AMD_NO_TRI_SCRATCH") && atoi(getenv("NUTILS_AMD_NO_TRI_SCRATCH"));
+    if (p.sym == 1 && !notri && (a->flags & NH_MATRIX_STORE) && !a->elist_dev && !pat->tri_failed) {
+      bool all = true;
+      const bool rag = (a->test.off_dev || a->trial.off_dev) && pat->nbuckets && pat->nelems == a->nelems;
+      for (int b = 0; b < (rag ? pat->nbuckets : 1) && all; ++b) {
+        MatK q = p;
+        if (rag) {
+          if (!pat->bucket_n[b]) continue;
+          q.maxnbt = pat->bucket_nbt[b], q.maxnbr = pat->bucket_nbr[b];
+        }
+        all = nh_gram_sym_applies(q, form, a->ndims);
+      }
+      if (all) {
+        if ((rc = nh_gather_prepare_tri(pat, a->test, nh_stream(stream))) != NH_OK) return rc;
+        if (pat->gsrc_tri) p.sym = 3, p.trirank = pat->tri_rank, p.tribase = pat->tri_base;
+      }
     }
   }
   // MFMA path: uniform shared tables, >= 16 local rows and columns, tile counts we instantiate
@@ -1058,7 +1080,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
   } else if ((rc = launch_generic(p)) != NH_OK)
     return rc;
   if (gather) {
-    return nh_gather_values(a->pattern, p.local, local_ld, slots_of(form), a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream), p.sym == 2);
+    return nh_gather_values(a->pattern, p.local, local_ld, slots_of(form), a->values_dev, (a->flags & NH_MATRIX_STORE) != 0, nh_stream(stream), p.sym == 3 ? 2 : p.sym == 2);
   }
   return NH_OK;
 }

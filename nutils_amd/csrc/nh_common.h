@@ -139,6 +139,15 @@ struct nh_pattern {
   // gsrc[gptr[k] .. gptr[k+1]) in ascending order (element, m, n) -- the order numpy.add.at accumulates them in -- and the row of k
   int32_t *gsrc;
   int32_t *gsrc_sym;  // the same map for producers that write the node pairs m >= n only: sources of (m < n) entries point to the (n, m) block, bit 31 set = transpose it
+  // triangular scratch (symmetric blocks on a symmetric pattern, nh_gram_sym.inc): an element writes the node pairs (m', n'), m' >= n', of its nodes SORTED BY DOF, packed
+  // row by row -- the LOWER triangle of the global matrix is gathered from them, the upper one is its mirror.  tri_rank [sum nb_e]: position of a node among the dofs of its
+  // element; tri_base [nelems + 1]: first packed pair of an element; gsrc_tri: the gather map over packed positions (sources of upper entries: 0xffffffff);
+  // gmirror [nnz]: for an entry above the diagonal the entry it mirrors, else -1
+  unsigned char *tri_rank;
+  i64 *tri_base;
+  int32_t *gsrc_tri;
+  int32_t *gmirror;
+  int tri_failed;
   unsigned *gptr;
   int32_t *grow;
   nh_fused_plan *fused;  // NH_MATRIX_FUSED: built on the first such assembly
@@ -159,7 +168,8 @@ struct GSlots {
 int nh_gather_prepare(nh_pattern *p, const nh_basis &test, const int32_t *elist, hipStream_t s);  // elist: element ids of the pattern's elements, or NULL
 int nh_gather_scratch(size_t doubles, double **out);
 int nh_local_vector(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);
-int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s, bool sym_sources = false);
+int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s, int sym_sources = 0);  // 1: gsrc_sym, 2: triangular scratch
+int nh_gather_prepare_tri(nh_pattern *p, const nh_basis &test, hipStream_t s);
 int nh_gather_prepare_sym(nh_pattern *p, const nh_basis &test, const int32_t *elist, hipStream_t s);
 int nh_local_scalar(const nh_matrix_args *a, double *local, bool *done, hipStream_t s);
 // owner-block assembly (NH_MATRIX_FUSED); *done = false: not applicable to this launch, nothing was written

@@ -216,6 +216,97 @@ __global__ void k_gather_values_2x2(i64 nnz, const unsigned *gptr, const int32_t
   }
 }
 
+// ---- triangular scratch: symmetric two-component blocks on a symmetric pattern (the producer is k_gram_sym in its packed mode) ---------------------------------------
+// The local matrix of a symmetric form is symmetric and so is the global one: an element writes only the node pairs (m', n'), m' >= n', of its nodes sorted by dof,
+// packed row by row (half the scratch, and rows of a node stay contiguous: the reads of neighbouring entries stay neighbours); entries on and below the diagonal are
+// gathered from them in the order of the map (ascending element: the reference's order), entries above are the transposed copies of their mirrors -- the sum of (c, r) is
+// the sum of (r, c) term by term, so the copy is what a second gather would give.
+__global__ void k_tri_rank(i64 nelems, BasisK test, unsigned char *rank, int *cnt) {
+  for (i64 e = blockIdx.x; e < nelems; e += gridDim.x) {
+    const int nb = test.off ? (int)(test.off[e + 1] - test.off[e]) : test.nb;
+    const i64 t0 = test.off ? test.off[e] : e * (i64)test.nb;
+    for (int m = threadIdx.x; m < nb; m += blockDim.x) {
+      const int dm = test.dofs[t0 + m];
+      int r = 0;
+      for (int j = 0; j < nb; ++j) r += test.dofs[t0 + j] < dm;
+      rank[t0 + m] = (unsigned char)r;
+    }
+    if (threadIdx.x == 0) cnt[e] = nb * (nb + 1) / 2;
+  }
+}
+// canonical packed position of every local position (e, m, n): the pair of the ranks if rank(m) >= rank(n), else none
+__global__ void k_tri_canon(i64 nelems, BasisK test, int nbr_uniform, const i64 *eoff, const unsigned char *rank, const i64 *tbase, unsigned *canon) {
+  for (i64 e = blockIdx.x; e < nelems; e += gridDim.x) {
+    const int nb = test.off ? (int)(test.off[e + 1] - test.off[e]) : test.nb;
+    const i64 t0 = test.off ? test.off[e] : e * (i64)test.nb;
+    const i64 e0 = eoff ? eoff[e] : e * (i64)nb * nbr_uniform;
+    for (int i = threadIdx.x; i < nb * nb; i += blockDim.x) {
+      const int m = i / nb, n = i - m * nb;
+      const int rm = rank[t0 + m], rn = rank[t0 + n];
+      canon[e0 + i] = rm >= rn ? (unsigned)(tbase[e] + rm * (rm + 1) / 2 + rn) : 0xffffffffu;
+    }
+  }
+}
+__global__ void k_tri_mirror(i64 nnz, const int32_t *grow, const i64 *srowptr, const int32_t *scol, int32_t *mirror) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const int r = grow[k], c = scol[k];
+  int out = -1;
+  if (c > r) {  // (r, c) above the diagonal: find (c, r)
+    i64 lo = srowptr[c], hi = srowptr[c + 1];
+    while (lo < hi) {
+      const i64 mid = (lo + hi) >> 1;
+      if (scol[mid] < r) lo = mid + 1;
+      else hi = mid;
+    }
+    out = (lo < srowptr[c + 1] && scol[lo] == r) ? (int32_t)lo : -2;  // -2: the pattern is not symmetric (the plan is refused)
+  }
+  mirror[k] = out;
+}
+__global__ void k_tri_check(i64 nnz, const int32_t *mirror, int *bad) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nnz && mirror[k] == -2) *bad = 1;
+}
+
+__global__ void k_gather_values_2x2_tri(i64 nnz, const unsigned *gptr, const int32_t *gsrc, const int32_t *grow, const i64 *srowptr, const int32_t *mirror, const double *local,
+                                        GSlots gs, double *values) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz || mirror[k] >= 0) return;
+  const unsigned b = gptr[k], e = gptr[k + 1];
+  const i64 r = grow[k], a0 = srowptr[r], len = srowptr[r + 1] - a0, pos = k - a0;
+  double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+  for (unsigned i0 = b; i0 < e; i0 += 4) {
+    unsigned idx[4];
+    double2 lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) idx[u] = i0 + u < e ? (unsigned)gsrc[i0 + u] : 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double2 *src = reinterpret_cast<const double2 *>(local + (i64)(idx[u] != 0xffffffffu ? idx[u] : 0u) * 4);
+      lo[u] = src[0], hi[u] = src[1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u < e) s00 += lo[u].x, s01 += lo[u].y, s10 += hi[u].x, s11 += hi[u].y;
+  }
+  double *d0 = values + a0 * gs.tot + len * gs.cum[0] + pos * gs.cnt[0] + gs.dpos[0][0];
+  double *d1 = values + a0 * gs.tot + len * gs.cum[1] + pos * gs.cnt[1] + gs.dpos[1][0];
+  d0[0] = s00, d0[1] = s01, d1[0] = s10, d1[1] = s11;
+}
+__global__ void k_mirror_2x2(i64 nnz, const int32_t *grow, const i64 *srowptr, const int32_t *mirror, GSlots gs, double *values) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const i64 km = mirror[k];
+  if (km < 0) return;
+  const i64 rs = grow[km], as = srowptr[rs], ls = srowptr[rs + 1] - as, ps = km - as;
+  const double *s0 = values + as * gs.tot + ls * gs.cum[0] + ps * gs.cnt[0] + gs.dpos[0][0];
+  const double *s1 = values + as * gs.tot + ls * gs.cum[1] + ps * gs.cnt[1] + gs.dpos[1][0];
+  const i64 r = grow[k], a0 = srowptr[r], len = srowptr[r + 1] - a0, pos = k - a0;
+  double *d0 = values + a0 * gs.tot + len * gs.cum[0] + pos * gs.cnt[0] + gs.dpos[0][0];
+  double *d1 = values + a0 * gs.tot + len * gs.cum[1] + pos * gs.cnt[1] + gs.dpos[1][0];
+  d0[0] = s0[0], d0[1] = s1[0], d1[0] = s0[1], d1[1] = s1[1];
+}
+
 // ---- pass 1 for small scalar elements: ONE THREAD per element, the local matrix in registers --------------------------------------------
 // (the one-wave-per-element kernel spends ~500 wave instructions on a trilinear element: lanes idle in the pointwise stages, LDS staging,
 // barriers; a thread that keeps the NBT x NBR sums in registers needs ~90 per element and no LDS at all)
@@ -1183,9 +1274,14 @@ __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
   }
 }
 
-int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s, bool sym_sources) {
+int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s, int sym_sources) {
   if (!p->nnz) return NH_OK;
-  if (sym_sources) {
+  if (sym_sources == 2) {
+    NH_REQUIRE(p->gsrc_tri && p->gmirror && store && slots.nct == 2 && slots.ncr == 2, "gather: the triangular scratch needs its maps, 2 x 2 blocks and NH_MATRIX_STORE");
+    const dim3 grid((unsigned)((p->nnz + 255) / 256));
+    hipLaunchKernelGGL(k_gather_values_2x2_tri, grid, dim3(256), 0, s, p->nnz, p->gptr, p->gsrc_tri, p->grow, p->srowptr, p->gmirror, local, slots, values);
+    hipLaunchKernelGGL(k_mirror_2x2, grid, dim3(256), 0, s, p->nnz, p->grow, p->srowptr, p->gmirror, slots, values);
+  } else if (sym_sources) {
     NH_REQUIRE(p->gsrc_sym && slots.nct == slots.ncr && (slots.nct == 2 || slots.nct == 3), "gather: symmetric sources need their map and 2 x 2 / 3 x 3 blocks");
     hipLaunchKernelGGL(k_gather_values_v<true>, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc_sym, p->grow, p->srowptr, local, slots, values, store);
   } else if (slots.nct == 2 && slots.ncr == 2 && slots.mask[0][0] && slots.mask[0][1] && slots.mask[1][0] && slots.mask[1][1] && slots.dpos[0][1] == slots.dpos[0][0] + 1 &&
@@ -1220,6 +1316,61 @@ int nh_gather_prepare_sym(nh_pattern *p, const nh_basis &test, const int32_t *el
     p->gsrc_sym = nullptr;
     nh_set_error("nh_gather_prepare_sym failed: %s", hipGetErrorString(e));
     return NH_EHIP;
+  }
+  return NH_OK;
+}
+
+// the maps of the triangular scratch, derived from the gather map (once per pattern); sets p->tri_failed when the pattern does not qualify
+int nh_gather_prepare_tri(nh_pattern *p, const nh_basis &test, hipStream_t s) {
+  if (p->gsrc_tri || p->tri_failed) return NH_OK;
+  NH_REQUIRE(p->gsrc && p->gptr && p->grow, "nh_gather_prepare_tri: the gather map comes first");
+  if (!(p->nrows == p->ncols && p->nbt == p->nbr && p->emap_len < (1ll << 31) && p->nnz < (1ll << 31))) {
+    p->tri_failed = 1;
+    return NH_OK;
+  }
+  unsigned *canon = nullptr;
+  int *cnt = nullptr, *bad = nullptr;
+  i64 ndof = 0;
+  int hbad = 0, rc = NH_OK;
+  hipError_t e = hipSuccess;
+  const BasisK tk = to_k(test);
+  if (test.off_dev) {
+    e = hipMemcpyAsync(&ndof, test.off_dev + p->nelems, sizeof(i64), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  } else
+    ndof = p->nelems * (i64)test.nb;
+  if (e == hipSuccess) e = hipMalloc((void **)&p->tri_rank, std::max<i64>(ndof, 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&cnt, (p->nelems + 1) * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void **)&p->tri_base, (p->nelems + 1) * sizeof(i64));
+  if (e == hipSuccess) e = hipMalloc((void **)&canon, std::max<i64>(p->emap_len, 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->gsrc_tri, std::max<i64>(p->emap_len, 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->gmirror, std::max<i64>(p->nnz, 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&bad, sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_tri_rank, dim3((unsigned)std::min<i64>(p->nelems, 1 << 20)), dim3(64), 0, s, p->nelems, tk, p->tri_rank, cnt);
+    rc = nh_scan_exclusive(cnt, p->tri_base, p->nelems, s);
+  }
+  if (e == hipSuccess && rc == NH_OK) {
+    hipLaunchKernelGGL(k_tri_canon, dim3((unsigned)std::min<i64>(p->nelems, 1 << 20)), dim3(64), 0, s, p->nelems, tk, p->nbr, p->eoff, p->tri_rank, p->tri_base, canon);
+    hipLaunchKernelGGL(k_gather_remap, dim3((unsigned)std::min<i64>((p->emap_len + 255) / 256, 1 << 16)), dim3(256), 0, s, p->emap_len, p->gsrc, canon, p->gsrc_tri);
+    const dim3 grid((unsigned)((p->nnz + 255) / 256));
+    hipLaunchKernelGGL(k_tri_mirror, grid, dim3(256), 0, s, p->nnz, p->grow, p->srowptr, p->scol, p->gmirror);
+    hipLaunchKernelGGL(k_tri_check, grid, dim3(256), 0, s, p->nnz, p->gmirror, bad);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
+  hipFree(canon), hipFree(cnt), hipFree(bad);
+  if (e != hipSuccess || rc != NH_OK || hbad) {
+    hipFree(p->tri_rank), hipFree(p->tri_base), hipFree(p->gsrc_tri), hipFree(p->gmirror);
+    p->tri_rank = nullptr, p->tri_base = nullptr, p->gsrc_tri = nullptr, p->gmirror = nullptr;
+    p->tri_failed = 1;
+    if (e != hipSuccess) {
+      nh_set_error("nh_gather_prepare_tri failed: %s", hipGetErrorString(e));
+      return NH_EHIP;
+    }
+    return rc;  // (a pattern that is not symmetric: no plan, no error)
   }
   return NH_OK;
 }

@@ -426,6 +426,7 @@ int nh_pattern_free(nh_pattern *p) {
   hipFree(p->bucket_store);
   hipFree(p->gsrc);
   hipFree(p->gsrc_sym);
+  hipFree(p->tri_rank), hipFree(p->tri_base), hipFree(p->gsrc_tri), hipFree(p->gmirror);
   hipFree(p->gptr);
   hipFree(p->grow);
   nh_fused_free(p->fused);
