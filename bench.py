@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.     # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 F64_MFMA_PEAK_TF = 78.6  # dense f64 MFMA (= f64 vector) peak, 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz
-TRAFFIC_FILE = 'profiles/r05_traffic.json'
+TRAFFIC_FILE = 'profiles/r06_traffic.json'
 
 
 def parse():
@@ -600,6 +600,8 @@ def main():
                         r = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd=os.path.dirname(os.path.abspath(__file__)))
                         line = next(l for l in r.stdout.splitlines() if l.startswith('RESULT '))
                         out['variants'][key] = json.loads(line[7:])
+                        if key == 'c5':  # (PMC traffic of the whole step -- element kernels of both size classes, gather, mirror: static, profiles/r06_c5_gram.md)
+                            out['variants'][key]['traffic'] = measured_traffic('c5 step: k_gram_sym (both size classes) + k_gather_values_2x2_tri + k_mirror_2x2', 256)
                     except Exception as e:  # noqa: BLE001 (secondary figures)
                         out['variants'][key] = {'error': f'{type(e).__name__}: {e}'[:200]}
         if not a.no_cpu and world == 1:
