@@ -103,3 +103,76 @@ def tensor_product(tables):
     out = numpy.zeros((prod.shape[0], ncoeffs(nvars, sum(degrees))))
     out[:, tgt.ravel()] = prod  # targets are distinct monomials: plain assignment
     return out
+
+
+@functools.lru_cache(maxsize=None)
+def powers(nvars, total):
+    '''(ncoeffs, nvars) integer array: the powers of the monomial at every coefficient position of a polynomial of degree `total`.'''
+    out = numpy.zeros((ncoeffs(nvars, total), nvars), dtype=int)
+    for pw in numpy.ndindex(*[total + 1] * nvars):
+        if sum(pw) <= total:
+            out[index(pw, total)] = pw
+    return out
+
+
+def monomials(points, nvars, total):
+    '''(npoints, ncoeffs): the monomials of the layout at the given points'''
+    points = numpy.asarray(points, dtype=float).reshape(-1, nvars)
+    pw = powers(nvars, total)
+    return numpy.prod(points[:, None, :] ** pw[None, :, :], axis=2) if nvars else numpy.ones((len(points), 1))
+
+
+@functools.lru_cache(maxsize=None)
+def _product_table(nvars, total):
+    '''(nc, nc) positions of the products of two monomials of the layout (degree `total`), -1 where the product exceeds the degree'''
+    pw = powers(nvars, total)
+    nc = len(pw)
+    tab = numpy.full((nc, nc), -1, dtype=int)
+    for i in range(nc):
+        for j in range(nc):
+            q = pw[i] + pw[j]
+            if q.sum() <= total:
+                tab[i, j] = index(tuple(int(x) for x in q), total)
+    return tab
+
+
+def _mul(p, q, tab):
+    out = numpy.zeros_like(p)
+    i, j = numpy.nonzero(tab >= 0)
+    numpy.add.at(out, tab[i, j], p[i] * q[j])
+    return out
+
+
+def compose_affine(coeffs, nvars, A, b):
+    '''Coefficients of  x -> p(A x + b)  for the polynomials p of the last axis (same degree, same layout): what the reference obtains for a function seen from the
+    other side of an interface by evaluating it in the opposite element's coordinates (function.py:1121-1133 `_Opposite`); here the change of coordinates is folded
+    into the coefficients once.  Exact algebra: every monomial prod_i y_i^k_i of p is expanded with y_i = sum_j A_ij x_j + b_i by polynomial products in the layout
+    (an affine map keeps the total degree).'''
+    coeffs = numpy.asarray(coeffs, dtype=float)
+    nc = coeffs.shape[-1]
+    total = degree(nvars, nc)
+    A, b = numpy.asarray(A, dtype=float).reshape(nvars, nvars), numpy.asarray(b, dtype=float).reshape(nvars)
+    if not nvars or not total:
+        return coeffs.copy()
+    tab = _product_table(nvars, total)
+    pw = powers(nvars, total)
+    one = numpy.zeros(nc)
+    one[index((0,) * nvars, total)] = 1.
+    lin = []  # y_i as polynomials of x
+    for i in range(nvars):
+        y = b[i] * one
+        for j in range(nvars):
+            y[index(tuple(int(k == j) for k in range(nvars)), total)] += A[i, j]
+        lin.append(y)
+    pows = [[one] for _ in range(nvars)]  # pows[i][k] = y_i^k
+    for i in range(nvars):
+        for k in range(1, total + 1):
+            pows[i].append(_mul(pows[i][-1], lin[i], tab))
+    M = numpy.zeros((nc, nc))  # row: monomial of p, column: monomial of the composition
+    for r in range(nc):
+        term = one
+        for i in range(nvars):
+            if pw[r, i]:
+                term = _mul(term, pows[i][pw[r, i]], tab)
+        M[r] = term
+    return coeffs @ M

@@ -338,7 +338,7 @@ def _children(node):
         return [node._func, node._geom]
     if t == '_Jacobian':
         return [node._geom]
-    if t == '_Derivative':
+    if t in ('_Derivative', '_Opposite'):
         return [node._arg]
     if t == '_Integral':
         return [node._integrand]
@@ -370,11 +370,13 @@ class _Factor:
     def __init__(self, basis, name=None, ncomp=1, cvals=None, rational=None, part=None):
         self.basis, self.name, self.ncomp, self.cvals, self.rational = basis, name, int(ncomp), cvals, rational
         self.geom = None  # the reference geometry node the gradient slots refer to
+        self.side = 0     # 1: the function is evaluated on the OPPOSITE side of an interface (function.py:1121-1133 `_Opposite`: jumps and means)
         self.part = part  # (index, offset, length, total): the argument is the concatenation of the coefficient vectors of several bases (function.vectorize), this is one of them
 
     def copy(self):
         f = _Factor(self.basis, self.name, self.ncomp, self.cvals, self.rational, self.part)
         f.geom = self.geom
+        f.side = self.side
         if hasattr(self, 'xnode'):
             f.xnode = self.xnode
         return f
@@ -513,6 +515,19 @@ class Matcher:
                 return self.conv(node._arg)
             finally:
                 self.rename = saved
+        if t == '_Opposite':
+            # everything inside is evaluated in the element on the other side of the interface: the factors change sides (twice: back), coefficient functions of the
+            # point are wrapped, so that the reference tabulates THEIR opposite values; measure and gradient geometry are the same map on both sides
+            out = []
+            for m in self.conv(node._arg):
+                facs = []
+                for f in m.factors:
+                    g = f.copy()
+                    if f.basis is not _SCALAR and f.cvals is None:
+                        g.side = 1 - f.side
+                    facs.append(g)
+                out.append(_Mono(m.A, m.axes, facs, [self.rf.opposite(pn) for pn in m.pw], m.measure))
+            return out
         if t == '_Gradient':
             geom = self.strip_broadcast(node._geom, 1)
             if geom.shape[-1] != self.S - 1:
@@ -972,7 +987,7 @@ class Matcher:
         groups = {}
         for m in monos:
             key = (m.A.shape, m.A.tobytes(), tuple(m.axes), None if m.measure is None else (id(m.measure[0]), m.measure[1]),
-                   tuple((id(f.basis), f.name, f.ncomp, f.part, None if f.rational is None else id(f.rational[1]), id(f.geom), id(f.cvals), id(getattr(f, 'xnode', None))) for f in m.factors))
+                   tuple((id(f.basis), f.name, f.ncomp, f.part, None if f.rational is None else id(f.rational[1]), id(f.geom), id(f.cvals), id(getattr(f, 'xnode', None)), f.side) for f in m.factors))
             groups.setdefault(key, []).append(m)
         if len(groups) == len(monos):
             return monos
@@ -1240,12 +1255,13 @@ class Emitter:
         self._basis[key] = len(self.plan['bases']) - 1
         return self._basis[key]
 
-    def scalar_basis(self, transforms):
-        '''the one-function basis of a scalar argument on the topology `transforms` (see _ScalarBasis)'''
-        key = ('$scalar', id(transforms))
+    def scalar_basis(self, transforms, topo=None):
+        '''the one-function basis of a scalar argument on the topology `transforms` (see _ScalarBasis), or on plan topology `topo` (interface lists)'''
+        key = ('$scalar', id(transforms)) if topo is None else ('$scalar', 'topo', topo)
         if key not in self._basis:
-            ne = len(transforms)
-            self.plan['bases'].append(dict(kind='plain', topo=self.topo(transforms), dofs=numpy.zeros(ne, dtype=numpy.int64), coeffs=numpy.ones((ne, 1)),
+            ti = self.topo(transforms) if topo is None else topo
+            ne = len(transforms) if topo is None else int(self.plan['topos'][topo]['nelems'])
+            self.plan['bases'].append(dict(kind='plain', topo=ti, dofs=numpy.zeros(ne, dtype=numpy.int64), coeffs=numpy.ones((ne, 1)),
                                            offsets=numpy.arange(ne + 1, dtype=numpy.int64), ndofs=1))
             self._basis[key] = len(self.plan['bases']) - 1
         return self._basis[key]
@@ -1336,6 +1352,104 @@ class Emitter:
         self.plan['samples'].append(spec)
         self._sample[key] = len(self.plan['samples']) - 1
         return self._sample[key]
+
+    # -- interfaces: a sample whose terms evaluate functions on BOTH sides (function.opposite, jump, mean: function.py:1121-1133, 1500-1600) --
+    def iface_sample(self, smp, transforms):
+        '''The interfaces of `smp` as the elements of a LIST topology of their own, one plan sample per group of interfaces that see the same points in the parent
+        coordinates of both sides.  Element k of the list is interface `_pos[k]`; `_ie[side][k]` is its parent element in `transforms` on either side, `points` are the
+        coordinates in the parent of side 0 (the side the measure, the geometry tables and the normal of the sample refer to), `_c1` those in the parent of side 1.'''
+        key = (id(smp), id(transforms), 'iface')
+        if key in self._sample:
+            return self._sample[key]
+        self._keep.append(smp)
+        import nutils.transform as rtransform
+        pts = smp.points
+        tr0, tr1 = smp.transforms[0], smp.transforms[-1]
+        if tr0.fromdims != tr0.todims - 1:
+            raise Unmatched('opposite sides on a sample that is no interface')
+        groups = {}
+        corners = numpy.vstack([numpy.zeros((1, tr0.fromdims)), numpy.eye(tr0.fromdims)])
+        for i in range(len(tr0)):
+            ie0, tail0 = transforms.index_with_tail(tr0[i])
+            ie1, tail1 = transforms.index_with_tail(tr1[i])
+            p = pts[i]
+            c0 = rtransform.apply(tail0, numpy.asarray(p.coords, dtype=float))
+            c1 = rtransform.apply(tail1, numpy.asarray(p.coords, dtype=float))
+            v = rtransform.apply(tail0, corners)
+            nu = _ext_normal((v[1:] - v[0]).T)
+            nu = (nu * (1 if nu[numpy.flatnonzero(numpy.abs(nu) > 1e-12)[0]] > 0 else -1)).round(12)
+            k = (c0.round(12).tobytes(), c1.round(12).tobytes(), numpy.asarray(self.weights(p)).round(14).tobytes(), nu.tobytes())
+            g = groups.setdefault(k, dict(ie0=[], ie1=[], pos=[], c0=c0, c1=c1, weights=self.weights(p), nu=nu))
+            g['ie0'].append(ie0), g['ie1'].append(ie1), g['pos'].append(i)
+        idx = []
+        for g in groups.values():
+            const = [a for a in range(g['c0'].shape[1]) if numpy.ptp(g['c0'][:, a]) == 0 and g['c0'][0, a] in (0., 1.)]
+            axis, oblique = (const[0], {}) if len(const) == 1 else (-1, dict(_bnd_normal=g['nu']))
+            self.plan['topos'].append(dict(kind='list', nelems=len(g['pos']), ndims=int(tr0.todims)))
+            self.plan['samples'].append(dict(topo=len(self.plan['topos']) - 1, points=g['c0'], weights=g['weights'], elist=None, bnd_axis=axis, _nl=len(g['pos']), _ne=len(g['pos']),
+                                             _pos=numpy.array(g['pos'], dtype=numpy.int64), _ie=[numpy.array(g['ie0']), numpy.array(g['ie1'])], _c1=g['c1'], _iface=True, **oblique))
+            idx.append(len(self.plan['samples']) - 1)
+        self._sample[key] = idx
+        return idx
+
+    def iface_variant(self, si, key):
+        '''Interface sample si, or a copy of it, for one (test basis, trial basis) pair: the front end assembles one pair of bases per sample, the four side combinations
+        of a jump against a jump are four samples over the same interfaces.'''
+        variants = self._sample.setdefault(('variants', si), {})
+        if key not in variants:
+            if not variants:
+                variants[key] = si  # (the first pair takes the sample itself)
+            else:
+                self.plan['samples'].append(dict(self.plan['samples'][si], _root=si))
+                variants[key] = len(self.plan['samples']) - 1
+        return variants[key]
+
+    def iface_affine(self, gnode, smp, si, transforms):
+        '''Per interface of sample si: (A, b) with xi_1 = A xi_0 + b, the parent coordinates of side 1 as a function of those of side 0 through the physical map --
+        A = (dx/dxi_1)^-1 dx/dxi_0, both Jacobians evaluated by the reference at the points of the sample and required to be constant per interface (affine elements).'''
+        key = ('affine', id(gnode), self.plan['samples'][si].get('_root', si))
+        if key not in self._geom:
+            rf = self.M.rf
+            s = self.plan['samples'][si]
+            nl, nq = s['_nl'], len(s['weights'])
+            nd = int(gnode.shape[-1])
+            xi = rf.transforms_coords(smp.spaces[0], transforms)
+            J0 = _point_values(smp, rf.grad(gnode, xi), s, tail=(nd, nd))
+            J1 = _point_values(smp, rf.opposite(rf.grad(gnode, xi)), s, tail=(nd, nd))
+            scale = max(numpy.abs(J0).max(), numpy.abs(J1).max())
+            if numpy.abs(J0 - J0[:, :1]).max() > 1e-12 * scale or numpy.abs(J1 - J1[:, :1]).max() > 1e-12 * scale:
+                raise Unmatched('opposite sides of a curved interface (the change of parent coordinates is not affine)')
+            A = numpy.linalg.solve(J1[:, 0], J0[:, 0])
+            c0, c1 = numpy.asarray(s['points'], dtype=float)[0], numpy.asarray(s['_c1'], dtype=float)[0]
+            b = c1 - numpy.einsum('kij,j->ki', A, c0)
+            self._geom[key] = A, b
+        return self._geom[key]
+
+    def iface_basis(self, basis, side, smp, si, transforms, gnode):
+        '''`basis` restricted to the parents of the interfaces of sample si on one side, as a plain basis of the interface list; side 1: the polynomials composed with the
+        affine change of parent coordinates, so that they are functions of the coordinates the sample's points and geometry tables are given in.'''
+        root = self.plan['samples'][si].get('_root', si)  # (variants share the bases of the sample they were copied from)
+        key = (id(basis), 'iface', side, root, None if side == 0 else id(gnode))
+        if key in self._basis:
+            return self._basis[key]
+        self._keep.append(basis)
+        from . import poly as _poly
+        s = self.plan['samples'][si]
+        nv = int(transforms.fromdims)
+        ies = s['_ie'][side]
+        dofs = [numpy.asarray(basis.get_dofs(int(e)), dtype=numpy.int64) for e in ies]
+        coeffs = [numpy.asarray(basis.get_coefficients(int(e)), dtype=float) for e in ies]
+        if any(c.ndim != 2 for c in coeffs):
+            raise Unmatched('basis with tensorial coefficients on an interface')
+        top = max(_poly.degree(nv, c.shape[1]) for c in coeffs)
+        coeffs = [_poly.change_degree(c, nv, top) for c in coeffs]
+        if side == 1:
+            A, b = self.iface_affine(gnode, smp, si, transforms)
+            coeffs = [_poly.compose_affine(c, nv, A[k], b[k]) for k, c in enumerate(coeffs)]
+        self.plan['bases'].append(dict(kind='plain', topo=s['topo'], dofs=numpy.concatenate(dofs), coeffs=numpy.concatenate(coeffs, axis=0),
+                                       offsets=numpy.cumsum([0] + [len(d) for d in dofs]).astype(numpy.int64), ndofs=len(basis)))
+        self._basis[key] = len(self.plan['bases']) - 1
+        return self._basis[key]
 
     @staticmethod
     def weights(p):
@@ -1474,7 +1588,10 @@ def match(array, arguments=None):
         for smp, m, fac in terms:
             by.setdefault((id(smp), fac), (smp, fac, []))[2].append(m)
         terms = [(smp, m, fac) for smp, fac, ms in by.values() for m in M.merge(ms)]
+    # samples with a term that evaluates a function on the opposite side (jumps, means): ALL their terms are written on the list of the interfaces
+    iface_smps = {id(smp) for smp, m, _ in terms if any(f.side for f in m.factors)}
     for smp, m, fac in terms:
+        iface = id(smp) in iface_smps
         if any(k == 'cdof' for k, _ in m.axes):
             raise Unmatched('basis weighted per dof outside a rational form')
         # constant-bound factors that are not the geometry: pointwise functions
@@ -1504,8 +1621,8 @@ def match(array, arguments=None):
                 if uses_gradient(i):
                     raise Unmatched('gradient of a scalar argument')
                 poly.append(i)
-            elif uses_gradient(i) or facs[i].ncomp > 1 or len([f for f in facs if f.basis is not _SCALAR]) <= 2:
-                form.append(i)
+            elif uses_gradient(i) or facs[i].ncomp > 1 or len([f for f in facs if f.basis is not _SCALAR]) <= 2 or iface:
+                form.append(i)  # (interfaces: the same argument lives on two bases -- one per side --, which a coefficient polynomial cannot name: point variables below)
             else:
                 poly.append(i)
         # more than two such factors (the convection u_j d_j(u_i) v_i: v, u, u): two stay in the form -- the exposed ones, then bound ones that the array is
@@ -1561,22 +1678,28 @@ def match(array, arguments=None):
             home = smp.transforms[0]
         else:
             raise Unmatched('boundary integral without any basis: the parent topology is unknown')
-        sis = E.sample(smp, home)
+        sis = E.iface_sample(smp, home) if iface else E.sample(smp, home)
+        if iface and m.measure is None:
+            raise Unmatched('interface term without a measure')
+        if iface and any(f.rational is not None for f in facs):
+            raise Unmatched('rational basis on an interface')
         for si, (combo, T) in [(si, ct) for si in (sis if isinstance(sis, list) else [sis]) for ct in combos]:
+            if iface:  # one sample per pair of (basis, side) in the form: see Emitter.iface_variant
+                si = E.iface_variant(si, tuple((id(facs[i].basis), facs[i].side) for i in form))
             s = E.plan['samples'][si]
             if m.measure is None:
                 # an integral over the REFERENCE elements (no J(geom): the weight-function projection of examples/platewithhole.py:83): the measure of the identity map
                 gnode, gi = None, E.geom_unit(si)
             else:
                 gnode, tip = m.measure
-                gi = _geom_index(E, gnode, smp, si, home)
+                gi = E.geom_tab(gnode, smp, si, home) if iface else _geom_index(E, gnode, smp, si, home)
             gg = -1
             gnodes = {id(facs[i].geom): facs[i].geom for i in form + pv if facs[i].geom is not None}
             if len(gnodes) > 1:
                 raise Unmatched('gradients with respect to different geometries')
             if gnodes:
                 g = next(iter(gnodes.values()))
-                gg = gi if g is gnode else _geom_index(E, g, smp, si, home)
+                gg = gi if g is gnode else E.geom_tab(g, smp, si, home) if iface else _geom_index(E, g, smp, si, home)
             term = dict(sample=si, fac=float(fac), measure=gi, geom=gg, test=-1, trial=-1, rows=False, cols=False, scale=None, fpoly=None)
             def on_home(bi):  # every basis of a term must be indexed by the elements of the sample's topology (no field of a coarser level)
                 b = E.plan['bases'][bi]
@@ -1586,10 +1709,13 @@ def match(array, arguments=None):
                     raise Unmatched('bases of different topologies in one term')
                 return bi
             ai = []
+            def basis_of(f):
+                if iface:
+                    return on_home(E.iface_basis(f.basis, f.side, smp, si, home, gnode))
+                return on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None))
             for i in form:
                 f = facs[i]
-                bi = on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None))
-                ai.append(E.arg(f.name, bi, f.ncomp, f.part))
+                ai.append(E.arg(f.name, basis_of(f), f.ncomp, f.part))
             if len(form) == 2:
                 Bt = numpy.ascontiguousarray(T)
                 if not exposed and ai[0] > ai[1]:  # both bound: canonical order, so that B(u, w) and B(w, u) merge
@@ -1604,8 +1730,7 @@ def match(array, arguments=None):
                 term['pvars'] = []
                 for j, i in enumerate(pv):
                     f = facs[i]
-                    bi = on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None))
-                    term['pvars'].append([E.arg(f.name, bi, f.ncomp, f.part), int(combo[2 * j]), int(combo[2 * j + 1])])
+                    term['pvars'].append([E.arg(f.name, basis_of(f), f.ncomp, f.part), int(combo[2 * j]), int(combo[2 * j + 1])])
             if m.pw:
                 node = m.pw[0]
                 for p in m.pw[1:]:
@@ -1624,10 +1749,10 @@ def match(array, arguments=None):
                 for i in poly:
                     f = facs[i]
                     if f.basis is _SCALAR:
-                        a = E.arg(f.name, on_home(E.scalar_basis(home)), 1)
+                        a = E.arg(f.name, on_home(E.scalar_basis(home, s['topo'] if iface else None)), 1)
                         E.plan['args'][a]['scalar'] = True
                     else:
-                        a = E.arg(f.name, on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None)), 1, f.part)
+                        a = E.arg(f.name, basis_of(f), 1, f.part)
                     pargs.append(a)
                 uniq = sorted(set(pargs))
                 term['fpoly'] = dict(args=uniq, powers=numpy.array([[pargs.count(a) for a in uniq]]), coeffs=[1.])

@@ -42,9 +42,8 @@ def test_seam_installed_in_the_reference():
 
 
 def test_seam_installed_examples_with_declined_systems():
-    '''examples whose functionals are only PARTLY inside the matched class (Navier-Stokes convection on mixed meshes, DG interface
-    terms): the Systems the matcher recognises are assembled from plans, the others take the reference's evaluator inside the same script, and the
-    examples' own unit tests pass unchanged'''
+    '''Navier-Stokes on Taylor-Hood elements and the discontinuous Galerkin Burgers equation (upwind flux: jumps and means across interfaces): every System of the
+    selected tests is assembled from plans, the examples' own unit tests pass unchanged'''
     # (finitestrain.py is matched entirely since round 5 -- 9 Systems, 0 declined; its 27 plans are replayed by tests/test_plans_host.py -- and its Newton minimisation through the CPU
     # evaluator alone takes 45 s: not run here)
     out = run('tests/seam_hook_run.py', 'drivencavity:test_baseline', 'burgers:test_1d_p1,test_1d_p2_legendre')

@@ -254,6 +254,45 @@ def main():
         rv = rf.derivative(res, 'v')
         emit(f'burgers_volume_{btype}{degree}_residual', rv, args)
         emit(f'burgers_volume_{btype}{degree}_jacobian', rf.derivative(rv, 'u'), args)
+    # ---- discontinuous Galerkin forms: jumps and means across interfaces (function.py:1121-1133 `_Opposite`, :1500-1600 jump / mean).  The complete Burgers residual
+    # of examples/burgers.py:51-56 (upwind flux on the periodic line, non-uniform cells) and a symmetric interior-penalty Laplace form on a graded 2-D mesh -- volume
+    # term, interface terms with {grad u}, [u] and the penalty, boundary terms -- as residual and Jacobian --------------------------------------------------
+    for btype, degree in (('discont', 1), ('legendre', 2)):
+        domain, geom = mesh.line(numpy.linspace(-.5, .5, 7) ** 3 * 4, periodic=True)
+        ns = Namespace()
+        ns.x = geom
+        ns.define_for('x', gradient='∇', normal='n', jacobians=('dV', 'dS'))
+        ns.u = domain.field('u', btype=btype, degree=degree)
+        ns.du = ns.u - rf.replace_arguments(ns.u, 'u:u0')
+        ns.v = domain.field('v', btype=btype, degree=degree)
+        ns.t = rf.field('t')
+        ns.dt = ns.t - rf.field('t0')
+        ns.f = '.5 u^2'
+        ns.C = 1
+        res = domain.integral('(v du / dt - ∇(v) f) dV' @ ns, degree=degree * 2) - domain.interfaces.integral('[v] n ({f} - .5 C [u] n) dS' @ ns, degree=degree * 2)
+        shapes = {k: v.shape for k, v in rf.arguments_for(res).items()}
+        rngb = numpy.random.default_rng(17)
+        args = {k: rngb.normal(size=shp) for k, shp in shapes.items() if k != 'v'}
+        args['t'], args['t0'] = numpy.array(.7), numpy.array(.45)
+        rv = rf.derivative(res, 'v')
+        emit(f'dg_burgers_{btype}{degree}_residual', rv, args)
+        emit(f'dg_burgers_{btype}{degree}_jacobian', rf.derivative(rv, 'u'), args)
+    for degree in (1, 2):
+        domain, geom = mesh.rectilinear([numpy.linspace(0, 1, 5) ** 2, numpy.linspace(0, 2, 4)])
+        ns = Namespace()
+        ns.x = geom
+        ns.define_for('x', gradient='∇', normal='n', jacobians=('dV', 'dS'))
+        ns.u = domain.field('u', btype='discont', degree=degree)
+        ns.v = domain.field('v', btype='discont', degree=degree)
+        ns.β = 7. * degree ** 2
+        res = domain.integral('∇_i(v) ∇_i(u) dV' @ ns, degree=2 * degree) \
+            - domain.interfaces.integral('([v] n_i {∇_i(u)} + {∇_i(v)} n_i [u] - β [v] [u]) dS' @ ns, degree=2 * degree) \
+            + domain.boundary.integral('(β v u - v n_i ∇_i(u) - u n_i ∇_i(v)) dS' @ ns, degree=2 * degree)
+        shapes = {k: v.shape for k, v in rf.arguments_for(res).items()}
+        args = {k: numpy.random.default_rng(19).normal(size=shp) for k, shp in shapes.items() if k != 'v'}
+        rv = rf.derivative(res, 'v')
+        emit(f'dg_sipg_p{degree}_residual', rv, args)
+        emit(f'dg_sipg_p{degree}_jacobian', rf.derivative(rv, 'u'), args)
     # ---- component blocks per sample: a block-diagonal volume form + a boundary form that couples all components.  The reference runs one loop per
     # sample and concatenates the triplets, so the off-diagonal blocks exist in the rows of the boundary elements only (nnz 364, not 520) --------------
     domain, geom = mesh.rectilinear([3, 4])
