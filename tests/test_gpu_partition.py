@@ -233,3 +233,33 @@ def test_element_partition_of_an_unstructured_mesh(shape, degree, ncomp, world, 
     vo, rpo, cio = matrix(numpy.arange(ne), numpy.ones(ne, dtype=bool))
     assert numpy.array_equal(rp, rpo) and numpy.array_equal(ci, cio)
     assert numpy.abs(v - vo).max() <= 1e-13 * numpy.abs(vo).max()
+
+
+@pytest.mark.parametrize('halo', ['reduce', 'recompute'])
+def test_element_partition_multiprocess_on_one_gpu(halo, tmp_path):
+    '''tools/partition_run.py as `torch.distributed.run` launches it -- three processes, all on the one GPU of this box, shared rows through gloo (host staging) --:
+    setup (all_gather_object of the column lists), pack / send / receive / add, owned blocks; merged in row order they equal the single-process matrix of the same
+    script (index arrays exact, values 1e-13).'''
+    import os, subprocess, sys
+    from nutils_amd import partition
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NUTILS_AMD_BENCH_ONE_GPU='1', MASTER_ADDR='127.0.0.1')
+    outs = {}
+    for world in (3, 1):
+        d = tmp_path / f'w{world}'
+        d.mkdir()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1', '--master-port', str(29520 + world),
+               'tools/partition_run.py', '--halo', halo, '--shape', '7,6,5', '--out', str(d)]
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+        blocks = []
+        for r in range(world):
+            z = numpy.load(d / f'rows{r}.npz')
+            blocks.append((z['rows'], z['lens'], z['cols'], z['vals']))
+        outs[world] = partition.merge_rows(blocks, 8 * 7 * 6 * 3)
+        if world == 3:
+            assert ('entries sent' in out.stdout) and ((' 0 of ' in out.stdout) == (halo == 'recompute') or halo == 'reduce')
+    v, rp, ci = outs[3]
+    vo, rpo, cio = outs[1]
+    assert numpy.array_equal(rp, rpo) and numpy.array_equal(ci, cio)
+    assert numpy.abs(v - vo).max() <= 1e-13 * numpy.abs(vo).max()
