@@ -962,7 +962,10 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     // Triangular scratch (default where it applies: k_gram_sym takes EVERY launch of this call, the sums are stored, the pattern is symmetric): node pairs of the
     // dof-sorted nodes, m' >= n', packed -- half the scratch written and read; the upper triangle of the matrix is mirrored from the lower (nh_gather.hip)
     static const bool notri = getenv("NUTILS_AMD_NO_TRI_SCRATCH") && atoi(getenv("NUTILS_AMD_NO_TRI_SCRATCH"));
-    if (p.sym == 1 && !notri && (a->flags & NH_MATRIX_STORE) && !a->elist_dev && !pat->tri_failed) {
+    bool allmask = true;
+    for (int c = 0; c < a->nct; ++c)
+      for (int d = 0; d < a->ncr; ++d) allmask = allmask && form.mask[c][d];
+    if (p.sym == 1 && !notri && allmask && (a->flags & NH_MATRIX_STORE) && !a->elist_dev && !pat->tri_failed) {
       bool all = true;
       const bool rag = (a->test.off_dev || a->trial.off_dev) && pat->nbuckets && pat->nelems == a->nelems;
       for (int b = 0; b < (rag ? pat->nbuckets : 1) && all; ++b) {

@@ -293,6 +293,29 @@ __global__ void k_gather_values_2x2_tri(i64 nnz, const unsigned *gptr, const int
   double *d1 = values + a0 * gs.tot + len * gs.cum[1] + pos * gs.cnt[1] + gs.dpos[1][0];
   d0[0] = s00, d0[1] = s01, d1[0] = s10, d1[1] = s11;
 }
+// scalar blocks on the triangular scratch: eight contributions in flight, like k_gather_values
+__global__ void k_gather_values_tri1(i64 nnz, const unsigned *gptr, const int32_t *gsrc, const int32_t *mirror, const double *local, double *values) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz || mirror[k] >= 0) return;
+  const unsigned b = gptr[k], e = gptr[k + 1];
+  double s = 0;
+  for (unsigned i0 = b; i0 < e; i0 += 8) {
+    unsigned idx[8];
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) idx[u] = i0 + u < e ? (unsigned)gsrc[i0 + u] : 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = idx[u] != 0xffffffffu ? local[idx[u]] : 0.;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < e) s += v[u];
+  }
+  values[k] = s;
+}
+__global__ void k_mirror_1(i64 nnz, const int32_t *mirror, double *values) {
+  const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nnz && mirror[k] >= 0) values[k] = values[mirror[k]];
+}
 __global__ void k_mirror_2x2(i64 nnz, const int32_t *grow, const i64 *srowptr, const int32_t *mirror, GSlots gs, double *values) {
   const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nnz) return;
@@ -1277,10 +1300,15 @@ __global__ __launch_bounds__(128) void k_local_rows_v(LocVK p) {
 int nh_gather_values(const nh_pattern *p, const double *local, i64 ld, const GSlots &slots, double *values, int store, hipStream_t s, int sym_sources) {
   if (!p->nnz) return NH_OK;
   if (sym_sources == 2) {
-    NH_REQUIRE(p->gsrc_tri && p->gmirror && store && slots.nct == 2 && slots.ncr == 2, "gather: the triangular scratch needs its maps, 2 x 2 blocks and NH_MATRIX_STORE");
+    NH_REQUIRE(p->gsrc_tri && p->gmirror && store && slots.nct == slots.ncr && slots.nct <= 2, "gather: the triangular scratch needs its maps, scalar or 2 x 2 blocks and NH_MATRIX_STORE");
     const dim3 grid((unsigned)((p->nnz + 255) / 256));
-    hipLaunchKernelGGL(k_gather_values_2x2_tri, grid, dim3(256), 0, s, p->nnz, p->gptr, p->gsrc_tri, p->grow, p->srowptr, p->gmirror, local, slots, values);
-    hipLaunchKernelGGL(k_mirror_2x2, grid, dim3(256), 0, s, p->nnz, p->grow, p->srowptr, p->gmirror, slots, values);
+    if (slots.nct == 1) {
+      hipLaunchKernelGGL(k_gather_values_tri1, grid, dim3(256), 0, s, p->nnz, p->gptr, p->gsrc_tri, p->gmirror, local, values);
+      hipLaunchKernelGGL(k_mirror_1, grid, dim3(256), 0, s, p->nnz, p->gmirror, values);
+    } else {
+      hipLaunchKernelGGL(k_gather_values_2x2_tri, grid, dim3(256), 0, s, p->nnz, p->gptr, p->gsrc_tri, p->grow, p->srowptr, p->gmirror, local, slots, values);
+      hipLaunchKernelGGL(k_mirror_2x2, grid, dim3(256), 0, s, p->nnz, p->grow, p->srowptr, p->gmirror, slots, values);
+    }
   } else if (sym_sources) {
     NH_REQUIRE(p->gsrc_sym && slots.nct == slots.ncr && (slots.nct == 2 || slots.nct == 3), "gather: symmetric sources need their map and 2 x 2 / 3 x 3 blocks");
     hipLaunchKernelGGL(k_gather_values_v<true>, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, s, p->nnz, p->gptr, p->gsrc_sym, p->grow, p->srowptr, local, slots, values, store);
