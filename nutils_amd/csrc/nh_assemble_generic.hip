@@ -961,7 +961,7 @@ int nh_assemble_matrix(const nh_matrix_args *a, void *stream) {
     }
     // Triangular scratch (default where it applies: k_gram_sym takes EVERY launch of this call, the sums are stored, the pattern is symmetric): node pairs of the
     // dof-sorted nodes, m' >= n', packed -- half the scratch written and read; the upper triangle of the matrix is mirrored from the lower (nh_gather.hip)
-    static const bool notri = getenv("NUTILS_AMD_NO_TRI_SCRATCH") && atoi(getenv("NUTILS_AMD_NO_TRI_SCRATCH"));
+    const bool notri = getenv("NUTILS_AMD_NO_TRI_SCRATCH") && atoi(getenv("NUTILS_AMD_NO_TRI_SCRATCH"));
     bool allmask = true;
     for (int c = 0; c < a->nct; ++c)
       for (int d = 0; d < a->ncr; ++d) allmask = allmask && form.mask[c][d];
