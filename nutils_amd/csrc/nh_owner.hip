@@ -228,7 +228,10 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
   __syncthreads();
   OTICK(0);
   // phase 1: lanes over (visit, point of the chunk q0 .. q0 + nql) -- inverse Jacobian, weight, physical gradients of the NB functions
-  auto element_phase = [&](const int q0, const int nql) {
+  // (LT: the tables are the copies in LDS -- a compile-time fact: a pointer that is `p.ldst ? LDS : global` makes every read of a table a FLAT load, which the
+  // stores of D in between serialise: 19 k of the 48 k cycles a block of 96^3 trilinear elasticity took, profiles/r06_owner.md)
+  auto element_phase_of = [&](auto lt_tag, const int q0, const int nql) {
+  constexpr bool LT = decltype(lt_tag)::value;
   for (int i = tid; i < nv * nql && !(ODBG(p) & 1); i += OWN_NT) {
     const int v = i / nql, ql = i - v * nql, q = q0 + ql;
     const i64 e = p.vlist[v0 + v];
@@ -249,14 +252,15 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
       for (int r = 0; r < ND; ++r)
 #pragma unroll
         for (int c = 0; c < ND; ++c) J[r][c] = 0;
-      const double *gT = p.ldst ? sgT : p.geom.gT;
 #pragma unroll
       for (int a = 0; a < NG; ++a) {
-        const double *t = gT + (a * nq + q) * S;
+        double t[ND];
+#pragma unroll
+        for (int c = 0; c < ND; ++c) t[c] = LT ? sgT[(a * nq + q) * S + 1 + c] : p.geom.gT[(a * nq + q) * S + 1 + c];
 #pragma unroll
         for (int r = 0; r < ND; ++r)
 #pragma unroll
-          for (int c = 0; c < ND; ++c) J[r][c] += (XLDS ? sX[v * XV + a * ND + r] : Xr[XLDS ? 0 : a][r]) * t[1 + c];
+          for (int c = 0; c < ND; ++c) J[r][c] += (XLDS ? sX[v * XV + a * ND + r] : Xr[XLDS ? 0 : a][r]) * t[c];
       }
       invert<ND>(J, Ji, det);
       if (p.geom.bnd_axis >= 0) {
@@ -277,21 +281,35 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
     } else
       geometry_at<ND>(p.geom, e, q, nq, nullptr, Ji, det, nullptr);
     sW[v * qc + ql] = sWq[q] * fabs(det) * (p.scale ? p.scale[e * nq + q] : 1.);
-    const double *T = p.ldst ? sT : p.test.T + bfn(p.test, e) * nq * S;
+    const double *Tg = p.test.T + bfn(p.test, e) * nq * S;
     double *D = sD + v * VS + ql * QS;
+    constexpr int NBC = NB % 4 == 0 ? 4 : 3;  // the table rows of NBC functions are read before their gradients are stored
 #pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      const double *t = T + (n * nq + q) * S;
-      if (USE0) D[n * SD] = t[0];
+    for (int n0 = 0; n0 < NB; n0 += NBC) {
+      double t[NBC][S];
 #pragma unroll
-      for (int c = 0; c < ND; ++c) {
-        double sum = 0;
+      for (int n = 0; n < NBC; ++n)
 #pragma unroll
-        for (int j = 0; j < ND; ++j) sum += t[1 + j] * Ji[j][c];
-        D[n * SD + (USE0 ? 1 : 0) + c] = sum;
+        for (int j = USE0 ? 0 : 1; j < S; ++j)
+          if (n0 + n < NB) t[n][j] = LT ? sT[((n0 + n) * nq + q) * S + j] : Tg[((n0 + n) * nq + q) * S + j];
+#pragma unroll
+      for (int n = 0; n < NBC; ++n) {
+        if (n0 + n >= NB) continue;
+        if (USE0) D[(n0 + n) * SD] = t[n][0];
+#pragma unroll
+        for (int c = 0; c < ND; ++c) {
+          double sum = 0;
+#pragma unroll
+          for (int j = 0; j < ND; ++j) sum += t[n][1 + j] * Ji[j][c];
+          D[(n0 + n) * SD + (USE0 ? 1 : 0) + c] = sum;
+        }
       }
     }
   }
+  };
+  auto element_phase = [&](const int q0, const int nql) {
+    if (p.ldst) element_phase_of(std::true_type(), q0, nql);
+    else element_phase_of(std::false_type(), q0, nql);
   };
   // phase 2: a wave per chunk of 64 contributions (the item words of the wave's first chunks were requested before phase 0: their latency is behind the element phase)
   // Gram sums of one contribution over the nql points of the tables in LDS
