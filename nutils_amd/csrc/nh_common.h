@@ -118,6 +118,11 @@ struct nh_owner_plan {
   i64 *cptr;        // [nblocks + 1]: chunks of block b
   uint32_t *isrc;   // [nchunks * 64]: bit 31 valid, bit 30 first item of its entry, bits 10-21 visit within the block, 5-9 m, 0-4 n
   uint32_t *idst;   // [nchunks * 64]: row within the block << 16 | position of the entry in its scalar row
+  // the staging chain of a block cut short (a level of dependent loads less for its rows and for its vertices):
+  i64 *prs;         // [nrows]: first entry of the scalar row at rank position i
+  int32_t *prl;     // [nrows]: its length
+  int32_t *vvert;   // [nvisits * 2^ndims] or null: vertex numbers of the visiting elements, made from the connectivity `vvert_src` (remade when a call brings another array)
+  const void *vvert_src;
 };
 void nh_owner_free(nh_owner_plan *o);
 

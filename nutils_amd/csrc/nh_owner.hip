@@ -106,6 +106,23 @@ __global__ void k_op_maxvisits(int nblocks, const i64 *vptr, int *out) {
   if (b < nblocks) atomicMax(out, (int)(vptr[b + 1] - vptr[b]));
 }
 
+// first entry and length of the scalar row at every rank position
+__global__ void k_op_rowinfo(i64 n, const int32_t *order, const i64 *srowptr, i64 *prs, int32_t *prl) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const i64 r = order[i];
+  prs[i] = srowptr[r];
+  prl[i] = (int32_t)(srowptr[r + 1] - srowptr[r]);
+}
+
+// vertex numbers of the visiting elements
+__global__ void k_op_vvert(i64 n, int ng, const int32_t *vlist, const int32_t *gdofs, int32_t *vvert) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const i64 v = i / ng;
+  vvert[i] = gdofs[(i64)vlist[v] * ng + (i - v * ng)];
+}
+
 // ---- kernel -------------------------------------------------------------------------------------------------------------------------------------------
 struct OwnK {
   int nq;
@@ -121,10 +138,11 @@ struct OwnK {
   int store;
   i64 nrows;
   int R, nsteps, vmax, ldst, rows16, qc;
-  const int32_t *order, *vlist;
+  const int32_t *vlist, *prl, *vvert;
+  const i64 *prs;
   const i64 *vptr, *cptr, *bptr;
   const uint32_t *isrc, *idst;
-  int debug;  // ablation builds: 1 = no geometry / D tables, 2 = no Gram sums, 4 = no segmented sum, 8 = no stores
+  int debug;  // ablation builds: 1 = no geometry / D tables, 2 = no Gram sums, 4 = no segmented sum, 8 = no stores, 16 = no vertex numbers (the thread's own index instead), 32 = no item words, 64 = no table copies
   unsigned long long *tdbg;  // ablation builds: cycles of wave 0 per phase, summed over the blocks
 };
 #ifdef NH_ABLATION
@@ -198,33 +216,46 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
 #pragma unroll
   for (int k = 0; k < PRE; ++k) {
     const i64 c = c0 + wave + (i64)k * nw;
-    pit[k] = c < c1 ? p.isrc[c * 64 + lane] : 0u;
-    pds[k] = c < c1 ? p.idst[c * 64 + lane] : 0u;
+    pit[k] = c < c1 && !(ODBG(p) & 32) ? p.isrc[c * 64 + lane] : 0x80000000u | (lane % 3 ? 0u : 0x40000000u);
+    pds[k] = c < c1 && !(ODBG(p) & 32) ? p.idst[c * 64 + lane] : 0u;
   }
   const i64 r0 = p.bptr[b];
   const int nr = (int)(p.bptr[b + 1] - r0);
-  for (int i = tid; i < nr; i += OWN_NT) {
-    const i64 r = p.order[r0 + i];
-    const i64 a0 = p.srowptr[r];
-    rs[i] = a0;
-    rl[i] = (int)(p.srowptr[r + 1] - a0);
+  // Staging was a chain of dependent loads (block ranges -> visits / rows -> vertex numbers / row starts -> vertices); the plan holds row starts by rank position and
+  // vertex numbers by visit, which leaves block ranges -> vertex numbers -> vertices.  (Walking the chain of a LATER block beside it, to have its lines in the L2 when it is dispatched, lost: 1.58 -> 1.68 .. 1.79 ms at 96^3
+  // for distances of 64 .. 2048 blocks -- the memory system is short of requests, not of latency; profiles/r06_owner.md.)
+  const bool stage_x = iso && XLDS;
+  // level 1
+  const int xv = tid / NG, xa = tid - xv * NG;  // this thread's (visit, vertex) pair among the first OWN_NT
+  const int my_vert = stage_x && tid < nv * NG && !(ODBG(p) & 16) ? p.vvert[v0 * NG + tid] : tid;
+  if (tid < nr) rs[tid] = p.prs[r0 + tid], rl[tid] = p.prl[r0 + tid];
+  for (int i = tid + OWN_NT; i < nr; i += OWN_NT) rs[i] = p.prs[r0 + i], rl[i] = p.prl[r0 + i];
+  // level 2
+  double my_x[ND];
+  if (stage_x && tid < nv * NG) {
+#pragma unroll
+    for (int d = 0; d < ND; ++d) my_x[d] = p.geom.verts[(i64)my_vert * ND + d];
   }
   if (!ISOF)
     for (int i = tid; i < 144; i += OWN_NT) sC[i] = p.C[i];
   for (int i = tid; i < nq; i += OWN_NT) sWq[i] = p.weights[i];
-  if (p.ldst) {
+  if (p.ldst && !(ODBG(p) & 64)) {
     for (int i = tid; i < NB * nq * S; i += OWN_NT) sT[i] = p.test.T[i];
     if (iso)
       for (int i = tid; i < NG * nq * S; i += OWN_NT) sgT[i] = p.geom.gT[i];
   }
-  if (iso && XLDS)
-    for (int i = tid; i < nv * NG; i += OWN_NT) {
+  if (stage_x) {
+    if (tid < nv * NG) {
+#pragma unroll
+      for (int d = 0; d < ND; ++d) sX[xv * XV + xa * ND + d] = my_x[d];
+    }
+    for (int i = tid + OWN_NT; i < nv * NG; i += OWN_NT) {
       const int v = i / NG, a = i - v * NG;
-      const i64 e = p.vlist[v0 + v];
-      const i64 vert = p.geom.gdofs[e * NG + a];
+      const i64 vert = p.vvert[v0 * NG + i];
 #pragma unroll
       for (int d = 0; d < ND; ++d) sX[v * XV + a * ND + d] = p.geom.verts[vert * ND + d];
     }
+  }
   __syncthreads();
   OTICK(0);
   // phase 1: lanes over (visit, point of the chunk q0 .. q0 + nql) -- inverse Jacobian, weight, physical gradients of the NB functions
@@ -342,13 +373,17 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
       // (the plan kept every entry inside a row of 16 lanes: DPP row shifts -- VALU moves -- instead of ds_bpermute through the LDS pipe: 9 % of the kernel at 96^3)
       auto step = [&](auto dtag) {
         constexpr int D = decltype(dtag)::value;
+        double o[SD][SD];  // (all shifts, then ONE masked region of adds: a test per value made a step 50-76 instructions for its 9 adds -- the kernel is bound by VALU issue)
 #pragma unroll
         for (int a = 0; a < SD; ++a)
 #pragma unroll
-          for (int bb = 0; bb < SD; ++bb) {
-            const double o = row_shl<D>(G[a][bb]);
-            if (D <= rem) G[a][bb] += o;
-          }
+          for (int bb = 0; bb < SD; ++bb) o[a][bb] = row_shl<D>(G[a][bb]);
+        if (D <= rem) {
+#pragma unroll
+          for (int a = 0; a < SD; ++a)
+#pragma unroll
+            for (int bb = 0; bb < SD; ++bb) G[a][bb] += o[a][bb];
+        }
       };
       if (p.nsteps > 0 && !(ODBG(p) & 4)) step(std::integral_constant<int, 1>());
       if (p.nsteps > 1 && !(ODBG(p) & 4)) step(std::integral_constant<int, 2>());
@@ -368,7 +403,7 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
       const int rowl = dst >> 16, pos = dst & 0xffff;
       const i64 a0 = rs[rowl];
       const int len = rl[rowl];
-      double *base = p.values + a0 * p.gs.tot;
+      double *base = p.values + a0 * (ISOF ? NC * NC : p.gs.tot);
       double tr = 0;
       if (ISOF) {
 #pragma unroll
@@ -378,7 +413,7 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
       for (int cc = 0; cc < NC; ++cc)
 #pragma unroll
         for (int dd = 0; dd < NC; ++dd) {
-          if (!p.gs.mask[cc][dd]) continue;  // (uniform)
+          if (!ISOF && !p.gs.mask[cc][dd]) continue;  // (uniform)
           double val;
           if constexpr (ISOF) {
             val = p.lam * G[cc < SD ? cc : 0][dd < SD ? dd : 0] + p.mu2 * G[dd < SD ? dd : 0][cc < SD ? cc : 0];
@@ -390,12 +425,15 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
 #pragma unroll
               for (int bb = 0; bb < SD; ++bb) val += sC[((cc * S + O + a) * NC + dd) * S + O + bb] * G[a][bb];
           }
-          double *ptr = base + (i64)len * p.gs.cum[cc] + (i64)pos * p.gs.cnt[cc] + p.gs.dpos[cc][dd];
+          // (ISOF: every component pair is there -- the launcher checks the layout: NC values per node column, NC scalar rows of `len` node columns each)
+          double *ptr = ISOF ? base + ((i64)len * cc + pos) * NC + dd : base + (i64)len * p.gs.cum[cc] + (i64)pos * p.gs.cnt[cc] + p.gs.dpos[cc][dd];
           *ptr = p.store ? val : *ptr + val;
         }
     }
   };
   if constexpr (GK == 0) {
+    // (A persistent grid -- the workgroup requests the ranges, rows and vertex numbers of its next block before the element phase of this one, copies the tables once --
+    // was built twice: the loop costs registers past the 128 a wave has at two workgroups per CU, 1.58 -> 1.98 ms with 24 spilled; profiles/r06_owner.md.)
     element_phase(0, nq);
     OTICK(1);
     __syncthreads();
@@ -449,7 +487,7 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
 
 void nh_owner_free(nh_owner_plan *o) {
   if (!o) return;
-  hipFree(o->order), hipFree(o->bptr), hipFree(o->vptr), hipFree(o->vlist), hipFree(o->cptr), hipFree(o->isrc), hipFree(o->idst);
+  hipFree(o->order), hipFree(o->bptr), hipFree(o->vptr), hipFree(o->vlist), hipFree(o->cptr), hipFree(o->isrc), hipFree(o->idst), hipFree(o->prs), hipFree(o->prl), hipFree(o->vvert);
   delete o;
 }
 
@@ -584,6 +622,10 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
     o->cptr = bp_keep(t, cptr);
     o->isrc = bp_keep(t, isrc);
     o->idst = bp_keep(t, idst);
+    OP_CHECK(hipMalloc((void **)&o->prs, sizeof(i64) * (size_t)std::max<i64>(nrows, 1)));
+    OP_CHECK(hipMalloc((void **)&o->prl, sizeof(int32_t) * (size_t)std::max<i64>(nrows, 1)));
+    hipLaunchKernelGGL(k_op_rowinfo, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, nrows, o->order, p->srowptr, o->prs, o->prl);
+    OP_CHECK(hipGetLastError());
     if (getenv("NH_OWNER_VERBOSE"))
       fprintf(stderr, "nh_owner plan: %d blocks of %d rows, %lld visits (%.2f per element, at most %d per block), %lld chunks for %lld items (%.2f lanes used), entries of up to %d items, %zu B of LDS\n",
               nblocks, R, (long long)nvisits, (double)nvisits / (double)ne, vmax, (long long)nchunks, (long long)ni, (double)ni / (64. * (double)nchunks), hflags[1],
@@ -593,6 +635,7 @@ done:
 #undef OP_CHECK
   bp_free(t);
   if (rc == NH_OK) p->owner = o;
+  else if (o) nh_owner_free(o);
   return rc;
 }
 
@@ -628,6 +671,12 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
             if ((!sa || !sb) && at(c, sa, d, sb) != 0.) use0 = true;
           }
     p.lam = lam, p.mu = mu, p.mu2 = mu2;
+    if (slots.tot != nc * nc) isof = false;  // (the closed form also takes the full layout for granted)
+    for (int c = 0; c < nc; ++c) {
+      if (slots.cnt[c] != nc || slots.cum[c] != c * nc) isof = false;
+      for (int d = 0; d < nc; ++d)
+        if (slots.dpos[c][d] != d) isof = false;
+    }
   }
   const bool iso = a->geom.kind == NH_GEOM_ISO && a->geom.ngb == (1 << a->ndims);
   const size_t ldsb = sizeof(double) * (size_t)a->nq * S * (a->test.nb + (iso ? (1 << a->ndims) : 0));
@@ -665,7 +714,16 @@ int nh_owner_vector(const nh_matrix_args *a, const GSlots &slots, bool *done, hi
   p.store = (a->flags & NH_MATRIX_STORE) != 0;
   p.nrows = pat->nrows;
   p.R = o->rows_per_block, p.nsteps = o->nsteps, p.vmax = o->max_visits, p.ldst = ldst, p.rows16 = o->rows16, p.qc = qc;
-  p.order = o->order, p.vlist = o->vlist, p.vptr = o->vptr, p.cptr = o->cptr, p.bptr = o->bptr, p.isrc = o->isrc, p.idst = o->idst;
+  if (xlds && (!o->vvert || o->vvert_src != (const void *)a->geom.gdofs_dev)) {  // (the connectivity of this call: remade when another array comes)
+    nh_owner_plan *ow = pat->owner;
+    const i64 n = o->nvisits * (1ll << a->ndims);
+    if (!ow->vvert) NH_CHECK_HIP(hipMalloc((void **)&ow->vvert, sizeof(int32_t) * (size_t)std::max<i64>(n, 1)));
+    hipLaunchKernelGGL(k_op_vvert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, 1 << a->ndims, o->vlist, a->geom.gdofs_dev, ow->vvert);
+    NH_CHECK_HIP(hipGetLastError());
+    ow->vvert_src = (const void *)a->geom.gdofs_dev;
+  }
+  p.prs = o->prs, p.prl = o->prl, p.vvert = o->vvert;
+  p.vlist = o->vlist, p.vptr = o->vptr, p.cptr = o->cptr, p.bptr = o->bptr, p.isrc = o->isrc, p.idst = o->idst;
   // threads: enough waves for the chunks of a block, and for the latencies of phase 1 when one block takes most of a CU's LDS
   int nt = lds > 80 * 1024 ? 1024 : lds > 52 * 1024 ? 512 : 256;
   if (getenv("NH_OWNER_NT")) nt = std::max(64, std::min(OWN_NT_MAX, atoi(getenv("NH_OWNER_NT")) & ~63));
