@@ -29,9 +29,9 @@ constexpr int MAXL = 8;    // term lists of one launch (nh_assemble_terms_multi)
 constexpr int TABARG = 256;  // doubles of the term table that fit the kernel arguments
 constexpr int TABPAD = 24;   // readable doubles behind them (records read whole, at the length of the longest kind)
 
-__device__ __forceinline__ i64 boff(const BasisK &b, i64 e) { return b.off ? b.off[e] : e * (i64)b.nb; }
-__device__ __forceinline__ int bnb(const BasisK &b, i64 e) { return b.off ? (int)(b.off[e + 1] - b.off[e]) : b.nb; }
-__device__ __forceinline__ i64 bfn(const BasisK &b, i64 e) { return b.off ? b.off[e] : (b.tab ? (i64)b.tab[e] * b.nb : 0); }
+__device__ __forceinline__ i64 boff(const BasisK &b, i64 e) { return b.off ? nh_g(b.off)[e] : e * (i64)b.nb; }
+__device__ __forceinline__ int bnb(const BasisK &b, i64 e) { return b.off ? (int)(nh_g(b.off)[e + 1] - nh_g(b.off)[e]) : b.nb; }
+__device__ __forceinline__ i64 bfn(const BasisK &b, i64 e) { return b.off ? nh_g(b.off)[e] : (b.tab ? (i64)nh_g(b.tab)[e] * b.nb : 0); }
 
 struct FieldK {
   BasisK b;
@@ -76,13 +76,13 @@ __device__ __forceinline__ void stage_coeffs(const FieldK *fields, int nfields, 
     const int el = i / uesz;
     int r = i - el * uesz;
     if (b0 + el >= nelems) continue;
-    const i64 e = elist ? elist[b0 + el] : b0 + el;
+    const i64 e = elist ? nh_g(elist)[b0 + el] : b0 + el;
     int f = 0;
     while (f + 1 < nfields && r >= fields[f + 1].ue0) ++f;
     const FieldK &F = fields[f];
     r -= F.ue0;
     const int n = r / F.ncomp, d = r - n * F.ncomp;
-    if (n < bnb(F.b, e)) ue[i] = F.u[(i64)F.b.dofs[boff(F.b, e) + n] * F.ncomp + d];
+    if (n < bnb(F.b, e)) ue[i] = nh_g(F.u)[(i64)nh_g(F.b.dofs)[boff(F.b, e) + n] * F.ncomp + d];
   }
 }
 
@@ -100,25 +100,32 @@ __device__ __forceinline__ void eval_fields(const FieldK *fields, int nfields, i
   if (shared) {
     const FieldK &F0 = fields[0];
     const int nb = bnb(F0.b, e);
-    const double *T = (TT && F0.tsame) ? TT + (size_t)q * S : F0.b.T + (bfn(F0.b, e) * nq + q) * S;
+    // (the staged copy in LDS or the table in global memory: two loops, each over a pointer of ONE address space -- a pointer selected at run time makes every read a
+    // flat load)
     double r[4][S];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int s = 0; s < S; ++s) r[f][s] = 0;
+    auto rows = [&](auto T) __attribute__((always_inline)) {
 #pragma unroll 4
-    for (int n = 0; n < nb; ++n) {
-      const double *Tn = T + (size_t)n * nq * S;
-      double tn[S];
+      for (int n = 0; n < nb; ++n) {
+        const auto Tn = T + (size_t)n * nq * S;
+        double tn[S];
 #pragma unroll
-      for (int s = 0; s < S; ++s) tn[s] = Tn[s];
+        for (int s = 0; s < S; ++s) tn[s] = Tn[s];
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
-        if (f < nfields) {
-          const double un = ue[fields[f].ue0 + n];
+        for (int f = 0; f < 4; ++f)
+          if (f < nfields) {
+            const double un = ue[fields[f].ue0 + n];
 #pragma unroll
-          for (int s = 0; s < S; ++s) r[f][s] += tn[s] * un;
-        }
+            for (int s = 0; s < S; ++s) r[f][s] += tn[s] * un;
+          }
+      }
+    };
+    if (TT && F0.tsame) rows(TT + (size_t)q * S);
+    else {
+      rows(nh_g(F0.b.T) + (bfn(F0.b, e) * nq + q) * S);
     }
 #pragma unroll
     for (int f = 0; f < 4; ++f)
@@ -138,18 +145,23 @@ __device__ __forceinline__ void eval_fields(const FieldK *fields, int nfields, i
   for (int f = 0; f < nfields; ++f) {
     const FieldK &F = fields[f];
     const int nb = bnb(F.b, e);
-    const double *T = (TT && F.tsame) ? TT + (size_t)q * S : F.b.T + (bfn(F.b, e) * nq + q) * S;
     const double *c = ue + F.ue0;
     for (int d = 0; d < F.ncomp; ++d) {
       double r[S];
 #pragma unroll
       for (int s = 0; s < S; ++s) r[s] = 0;
+      auto rows = [&](auto T) __attribute__((always_inline)) {
 #pragma unroll 4
-      for (int n = 0; n < nb; ++n) {
-        const double un = c[n * F.ncomp + d];
-        const double *Tn = T + (size_t)n * nq * S;
+        for (int n = 0; n < nb; ++n) {
+          const double un = c[n * F.ncomp + d];
+          const auto Tn = T + (size_t)n * nq * S;
 #pragma unroll
-        for (int s = 0; s < S; ++s) r[s] += Tn[s] * un;
+          for (int s = 0; s < S; ++s) r[s] += Tn[s] * un;
+        }
+      };
+      if (TT && F.tsame) rows(TT + (size_t)q * S);
+      else {
+        rows(nh_g(F.b.T) + (bfn(F.b, e) * nq + q) * S);
       }
       double *o = u + (F.c0 + d) * S;
       o[0] = r[0];
@@ -221,10 +233,10 @@ __device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, 
     __syncthreads();  // table staged; G of the previous batch consumed
     i64 cls0 = -1;
     if (p.tstage) {  // the class of the batch's first element (it stays staged while consecutive batches keep it)
-      cls0 = bfn(p.blocks[0].test, p.elist ? p.elist[b0] : b0);
+      cls0 = bfn(p.blocks[0].test, p.elist ? nh_g(p.elist)[b0] : b0);
       if (*tag != cls0) {
         const int n = p.blocks[0].maxnb * p.nq * S;
-        for (int i = tid; i < n; i += NTB) TS[i] = p.blocks[0].test.T[cls0 * p.nq * S + i];
+        for (int i = tid; i < n; i += NTB) TS[i] = nh_g(p.blocks[0].test.T)[cls0 * p.nq * S + i];
       }
     }
     stage_coeffs(p.fields, p.nfields, p.uesz, UE, p.eb, b0, p.nelems, p.elist, tid);
@@ -235,10 +247,10 @@ __device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, 
       const i64 ie = b0 + el;
       double *g = G + (size_t)t * p.ct * S;
       if (ie >= p.nelems) continue;
-      const i64 e = p.elist ? p.elist[ie] : ie;
+      const i64 e = p.elist ? nh_g(p.elist)[ie] : ie;
       double Ji[ND][ND], det;
       geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);
-      const double wdet = p.weights[q] * fabs(det);
+      const double wdet = nh_g(p.weights)[q] * fabs(det);
       double *u = U + (size_t)tid * p.fct * S;
       // (wave-uniform choice: a pointer that is LDS for some lanes and global for others would be a flat access)
       if (p.tstage && __all(bfn(p.blocks[0].test, e) == cls0)) eval_fields<ND>(p.fields, p.nfields, e, q, p.nq, Ji, UE + (size_t)el * p.uesz, TS, u);
@@ -251,7 +263,7 @@ __device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, 
         const double *H = tab + p.toff[t2];
         const int blk = (int)H[0], fld = (int)H[1], pol = (int)H[2], hasC = (int)H[3], hasf = (int)H[4];
         const BlockK &B = p.blocks[blk];
-        double coef = p.scale[t2] ? p.scale[t2][ie * p.nq + q] : 1.;
+        double coef = p.scale[t2] ? nh_g(p.scale[t2])[ie * p.nq + q] : 1.;
         if (pol >= 0) coef *= pick(pv, pol);
         if (p.qoff[t2]) coef *= point_factor<S>(tab + p.qoff[t2], u);
         const double *fv = H + 5, *C = fv + B.nct * S;
@@ -290,7 +302,7 @@ __device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, 
       int r = k - el * p.rowsper;
       const i64 ie = b0 + el;
       if (ie >= p.nelems) continue;
-      const i64 e = p.elist ? p.elist[ie] : ie;
+      const i64 e = p.elist ? nh_g(p.elist)[ie] : ie;
       int blk = 0;
       if (p.nblocks > 1 && r >= p.blocks[0].maxnb * p.blocks[0].nct) r -= p.blocks[0].maxnb * p.blocks[0].nct, blk = 1;
       const BlockK &B = p.blocks[blk];
@@ -298,16 +310,16 @@ __device__ __forceinline__ void terms_body(const TermsK &p, const unsigned bid, 
       if (m >= bnb(B.test, e)) continue;
       const double *g = G + ((size_t)el * p.nq * p.ct + (B.c0 + c)) * S;
       double acc = 0;
-      auto row = [&](const double *T) {
+      auto row = [&](auto T) __attribute__((always_inline)) {
         for (int q = 0; q < p.nq; ++q) {
 #pragma unroll
           for (int s = 0; s < S; ++s) acc += T[q * S + s] * g[(size_t)q * p.ct * S + s];
         }
       };
       if (p.tstage && bfn(B.test, e) == cls0) row(TS + (size_t)m * p.nq * S);
-      else row(B.test.T + (bfn(B.test, e) + m) * p.nq * S);
-      if (B.local) B.local[(boff(B.test, e) + m) * B.nct + c] = acc;
-      else atomicAdd(B.out + (i64)B.test.dofs[boff(B.test, e) + m] * B.nct + c, acc);
+      else row(nh_g(B.test.T) + (bfn(B.test, e) + m) * p.nq * S);
+      if (B.local) nh_gw(B.local)[(boff(B.test, e) + m) * B.nct + c] = acc;
+      else __hip_atomic_fetch_add(nh_gw(B.out) + (i64)nh_g(B.test.dofs)[boff(B.test, e) + m] * B.nct + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(NTB) void k_mterms(MTermsK p) {
       const i64 e = meta[el * 8];
       const i64 ip = (p.emap_by_elem ? e : ie) * p.nq + q;  // index of the point in the scale arrays
       if (t != tid) geometry_at<ND>(p.geom, e, q, p.nq, nullptr, Ji, det, nullptr);  // (more points than threads: batches of one element)
-      const double wdet = p.weights[q] * fabs(det);
+      const double wdet = nh_g(p.weights)[q] * fabs(det);
       double *u = U + (size_t)tid * p.fct * S;
       eval_fields<ND>(p.fields, p.nfields, e, q, p.nq, Ji, UE + (size_t)el * p.uesz, TT + (size_t)(meta[el * 8 + 6] & 0xff) * p.maxnbt * p.nq * S, u);
       double pv[MAXP];

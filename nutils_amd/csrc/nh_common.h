@@ -104,6 +104,20 @@ struct nh_fused_plan {
   double p1hex_tab[32];      // tables of the sum-factorised routine (P1Tab of nh_gather.hip)
 };
 
+// A pointer the device code LOADS from memory (a parameter block in device memory, not the kernel argument segment) has no known address space: every access through it
+// is a FLAT instruction.  Where such a pointer is hot, the access goes through a pointer cast to the global address space (nh_g: read, nh_gw: write).
+#ifdef __HIPCC__
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T *nh_g(const T *p) {
+  return (const __attribute__((address_space(1))) T *)p;
+}
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *nh_gw(T *p) {
+  return (__attribute__((address_space(1))) T *)p;
+}
+#endif
+
+
 // row tasks of the owner kernel for vector-valued blocks (nh_owner.hip): the contributions (visit, m, n) to the scalar entries of a block's rows as lane items, sorted by
 // (row, position in the row, element) and packed into chunks of 64 lanes such that the items of one entry never straddle a chunk
 struct nh_owner_plan {
