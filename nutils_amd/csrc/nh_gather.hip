@@ -1617,9 +1617,7 @@ int nh_fused_scalar(const nh_matrix_args *a, bool *done, hipStream_t s) {
   const size_t lds1 = fused_lds_bytes(f->rows_per_block, f->max_ents);  // row tables + accumulator
   const size_t ldsx = (ldst ? ldsb : 0) + lds1;
   int nt = FUSED_NT;
-#ifdef NH_ABLATION
   if (getenv("NH_FUSED_NT")) nt = std::min(FUSED_NT_MAX, std::max(64, atoi(getenv("NH_FUSED_NT")) & ~63));
-#endif
   dim3 grid((unsigned)f->nblocks), block(nt);
   // trilinear hexahedra with the 2 x 2 x 2 Gauss scheme: the sum-factorised element routine (the answer for a set of table pointers is remembered in the plan)
   {
