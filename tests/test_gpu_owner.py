@@ -142,3 +142,33 @@ def test_owner_plan_serves_other_forms():
             out.append(device.to_host(values))
         close(out[1], out[0])
     assert pattern.owner_info()[0] > 0
+
+
+def test_owner_plan_follows_the_connectivity_of_the_call():
+    '''The plan keeps the vertex numbers of the visiting elements (one level of dependent loads less per block), made from the connectivity array of the call that
+    needed them first: a later call with ANOTHER connectivity array for the same pattern (the vertices renumbered) rebuilds them; back to the first array as well.'''
+    from nutils_amd import device, kernels
+    from oracle import assemble as oa
+    common, ndofs, rng = _mesh(3, 10, 1, True)
+    pattern, nd, geom = common['pattern'], 3, common['geom']
+    rowptr, colidx = pattern.expand(nd, nd, None)
+    C = oa.elasticity_coefficient(3, 1.3, .7)
+    gT, gdofs, verts = geom._keep
+    gdofs, verts = device.to_host(gdofs), device.to_host(verts).reshape(-1, 3)
+    perm = rng.permutation(len(verts))  # new number of old vertex i
+    verts2 = numpy.empty_like(verts)
+    verts2[perm] = verts
+    geom2 = kernels.geometry_iso(8, gT, device.to_dev(perm[gdofs].ravel(), 'int32'), device.to_dev(verts2, 'float64'))
+    ref = None
+    for g in (geom, geom2, geom):
+        kw = dict(common, geom=g)
+        out = []
+        for mode in (dict(gather=True), dict(fused=True, store=True)):
+            values = device.to_dev(numpy.full(colidx.numel(), numpy.nan), 'float64') if mode.get('store') else device.zeros(colidx.numel(), 'float64')
+            kernels.assemble_matrix(nct=nd, ncr=nd, C=C, mask=None, values=values, **kw, **mode)
+            out.append(device.to_host(values))
+        close(out[1], out[0])
+        if ref is None:
+            ref = out[1]
+        assert numpy.array_equal(out[1], ref)  # (the same elements with the same coordinates: the same sums in the same order)
+    assert pattern.owner_info()[0] > 0
