@@ -645,11 +645,29 @@ __device__ __forceinline__ int fused_stage_rows(const FusK &p, int b, const FusL
 }
 // the rows of the block, half a wave per row (row starts and offsets are staged: no chain of dependent global loads); a row is one contiguous piece of the value array
 __device__ __forceinline__ void fused_flush_rows(const FusK &p, const FusLds &l, int nr) {
-  const int hl = threadIdx.x & 31, NT = blockDim.x;
-  for (int i = threadIdx.x >> 5; i < nr; i += NT >> 5) {
-    const int lo = l.eoff[i], len = l.eoff[i + 1] - lo;
-    double *dst = p.values + l.rstart[i];
-    for (int j = hl; j < len; j += 32) dst[j] = p.store ? l.acc[lo + j] : dst[j] + l.acc[lo + j];
+  const int hl = threadIdx.x & 31, NT = blockDim.x, step = NT >> 5;
+  // four rows per half-wave and trip: their offsets, starts and first 32 entries are read from LDS together (one row per trip was a chain of two LDS latencies and a
+  // store per 216 bytes: 0.13 of the 0.52 ms of 128^3 trilinear Laplace went to this loop, profiles/r05_owner_vector.md)
+  for (int i0 = threadIdx.x >> 5; i0 < nr; i0 += 4 * step) {
+    int lo[4], len[4];
+    i64 rs[4];
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * step;
+      const bool in = i < nr;
+      lo[k] = in ? l.eoff[i] : 0;
+      len[k] = in ? l.eoff[i + 1] - lo[k] : 0;
+      rs[k] = in ? l.rstart[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = hl < len[k] ? l.acc[lo[k] + hl] : 0.;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double *dst = p.values + rs[k];
+      if (hl < len[k]) dst[hl] = p.store ? v[k] : dst[hl] + v[k];
+      for (int j = hl + 32; j < len[k]; j += 32) dst[j] = p.store ? l.acc[lo[k] + j] : dst[j] + l.acc[lo[k] + j];
+    }
   }
 }
 
@@ -1448,9 +1466,7 @@ static int nh_fused_prepare(nh_pattern *p, const nh_matrix_args *a, hipStream_t 
     // rows per block: the largest candidate whose fullest block fits the LDS of a workgroup (two per CU)
     const int cand[] = {512, 256, 128, 64};
     int forced = 0;
-#ifdef NH_ABLATION
     if (getenv("NH_FUSED_ROWS")) forced = std::min(512, std::max(16, atoi(getenv("NH_FUSED_ROWS"))));
-#endif
     for (int ci = 0; ci < 4 && !R; ++ci) {
       const int Rc = forced ? forced : cand[ci];
       const int tn = t.n;
