@@ -12,5 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   bash tools/pmc.sh r6u_$c $c -- python tools/c3_bench.py 64 6 uniform 2>&1 | grep -A2 "k_p2hex_rows_uniform" | tee -a gpurun_out/r6f_traffic.txt
   echo "== c5 $c" | tee -a gpurun_out/r6f_traffic.txt
   bash tools/pmc.sh r6c5_$c $c -- python tools/ragged_probe.py 256 6 2>&1 | grep -A2 "k_gram_sym\|k_gather_values_2x2_tri\|k_mirror_2x2" | tee -a gpurun_out/r6f_traffic.txt
-  rm -rf gpurun_out/pmc_r6u_$c gpurun_out/pmc_r6c5_$c
+  echo "== owner_v $c" | tee -a gpurun_out/r6f_traffic.txt
+  bash tools/pmc.sh r6ov_$c $c -- python tools/vector_probe.py 96 6 2>&1 | grep -A2 "k_owner_rows_v" | tee -a gpurun_out/r6f_traffic.txt
+  rm -rf gpurun_out/pmc_r6u_$c gpurun_out/pmc_r6c5_$c gpurun_out/pmc_r6ov_$c
 done
