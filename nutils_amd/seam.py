@@ -262,6 +262,11 @@ def prepare_arguments(plan, arguments):
     return arguments
 
 
+# pointwise functions of one argument a point plan may carry in `post` (names of the reference's wrappers = numpy's)
+_POINTWISE = {n: getattr(numpy, n) for n in ('sqrt', 'abs', 'absolute', 'exp', 'log', 'log2', 'log10', 'sin', 'cos', 'tan', 'arcsin', 'arccos', 'arctan', 'sinh', 'cosh', 'tanh',
+                                              'arctanh', 'sign', 'negative', 'square', 'reciprocal')}
+
+
 def run(plan, arguments, evaluator):
     '''Evaluate a plan with `evaluator(integral, arguments, kind)` -> float | array | (values, rowptr, colidx): the whole array at once, or -- when it is differentiated
     to an argument that is a concatenation of coefficient vectors -- block by block, the blocks placed at their offsets (vectors) / merged into one CSR (matrices: the
@@ -279,6 +284,9 @@ def run(plan, arguments, evaluator):
                 out += vals.reshape(out.shape)
             else:  # (the rows of one plan sample are distinct; terms located in different topologies arrive as different plan samples over the same rows)
                 out[dest] += vals.reshape((len(dest),) + out.shape[1:])
+        for name in plan.get('post') or ():
+            with numpy.errstate(all='ignore'):
+                out = _POINTWISE[str(name)](out)
         return out
     if not b.split:
         return evaluator(b.integral, arguments, kind)
@@ -1313,7 +1321,7 @@ class Emitter:
         if spec is None:
             # generic: every element of the sample located in `transforms`; groups of elements that see the same points in parent coordinates
             groups = {}
-            face = tr.fromdims < tr.todims
+            face = tr.fromdims < tr.todims and transforms is not tr  # (a boundary sample located in ITSELF has no parent elements: match_points, functions without a basis)
             corners = numpy.vstack([numpy.zeros((1, tr.fromdims)), numpy.eye(tr.fromdims)])
             for i in range(len(tr)):
                 ie, tail = transforms.index_with_tail(tr[i])
@@ -1793,6 +1801,18 @@ def match_points(array):
     M.points_mode = True
     tr = smp.transforms[0]
     M.sample, M.S = smp, 1 + tr.todims
+    # pointwise functions of one argument at the top (`sqrt(u_i u_i)`, examples/drivencavity.py:180): the plan evaluates what is inside, the host applies them to the
+    # point values it returns (Sample.eval hands out host arrays)
+    post = []
+    while True:
+        inner = func
+        while _kind(inner) == '_Transpose' and tuple(inner._axes) == tuple(range(len(inner._axes))):  # (the scalar `sqrt(..)` of an expression arrives under a Transpose of no axes)
+            inner = inner._arg
+        if _kind(inner) == '_Wrapper' and _name(inner) in _POINTWISE and len(inner._args) == 1 and inner._args[0].shape == func.shape and inner._args[0].dtype == float:
+            post.append(_name(inner))
+            func = inner._args[0]
+        else:
+            break
     monos = M.conv(func)
     E = Emitter(M)
     anybasis = next((f.basis for m in monos for f in m.factors if f.basis is not _SCALAR and f.basis is not _XGEOM), None)
@@ -1803,9 +1823,9 @@ def match_points(array):
         b = next((f.basis for f in m.factors if f.basis is not _SCALAR and f.basis is not _XGEOM), anybasis)
         if b is not None:
             return E.basis_transforms(b)
-        if tr.fromdims == tr.todims:
-            return tr
-        raise Unmatched('boundary sample without any basis: the parent topology is unknown')
+        # no basis anywhere in the function (coordinates, constants, scalar arguments at the points of a sample): the sample's own elements are the topology -- nothing
+        # in such a term refers to a parent element (coordinates a kernel cannot evaluate from a structural description are tabulated at the points)
+        return tr
     nd = M.S - 1
     pterms = []
     nconst = [0]
@@ -1922,6 +1942,8 @@ def match_points(array):
         plan['derived'] = {n: ast for n, ast in M.derived.items() if n in used}
     plan['shape'] = [int(n) for n in array.shape]
     plan['kind'] = 'points'
+    if post:
+        plan['post'] = post[::-1]  # innermost first
     plan['_source'] = array
     return plan
 
