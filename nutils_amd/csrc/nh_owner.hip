@@ -565,10 +565,12 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
     // (elements of more than 9 functions -- triquadratic: 27 -- take their points in chunks and hold the sums of a block's contributions in registers meanwhile: boxes of at
     // most 8 rows, the nodes one element owns, so that a workgroup of four waves holds them in four chunks of 64 each)
     const bool big = nbt > 9;
-    const int cand[] = {64, 32, 16, 8, 4, 2, 1};
+    // (24 rows at one workgroup of 1024 threads per CU beat 16 rows at two of 512 where the tables fit 100 kB: 96^3 trilinear elasticity 1.39 -> 1.34 ms, fewer visits per element)
+    const int cand[] = {64, 32, 24, 16, 8, 4, 2, 1};
+    const size_t cand_budget[] = {0, 0, 100 * 1024, 0, 0, 0, 0, 0};  // 0: the common budget
     int forced = getenv("NH_OWNER_ROWS") ? std::max(1, std::min(256, atoi(getenv("NH_OWNER_ROWS")))) : 0;
     int qc = a->nq;
-    for (int ci = big ? 3 : 0; ci < 7; ++ci) {
+    for (int ci = big ? 4 : 0; ci < 8; ++ci) {
       const int Rc = forced ? forced : cand[ci];
       const int tn = t.n;
       OP_CHECK(hipMemsetAsync(flags, 0, 3 * sizeof(int), s));
@@ -579,7 +581,8 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
       OP_CHECK(hipStreamSynchronize(s));
       for (int parts = 1; parts <= (big ? 8 : 1) && !R; ++parts) {
         const int q = (a->nq + parts - 1) / parts;
-        if (hflags[2] < 4096 && owner_lds(Rc, hflags[2], a->nq, q, nbt, a->ndims, sd, isof, ldst, iso, parts > 1) <= budget) R = Rc, vmax = hflags[2], qc = q;  // (without the staged vertices if need be)
+        const size_t bud = (!forced && cand_budget[ci] && !getenv("NH_OWNER_LDS")) ? cand_budget[ci] : budget;
+        if (hflags[2] < 4096 && owner_lds(Rc, hflags[2], a->nq, q, nbt, a->ndims, sd, isof, ldst, iso, parts > 1) <= bud) R = Rc, vmax = hflags[2], qc = q;  // (without the staged vertices if need be)
       }
       if (R) break;
       if (getenv("NH_OWNER_VERBOSE")) fprintf(stderr, "nh_owner plan: %d rows per block -> at most %d visits, %zu B of LDS: over the budget\n", Rc, hflags[2], owner_lds(Rc, hflags[2], a->nq, a->nq, nbt, a->ndims, sd, isof, ldst, iso));
