@@ -51,7 +51,7 @@ def save(path, plan, expect=None):
             arrays[key] = obj
             return {'__array__': key}
         if isinstance(obj, dict):
-            return {k: enc(v) for k, v in obj.items()}
+            return {k: enc(v) for k, v in obj.items() if not str(k).startswith('_')}  # ('_built', '_source': run-time attachments, also of the parts of a 'stack' plan)
         if isinstance(obj, (list, tuple)):
             return [enc(v) for v in obj]
         if isinstance(obj, (numpy.integer, numpy.bool_)):
@@ -271,9 +271,21 @@ def run(plan, arguments, evaluator):
     '''Evaluate a plan with `evaluator(integral, arguments, kind)` -> float | array | (values, rowptr, colidx): the whole array at once, or -- when it is differentiated
     to an argument that is a concatenation of coefficient vectors -- block by block, the blocks placed at their offsets (vectors) / merged into one CSR (matrices: the
     blocks are disjoint, every row is the concatenation of its blocks' rows in column order, as matrix/__init__.py:103-151 merges the blocks of a System).'''
+    kind = plan['kind']
+
+    def posted(x):
+        for name in plan.get('post') or ():
+            with numpy.errstate(all='ignore'):
+                x = _POINTWISE[str(name)](x)
+        return x
+    if kind == 'stack':  # an array of integrals without dof axes: one scalar plan per entry (None: the entry is zero)
+        out = numpy.zeros([int(n) for n in plan['shape']])
+        for idx, part in zip(numpy.ndindex(*out.shape), plan['parts']):
+            if part is not None:
+                out[idx] = float(run(part, arguments, evaluator))
+        return posted(out)
     b = build(plan)
     arguments = prepare_arguments(plan, arguments)
-    kind = plan['kind']
     if kind == 'points':
         # the point axis of the result: the elements of the sample in order, each with its points (loop_concatenate, sample.py:966-975), placed by the sample's point
         # indices (_ReorderPoints: Inflate, sample.py:978-989); a sample whose elements carry different point tables arrives as one plan sample per table
@@ -284,12 +296,10 @@ def run(plan, arguments, evaluator):
                 out += vals.reshape(out.shape)
             else:  # (the rows of one plan sample are distinct; terms located in different topologies arrive as different plan samples over the same rows)
                 out[dest] += vals.reshape((len(dest),) + out.shape[1:])
-        for name in plan.get('post') or ():
-            with numpy.errstate(all='ignore'):
-                out = _POINTWISE[str(name)](out)
-        return out
+        return posted(out)
     if not b.split:
-        return evaluator(b.integral, arguments, kind)
+        out = evaluator(b.integral, arguments, kind)
+        return posted(numpy.float64(out)) if kind == 'scalar' and plan.get('post') else out
     if kind == 'vector':
         out = numpy.zeros(b.dims[0])
         for (off,), blk in b.blocks:
@@ -1583,9 +1593,42 @@ def match(array, arguments=None):
     '''function-level array of the reference (sum of integrals, possibly differentiated with function.derivative) -> plan.
 
     The result kind follows the array: rank 0 -> 'scalar'; dof axes exposed by basis arrays or derivatives: one -> 'vector' (shape of the
-    reference array), two -> 'matrix' (as_csr of the array flattened to (rows, cols), rows = first exposed argument).'''
+    reference array), two -> 'matrix' (as_csr of the array flattened to (rows, cols), rows = first exposed argument).  An array of integrals without dof axes
+    (`boundary.integrate('t_i dS')`, examples/elasticity.py:72) becomes a plan of kind 'stack': one scalar plan per entry.'''
+    # (Pointwise functions on top of an integral -- `numpy.sqrt(abs(domain.integral('∇_k(u_k)^2 dV')))`, examples/cylinderflow.py:148,162 -- stay with the reference: the
+    # matcher expands the integrand into monomials, (d0u0)^2 + 2 d0u0 d1u1 + (d1u1)^2, whose sum cancels to rounding level -- 1e-16 of the terms, inside every bar on the
+    # integral itself -- and the square root of THAT is 1e-8 where the reference's test asks for < 1e-13.  Built, measured on that example, withdrawn.)
+    post, inner = [], array
     M = Matcher()
-    terms, derivs = M.integral(array)
+    terms, derivs = M.integral(inner)
+    free = [m for _, m, _ in terms if m.axes and all(k == 'free' for k, _ in m.axes) and numpy.prod(m.A.shape[:m.nfree]) > 1]
+    if free and not derivs and all(all(k == 'free' for k, _ in m.axes) for _, m, _ in terms) and 0 < inner.ndim <= 2 and int(numpy.prod(inner.shape)) <= 64:
+        parts = []
+        for idx in numpy.ndindex(*[int(n) for n in inner.shape]):
+            sub = []
+            for smp, m, fac in terms:
+                sel = [0] * m.nfree
+                for i, (_, j) in enumerate(m.axes):
+                    sel[j] = idx[i] if m.A.shape[j] > 1 else 0
+                A = m.A[tuple(sel)]
+                if numpy.abs(A).sum():
+                    sub.append((smp, _Mono(A, [], m.factors, m.pw, m.measure), fac))
+            parts.append(_match_terms(M, sub, [], (), None) if sub else None)
+        plan = dict(kind='stack', shape=[int(n) for n in inner.shape], parts=parts, derivs=[], args=[a for pl in parts if pl for a in pl['args']])
+        plan['_source'] = array
+    else:
+        if post and (derivs or inner.ndim):
+            raise Unmatched('pointwise function of a differentiated / array-valued integral')
+        plan = _match_terms(M, terms, derivs, inner.shape, array)
+    if post:
+        if plan['kind'] not in ('scalar', 'stack'):
+            raise Unmatched('pointwise function of an array with dof axes')
+        plan['post'] = post[::-1]  # innermost first
+    return plan
+
+
+def _match_terms(M, terms, derivs, shape, source):
+    '''the monomials of a sum of integrals -> plan (see match)'''
     E = Emitter(M)
     nexposed = None
     # terms without any basis (constants, coefficient functions: `sigma_wall dS`) are located in the topology of the bases seen elsewhere
@@ -1774,11 +1817,11 @@ def match(array, arguments=None):
     used = {a['name'] for a in plan['args']}
     if any(n in used for n in M.derived):
         plan['derived'] = {n: ast for n, ast in M.derived.items() if n in used}
-    plan['shape'] = [int(n) for n in array.shape]
+    plan['shape'] = [int(n) for n in shape]
     plan['kind'] = 'scalar' if nexposed == 0 else 'vector' if nexposed == 1 else 'matrix'
     if nexposed > 2:
         raise Unmatched('arrays with more than two dof axes')
-    plan['_source'] = array  # (not stored: tools/hip_plan_capture.py evaluates it through the un-hooked reference to pin the plan's expected result)
+    plan['_source'] = source  # (not stored: tools/hip_plan_capture.py evaluates it through the un-hooked reference to pin the plan's expected result)
     return plan
 
 
@@ -2113,8 +2156,9 @@ def install(executor=None):
                     build(plan)
                 else:
                     plan = match(array)
-                    if not build(plan).integral.terms:
-                        raise Unmatched('empty integral')
+                    for part in (plan['parts'] if plan['kind'] == 'stack' else [plan]):
+                        if part is not None and not build(part).integral.terms:
+                            raise Unmatched('empty integral')
             except Unmatched as e:
                 plan = e
                 if _kind(array) in ('_ConcatenatePoints', '_ReorderPoints'):
@@ -2196,7 +2240,7 @@ def install(executor=None):
                 dense[numpy.repeat(numpy.arange(n), numpy.diff(rp)), ci] = v
                 results[i] = dense.reshape(plan['shape'])
             else:
-                results[i] = numpy.asarray(out) if plan['kind'] in ('vector', 'points') else numpy.float64(out)
+                results[i] = numpy.asarray(out) if plan['kind'] in ('vector', 'points', 'stack') else numpy.float64(out)
         if rest:
             st['fallback'].append(len(rest))
             for i, r in zip(rest, st['evaluate'](*[arrays[i] for i in rest], arguments=arguments)):

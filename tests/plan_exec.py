@@ -41,7 +41,7 @@ def _pack(plan, out):
         return dict(values=out[0], rowptr=out[1], colidx=out[2])
     if plan['kind'] == 'points':
         return dict(points=numpy.asarray(out, dtype=float))
-    if plan['kind'] == 'vector':
+    if plan['kind'] in ('vector', 'stack'):
         return dict(vector=numpy.asarray(out, dtype=float))
     return dict(scalar=numpy.asarray(float(out)))
 
@@ -124,7 +124,7 @@ def compare_example(plan, out, expect, args, rtol=1e-13, floor=32 * 2.3e-16):
                                                                     if numpy.size(v) and numpy.asarray(v).dtype.kind in 'fiub'])
         err = (numpy.abs(mine - ref).max() / (rtol * scale)) if ref.size else 0.
     else:
-        ref = numpy.asarray(expect['vector'] if plan['kind'] == 'vector' else expect['scalar'], dtype=float)
+        ref = numpy.asarray(expect['scalar'] if plan['kind'] == 'scalar' else expect['vector'], dtype=float)  # ('stack': an array of scalar integrals, held to the bar of a vector)
         mine = numpy.asarray(out, dtype=float).reshape(ref.shape)
         if 'abssum' in expect:
             # per ENTRY: 1e-13 of the largest entry of the reference's result + 32 ulp of the sum of the |products| the entry is made of (stored at capture: the same integral

@@ -75,6 +75,10 @@ def main(modules):
         dp = Counter(st['declined_points'])
         print(f'    point evaluations from plans: {matched["points"]}; declined: {sum(dp.values())}' + (' (' + '; '.join(f'{n} x {r}' for r, n in dp.most_common()) + ')' if dp else '')
               + (f'; integer / boolean index functions of the library left to the reference: {len(st["internal_points"])}' if st['internal_points'] else ''))
+        # arrays handed to function.evaluate directly (integrals of functionals, norms, forces: `domain.integral(..).eval()`) that the matcher declined
+        de = Counter(str(pl) for _, pl in st['plans'].values() if isinstance(pl, seam.Unmatched))
+        ev = matched['scalar'] + matched['vector'] + matched['matrix'] + matched['stack']
+        print(f'    integrals evaluated from plans (function.evaluate / as_csr): {ev}; arrays declined: {sum(de.values())}' + (' (' + '; '.join(f'{n} x {r}' for r, n in de.most_common()) + ')' if de else ''))
         if name in ZERO_DECLINED_POINTS:
             ok = ok and matched['points'] > 0 and not dp
         ok = ok and res.wasSuccessful() and res.testsRun > 0 and matched['System'] > 0

@@ -88,15 +88,15 @@ def main(out, modules):
             else:
                 ret = numpy.asarray(res, dtype=float).reshape(plan['shape'])
                 expect = dict(vector=ref.reshape(plan['shape']))
-            if plan['kind'] in ('vector', 'scalar'):
+            if plan['kind'] in ('vector', 'scalar', 'stack'):
                 # what every entry is a sum OF: the same integral with every factor replaced by its absolute value (af_oracle absolute=True) -- the scale of the rounding
                 # error of an entry whatever cancels in it (a residual at its own solution, an energy difference); stored beside the result, 32 ulp of it is the floor of the comparison
                 ab = seam.run(plan, arguments, lambda integral, args, kind: af_oracle.evaluate(integral, args, absolute=True))
-                expect['abssum'] = numpy.asarray(ab, dtype=float).reshape(numpy.shape(expect['vector' if plan['kind'] == 'vector' else 'scalar']))
+                expect['abssum'] = numpy.asarray(ab, dtype=float).reshape(numpy.shape(expect['scalar' if plan['kind'] == 'scalar' else 'vector']))
             if plan['kind'] != 'matrix':
                 err = plan_exec.compare_example(plan, ret, expect, arguments)
                 if os.environ.get('CAPTURE_VERBOSE'):
-                    print(f'  {name} {plan["kind"]}: |ref| {float(numpy.abs(ref).max()):.3e}, term scale {plan_exec.term_scale(plan, arguments):.3e}, error / tolerance {err:.2e}')
+                    print(f'  {name} {plan["kind"]}: |ref| {float(numpy.abs(ref).max()):.3e}, error / tolerance {err:.2e}')
             numeric = {k: numpy.asarray(v, dtype=float) for k, v in (arguments or {}).items() if numpy.asarray(v).dtype.kind in 'fiub'}
             if id(plan) not in seen:
                 for k, v in numeric.items():
@@ -153,6 +153,9 @@ def signature(plan):
     '''What a plan IS, independent of the order in which the reference happened to visit its terms and samples (that order follows object hashes inside the reference's
     simplifier and changes from process to process): kind, shape, derivatives, the multiset of its terms (tensor, factor, exposure, coefficient kinds) and of its tables.'''
     import json
+
+    if plan['kind'] == 'stack':  # an array of scalar plans
+        return json.dumps(['stack', [int(n) for n in plan['shape']], [None if part is None else signature(part) for part in plan['parts']]])
 
     def arr(x):
         return None if x is None else [round(float(v), 10) for v in numpy.asarray(x, dtype=float).ravel()]
