@@ -51,7 +51,7 @@ def save(path, plan, expect=None):
             arrays[key] = obj
             return {'__array__': key}
         if isinstance(obj, dict):
-            return {k: enc(v) for k, v in obj.items() if not str(k).startswith('_')}  # ('_built', '_source': run-time attachments, also of the parts of a 'stack' plan)
+            return {k: enc(v) for k, v in obj.items() if k not in ('_built', '_source', '_failed')}  # (run-time attachments, also of the parts of a 'stack' plan)
         if isinstance(obj, (list, tuple)):
             return [enc(v) for v in obj]
         if isinstance(obj, (numpy.integer, numpy.bool_)):
