@@ -1725,9 +1725,12 @@ def _match_terms(M, terms, derivs, shape, source):
             home = E.basis_transforms(facs[form[0]].basis)
         elif anybasis is not None:
             home = E.basis_transforms(anybasis)
-        elif smp.transforms[0].fromdims == smp.transforms[0].todims:
-            home = smp.transforms[0]
         else:
+            # no basis in any term (lengths, areas, integrals of coefficient functions over a boundary): the sample's own elements are the topology; on a boundary the
+            # measure is then tabulated with the coefficient functions (no parent element to take a Jacobian in)
+            home = smp.transforms[0]
+        selfhome = home is smp.transforms[0] and home.fromdims != home.todims
+        if selfhome and (form or pv or poly and any(facs[i].basis is not _SCALAR for i in poly)):
             raise Unmatched('boundary integral without any basis: the parent topology is unknown')
         sis = E.iface_sample(smp, home) if iface else E.sample(smp, home)
         if iface and m.measure is None:
@@ -1741,6 +1744,8 @@ def _match_terms(M, terms, derivs, shape, source):
             if m.measure is None:
                 # an integral over the REFERENCE elements (no J(geom): the weight-function projection of examples/platewithhole.py:83): the measure of the identity map
                 gnode, gi = None, E.geom_unit(si)
+            elif selfhome:
+                gnode, gi = None, E.geom_unit(si)  # (the measure joins the pointwise factor below)
             else:
                 gnode, tip = m.measure
                 gi = E.geom_tab(gnode, smp, si, home) if iface else _geom_index(E, gnode, smp, si, home)
@@ -1782,9 +1787,10 @@ def _match_terms(M, terms, derivs, shape, source):
                 for j, i in enumerate(pv):
                     f = facs[i]
                     term['pvars'].append([E.arg(f.name, basis_of(f), f.ncomp, f.part), int(combo[2 * j]), int(combo[2 * j + 1])])
-            if m.pw:
-                node = m.pw[0]
-                for p in m.pw[1:]:
+            pwn = list(m.pw) + ([M.rf.jacobian(m.measure[0], m.measure[1])] if selfhome and m.measure is not None else [])
+            if pwn:
+                node = pwn[0]
+                for p in pwn[1:]:
                     node = node * p
                 term['scale'] = _point_values(smp, node, s)
             if s.get('_bnd_normal') is not None and gnode is not None:  # (oblique face: see Emitter.sample; the reference measure of a face is that of its own parameters)
