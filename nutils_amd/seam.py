@@ -1273,6 +1273,41 @@ class Emitter:
         self._basis[key] = len(self.plan['bases']) - 1
         return self._basis[key]
 
+    def restricted_basis(self, basis, transforms):
+        '''`basis` (of a coarser topology: the field of the level before, examples/adaptivity.py:62-63) written on the elements of `transforms`: element i lies in element
+        `ie` of the basis' own topology behind an affine map (index_with_tail), its polynomials are composed with that map -- a plain basis of `transforms` with the same dofs.'''
+        key = (id(basis), 'restricted', id(transforms))
+        if key in self._basis:
+            return self._basis[key]
+        self._keep.append(basis)
+        import nutils.transform as rtransform
+        from . import poly as _poly
+        own = self.basis_transforms(basis)
+        nv = int(transforms.fromdims)
+        if int(own.fromdims) != nv or int(own.todims) != int(transforms.todims):
+            raise Unmatched('bases of different topologies in one term')
+        corners = numpy.vstack([numpy.zeros((1, nv)), numpy.eye(nv)])
+        dofs, coeffs = [], []
+        for i in range(len(transforms)):
+            try:
+                ie, tail = own.index_with_tail(transforms[i])
+            except (ValueError, KeyError, IndexError):
+                raise Unmatched('bases of different topologies in one term (an element of the sample lies in no element of the basis)')
+            c = numpy.asarray(basis.get_coefficients(int(ie)), dtype=float)
+            if c.ndim != 2:
+                raise Unmatched('basis with tensorial coefficients restricted to a finer topology')
+            if tail:
+                v = rtransform.apply(tail, corners)
+                c = _poly.compose_affine(c, nv, (v[1:] - v[0]).T, v[0])
+            dofs.append(numpy.asarray(basis.get_dofs(int(ie)), dtype=numpy.int64))
+            coeffs.append(c)
+        top = max(_poly.degree(nv, c.shape[1]) for c in coeffs)
+        coeffs = [_poly.change_degree(c, nv, top) for c in coeffs]
+        self.plan['bases'].append(dict(kind='plain', topo=self.topo(transforms), dofs=numpy.concatenate(dofs), coeffs=numpy.concatenate(coeffs, axis=0),
+                                       offsets=numpy.cumsum([0] + [len(d) for d in dofs]).astype(numpy.int64), ndofs=len(basis)))
+        self._basis[key] = len(self.plan['bases']) - 1
+        return self._basis[key]
+
     def scalar_basis(self, transforms, topo=None):
         '''the one-function basis of a scalar argument on the topology `transforms` (see _ScalarBasis), or on plan topology `topo` (interface lists)'''
         key = ('$scalar', id(transforms)) if topo is None else ('$scalar', 'topo', topo)
@@ -1768,6 +1803,8 @@ def _match_terms(M, terms, derivs, shape, source):
             def basis_of(f):
                 if iface:
                     return on_home(E.iface_basis(f.basis, f.side, smp, si, home, gnode))
+                if f.rational is None and f.cvals is None and E.basis_transforms(f.basis) is not home and E.topo(E.basis_transforms(f.basis)) != s['topo']:
+                    return on_home(E.restricted_basis(f.basis, home))  # (a field of the coarser level in an integral over the refined one)
                 return on_home(E.basis(f.basis, f.rational, (smp, si) if f.rational is not None else None))
             for i in form:
                 f = facs[i]
