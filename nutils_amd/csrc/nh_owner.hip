@@ -193,6 +193,15 @@ __device__ __forceinline__ double lds_rd(unsigned a) {
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
   return v;
 }
+// the same in two statements, for groups of any size: the wait, then every value of the complete group through an (empty) statement of its own -- volatile asm statements
+// keep their order, and what uses a value cannot be scheduled in front of the statement that hands it on
+template <int N>
+__device__ __forceinline__ void lds_wait_n() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+}
+__device__ __forceinline__ void lds_tie(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ unsigned lds_addr(const double *p) { return (unsigned)(size_t)p; }
+
 // wait until at most N LDS operations are outstanding; the values of the group that is complete then pass THROUGH the statement, so that nothing that uses them is
 // scheduled in front of the wait (to the compiler the result of an asm statement is there as soon as the statement has been issued)
 template <int N, int SD>
@@ -337,6 +346,33 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
       for (int r = 0; r < ND; ++r)
 #pragma unroll
         for (int c = 0; c < ND; ++c) J[r][c] = 0;
+#ifndef NH_OWNER_NO_B64
+      if constexpr (LT && XLDS) {
+        // (ds_read_b64 per double, as in the Gram loop below: a vertex and a table row per group, the next group in flight)
+        const unsigned at = lds_addr(sgT + q * S + 1), ax = lds_addr(sX + v * XV), ts = (unsigned)(nq * S * 8);
+        double tb[2][ND], xb[2][ND];
+        auto issue = [&](auto a) {
+          constexpr int A = decltype(a)::value;
+          const unsigned ta = at + A * ts;
+          static_for<ND>([&](auto c) {
+            tb[A & 1][c] = lds_rd<c * 8>(ta);
+            xb[A & 1][c] = lds_rd<(A * ND + c) * 8>(ax);
+          });
+        };
+        issue(std::integral_constant<int, 0>());
+        static_for<NG>([&](auto a) {
+          constexpr int A = decltype(a)::value;
+          if constexpr (A + 1 < NG) issue(std::integral_constant<int, A + 1>());
+          lds_wait_n<(A + 1 < NG ? 2 * ND : 0)>();
+#pragma unroll
+          for (int c = 0; c < ND; ++c) lds_tie(tb[A & 1][c]), lds_tie(xb[A & 1][c]);
+#pragma unroll
+          for (int r = 0; r < ND; ++r)
+#pragma unroll
+            for (int c = 0; c < ND; ++c) J[r][c] += xb[A & 1][r] * tb[A & 1][c];
+        });
+      } else
+#endif
 #pragma unroll
       for (int a = 0; a < NG; ++a) {
         double t[ND];
@@ -372,6 +408,26 @@ __global__ __launch_bounds__(GK ? 256 : XLDS ? OWN_NT_MAX : OWN_NT_MAX / 2) void
 #pragma unroll
     for (int n0 = 0; n0 < NB; n0 += NBC) {
       double t[NBC][S];
+#ifndef NH_OWNER_NO_B64
+      if constexpr (LT) {
+        const unsigned at = lds_addr(sT + q * S), ts = (unsigned)(nq * S * 8);
+        static_for<NBC>([&](auto n) {
+          constexpr int N = decltype(n)::value;
+          if (n0 + N < NB) {
+            const unsigned ta = at + (n0 + N) * ts;
+            static_for<S>([&](auto j) {
+              if constexpr (USE0 || j > 0) t[N][j] = lds_rd<j * 8>(ta);
+            });
+          }
+        });
+        lds_wait_n<0>();
+#pragma unroll
+        for (int n = 0; n < NBC; ++n)
+#pragma unroll
+          for (int j = USE0 ? 0 : 1; j < S; ++j)
+            if (n0 + n < NB) lds_tie(t[n][j]);
+      } else
+#endif
 #pragma unroll
       for (int n = 0; n < NBC; ++n)
 #pragma unroll
