@@ -707,9 +707,9 @@ static int nh_owner_prepare(nh_pattern *p, const nh_matrix_args *a, int sd, bool
     // (elements of more than 9 functions -- triquadratic: 27 -- take their points in chunks and hold the sums of a block's contributions in registers meanwhile: boxes of at
     // most 8 rows, the nodes one element owns, so that a workgroup of four waves holds them in four chunks of 64 each)
     const bool big = nbt > 9;
-    // (24 rows at one workgroup of 1024 threads per CU beat 16 rows at two of 512 where the tables fit 100 kB: 96^3 trilinear elasticity 1.39 -> 1.34 ms, fewer visits per element)
+    // (boxes of up to 24 rows often have no more visits than those of up to 16 -- 45 at most on a hexahedral mesh -- and are fewer: 96^3 trilinear elasticity 1.39 -> 1.35 ms)
     const int cand[] = {64, 32, 24, 16, 8, 4, 2, 1};
-    const size_t cand_budget[] = {0, 0, 100 * 1024, 0, 0, 0, 0, 0};  // 0: the common budget
+    const size_t cand_budget[] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0: the common budget (two workgroups per CU)
     int forced = getenv("NH_OWNER_ROWS") ? std::max(1, std::min(256, atoi(getenv("NH_OWNER_ROWS")))) : 0;
     int qc = a->nq;
     for (int ci = big ? 4 : 0; ci < 8; ++ci) {
